@@ -1,0 +1,153 @@
+/*
+ * lfbm5d_oracle.h -- CPU restatement ("oracle") of the LFBM5D hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the timed CPU baseline.  The product path is lfbm5d_amd/csrc (HIP) and fails loudly
+ * without a GPU.
+ *
+ * What it restates (reference = V-Sense/LFBM5D, paths relative to /root/reference):
+ *   src/bm5d_core_processing.cpp  bm5d_1st_step :90-822, bm5d_2nd_step :859-1659, transforms
+ *                                 :1679-2264, 5D filters :2281-3123, weights :3140-3173,
+ *                                 normalisation tables :3191-3276, block matching :3301-3945
+ *   src/bm5d.cpp                  run_bm5d_1st_step :88-747, run_bm5d_2nd_step :782-1452
+ *                                 (nb_threads == 1 branch only)
+ *   src/bm3d.cpp                  preProcess :1101-1169, dct_2d_inverse :1039-1071
+ *   src/lib_transforms.cpp        bior1.5 :46-277, Hadamard :290-321, Haar :403-471
+ *   src/utilities.cpp             add_noise :154-185, symetrize :215-298, colour :482-599,
+ *                                 estimate_sigma :633-684, ind_initialize :697-736, psnr :412-435
+ *   src/utilities_LF.cpp          compute_LF_angular_search_window :881-901,
+ *                                 compute_LF_estimate :913-954, LF_denoised_percent :967-995,
+ *                                 den-aware ind_initialize :1000-1099
+ *   src/mt19937ar.c               MT19937 (init_genrand / genrand_res53)
+ *
+ * Third-party arithmetic not in the reference tree: FFTW3 single precision (unpinned; any
+ * libfftw3f), kinds REDFT10 / REDFT01.  Restated from the published definitions
+ *   REDFT10: Y_k = 2 sum_j x_j cos(pi (j+1/2) k / n)
+ *   REDFT01: Y_j = X_0 + 2 sum_{k>=1} X_k cos(pi k (j+1/2) / n)
+ * evaluated directly with double accumulation and rounded to float once per 1-D/2-D plan.
+ *
+ * Parity pin status: the reference has no tests and no golden vectors, and it cannot be built here
+ * (needs FFTW3 + libpng headers that the image lacks).  Pinned against compiled reference code:
+ * Haar / Hadamard / bior1.5 / MT19937 (oracle/_ref, built from lib_transforms.cpp and mt19937ar.c).
+ * Pinned against an independent implementation of the published definition: DCT-II/III (scipy).
+ * Everything else (BM, SADCT, filters, schedule): restated from the source, checked against the
+ * end-to-end PSNRs recorded in SURVEY.md section 6 -- "parity unpinned" for those parts.
+ *
+ * Where the reference leaves behaviour unspecified the oracle fixes it (and the HIP path follows):
+ *   - std::partial_sort / std::sort tie order in block matching: ties keep candidate scan order.
+ */
+#ifndef LFBM5D_ORACLE_H
+#define LFBM5D_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum ints of the reference (bm5d.cpp:36-48) */
+enum {
+    ORC_YUV = 0, ORC_YCBCR = 1, ORC_OPP = 2, ORC_RGB = 3,
+    ORC_ID = 4, ORC_DCT = 5, ORC_SADCT = 6, ORC_BIOR = 7, ORC_HADAMARD = 8, ORC_HAAR = 9,
+    ORC_ROWMAJOR = 11, ORC_COLMAJOR = 12
+};
+
+typedef struct {
+    float    sigma;        /* noise std-dev (0..255 scale) */
+    float    lambda;       /* HT threshold factor (step 1 only) */
+    unsigned N;            /* max similar patches */
+    unsigned nSim, nDisp;  /* half sizes of the self / disparity search windows */
+    unsigned k, p;         /* patch side, reference-patch stride */
+    unsigned useSD;
+    unsigned tau_2D, tau_4D, tau_5D;
+    unsigned color_space;
+} orc_params;
+
+typedef struct {
+    unsigned long long groups;        /* 5D groups processed */
+    unsigned long long sadct_groups;  /* of which used the shape-adaptive 4D transform */
+    unsigned long long stack_patches; /* sum of nSx_r */
+    unsigned long long windows;       /* angular search windows visited (run API) */
+    unsigned long long passes;        /* core passes executed (run API) */
+    double   bm_seconds;
+    double   total_seconds;
+} orc_stats;
+
+/* ---- leaf transforms (1-D vectors, in place) ---- */
+void orc_haar_forward(float* v, unsigned n);
+void orc_haar_inverse(float* v, unsigned n);
+void orc_hadamard(float* v, unsigned n);
+/* bior1.5 on an n x n patch (row-major, contiguous); n power of two */
+void orc_bior_forward(const float* in, unsigned in_stride, float* out, unsigned n);
+void orc_bior_inverse(float* patch, unsigned n);
+/* raw FFTW-kind transforms (unnormalised) */
+void orc_redft10(const float* x, float* y, unsigned n);
+void orc_redft01(const float* x, float* y, unsigned n);
+/* orthonormalised 2-D patch DCT as the reference applies it (bm3d.cpp:745-757,:1039-1071) */
+void orc_dct2d_forward(const float* in, unsigned in_stride, float* out, unsigned k);
+void orc_dct2d_inverse(float* patch, unsigned k);
+/* angular transforms on one vector of aw*ah values (index st = s*aw + t) */
+void orc_dct4d_forward(float* v, unsigned aw, unsigned ah);
+void orc_dct4d_inverse(float* v, unsigned aw, unsigned ah);
+/* shape-adaptive DCT; mask[aw*ah] in {0,1}; mask_dct receives the coefficient support */
+void orc_sadct_forward(float* v, const unsigned* mask, unsigned aw, unsigned ah, unsigned* mask_dct);
+void orc_sadct_inverse(float* v, const unsigned* mask, unsigned aw, unsigned ah);
+void orc_kaiser_window(float* out, unsigned k);
+
+/* ---- block matching ---- */
+/* Self similarity on one channel image (W x H).  refs: list of n_refs flat indices i*W+j.
+ * out_idx[n_refs*N] (flat patch indices), out_cnt[n_refs] = number of valid entries (nSx_r; 2 when
+ * the single-patch duplicate rule fires).  Follows core:3301-3461 / :3631-3788. */
+int orc_bm_self(const float* img, unsigned W, unsigned H, unsigned k, unsigned N, unsigned nHW,
+                unsigned nSim, float tauMatch, const unsigned* refs, unsigned n_refs,
+                unsigned* out_idx, unsigned* out_cnt);
+/* Disparity search img1 -> img2: best[W*H] = flat index of the best match in img2 for the patch
+ * at each position of rows/cols [nDisp, dim-k-nDisp]; shape[W*H] = best distance < threshold.
+ * Positions outside that range are left untouched.  Follows core:3479-3611. */
+int orc_bm_stereo(const float* img1, const float* img2, unsigned W, unsigned H, unsigned k,
+                  unsigned nDisp, float tauMatch, unsigned* best, unsigned char* shape);
+
+/* ---- one core pass (bm5d_1st_step / bm5d_2nd_step) on a padded angular window ----
+ * Buffers are [A][C*Wb*Hb] contiguous, A = aw*ah.  step = 1 (HT) or 2 (Wiener; basic != NULL).
+ * ref_row_begin/end select a slice of the reference-patch ROW list (multi-GPU sharding oracle);
+ * pass 0,-1 for all rows. */
+int orc_pass(int step, const orc_params* P, unsigned aw, unsigned ah,
+             unsigned Wb, unsigned Hb, unsigned C,
+             const float* noisy, const float* basic, float* num, float* den,
+             const unsigned* mask, const unsigned* procSAI, unsigned cst, unsigned pst,
+             int ref_row_begin, int ref_row_end, orc_stats* stats);
+
+/* ---- whole steps (run_bm5d_1st_step / run_bm5d_2nd_step, nb_threads == 1 semantics) ----
+ * LF buffers are [awidth*aheight][C*W*H] contiguous, mutated in place exactly like the reference
+ * (colour forward at entry, inverse at exit).  max_windows > 0 stops after that many angular
+ * windows (bounded CPU-baseline sampling); the estimate is still formed.  Returns 0 / 1. */
+int orc_run_step1(const orc_params* P, float* LF_noisy, const unsigned* mask, float* LF_basic,
+                  unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
+                  unsigned W, unsigned H, unsigned C, int max_windows, orc_stats* stats);
+int orc_run_step2(const orc_params* P, float* LF_noisy, const unsigned* mask, float* LF_basic,
+                  float* LF_denoised, unsigned ang_major, unsigned awidth, unsigned aheight,
+                  unsigned an, unsigned W, unsigned H, unsigned C, int max_windows,
+                  orc_stats* stats);
+
+/* ---- host helpers on the path ---- */
+void orc_mt_seed(unsigned long s);
+unsigned long orc_mt_int32(void);
+double orc_mt_res53(void);
+/* Box-Muller noise exactly as add_noise (utilities.cpp:176-183) but on the already seeded stream */
+void orc_add_noise(const float* img, float* out, unsigned long long n, float sigma);
+void orc_symetrize(const float* img, float* out, unsigned W, unsigned H, unsigned C, unsigned N);
+void orc_unsymetrize(float* img, const float* sym, unsigned W, unsigned H, unsigned C, unsigned N);
+int  orc_color_transform(float* img, unsigned color_space, unsigned W, unsigned H, unsigned C,
+                         int forward);
+int  orc_sigma_table(float sigma, unsigned C, unsigned color_space, float* out);
+unsigned orc_ind_initialize(unsigned max_size, unsigned N, unsigned step, unsigned* out);
+void orc_search_window(int aidx, unsigned asize, unsigned an, int* c_asw, int* min_asw, int* max_asw);
+float orc_denoised_percent(const float* den, const unsigned* mask, unsigned A, unsigned W,
+                           unsigned H, unsigned C, unsigned N, unsigned k);
+void orc_psnr(const float* a, const float* b, unsigned long long n, float* psnr, float* rmse);
+void orc_set_threads(int n);
+int  orc_get_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
