@@ -1,0 +1,156 @@
+/*
+ * lfbm5d.h -- C-ABI of the MI355X-native LFBM5D denoising core (liblfbm5d_hip.so).
+ *
+ * The reference (V-Sense/LFBM5D) has no FFI layer; its seam for this path is two pairs of C++ free
+ * functions with std::vector arguments:
+ *   outer seam  run_bm5d_1st_step  src/bm5d.h:11-35   (called from src/main.cpp:195)
+ *               run_bm5d_2nd_step  src/bm5d.h:38-62   (called from src/main.cpp:242)
+ *   inner seam  bm5d_1st_step      src/bm5d_core_processing.h:6-42  (called from bm5d.cpp:351)
+ *               bm5d_2nd_step      src/bm5d_core_processing.h:44-80 (called from bm5d.cpp:1050)
+ * Every entry point below names the reference function it replaces.  Plain pointers, sizes and POD
+ * structs only; return value 0 = success, 1 = failure (EXIT_SUCCESS / EXIT_FAILURE like the
+ * reference), message via lfbm5d_last_error().  No C++ types, no exceptions cross this boundary.
+ * One host thread per context.  All compute runs on the GPU: there is no CPU fallback, creation
+ * fails when no HIP device is present.
+ *
+ * Light-field layout (same as the reference, utilities_LF.cpp:140-146): asize = awidth*aheight
+ * sub-aperture images (SAIs), each C planes of H*W float32 (planar, values nominally 0..255),
+ * SAI index st = s*awidth + t (ang_major = LFBM5D_ROWMAJOR) or s + t*aheight (LFBM5D_COLMAJOR);
+ * buffers are [asize][C*H*W] contiguous.
+ */
+#ifndef LFBM5D_H
+#define LFBM5D_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* enum ints of the reference (src/bm5d.cpp:36-48) */
+#define LFBM5D_YUV       0
+#define LFBM5D_YCBCR     1
+#define LFBM5D_OPP       2
+#define LFBM5D_RGB       3
+#define LFBM5D_ID        4
+#define LFBM5D_DCT       5
+#define LFBM5D_SADCT     6
+#define LFBM5D_BIOR      7
+#define LFBM5D_HADAMARD  8
+#define LFBM5D_HAAR      9
+#define LFBM5D_ROWMAJOR  11
+#define LFBM5D_COLMAJOR  12
+
+typedef struct lfbm5d_ctx lfbm5d_ctx;
+
+/* The parameter tail of run_bm5d_1st_step / run_bm5d_2nd_step (bm5d.h:11-62). */
+typedef struct {
+    float    sigma;        /* sigma                                   */
+    float    lambda;       /* lambdaHard5D (ignored by step 2)        */
+    unsigned N;            /* NHard / NWien                           */
+    unsigned nSim;         /* nSim                                    */
+    unsigned nDisp;        /* nDisp                                   */
+    unsigned k;            /* kHard / kWien                           */
+    unsigned p;            /* pHard / pWien                           */
+    unsigned useSD;        /* useSD                                   */
+    unsigned tau_2D;       /* LFBM5D_ID | _DCT | _BIOR                */
+    unsigned tau_4D;       /* LFBM5D_ID | _DCT | _SADCT               */
+    unsigned tau_5D;       /* LFBM5D_HADAMARD | _HAAR | _DCT          */
+    unsigned color_space;  /* LFBM5D_YUV | _YCBCR | _OPP | _RGB       */
+} lfbm5d_params;
+
+/* Counters and HIP-event timings accumulated since the last lfbm5d_reset_stats(). */
+typedef struct {
+    unsigned long long windows;        /* angular search windows visited                      */
+    unsigned long long passes;         /* core passes (bm5d_*_step calls)                     */
+    unsigned long long groups;         /* 5-D groups processed on this rank                   */
+    unsigned long long stack_patches;  /* sum of nSx_r over those groups                      */
+    unsigned long long sadct_groups;   /* groups that used the shape-adaptive 4-D transform   */
+    double algorithmic_bytes;          /* sum_groups (4*S + 16) B * nSx*A*k^2*C  */
+    double ms_bm;                      /* block-matching kernels, HIP-event time              */
+    double ms_group;                   /* 5-D transform + shrink kernel                       */
+    double ms_aggregate;               /* aggregation kernel                                  */
+    double ms_other;                   /* padding / estimate / reductions / colour            */
+    double ms_comm;                    /* RCCL all-reduce                                     */
+    unsigned long long launches_group; /* launches of the transform kernel                    */
+    unsigned long long launches_aggregate;
+} lfbm5d_stats;
+
+/* ---- context ---- */
+/* Binds HIP device `device` (index within the visible devices), creates the stream the whole path
+ * runs on.  Fails (returns 1, *out = NULL) when no HIP device is available. */
+int  lfbm5d_create(lfbm5d_ctx** out, int device);
+void lfbm5d_destroy(lfbm5d_ctx* ctx);
+const char* lfbm5d_last_error(const lfbm5d_ctx* ctx); /* ctx may be NULL: creation errors */
+void lfbm5d_reset_stats(lfbm5d_ctx* ctx);
+void lfbm5d_get_stats(const lfbm5d_ctx* ctx, lfbm5d_stats* out);
+/* The HIP stream (hipStream_t) the context launches on, for callers that time with events. */
+void* lfbm5d_stream(lfbm5d_ctx* ctx);
+
+/* ---- multi-GPU: one process per GPU; reference patches of a pass are sharded by rows over the
+ * ranks and the window's aggregation buffers are summed with an RCCL all-reduce over xGMI.
+ * Replaces the reference's only parallelism, the OpenMP tile loop + undivide_LF merge
+ * (bm5d.cpp:411-708, utilities_LF.cpp:438-515). ---- */
+#define LFBM5D_UNIQUE_ID_BYTES 128
+int lfbm5d_comm_unique_id(void* id_out /* LFBM5D_UNIQUE_ID_BYTES */);
+int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);
+/* Shard without a communicator (tests): this rank only processes its rows; no reduction. */
+int lfbm5d_set_shard(lfbm5d_ctx* ctx, int rank, int world);
+/* Row range [begin,end) of n_rows reference-patch rows owned by `rank` of `world`. */
+void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, unsigned* end);
+
+/* ---- outer seam, device-resident: LF buffers already in HBM ----
+ * lfbm5d_step1_device == run_bm5d_1st_step (bm5d.h:11-35, nb_threads == 1 semantics):
+ *   d_noisy  [asize][C*H*W]  in/out: colour-transformed at entry and back at exit, exactly like the
+ *                            reference mutates LF_noisy (bm5d.cpp:133, :713)
+ *   h_mask   [asize] host    LF_SAI_mask (0 = empty SAI)
+ *   d_basic  [asize][C*H*W]  out: basic estimate (RGB)
+ * lfbm5d_step2_device == run_bm5d_2nd_step (bm5d.h:38-62): d_basic is in/out (bm5d.cpp:829,:1416),
+ *   d_denoised is the output. */
+int lfbm5d_step1_device(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* d_noisy,
+                        const unsigned* h_mask, float* d_basic, unsigned ang_major,
+                        unsigned awidth, unsigned aheight, unsigned an, unsigned W, unsigned H,
+                        unsigned C);
+int lfbm5d_step2_device(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* d_noisy,
+                        const unsigned* h_mask, float* d_basic, float* d_denoised,
+                        unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
+                        unsigned W, unsigned H, unsigned C);
+
+/* ---- outer seam, host buffers (what the run_bm5d_* wrappers of the drop-in call): same
+ * semantics, the library stages through HBM (PCIe-inclusive). ---- */
+int lfbm5d_step1_host(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* h_noisy,
+                      const unsigned* h_mask, float* h_basic, unsigned ang_major, unsigned awidth,
+                      unsigned aheight, unsigned an, unsigned W, unsigned H, unsigned C);
+int lfbm5d_step2_host(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* h_noisy,
+                      const unsigned* h_mask, float* h_basic, float* h_denoised,
+                      unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
+                      unsigned W, unsigned H, unsigned C);
+
+/* ---- inner seam: one core pass on a mirror-padded angular window, device pointers ----
+ * == bm5d_1st_step (step = 1) / bm5d_2nd_step (step = 2) (bm5d_core_processing.h:6-80).
+ * Buffers are [A][C*Wb*Hb], A = aw*ah; d_basic may be NULL for step 1; d_num / d_den are
+ * accumulated into.  h_mask / h_procSAI are host arrays of A entries (LF_SAI_mask, procSAI). */
+int lfbm5d_pass_device(lfbm5d_ctx* ctx, int step, const lfbm5d_params* P, unsigned aw,
+                       unsigned ah, unsigned Wb, unsigned Hb, unsigned C, const float* d_noisy,
+                       const float* d_basic, float* d_num, float* d_den, const unsigned* h_mask,
+                       const unsigned* h_procSAI, unsigned cst, unsigned pst);
+
+/* ---- inspection of the last pass's block matching (parity tests) ----
+ * n_refs reference patches in raster order; h_refs[n_refs] flat index i*Wb+j;
+ * h_self_idx[n_refs*N], h_self_cnt[n_refs] (precompute_BM, core:3301);
+ * h_best[A*Wb*Hb] / h_shape[A*Wb*Hb] (precompute_BM_stereo, core:3479; entry st == pst unused).
+ * Any output pointer may be NULL.  Returns the number of reference patches via n_refs. */
+int lfbm5d_last_bm(lfbm5d_ctx* ctx, unsigned* n_refs, unsigned* h_refs, unsigned* h_self_idx,
+                   unsigned* h_self_cnt, unsigned* h_best, unsigned char* h_shape);
+
+/* ---- device memory helpers so hosts without a HIP binding (ctypes, cgo, JNI) can stage data ---- */
+int lfbm5d_malloc(void** dptr, size_t bytes);
+int lfbm5d_free(void* dptr);
+int lfbm5d_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int lfbm5d_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int lfbm5d_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,257 @@
+"""ctypes binding of liblfbm5d_hip.so (include/lfbm5d.h) and the reference-named wrappers.
+
+Device buffers are torch CUDA tensors (torch is plumbing for HBM allocations and, in bench.py,
+torch.distributed for the rendezvous); the C-ABI itself only sees raw pointers.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# enum ints of the reference (src/bm5d.cpp:36-48)
+YUV, YCBCR, OPP, RGB, ID, DCT, SADCT, BIOR, HADAMARD, HAAR = range(10)
+ROWMAJOR, COLMAJOR = 11, 12
+TAU = {"id": ID, "dct": DCT, "sadct": SADCT, "bior": BIOR, "hw": HADAMARD, "haar": HAAR}
+COLOR_SPACE = {"yuv": YUV, "ycbcr": YCBCR, "opp": OPP, "rgb": RGB}
+UNIQUE_ID_BYTES = 128
+
+
+class LfBm5dError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """lfbm5d_params: the parameter tail of run_bm5d_*_step (bm5d.h:11-62)."""
+    _fields_ = [("sigma", C.c_float), ("lambda_", C.c_float), ("N", C.c_uint), ("nSim", C.c_uint),
+                ("nDisp", C.c_uint), ("k", C.c_uint), ("p", C.c_uint), ("useSD", C.c_uint),
+                ("tau_2D", C.c_uint), ("tau_4D", C.c_uint), ("tau_5D", C.c_uint),
+                ("color_space", C.c_uint)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("windows", C.c_ulonglong), ("passes", C.c_ulonglong), ("groups", C.c_ulonglong),
+                ("stack_patches", C.c_ulonglong), ("sadct_groups", C.c_ulonglong),
+                ("algorithmic_bytes", C.c_double), ("ms_bm", C.c_double), ("ms_group", C.c_double),
+                ("ms_aggregate", C.c_double), ("ms_other", C.c_double), ("ms_comm", C.c_double),
+                ("launches_group", C.c_ulonglong), ("launches_aggregate", C.c_ulonglong)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def library_path():
+    return os.path.join(_HERE, "liblfbm5d_hip.so")
+
+
+def build_library(force=False):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950; works without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension.  Fails loudly if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise LfBm5dError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  lfbm5d_amd has no CPU fallback.")
+    L = C.CDLL(path)
+    vp, up, fp = C.c_void_p, C.POINTER(C.c_uint), C.c_void_p
+    L.lfbm5d_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.lfbm5d_destroy.argtypes = [vp]
+    L.lfbm5d_last_error.argtypes = [vp]
+    L.lfbm5d_last_error.restype = C.c_char_p
+    L.lfbm5d_reset_stats.argtypes = [vp]
+    L.lfbm5d_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.lfbm5d_stream.argtypes = [vp]
+    L.lfbm5d_stream.restype = vp
+    L.lfbm5d_comm_unique_id.argtypes = [vp]
+    L.lfbm5d_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.lfbm5d_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.lfbm5d_shard_rows.argtypes = [C.c_uint, C.c_int, C.c_int, up, up]
+    L.lfbm5d_shard_rows.restype = None
+    tail = [C.c_uint] * 7
+    L.lfbm5d_step1_device.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
+    L.lfbm5d_step2_device.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
+    L.lfbm5d_step1_host.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
+    L.lfbm5d_step2_host.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
+    L.lfbm5d_pass_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint, C.c_uint, C.c_uint,
+                                     C.c_uint, C.c_uint, fp, fp, fp, fp, up, up, C.c_uint, C.c_uint]
+    L.lfbm5d_last_bm.argtypes = [vp, up, vp, vp, vp, vp, vp]
+    L.lfbm5d_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.lfbm5d_free.argtypes = [vp]
+    L.lfbm5d_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+    L.lfbm5d_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+    L.lfbm5d_device_count.restype = C.c_int
+    _lib = L
+    return L
+
+
+def shard_rows(n_rows, rank, world):
+    b, e = C.c_uint(), C.c_uint()
+    lib().lfbm5d_shard_rows(n_rows, rank, world, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+def make_params(sigma, lam, N, nSim, nDisp, k, p, tau_2D, tau_4D, tau_5D, useSD=0, color_space=OPP):
+    t = lambda v: TAU[v] if isinstance(v, str) else int(v)
+    cs = COLOR_SPACE[color_space] if isinstance(color_space, str) else int(color_space)
+    return Params(float(sigma), float(lam), int(N), int(nSim), int(nDisp), int(k), int(p),
+                  int(bool(useSD)), t(tau_2D), t(tau_4D), t(tau_5D), cs)
+
+
+def _u32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint32))
+
+
+def _dev_ptr(t):
+    import torch
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise LfBm5dError("device entry points need contiguous float32 CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """lfbm5d_ctx: one per process / GPU."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        if self._L.lfbm5d_create(C.byref(h), int(device)) != 0:
+            raise LfBm5dError(self._L.lfbm5d_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.lfbm5d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise LfBm5dError(self._L.lfbm5d_last_error(self._h).decode())
+
+    # ---- multi-GPU ----
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * UNIQUE_ID_BYTES)()
+        if lib().lfbm5d_comm_unique_id(buf) != 0:
+            raise LfBm5dError("ncclGetUniqueId failed")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._ck(self._L.lfbm5d_comm_init(self._h, buf, rank, world))
+
+    def set_shard(self, rank, world):
+        self._ck(self._L.lfbm5d_set_shard(self._h, rank, world))
+
+    # ---- stats ----
+    def reset_stats(self):
+        self._L.lfbm5d_reset_stats(self._h)
+
+    def stats(self):
+        s = Stats()
+        self._L.lfbm5d_get_stats(self._h, C.byref(s))
+        return s
+
+    def stream(self):
+        return self._L.lfbm5d_stream(self._h)
+
+    # ---- outer seam ----
+    def step1(self, P, noisy, mask, basic, ang_major, awidth, aheight, an, W, H, Cc):
+        """run_bm5d_1st_step on device tensors (torch CUDA) or host arrays (numpy float32)."""
+        m = _u32(mask)
+        mp = m.ctypes.data_as(C.POINTER(C.c_uint))
+        tail = (ang_major, awidth, aheight, an, W, H, Cc)
+        if isinstance(noisy, np.ndarray):
+            self._ck(self._L.lfbm5d_step1_host(self._h, C.byref(P), noisy.ctypes.data_as(C.c_void_p), mp,
+                                               basic.ctypes.data_as(C.c_void_p), *tail))
+        else:
+            self._ck(self._L.lfbm5d_step1_device(self._h, C.byref(P), _dev_ptr(noisy), mp, _dev_ptr(basic), *tail))
+
+    def step2(self, P, noisy, mask, basic, denoised, ang_major, awidth, aheight, an, W, H, Cc):
+        m = _u32(mask)
+        mp = m.ctypes.data_as(C.POINTER(C.c_uint))
+        tail = (ang_major, awidth, aheight, an, W, H, Cc)
+        if isinstance(noisy, np.ndarray):
+            self._ck(self._L.lfbm5d_step2_host(self._h, C.byref(P), noisy.ctypes.data_as(C.c_void_p), mp,
+                                               basic.ctypes.data_as(C.c_void_p),
+                                               denoised.ctypes.data_as(C.c_void_p), *tail))
+        else:
+            self._ck(self._L.lfbm5d_step2_device(self._h, C.byref(P), _dev_ptr(noisy), mp, _dev_ptr(basic),
+                                                 _dev_ptr(denoised), *tail))
+
+    # ---- inner seam ----
+    def core_pass(self, step, P, aw, ah, Wb, Hb, Cc, noisy, basic, num, den, mask, procSAI, cst, pst):
+        """bm5d_1st_step / bm5d_2nd_step on a padded window held in CUDA tensors."""
+        m, pr = _u32(mask), _u32(procSAI)
+        self._ck(self._L.lfbm5d_pass_device(
+            self._h, step, C.byref(P), aw, ah, Wb, Hb, Cc, _dev_ptr(noisy),
+            _dev_ptr(basic) if basic is not None else None, _dev_ptr(num), _dev_ptr(den),
+            m.ctypes.data_as(C.POINTER(C.c_uint)), pr.ctypes.data_as(C.POINTER(C.c_uint)), cst, pst))
+
+    def last_bm(self, N, A, plane):
+        """Block-matching tables of the last pass, as numpy arrays."""
+        n = C.c_uint()
+        self._ck(self._L.lfbm5d_last_bm(self._h, C.byref(n), None, None, None, None, None))
+        R = n.value
+        refs = np.zeros(R, np.uint32)
+        idx = np.zeros((R, max(N, 1)), np.uint32)
+        cnt = np.zeros(R, np.uint32)
+        best = np.zeros((A, plane), np.uint32)
+        shape = np.zeros((A, plane), np.uint8)
+        self._ck(self._L.lfbm5d_last_bm(self._h, C.byref(n), refs.ctypes.data, idx.ctypes.data, cnt.ctypes.data,
+                                        best.ctypes.data, shape.ctypes.data))
+        return refs, idx, cnt, best, shape
+
+
+_default_ctx = None
+
+
+def _ctx():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def run_bm5d_1st_step(sigma, lambdaHard5D, LF_noisy, LF_SAI_mask, LF_basic, ang_major, awidth, aheight,
+                      anHard, width, height, chnls, NHard, nSim, nDisp, kHard, pHard, useSD, tau_2D, tau_4D,
+                      tau_5D, color_space, nb_threads=1, ctx=None):
+    """Same argument list as the reference's run_bm5d_1st_step (src/bm5d.h:11-35).  LF_noisy is
+    mutated in place and LF_basic filled, like the reference; nb_threads is accepted and ignored
+    (the GPU path always has the untiled, nb_threads == 1 semantics).  Returns 0 (EXIT_SUCCESS)
+    or raises LfBm5dError with the library's message."""
+    P = make_params(sigma, lambdaHard5D, NHard, nSim, nDisp, kHard, pHard, tau_2D, tau_4D, tau_5D, useSD, color_space)
+    (ctx or _ctx()).step1(P, LF_noisy, LF_SAI_mask, LF_basic, ang_major, awidth, aheight, anHard, width, height, chnls)
+    return 0
+
+
+def run_bm5d_2nd_step(sigma, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, ang_major, awidth, aheight,
+                      anWien, width, height, chnls, NWien, nSim, nDisp, kWien, pWien, useSD, tau_2D, tau_4D,
+                      tau_5D, color_space, nb_threads=1, ctx=None):
+    """Same argument list as the reference's run_bm5d_2nd_step (src/bm5d.h:38-62)."""
+    P = make_params(sigma, 0.0, NWien, nSim, nDisp, kWien, pWien, tau_2D, tau_4D, tau_5D, useSD, color_space)
+    (ctx or _ctx()).step2(P, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, ang_major, awidth, aheight, anWien,
+                          width, height, chnls)
+    return 0

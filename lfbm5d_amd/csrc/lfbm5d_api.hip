@@ -1,0 +1,707 @@
+/*
+ * lfbm5d_api.hip -- the C-ABI of include/lfbm5d.h: context, device-resident window schedule
+ * (run_bm5d_1st_step / run_bm5d_2nd_step, bm5d.cpp:165-407 / :861-1106, nb_threads == 1 semantics),
+ * one core pass (bm5d_1st_step / bm5d_2nd_step) as a sequence of HIP kernels on one stream, and the
+ * RCCL reduction that replaces the reference's tile merge.
+ *
+ * Everything stays in HBM between passes; the host only reads back the few counters the greedy
+ * schedule needs (zero-weight pixel counts per SAI, coverage count per window).
+ */
+#include "../../include/lfbm5d.h"
+#include "lfbm5d_kernels.h"
+
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lfbm5d;
+
+namespace {
+
+std::string g_create_error;
+
+const double kSqrt2 = 1.414213562373095;     /* core:33 */
+const double kSqrt2Inv = 0.7071067811865475; /* core:34 */
+const double kPi = 3.14159265358979323846;
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct PassEvents { hipEvent_t e[5]; bool comm; };
+
+} /* namespace */
+
+struct lfbm5d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int rank = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    lfbm5d_stats stats;
+    /* per-pass work buffers (grow only) */
+    DevBuf est, refs, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, counters, tb, small;
+    /* step-level buffers */
+    DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
+    unsigned* h_small = nullptr; /* pinned, 64 uints */
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    std::vector<PassEvents> pending;
+    /* last pass (inspection) */
+    unsigned last_n_refs = 0, last_N = 0, last_A = 0; size_t last_plane = 0;
+    std::vector<unsigned> last_refs_host;
+    /* cached reference grid */
+    unsigned grid_key[5] = {0, 0, 0, 0, 0};
+    unsigned n_ref_rows = 0, n_ref_cols = 0;
+};
+
+namespace {
+
+#define HIPCK(ctx, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+int fail(lfbm5d_ctx* c, const std::string& m) { c->err = m; return 1; }
+
+hipEvent_t get_event(lfbm5d_ctx* c) {
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e; (void)hipEventCreate(&e); c->ev_pool.push_back(e);
+    }
+    return c->ev_pool[c->ev_used++];
+}
+
+/* fold finished passes' event times into the stats (stream must be idle) */
+void drain_events(lfbm5d_ctx* c) {
+    for (const PassEvents& pe : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pe.e[0], pe.e[1]) == hipSuccess) c->stats.ms_bm += ms;
+        if (hipEventElapsedTime(&ms, pe.e[1], pe.e[2]) == hipSuccess) c->stats.ms_group += ms;
+        if (hipEventElapsedTime(&ms, pe.e[2], pe.e[3]) == hipSuccess) c->stats.ms_aggregate += ms;
+        if (pe.comm && hipEventElapsedTime(&ms, pe.e[3], pe.e[4]) == hipSuccess) c->stats.ms_comm += ms;
+    }
+    c->pending.clear();
+    c->ev_used = 0;
+}
+
+/* utilities.cpp:633-684 */
+int sigma_table(float sigma, unsigned C, unsigned cs, float* out) {
+    if (C == 1) { out[0] = sigma; return 0; }
+    if (cs == LFBM5D_YUV) {
+        out[0] = std::sqrt(0.299f * 0.299f + 0.587f * 0.587f + 0.114f * 0.114f) * sigma;
+        out[1] = std::sqrt(0.14713f * 0.14713f + 0.28886f * 0.28886f + 0.436f * 0.436f) * sigma;
+        out[2] = std::sqrt(0.615f * 0.615f + 0.51498f * 0.51498f + 0.10001f * 0.10001f) * sigma;
+    } else if (cs == LFBM5D_YCBCR) {
+        out[0] = std::sqrt(0.299f * 0.299f + 0.587f * 0.587f + 0.114f * 0.114f) * sigma;
+        out[1] = std::sqrt(0.169f * 0.169f + 0.331f * 0.331f + 0.500f * 0.500f) * sigma;
+        out[2] = std::sqrt(0.500f * 0.500f + 0.419f * 0.419f + 0.081f * 0.081f) * sigma;
+    } else if (cs == LFBM5D_OPP) {
+        out[0] = std::sqrt(0.333f * 0.333f + 0.333f * 0.333f + 0.333f * 0.333f) * sigma;
+        out[1] = std::sqrt(0.5f * 0.5f + 0.0f * 0.0f + 0.5f * 0.5f) * sigma;
+        out[2] = std::sqrt(0.25f * 0.25f + 0.5f * 0.5f + 0.25f * 0.25f) * sigma;
+    } else if (cs == LFBM5D_RGB) {
+        out[0] = out[1] = out[2] = sigma;
+    } else return 1;
+    return 0;
+}
+
+/* utilities.cpp:697-712 */
+void ind_init(std::vector<unsigned>& v, unsigned max_size, unsigned N, unsigned step) {
+    v.clear();
+    unsigned ind = N;
+    while (ind < max_size - N) { v.push_back(ind); ind += step; }
+    if (v.back() < max_size - N - 1) v.push_back(max_size - N - 1);
+}
+
+/* bm3d.cpp:1101-1169, core:3191-3252, lib_transforms.cpp:215-277 */
+void build_tables(GroupTables& t, unsigned k, unsigned aw, unsigned ah) {
+    std::memset(&t, 0, sizeof(t));
+    static const float q8[4][4] = {{0.1924f, 0.2989f, 0.3846f, 0.4325f}, {0.2989f, 0.4642f, 0.5974f, 0.6717f},
+                                   {0.3846f, 0.5974f, 0.7688f, 0.8644f}, {0.4325f, 0.6717f, 0.8644f, 0.9718f}};
+    static const float q12[6][6] = {{0.1924f, 0.2615f, 0.3251f, 0.3782f, 0.4163f, 0.4362f},
+                                    {0.2615f, 0.3554f, 0.4419f, 0.5139f, 0.5657f, 0.5927f},
+                                    {0.3251f, 0.4419f, 0.5494f, 0.6390f, 0.7033f, 0.7369f},
+                                    {0.3782f, 0.5139f, 0.6390f, 0.7433f, 0.8181f, 0.8572f},
+                                    {0.4163f, 0.5657f, 0.7033f, 0.8181f, 0.9005f, 0.9435f},
+                                    {0.4362f, 0.5927f, 0.7369f, 0.8572f, 0.9435f, 0.9885f}};
+    const float coef = 0.5f / (float)k;
+    for (unsigned i = 0; i < k; i++)
+        for (unsigned j = 0; j < k; j++) {
+            const unsigned h = k / 2, a = i < h ? i : k - 1 - i, b = j < h ? j : k - 1 - j;
+            t.kaiser[i * k + j] = k == 8 ? q8[a][b] : (k == 12 ? q12[a][b] : 1.0f);
+            if (i == 0 && j == 0) { t.cn2[0] = 0.5f * coef; t.cni2[0] = 2.0f; }
+            else if (i * j == 0)  { t.cn2[i * k + j] = (float)(kSqrt2Inv * coef); t.cni2[i * k + j] = (float)kSqrt2; }
+            else                  { t.cn2[i * k + j] = coef; t.cni2[i * k + j] = 1.0f; }
+            t.cos2[i * k + j] = (float)std::cos(kPi * (j + 0.5) * i / k);
+        }
+    const float c4 = 0.5f / (std::sqrt((float)aw) * std::sqrt((float)ah));
+    for (unsigned i = 0; i < ah; i++)
+        for (unsigned j = 0; j < aw; j++) {
+            if (i == 0 && j == 0) { t.cn4[0] = (float)(0.5f * c4); t.cni4[0] = 2.0f; }
+            else if (i * j == 0)  { t.cn4[i * aw + j] = (float)(kSqrt2Inv * c4); t.cni4[i * aw + j] = (float)kSqrt2; }
+            else                  { t.cn4[i * aw + j] = c4; t.cni4[i * aw + j] = 1.0f; }
+        }
+    for (unsigned u = 0; u < 3; u++)
+        for (unsigned j = 0; j < 3; j++) t.cos3[u * 3 + j] = (float)std::cos(kPi * (j + 0.5) * u / 3.0);
+    for (unsigned n = 1; n <= 3; n++) {
+        for (unsigned u = 0; u < n; u++)
+            for (unsigned j = 0; j < n; j++) t.cos1[n][u * n + j] = (float)std::cos(kPi * (j + 0.5) * u / n);
+        const float c1 = (float)((float)kSqrt2 / std::sqrt((double)n));
+        t.cn1[n][0] = (float)(kSqrt2Inv * c1); t.cni1[n][0] = (float)kSqrt2;
+        for (unsigned i = 1; i < n; i++) { t.cn1[n][i] = c1; t.cni1[n][i] = 1.0f; }
+        t.c1inv[n] = 0.5f * (float)kSqrt2Inv / std::sqrt((float)n);
+    }
+    const float cn = 1.f / (std::sqrt(2.f) * 128.f), s = 1.f / std::sqrt(2.f);
+    const float a1[10] = {3.f, -3.f, -22.f, 22.f, 128.f, 128.f, 22.f, -22.f, -3.f, 3.f};
+    const float b1[10] = {3.f, 3.f, -22.f, -22.f, 128.f, -128.f, 22.f, 22.f, -3.f, -3.f};
+    for (int i = 0; i < 10; i++) { t.lpd[i] = a1[i] * cn; t.hpr[i] = b1[i] * cn; }
+    t.hpd[4] = -s; t.hpd[5] = s; t.lpr[4] = s; t.lpr[5] = s;
+    t.coef2inv = 1.0f / (float)(k * 2);
+    t.coef4inv = 1.0f / (std::sqrt((float)aw) * std::sqrt((float)ah) * 2.0f);
+}
+
+bool is_pow2(unsigned n) { return n && !(n & (n - 1)); }
+
+int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsigned ah, unsigned C) {
+    if (aw != 3 || ah != 3) return fail(c, "unsupported: angular search window must be 3x3 (aswSize 1)");
+    if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
+    if (P->k != 8 && P->k != 12 && P->k != 16) return fail(c, "unsupported: patch size k must be 8, 12 or 16");
+    if (P->tau_2D == LFBM5D_BIOR && !is_pow2(P->k)) return fail(c, "bior1.5 needs a power-of-two patch size");
+    if (P->tau_2D != LFBM5D_ID && P->tau_2D != LFBM5D_DCT && P->tau_2D != LFBM5D_BIOR) return fail(c, "bad tau_2D");
+    if (P->tau_4D != LFBM5D_ID && P->tau_4D != LFBM5D_DCT && P->tau_4D != LFBM5D_SADCT) return fail(c, "bad tau_4D");
+    if (P->tau_5D != LFBM5D_HAAR && P->tau_5D != LFBM5D_HADAMARD)
+        return fail(c, "unsupported: tau_5D must be haar or hw (5th-dimension DCT is not built yet)");
+    if (!is_pow2(P->N) || P->N > (unsigned)kMaxN) return fail(c, "unsupported: N must be a power of two <= 16");
+    if (P->nSim < 1 || P->nDisp < 1 || P->p < 1) return fail(c, "bad search window / step");
+    (void)step;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* One core pass                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsigned ah, unsigned Wb,
+              unsigned Hb, unsigned C, const float* d_noisy, const float* d_basic, float* d_num,
+              float* d_den, const unsigned* h_mask, const unsigned* h_proc, unsigned cst, unsigned pst) {
+    if (validate(c, step, P, aw, ah, C)) return 1;
+    if (step == 2 && !d_basic) return fail(c, "step 2 needs the basic estimate");
+    if (pst != cst) return fail(c, "unsupported: non-centre pass (greyscale subset path, core:531-821) is not built yet");
+    const unsigned A = aw * ah, k = P->k, k2 = k * k, N = P->N, nHW = P->nSim + P->nDisp;
+    const size_t plane = (size_t)Wb * Hb;
+    hipStream_t s = c->stream;
+    if (Hb < 2 * nHW + k + 1 || Wb < 2 * nHW + k + 1) return fail(c, "window smaller than the search range");
+
+    float sig[3] = {0, 0, 0};
+    if (sigma_table(P->sigma, C, P->color_space, sig)) return fail(c, "bad color space");
+    const float tauMatch = (C == 1 ? 3.f : 1.f) * (sig[0] < 35.0f ? (step == 1 ? 3000 : 2000) : 5000); /* core:146/:915 */
+    const float thr = tauMatch * k * k;                                                                  /* core:3315 */
+    float lambda = P->lambda;
+    if (step == 1 && P->tau_2D == LFBM5D_ID && P->tau_4D == LFBM5D_DCT) lambda /= (float)kSqrt2;          /* core:206-207 */
+    unsigned mask_bits = 0, proc_bits = 0;
+    for (unsigned st = 0; st < A; st++) { if (h_mask[st]) mask_bits |= 1u << st; if (h_proc[st]) proc_bits |= 1u << st; }
+    if (!((mask_bits >> pst) & 1)) return fail(c, "processed SAI is empty");
+
+    /* reference grid (core:149-156); cached while the geometry is unchanged */
+    const unsigned key[5] = {Wb, Hb, k, nHW, P->p};
+    if (std::memcmp(key, c->grid_key, sizeof(key)) != 0 || c->last_refs_host.empty()) {
+        std::vector<unsigned> rows, cols;
+        ind_init(rows, Hb - k + 1, nHW, P->p);
+        ind_init(cols, Wb - k + 1, nHW, P->p);
+        c->n_ref_rows = (unsigned)rows.size(); c->n_ref_cols = (unsigned)cols.size();
+        c->last_refs_host.resize(rows.size() * cols.size());
+        for (size_t i = 0; i < rows.size(); i++)
+            for (size_t j = 0; j < cols.size(); j++) c->last_refs_host[i * cols.size() + j] = rows[i] * Wb + cols[j];
+        HIPCK(c, c->refs.reserve(c->last_refs_host.size() * sizeof(unsigned)));
+        HIPCK(c, hipMemcpyAsync(c->refs.p, c->last_refs_host.data(), c->last_refs_host.size() * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        HIPCK(c, hipStreamSynchronize(s));
+        std::memcpy(c->grid_key, key, sizeof(key));
+    }
+    const unsigned R = c->n_ref_rows * c->n_ref_cols;
+
+    const unsigned NsS = 2 * P->nSim + 1, NsD = 2 * P->nDisp + 1;
+    unsigned slots[kMaxA]; unsigned n_slots = 0;
+    for (unsigned st = 0; st < A; st++) if (st != pst && ((mask_bits >> st) & 1)) slots[n_slots++] = st;
+    const unsigned Nst = N > 1 ? N : 1;
+    HIPCK(c, c->est.reserve(A * plane * sizeof(float)));
+    HIPCK(c, c->refmap.reserve(plane * sizeof(int)));
+    if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
+    HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * plane * sizeof(float)));
+    HIPCK(c, c->self_idx.reserve((size_t)R * Nst * sizeof(unsigned)));
+    HIPCK(c, c->self_cnt.reserve((size_t)R * sizeof(unsigned)));
+    HIPCK(c, c->best.reserve(A * plane * sizeof(unsigned)));
+    HIPCK(c, c->shape.reserve(A * plane));
+    HIPCK(c, c->filt.reserve((size_t)R * Nst * A * C * k2 * sizeof(float)));
+    HIPCK(c, c->wgt.reserve((size_t)R * C * sizeof(float)));
+    HIPCK(c, c->tb.reserve(sizeof(GroupTables)));
+    if (!c->counters.p) {
+        HIPCK(c, c->counters.reserve(4 * sizeof(unsigned long long)));
+        HIPCK(c, hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), s));
+    }
+    GroupTables tb;
+    build_tables(tb, k, aw, ah);
+    HIPCK(c, hipMemcpyAsync(c->tb.p, &tb, sizeof(tb), hipMemcpyHostToDevice, s));
+    HIPCK(c, hipStreamSynchronize(s)); /* tb is a stack object */
+
+    PassEvents pe; pe.comm = false;
+    for (int i = 0; i < 5; i++) pe.e[i] = get_event(c);
+
+    /* current estimate for matching, channel 0 (core:167-170) */
+    const float* sub = step == 1 ? d_noisy : d_basic;
+    for (unsigned st = 0; st < A; st++) {
+        if (!((mask_bits >> st) & 1)) continue;
+        const size_t o = (size_t)st * C * plane;
+        HIPCK(c, launch_estimate(s, d_num + o, d_den + o, sub + o, c->est.as<float>() + st * plane, plane));
+    }
+    /* multi-GPU: ranks > 0 accumulate their shard into zeroed buffers; the all-reduce restores
+     * base + all contributions on every rank */
+    if (c->world > 1 && c->rank > 0) {
+        HIPCK(c, hipMemsetAsync(d_num, 0, A * C * plane * sizeof(float), s));
+        HIPCK(c, hipMemsetAsync(d_den, 0, A * C * plane * sizeof(float), s));
+    }
+
+    HIPCK(c, hipEventRecord(pe.e[0], s));
+    /* block matching (core:209-236) */
+    ScanArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.est = c->est.as<float>(); sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst; sa.two_thr = 2 * thr;
+    if (N > 1) {
+        HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
+        HIPCK(c, launch_fill_i32(s, c->refmap.as<int>(), -1, plane));
+        HIPCK(c, launch_refmap(s, c->refs.as<unsigned>(), R, c->refmap.as<int>()));
+        sa.stereo = 0; sa.b = nHW; sa.trim = 0; sa.half = P->nSim;
+        sa.refmap = c->refmap.as<int>(); sa.scores = c->scores.as<float>();
+        sa.n_tables = (P->nSim + 1) * NsS;
+        HIPCK(c, launch_bm_scan(s, sa));
+        HIPCK(c, launch_self_select(s, c->scores.as<float>(), c->refs.as<unsigned>(), R, Wb, P->nSim, N, thr,
+                                    c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
+    } else {
+        HIPCK(c, launch_self_trivial(s, c->refs.as<unsigned>(), R, c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
+    }
+    if (n_slots) {
+        sa.stereo = 1; sa.b = P->nDisp; sa.trim = k - 1; sa.half = P->nDisp;
+        sa.tables = c->tables.as<float>();
+        for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
+        sa.n_tables = n_slots * NsD * NsD;
+        HIPCK(c, launch_bm_scan(s, sa));
+        for (unsigned i = 0; i < n_slots; i++)
+            HIPCK(c, launch_stereo_argmin(s, c->tables.as<float>(), i, slots[i], Wb, Hb, k, P->nDisp, thr,
+                                          c->best.as<unsigned>(), c->shape.as<unsigned char>()));
+    }
+    HIPCK(c, hipEventRecord(pe.e[1], s));
+
+    /* shard of reference-patch rows owned by this rank */
+    unsigned rb = 0, re = c->n_ref_rows;
+    lfbm5d_shard_rows(c->n_ref_rows, c->rank, c->world, &rb, &re);
+    const unsigned ref_begin = rb * c->n_ref_cols, n_groups = (re - rb) * c->n_ref_cols;
+
+    GroupArgs ga;
+    std::memset(&ga, 0, sizeof(ga));
+    ga.noisy = d_noisy; ga.basic = d_basic; ga.num = d_num; ga.den = d_den;
+    ga.refs = c->refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
+    ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = c->tb.as<GroupTables>();
+    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.counters = c->counters.as<unsigned long long>();
+    ga.ref_begin = ref_begin; ga.n_groups = n_groups;
+    ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
+    ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;
+    ga.tau2 = P->tau_2D; ga.tau4 = P->tau_4D; ga.tau5 = P->tau_5D; ga.useSD = P->useSD;
+    ga.step = step; ga.lambda = lambda;
+    for (int i = 0; i < 3; i++) ga.sigma[i] = sig[i];
+    if (group_lds_bytes(ga) > 160 * 1024 - 4096) return fail(c, "unsupported: N*k*k stack does not fit the 160 KiB LDS");
+    if (n_groups) HIPCK(c, launch_group(s, ga));
+    HIPCK(c, hipEventRecord(pe.e[2], s));
+
+    AggArgs aa;
+    std::memset(&aa, 0, sizeof(aa));
+    aa.num = d_num; aa.den = d_den; aa.filt = ga.filt; aa.wgt = ga.wgt; aa.refs = ga.refs;
+    aa.self_idx = ga.self_idx; aa.self_cnt = ga.self_cnt; aa.best = ga.best; aa.shape = ga.shape; aa.tb = ga.tb;
+    aa.ref_begin = ref_begin; aa.n_groups = n_groups; aa.n_ref_rows = c->n_ref_rows; aa.n_ref_cols = c->n_ref_cols;
+    aa.Wb = Wb; aa.Hb = Hb; aa.C = C; aa.A = A; aa.k = k; aa.N = Nst; aa.pst = pst; aa.p = P->p;
+    aa.nHW = nHW; aa.nSim = P->nSim; aa.nDisp = P->nDisp;
+    aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D;
+    if (n_groups) HIPCK(c, launch_aggregate(s, aa));
+    HIPCK(c, hipEventRecord(pe.e[3], s));
+
+    if (c->comm) { /* sum the window's aggregation buffers over the ranks (xGMI) */
+        const size_t cnt = (size_t)A * C * plane;
+        if (ncclAllReduce(d_num, d_num, cnt, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(num) failed");
+        if (ncclAllReduce(d_den, d_den, cnt, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(den) failed");
+        HIPCK(c, hipEventRecord(pe.e[4], s));
+        pe.comm = true;
+    }
+    c->pending.push_back(pe);
+
+    c->stats.passes += 1;
+    c->stats.groups += n_groups;
+    c->stats.launches_group += n_groups ? 1 : 0;
+    c->stats.launches_aggregate += n_groups ? 1 : 0;
+    c->last_n_refs = R; c->last_N = Nst; c->last_A = A; c->last_plane = plane;
+    return 0;
+}
+
+/* utilities_LF.cpp:881-901 */
+void search_window(int aidx, unsigned asize, unsigned an, int& cc, int& mn, int& mx) {
+    mn = aidx - (int)an; mx = aidx + (int)an;
+    int shift = mn < 0 ? -mn : 0;
+    mn += shift; mx += shift; cc = (int)an - shift;
+    shift = mx >= (int)asize ? ((int)asize - mx - 1) : 0;
+    mn += shift; mx += shift; cc -= shift;
+}
+
+/* fold the device counters (sum nSx, sadct groups) into the stats; stream must be idle */
+int fold_counters(lfbm5d_ctx* c, const lfbm5d_params* P, unsigned A, unsigned C, int step) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (!c->counters.p) return 0;
+    HIPCK(c, hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemsetAsync(c->counters.p, 0, sizeof(h), c->stream));
+    c->stats.stack_patches += h[0];
+    c->stats.sadct_groups += h[1];
+    /* gather 4 B * S + aggregation 16 B per stacked pixel */
+    c->stats.algorithmic_bytes += (double)h[0] * A * P->k * P->k * C * (4.0 * (step == 2 ? 2 : 1) + 16.0);
+    return 0;
+}
+
+/* bm5d.cpp:165-407 (step 1) / :861-1106 (step 2) on device-resident buffers */
+int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
+             float* d_basic, float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight,
+             unsigned an, unsigned W, unsigned H, unsigned C) {
+    const unsigned asize = awidth * aheight;
+    const unsigned cs = aheight / 2, ct = awidth / 2;
+    const unsigned cst = ang_major == LFBM5D_ROWMAJOR ? cs * awidth + ct : cs + ct * aheight;
+    const unsigned asw = 2 * an + 1;
+    if (asw > aheight || asw > awidth) {
+        std::printf("Wrong size of angular search window, the angular search window must be smaller than the light field angular size.\n");
+        return fail(c, "angular search window larger than the light field");
+    }
+    if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return fail(c, "bad ang_major");
+    if (validate(c, step, P, asw, asw, C)) return 1;
+    hipStream_t s = c->stream;
+    const unsigned nHW = P->nSim + P->nDisp;
+    const size_t img = (size_t)C * W * H;
+    const unsigned hb = H + 2 * nHW, wb = W + 2 * nHW;
+    const size_t imgb = (size_t)C * wb * hb;
+    const unsigned Aw = asw * asw;
+    unsigned tau_4D = P->tau_4D;
+
+    if (C == 3 && P->color_space != LFBM5D_RGB) {
+        if (P->color_space > LFBM5D_RGB) return fail(c, "bad color space");
+        for (unsigned st = 0; st < asize; st++) {
+            if (!h_mask[st]) continue;
+            HIPCK(c, launch_color(s, d_noisy + st * img, P->color_space, W * H, 1));
+            if (step == 2) HIPCK(c, launch_color(s, d_basic + st * img, P->color_space, W * H, 1));
+        }
+    }
+    HIPCK(c, c->g_num.reserve(asize * img * sizeof(float)));
+    HIPCK(c, c->g_den.reserve(asize * img * sizeof(float)));
+    HIPCK(c, hipMemsetAsync(c->g_num.p, 0, asize * img * sizeof(float), s));
+    HIPCK(c, hipMemsetAsync(c->g_den.p, 0, asize * img * sizeof(float), s));
+    HIPCK(c, c->w_noisy.reserve(Aw * imgb * sizeof(float)));
+    if (step == 2) HIPCK(c, c->w_basic.reserve(Aw * imgb * sizeof(float)));
+    HIPCK(c, c->w_num.reserve(Aw * imgb * sizeof(float)));
+    HIPCK(c, c->w_den.reserve(Aw * imgb * sizeof(float)));
+    HIPCK(c, c->small.reserve((asize + 8) * sizeof(unsigned)));
+    float* g_num = c->g_num.as<float>(); float* g_den = c->g_den.as<float>();
+    float* w_noisy = c->w_noisy.as<float>(); float* w_basic = c->w_basic.as<float>();
+    float* w_num = c->w_num.as<float>(); float* w_den = c->w_den.as<float>();
+    unsigned* d_small = c->small.as<unsigned>();
+    std::vector<unsigned> h_cnt(asize + 8);
+
+    std::vector<unsigned> proc(asize);
+    for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
+    unsigned remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
+    const unsigned total = remaining;
+    unsigned ps = 0, pt = 0, pst = 0;
+    while (remaining) {
+        if (remaining == total && h_mask[cst]) { ps = cs; pt = ct; }
+        else { /* bm5d.cpp:187-213: SAI with most exact-zero weights, last index wins ties */
+            HIPCK(c, hipMemsetAsync(d_small, 0, asize * sizeof(unsigned), s));
+            HIPCK(c, launch_count_zeros(s, g_den, img, asize, d_small));
+            HIPCK(c, hipMemcpyAsync(h_cnt.data(), d_small, asize * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIPCK(c, hipStreamSynchronize(s));
+            long best_cnt = -1;
+            for (unsigned st = 0; st < asize; st++) {
+                if (proc[st]) continue;
+                if ((long)h_cnt[st] >= best_cnt) { pst = st; best_cnt = (long)h_cnt[st]; }
+            }
+            if (ang_major == LFBM5D_ROWMAJOR) { ps = pst / awidth; pt = pst - ps * awidth; }
+            else { pt = pst / aheight; ps = pst - pt * aheight; }
+        }
+        int cs_w, mins, maxs, ct_w, mint, maxt;
+        search_window((int)ps, aheight, an, cs_w, mins, maxs);
+        search_window((int)pt, awidth, an, ct_w, mint, maxt);
+        const unsigned cst_w = ang_major == LFBM5D_ROWMAJOR ? cs_w * asw + ct_w : cs_w + ct_w * asw;
+        std::vector<unsigned> st_idx(Aw), mask_w(Aw), proc_w(Aw);
+        for (unsigned si = 0; si < asw; si++)
+            for (unsigned ti = 0; ti < asw; ti++) {
+                const unsigned S = si + mins, T = ti + mint;
+                if (ang_major == LFBM5D_ROWMAJOR) st_idx[si * asw + ti] = S * awidth + T;
+                else st_idx[si + ti * asw] = S + T * aheight;
+            }
+        for (unsigned i = 0; i < Aw; i++) {
+            const unsigned st = st_idx[i];
+            mask_w[i] = h_mask[st];
+            if (!h_mask[st]) continue;
+            HIPCK(c, launch_symetrize(s, d_noisy + st * img, w_noisy + i * imgb, W, H, C, nHW));
+            if (step == 2) HIPCK(c, launch_symetrize(s, d_basic + st * img, w_basic + i * imgb, W, H, C, nHW));
+            HIPCK(c, launch_symetrize(s, g_num + st * img, w_num + i * imgb, W, H, C, nHW));
+            HIPCK(c, launch_symetrize(s, g_den + st * img, w_den + i * imgb, W, H, C, nHW));
+        }
+        for (unsigned i = 0; i < Aw; i++) proc_w[i] = !mask_w[i];
+        unsigned rem_w = (unsigned)std::count(proc_w.begin(), proc_w.end(), 0u);
+        const unsigned tot_w = rem_w;
+        if (tot_w != Aw && tau_4D == LFBM5D_DCT) tau_4D = LFBM5D_SADCT; /* bm5d.cpp:276-280 */
+        lfbm5d_params Pw = *P;
+        Pw.tau_4D = tau_4D;
+        unsigned ps_w = 0, pt_w = 0, pst_w = 0;
+        while (rem_w) {
+            if (rem_w == tot_w && mask_w[cst_w]) { ps_w = cs_w; pt_w = ct_w; pst_w = cst_w; }
+            else {
+                HIPCK(c, hipMemsetAsync(d_small, 0, Aw * sizeof(unsigned), s));
+                HIPCK(c, launch_count_zeros(s, w_den, imgb, Aw, d_small));
+                HIPCK(c, hipMemcpyAsync(h_cnt.data(), d_small, Aw * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                HIPCK(c, hipStreamSynchronize(s));
+                long best_cnt = -1;
+                for (unsigned i = 0; i < Aw; i++) {
+                    if (proc_w[i]) continue;
+                    if ((long)h_cnt[i] >= best_cnt) { pst_w = i; best_cnt = (long)h_cnt[i]; }
+                }
+                if (ang_major == LFBM5D_ROWMAJOR) { ps_w = pst_w / asw; pt_w = pst_w - ps_w * asw; }
+                else { pt_w = pst_w / asw; ps_w = pst_w - pt_w * asw; }
+            }
+            if (pass_impl(c, step, &Pw, asw, asw, wb, hb, C, w_noisy, step == 2 ? w_basic : nullptr, w_num, w_den,
+                          mask_w.data(), proc_w.data(), cst_w, pst_w)) return 1;
+            proc_w[pst_w] += 1;
+            const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (mins + ps_w) * awidth + (mint + pt_w)
+                                                             : (mins + ps_w) + (mint + pt_w) * aheight;
+            proc[st] += 1;
+            /* LF_denoised_percent (utilities_LF.cpp:967-995): counts (i,j,c) triples, divides without C */
+            HIPCK(c, hipMemsetAsync(d_small, 0, sizeof(unsigned), s));
+            unsigned n_mask = 0;
+            for (unsigned i = 0; i < Aw; i++) {
+                if (!mask_w[i]) continue;
+                n_mask++;
+                HIPCK(c, launch_count_denoised(s, w_den + i * imgb, W, H, C, nHW, P->k, d_small));
+            }
+            HIPCK(c, hipMemcpyAsync(h_cnt.data(), d_small, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIPCK(c, hipStreamSynchronize(s));
+            const float pct = (float)h_cnt[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
+            if (pct >= 100.0f)
+                for (unsigned i = 0; i < Aw; i++)
+                    if (proc_w[i] == 0) { proc_w[i] += 1; proc[st_idx[i]] += 1; }
+            rem_w = (unsigned)std::count(proc_w.begin(), proc_w.end(), 0u);
+        }
+        for (unsigned i = 0; i < Aw; i++) {
+            const unsigned st = st_idx[i];
+            if (!h_mask[st]) continue;
+            HIPCK(c, launch_unsymetrize(s, g_num + st * img, w_num + i * imgb, W, H, C, nHW));
+            HIPCK(c, launch_unsymetrize(s, g_den + st * img, w_den + i * imgb, W, H, C, nHW));
+        }
+        remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
+        c->stats.windows += 1;
+    }
+    /* final estimate (bm5d.cpp:405) and inverse colour transforms (bm5d.cpp:711-714 / :1414-1418) */
+    const float* sub = step == 1 ? d_noisy : d_basic;
+    for (unsigned st = 0; st < asize; st++) {
+        if (!h_mask[st]) continue;
+        HIPCK(c, launch_estimate(s, g_num + st * img, g_den + st * img, sub + st * img, d_out + st * img, img));
+    }
+    if (C == 3 && P->color_space != LFBM5D_RGB)
+        for (unsigned st = 0; st < asize; st++) {
+            if (!h_mask[st]) continue;
+            HIPCK(c, launch_color(s, d_out + st * img, P->color_space, W * H, 0));
+            if (step == 2) HIPCK(c, launch_color(s, d_basic + st * img, P->color_space, W * H, 0));
+            HIPCK(c, launch_color(s, d_noisy + st * img, P->color_space, W * H, 0));
+        }
+    HIPCK(c, hipStreamSynchronize(s));
+    drain_events(c);
+    return fold_counters(c, P, Aw, C, step);
+}
+
+} /* namespace */
+
+/* ============================================================================================ */
+/* C API                                                                                        */
+/* ============================================================================================ */
+extern "C" {
+
+int lfbm5d_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lfbm5d_create(lfbm5d_ctx** out, int device) {
+    if (!out) return 1;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = "no HIP device available (liblfbm5d_hip has no CPU fallback)";
+        return 1;
+    }
+    if (device < 0 || device >= n) { g_create_error = "device index out of range"; return 1; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return 1; }
+    lfbm5d_ctx* c = new lfbm5d_ctx();
+    c->device = device;
+    std::memset(&c->stats, 0, sizeof(c->stats));
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return 1; }
+    if ((e = hipHostMalloc((void**)&c->h_small, 64 * sizeof(unsigned))) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return 1; }
+    *out = c;
+    return 0;
+}
+
+void lfbm5d_destroy(lfbm5d_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) ncclCommDestroy(c->comm);
+    DevBuf* bufs[] = {&c->est, &c->refs, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
+                      &c->shape, &c->filt, &c->wgt, &c->counters, &c->tb, &c->small, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out};
+    for (DevBuf* b : bufs) b->release();
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* lfbm5d_last_error(const lfbm5d_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+void lfbm5d_reset_stats(lfbm5d_ctx* c) { if (c) std::memset(&c->stats, 0, sizeof(c->stats)); }
+void lfbm5d_get_stats(const lfbm5d_ctx* c, lfbm5d_stats* out) { if (c && out) *out = c->stats; }
+void* lfbm5d_stream(lfbm5d_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, unsigned* end) {
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    *begin = (unsigned)(((unsigned long long)n_rows * (unsigned)rank) / (unsigned)world);
+    *end = (unsigned)(((unsigned long long)n_rows * (unsigned)(rank + 1)) / (unsigned)world);
+}
+
+int lfbm5d_comm_unique_id(void* id_out) {
+    ncclUniqueId id;
+    static_assert(sizeof(ncclUniqueId) <= LFBM5D_UNIQUE_ID_BYTES, "unique id size");
+    if (ncclGetUniqueId(&id) != ncclSuccess) return 1;
+    std::memset(id_out, 0, LFBM5D_UNIQUE_ID_BYTES);
+    std::memcpy(id_out, &id, sizeof(id));
+    return 0;
+}
+
+int lfbm5d_comm_init(lfbm5d_ctx* c, const void* idb, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return 1;
+    (void)hipSetDevice(c->device);
+    c->rank = rank; c->world = world;
+    if (world == 1) return 0;
+    ncclUniqueId id;
+    std::memcpy(&id, idb, sizeof(id));
+    if (ncclCommInitRank(&c->comm, world, id, rank) != ncclSuccess) return fail(c, "ncclCommInitRank failed");
+    return 0;
+}
+
+int lfbm5d_set_shard(lfbm5d_ctx* c, int rank, int world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return 1;
+    c->rank = rank; c->world = world;
+    return 0;
+}
+
+int lfbm5d_pass_device(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsigned ah,
+                       unsigned Wb, unsigned Hb, unsigned C, const float* d_noisy, const float* d_basic,
+                       float* d_num, float* d_den, const unsigned* h_mask, const unsigned* h_procSAI,
+                       unsigned cst, unsigned pst) {
+    if (!c || !P) return 1;
+    (void)hipSetDevice(c->device);
+    if (pass_impl(c, step, P, aw, ah, Wb, Hb, C, d_noisy, d_basic, d_num, d_den, h_mask, h_procSAI, cst, pst)) return 1;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    return fold_counters(c, P, aw * ah, C, step);
+}
+
+int lfbm5d_step1_device(lfbm5d_ctx* c, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
+                        float* d_basic, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
+                        unsigned W, unsigned H, unsigned C) {
+    if (!c || !P) return 1;
+    (void)hipSetDevice(c->device);
+    return run_step(c, 1, P, d_noisy, h_mask, nullptr, d_basic, ang_major, awidth, aheight, an, W, H, C);
+}
+
+int lfbm5d_step2_device(lfbm5d_ctx* c, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
+                        float* d_basic, float* d_denoised, unsigned ang_major, unsigned awidth,
+                        unsigned aheight, unsigned an, unsigned W, unsigned H, unsigned C) {
+    if (!c || !P) return 1;
+    (void)hipSetDevice(c->device);
+    return run_step(c, 2, P, d_noisy, h_mask, d_basic, d_denoised, ang_major, awidth, aheight, an, W, H, C);
+}
+
+int lfbm5d_step1_host(lfbm5d_ctx* c, const lfbm5d_params* P, float* h_noisy, const unsigned* h_mask,
+                      float* h_basic, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
+                      unsigned W, unsigned H, unsigned C) {
+    if (!c || !P) return 1;
+    (void)hipSetDevice(c->device);
+    const size_t bytes = (size_t)awidth * aheight * C * W * H * sizeof(float);
+    HIPCK(c, c->h2d_noisy.reserve(bytes));
+    HIPCK(c, c->h2d_out.reserve(bytes));
+    HIPCK(c, hipMemcpy(c->h2d_noisy.p, h_noisy, bytes, hipMemcpyHostToDevice));
+    HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
+    if (run_step(c, 1, P, c->h2d_noisy.as<float>(), h_mask, nullptr, c->h2d_out.as<float>(), ang_major, awidth, aheight, an, W, H, C)) return 1;
+    HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h_basic, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lfbm5d_step2_host(lfbm5d_ctx* c, const lfbm5d_params* P, float* h_noisy, const unsigned* h_mask,
+                      float* h_basic, float* h_denoised, unsigned ang_major, unsigned awidth,
+                      unsigned aheight, unsigned an, unsigned W, unsigned H, unsigned C) {
+    if (!c || !P) return 1;
+    (void)hipSetDevice(c->device);
+    const size_t bytes = (size_t)awidth * aheight * C * W * H * sizeof(float);
+    HIPCK(c, c->h2d_noisy.reserve(bytes));
+    HIPCK(c, c->h2d_basic.reserve(bytes));
+    HIPCK(c, c->h2d_out.reserve(bytes));
+    HIPCK(c, hipMemcpy(c->h2d_noisy.p, h_noisy, bytes, hipMemcpyHostToDevice));
+    HIPCK(c, hipMemcpy(c->h2d_basic.p, h_basic, bytes, hipMemcpyHostToDevice));
+    HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
+    if (run_step(c, 2, P, c->h2d_noisy.as<float>(), h_mask, c->h2d_basic.as<float>(), c->h2d_out.as<float>(), ang_major, awidth, aheight, an, W, H, C)) return 1;
+    HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h_basic, c->h2d_basic.p, bytes, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h_denoised, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lfbm5d_last_bm(lfbm5d_ctx* c, unsigned* n_refs, unsigned* h_refs, unsigned* h_self_idx,
+                   unsigned* h_self_cnt, unsigned* h_best, unsigned char* h_shape) {
+    if (!c) return 1;
+    (void)hipSetDevice(c->device);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const unsigned R = c->last_n_refs;
+    if (n_refs) *n_refs = R;
+    if (!R) return 0;
+    if (h_refs) std::memcpy(h_refs, c->last_refs_host.data(), R * sizeof(unsigned));
+    if (h_self_idx) HIPCK(c, hipMemcpy(h_self_idx, c->self_idx.p, (size_t)R * c->last_N * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (h_self_cnt) HIPCK(c, hipMemcpy(h_self_cnt, c->self_cnt.p, (size_t)R * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (h_best) HIPCK(c, hipMemcpy(h_best, c->best.p, c->last_A * c->last_plane * sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (h_shape) HIPCK(c, hipMemcpy(h_shape, c->shape.p, c->last_A * c->last_plane, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lfbm5d_malloc(void** dptr, size_t bytes) { return hipMalloc(dptr, bytes) == hipSuccess ? 0 : 1; }
+int lfbm5d_free(void* dptr) { return hipFree(dptr) == hipSuccess ? 0 : 1; }
+int lfbm5d_memcpy_h2d(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1; }
+int lfbm5d_memcpy_d2h(void* dst, const void* src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1; }
+
+} /* extern "C" */

@@ -1,0 +1,124 @@
+/*
+ * lfbm5d_kernels.h -- launchers of the HIP kernels behind the C-ABI (include/lfbm5d.h).
+ * Internal to liblfbm5d_hip.so.  All launchers enqueue on the given stream and return
+ * hipGetLastError(); nothing here synchronises or allocates.
+ */
+#ifndef LFBM5D_KERNELS_H
+#define LFBM5D_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+namespace lfbm5d {
+
+constexpr int kMaxK = 16;       /* patch side supported by the group kernel */
+constexpr int kMaxA = 9;        /* SAIs per angular window (an = 1) */
+constexpr int kMaxN = 16;      /* max similar patches (power of two) */
+
+/* Normalisation tables and filter taps, computed on the host exactly as the reference's
+ * preProcess / preProcess_4d / preProcess_4d_sadct / bior15_coef do (bm3d.cpp:1101-1169,
+ * core:3191-3252, lib_transforms.cpp:215-277), uploaded once per pass configuration. */
+struct GroupTables {
+    float kaiser[kMaxK * kMaxK];
+    float cn2[kMaxK * kMaxK];   /* coef_norm      (2-D patch DCT) */
+    float cni2[kMaxK * kMaxK];  /* coef_norm_inv                  */
+    float cos2[kMaxK * kMaxK];  /* cos(pi (j+1/2) u / k) at [u*k + j] */
+    float cn4[kMaxA];           /* coef_norm_4d */
+    float cni4[kMaxA];
+    float cos3[9];              /* cos(pi (j+1/2) u / 3) */
+    float cos1[4][9];           /* SADCT: cos(pi (j+1/2) u / n) at [n][u*n + j], n = 1..3 */
+    float cn1[4][3];            /* SADCT 1-D norms for length n (core:3229-3252) */
+    float cni1[4][3];
+    float c1inv[4];             /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
+    float lpd[10], hpd[10], lpr[10], hpr[10];
+    float coef2inv;             /* 1 / (2k)                       (bm3d.cpp:1064) */
+    float coef4inv;             /* 1 / (2 sqrt(aw) sqrt(ah))      (core:1945)     */
+};
+
+struct GroupArgs {
+    const float* noisy;         /* [A][C][Hb][Wb] */
+    const float* basic;         /* step 2 only */
+    float* num;
+    float* den;
+    const unsigned* refs;       /* [R] flat positions, raster order */
+    const unsigned* self_idx;   /* [R][N] */
+    const unsigned* self_cnt;   /* [R] */
+    const unsigned* best;       /* [A][Wb*Hb] disparity match */
+    const unsigned char* shape; /* [A][Wb*Hb] */
+    const GroupTables* tb;
+    float* filt;                /* [R][N][A][C][k2] filtered patches (pixel domain) */
+    float* wgt;                 /* [R][C] aggregation weights */
+    unsigned long long* counters; /* [0] sum nSx, [1] sadct groups */
+    unsigned ref_begin, n_groups;
+    unsigned Wb, Hb, C, A, k, N, pst;
+    unsigned mask_bits, proc_bits;
+    unsigned tau2, tau4, tau5, useSD;
+    int step;
+    float lambda;
+    float sigma[3];
+};
+
+struct AggArgs {
+    float* num;
+    float* den;
+    const float* filt;
+    const float* wgt;
+    const unsigned* refs;
+    const unsigned* self_idx;
+    const unsigned* self_cnt;
+    const unsigned* best;
+    const unsigned char* shape;
+    const GroupTables* tb;
+    unsigned ref_begin, n_groups;   /* groups [ref_begin, ref_begin + n_groups) of this rank */
+    unsigned n_ref_rows, n_ref_cols;
+    unsigned Wb, Hb, C, A, k, N, pst, p, nHW, nSim, nDisp;
+    unsigned mask_bits, proc_bits, tau4;
+};
+
+struct ScanArgs {
+    const float* est;           /* [A][Wb*Hb] channel-0 estimates */
+    unsigned W, H, k, b, trim;
+    unsigned half;              /* nSim (self) or nDisp (stereo) */
+    int stereo;                 /* 0: self similarity, 1: disparity */
+    unsigned pst;
+    float two_thr;
+    /* self */
+    const int* refmap;          /* [W*H] reference slot or -1 */
+    float* scores;              /* [R][Ns*Ns], pre-filled with 2*threshold */
+    /* stereo */
+    float* tables;              /* [n_slots][Ns*Ns][W*H] */
+    unsigned st_of_slot[kMaxA];
+    unsigned n_tables;          /* grid size */
+};
+
+hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward);
+hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigned W, unsigned H,
+                            unsigned C, unsigned N);
+hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsigned W, unsigned H,
+                              unsigned C, unsigned N);
+/* est = den ? num/den : sub on `n` elements */
+hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub,
+                           float* est, size_t n);
+hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n);
+hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n);
+/* counts[i] += number of exact zeros in seg i; segments are `seg` floats long, n_seg of them */
+hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsigned n_seg,
+                              unsigned* counts);
+/* LF_denoised_percent numerator on a padded window image (utilities_LF.cpp:985-992) */
+hipError_t launch_count_denoised(hipStream_t s, const float* den, unsigned W, unsigned H, unsigned C,
+                                 unsigned N, unsigned k, unsigned* count);
+hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, int* refmap);
+hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a);
+hipError_t launch_self_select(hipStream_t s, const float* scores, const unsigned* refs, unsigned n_refs,
+                              unsigned W, unsigned nSim, unsigned N, float thr, unsigned* self_idx,
+                              unsigned* self_cnt);
+hipError_t launch_self_trivial(hipStream_t s, const unsigned* refs, unsigned n_refs, unsigned* self_idx,
+                               unsigned* self_cnt);
+hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, unsigned slot, unsigned st,
+                                unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
+                                unsigned* best, unsigned char* shape);
+hipError_t launch_group(hipStream_t s, const GroupArgs& a);
+size_t group_lds_bytes(const GroupArgs& a);
+hipError_t launch_aggregate(hipStream_t s, const AggArgs& a);
+
+} /* namespace lfbm5d */
+#endif

@@ -1,0 +1,724 @@
+/*
+ * lfbm5d_kernels.hip -- HIP kernels of the LFBM5D core for gfx950 (MI355X), except block matching
+ * (lfbm5d_bm.hip).
+ *
+ *   k_group      one workgroup per (5-D group, channel): gathers the nSx * A patches of the group
+ *                into an LDS-resident stack, 2-D transform (id / DCT / bior1.5), 4-D angular
+ *                transform (DCT or shape-adaptive DCT), 5th-dimension Haar/Hadamard + hard
+ *                threshold or Wiener shrinkage, inverses, and writes the filtered patches plus the
+ *                group weight.  Restates core:277-481 / :1054-1282.  LDS-bound (about 8 passes
+ *                over a 72 KiB stack), no MFMA: the largest transform is 16 points.
+ *   k_aggregate  per 16x16 output tile and SAI: gathers every filtered patch that overlaps the
+ *                tile, in the reference's own order (reference patches in raster order, then match
+ *                index), so num/den are reproducible run to run and need no float atomics.
+ *                Restates core:484-528.
+ *   small elementwise / reduction kernels for the window schedule of bm5d.cpp:165-407.
+ */
+#include "lfbm5d_kernels.h"
+
+namespace lfbm5d {
+
+namespace {
+
+/* ============================== elementwise helpers ======================================= */
+
+__global__ void k_color(float* __restrict__ img, unsigned cs, unsigned n, int fwd) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    /* utilities.cpp:482-599, same expressions; contraction off to keep their rounding */
+    float x, y, z;
+    {
+#pragma clang fp contract(off)
+    const float R = img[i], G = img[i + n], B = img[i + 2 * n];
+    if (cs == 0) { /* YUV */
+        if (fwd) { x = 0.299f * R + 0.587f * G + 0.114f * B; y = -0.14713f * R - 0.28886f * G + 0.436f * B; z = 0.615f * R - 0.51498f * G - 0.10001f * B; }
+        else     { x = R + 1.13983f * B; y = R - 0.39465f * G - 0.5806f * B; z = R + 2.03211f * G; }
+    } else if (cs == 1) { /* YCbCr */
+        if (fwd) { x = 0.299f * R + 0.587f * G + 0.114f * B; y = -0.169f * R - 0.331f * G + 0.500f * B; z = 0.500f * R - 0.419f * G - 0.081f * B; }
+        else     { x = 1.000f * R + 0.000f * G + 1.402f * B; y = 1.000f * R - 0.344f * G - 0.714f * B; z = 1.000f * R + 1.772f * G + 0.000f * B; }
+    } else {       /* OPP */
+        if (fwd) { x = 0.333f * R + 0.333f * G + 0.333f * B; y = 0.500f * R + 0.000f * G - 0.500f * B; z = 0.250f * R - 0.500f * G + 0.250f * B; }
+        else     { x = 1.0f * R + 1.0f * G + 0.666f * B; y = 1.0f * R + 0.0f * G - 1.333f * B; z = 1.0f * R - 1.0f * G + 0.666f * B; }
+    }
+    }
+    img[i] = x; img[i + n] = y; img[i + 2 * n] = z;
+}
+
+__device__ __forceinline__ int mirror(int x, int n) { return x < 0 ? -x - 1 : (x >= n ? 2 * n - x - 1 : x); }
+
+/* utilities.cpp:215-263 in closed form: padded (i,j) reads source (mirror(i-N), mirror(j-N)) */
+__global__ void k_symetrize(const float* __restrict__ src, float* __restrict__ dst, int W, int H, int C, int N) {
+    const int w = W + 2 * N, h = H + 2 * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)w * h * C) return;
+    const int c = (int)(i / ((size_t)w * h));
+    const int r = (int)(i % ((size_t)w * h));
+    const int y = mirror(r / w - N, H), x = mirror(r % w - N, W);
+    dst[i] = src[(size_t)c * W * H + (size_t)y * W + x];
+}
+
+__global__ void k_unsymetrize(float* __restrict__ dst, const float* __restrict__ src, int W, int H, int C, int N) {
+    const int w = W + 2 * N, h = H + 2 * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)W * H * C) return;
+    const int c = (int)(i / ((size_t)W * H));
+    const int r = (int)(i % ((size_t)W * H));
+    dst[i] = src[(size_t)c * w * h + (size_t)(r / W + N) * w + r % W + N];
+}
+
+/* compute_LF_estimate utilities_LF.cpp:944-950 (IEEE division) */
+__global__ void k_estimate(const float* __restrict__ num, const float* __restrict__ den,
+                           const float* __restrict__ sub, float* __restrict__ est, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = den[i];
+    est[i] = d ? __fdiv_rn(num[i], d) : sub[i];
+}
+
+__global__ void k_fill_f32(float* p, float v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_fill_i32(int* p, int v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__device__ __forceinline__ unsigned block_sum_u32(unsigned v, unsigned* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned t = 0;
+    if (threadIdx.x == 0) for (unsigned w = 0; w < blockDim.x / 64; w++) t += red[w];
+    return t; /* valid in thread 0 */
+}
+
+__global__ void k_count_zeros(const float* __restrict__ den, size_t seg, unsigned* __restrict__ counts) {
+    __shared__ unsigned red[4];
+    const float* p = den + (size_t)blockIdx.y * seg;
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < seg; i += (size_t)gridDim.x * blockDim.x)
+        c += p[i] == 0.0f ? 1u : 0u;
+    const unsigned t = block_sum_u32(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(&counts[blockIdx.y], t);
+}
+
+__global__ void k_count_denoised(const float* __restrict__ den, int W, int H, int C, int N, int k,
+                                 unsigned* __restrict__ count) {
+    __shared__ unsigned red[4];
+    const int w = W + 2 * N, h = H + 2 * N;
+    const int sw = W - k + 1, sh = H - k + 1;
+    const size_t total = (size_t)sw * sh * C;
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i / ((size_t)sw * sh));
+        const int r = (int)(i % ((size_t)sw * sh));
+        c += den[(size_t)ch * w * h + (size_t)(N + r / sw) * w + N + r % sw] > 0.0f ? 1u : 0u;
+    }
+    const unsigned t = block_sum_u32(c, red);
+    if (threadIdx.x == 0 && t) atomicAdd(count, t);
+}
+
+/* ================================== group kernel ========================================== */
+
+constexpr int kThreads = 256;
+
+struct ShapeInfo {           /* SADCT bookkeeping of one group (core:302-323, :2036-2049, :2102-2104) */
+    int mask[kMaxA], idx[kMaxA], mask_col[kMaxA], idx_col[kMaxA], mask_dct[kMaxA];
+    int row_n[3], col_n[3];
+    int use_sadct;
+};
+
+__device__ void build_shape(ShapeInfo& sh, const int* m) {
+    int size = 0;
+    for (int i = 0; i < 9; i++) { sh.mask[i] = m[i]; sh.idx[i] = 0; sh.mask_col[i] = 0; sh.idx_col[i] = 0; sh.mask_dct[i] = 0; size += m[i]; }
+    for (int s = 0; s < 3; s++) {
+        int r = 0;
+        for (int t = 0; t < 3; t++) if (m[s * 3 + t]) sh.idx[s * 3 + r++] = t;
+        sh.row_n[s] = r;
+        for (int t = 0; t < r; t++) sh.mask_col[s * 3 + t] = 1;
+    }
+    for (int t = 0; t < 3; t++) {
+        int r = 0;
+        for (int s = 0; s < 3; s++) if (sh.mask_col[s * 3 + t]) sh.idx_col[(r++) * 3 + t] = s;
+        sh.col_n[t] = r;
+        for (int s = 0; s < r; s++) sh.mask_dct[s * 3 + t] = 1;
+    }
+    sh.use_sadct = size != 9;
+}
+
+/* orthonormalised 3x3 angular DCT as the reference applies it (core:1862-1954) */
+__device__ __forceinline__ void dct9_fwd(float* x, const GroupTables* tb) {
+    float t[9];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            t[s * 3 + u] = 2.0f * (x[s * 3] * tb->cos3[u * 3] + x[s * 3 + 1] * tb->cos3[u * 3 + 1] + x[s * 3 + 2] * tb->cos3[u * 3 + 2]);
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            x[v * 3 + u] = 2.0f * (t[u] * tb->cos3[v * 3] + t[3 + u] * tb->cos3[v * 3 + 1] + t[6 + u] * tb->cos3[v * 3 + 2]) * tb->cn4[v * 3 + u];
+}
+__device__ __forceinline__ void dct9_inv(float* x, const GroupTables* tb) {
+    float t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[i] *= tb->cni4[i];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            t[s * 3 + j] = x[s * 3] + 2.0f * (x[s * 3 + 1] * tb->cos3[3 + j] + x[s * 3 + 2] * tb->cos3[6 + j]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
+}
+
+/* 1-D REDFT10 / REDFT01 of runtime length n <= 3 (SADCT rows / columns) */
+__device__ void r10_small(const float* x, float* y, int n, const GroupTables* tb) {
+    for (int u = 0; u < n; u++) {
+        float a = 0.0f;
+        for (int j = 0; j < n; j++) a += x[j] * tb->cos1[n][u * n + j];
+        y[u] = 2.0f * a;
+    }
+}
+__device__ void r01_small(const float* x, float* y, int n, const GroupTables* tb) {
+    for (int j = 0; j < n; j++) {
+        float a = 0.0f;
+        for (int u = 1; u < n; u++) a += x[u] * tb->cos1[n][u * n + j];
+        y[j] = x[0] + 2.0f * a;
+    }
+}
+/* core:1969-2116 on one 3x3 vector */
+__device__ __noinline__ void sadct9_fwd(float* v, const ShapeInfo& sh, const GroupTables* tb) {
+    float x[3], y[3];
+    for (int s = 0; s < 3; s++) {
+        const int n = sh.row_n[s];
+        if (n == 1) v[s * 3] = v[s * 3 + sh.idx[s * 3]];
+        else if (n > 1) {
+            for (int t = 0; t < n; t++) x[t] = v[s * 3 + sh.idx[s * 3 + t]];
+            r10_small(x, y, n, tb);
+            for (int t = 0; t < n; t++) v[s * 3 + t] = y[t] * tb->cn1[n][t];
+        }
+    }
+    for (int t = 0; t < 3; t++) {
+        const int n = sh.col_n[t];
+        if (n == 1) v[t] = v[sh.idx_col[t] * 3 + t];
+        else if (n > 1) {
+            for (int s = 0; s < n; s++) x[s] = v[sh.idx_col[s * 3 + t] * 3 + t];
+            r10_small(x, y, n, tb);
+            for (int s = 0; s < n; s++) v[s * 3 + t] = y[s] * tb->cn1[n][s];
+        }
+    }
+    const float coef = 0.5f * 0.70710678118654752f;
+    for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask_dct[i] * coef;
+}
+/* core:2131-2264 */
+__device__ __noinline__ void sadct9_inv(float* v, const ShapeInfo& sh, const GroupTables* tb) {
+    float x[3], y[3];
+    const float coef = 2.0f * 1.41421356237309505f;
+    for (int t = 0; t < 3; t++) {
+        const int n = sh.col_n[t];
+        if (n == 1) v[sh.idx_col[t] * 3 + t] = v[t] * coef;
+        else if (n > 1) {
+            for (int s = 0; s < n; s++) x[s] = v[s * 3 + t] * tb->cni1[n][s] * coef;
+            r01_small(x, y, n, tb);
+            for (int s = 0; s < n; s++) v[sh.idx_col[s * 3 + t] * 3 + t] = y[s] * tb->c1inv[n];
+        }
+    }
+    for (int s = 0; s < 3; s++) {
+        const int n = sh.row_n[s];
+        if (n == 1) v[s * 3 + sh.idx[s * 3]] = v[s * 3];
+        else if (n > 1) {
+            for (int t = 0; t < n; t++) x[t] = v[s * 3 + t] * tb->cni1[n][t];
+            r01_small(x, y, n, tb);
+            for (int t = 0; t < n; t++) v[s * 3 + sh.idx[s * 3 + t]] = y[t] * tb->c1inv[n];
+        }
+    }
+    for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask[i];
+}
+
+/* lib_transforms.cpp:403-471 / :290-321 on a register vector of compile-time length */
+template <int NS> __device__ __forceinline__ void haar_fwd(float* v) {
+    const float s = 0.70710678118654752f;
+#pragma unroll
+    for (int n = NS; n > 1; n /= 2) {
+        float t[NS > 1 ? NS : 1];
+#pragma unroll
+        for (int i = 0; i < n / 2; i++) { t[i] = (v[2 * i] + v[2 * i + 1]) * s; t[n / 2 + i] = (v[2 * i] - v[2 * i + 1]) * s; }
+#pragma unroll
+        for (int i = 0; i < n; i++) v[i] = t[i];
+    }
+}
+template <int NS> __device__ __forceinline__ void haar_inv(float* v) {
+    const float s = 0.70710678118654752f;
+#pragma unroll
+    for (int h = 1; h < NS; h *= 2) {
+        float t[NS > 1 ? NS : 1];
+#pragma unroll
+        for (int i = 0; i < h; i++) { t[2 * i] = (v[i] + v[h + i]) * s; t[2 * i + 1] = (v[i] - v[h + i]) * s; }
+#pragma unroll
+        for (int i = 0; i < 2 * h; i++) v[i] = t[i];
+    }
+}
+template <int NS> __device__ __forceinline__ void hadamard(float* v) {
+    /* sums to the first half, differences to the second, recurse on both: log2(NS) levels of
+     * the same butterfly applied block-wise */
+#pragma unroll
+    for (int n = NS; n > 1; n /= 2) {
+        float t[NS > 1 ? NS : 1];
+#pragma unroll
+        for (int b = 0; b < NS; b += n)
+#pragma unroll
+            for (int i = 0; i < n / 2; i++) { t[b + i] = v[b + 2 * i] + v[b + 2 * i + 1]; t[b + n / 2 + i] = v[b + 2 * i] - v[b + 2 * i + 1]; }
+#pragma unroll
+        for (int i = 0; i < NS; i++) v[i] = t[i];
+    }
+}
+
+/* 5th-dimension filter of one (st, pq) fibre held in registers.
+ * HT: core:2408-2505 / :2281-2391; Wiener: core:2826-2925 / :2706-2810. */
+template <int NS, int STEP>
+__device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stride, unsigned tau5,
+                                        float T, float sig2, bool in_shape, float& wacc, float& s1, float& s2) {
+    float o[NS], e[NS];
+#pragma unroll
+    for (int n = 0; n < NS; n++) o[n] = S0[base + n * stride];
+    if (STEP == 2) {
+#pragma unroll
+        for (int n = 0; n < NS; n++) e[n] = S1[base + n * stride];
+    }
+    const bool haar = tau5 == 9;
+    if (NS > 1) {
+        if (haar) { haar_fwd<NS>(o); if (STEP == 2) haar_fwd<NS>(e); }
+        else      { hadamard<NS>(o); if (STEP == 2) hadamard<NS>(e); }
+    }
+    if (in_shape) {
+        if (STEP == 1) {
+            const float Th = haar ? T : T * sqrtf((float)NS);
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                if (fabsf(o[n]) > Th) wacc += 1.0f; else o[n] = 0.0f;
+            }
+        } else {
+            const float hc = 1.0f / (float)NS;
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                float value = haar ? e[n] * e[n] : e[n] * e[n] * hc;
+                value = __fdiv_rn(value, value + sig2);
+                e[n] = haar ? o[n] * value : o[n] * value * hc;
+                wacc += value;
+            }
+        }
+    }
+    float* r = STEP == 1 ? o : e;
+    if (NS > 1) {
+        if (haar) haar_inv<NS>(r);
+        else {
+            hadamard<NS>(r);
+            if (STEP == 1) {
+                const float hc = 1.0f / (float)NS;
+#pragma unroll
+                for (int n = 0; n < NS; n++) r[n] *= hc;
+            }
+        }
+    }
+    float* dst = STEP == 1 ? S0 : S1;
+#pragma unroll
+    for (int n = 0; n < NS; n++) { dst[base + n * stride] = r[n]; s1 += r[n]; s2 += r[n] * r[n]; }
+}
+
+__device__ __forceinline__ int per_ext(int j, int L, int N) { int m = (j - L) % N; return m < 0 ? m + N : m; }
+
+/* 2-D forward transform of `np` patches stored back to back at S (k*k floats each).  All threads
+ * of the workgroup call this. */
+__device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const GroupTables* tb) {
+    const int k2 = k * k, tid = threadIdx.x;
+    const int ppi = kThreads / k2 > 0 ? kThreads / k2 : 1; /* patches per iteration */
+    for (int p0 = 0; p0 < np; p0 += ppi) {
+        const int slot = tid / k2, pq = tid % k2, patch = p0 + slot;
+        const bool on = slot < ppi && patch < np;
+        float* X = S + (size_t)patch * k2;
+        float* Tm = tmp + slot * k2;
+        const int i = pq / k, j = pq % k;
+        if (tau2 == 5) { /* DCT: REDFT10 rows, REDFT10 columns, * coef_norm (bm3d.cpp:745-757) */
+            if (on) { float a = 0.0f; for (int t = 0; t < k; t++) a += X[i * k + t] * tb->cos2[j * k + t]; Tm[pq] = 2.0f * a; }
+            __syncthreads();
+            if (on) { float a = 0.0f; for (int t = 0; t < k; t++) a += Tm[t * k + j] * tb->cos2[i * k + t]; X[pq] = 2.0f * a * tb->cn2[pq]; }
+            __syncthreads();
+        } else {         /* bior1.5 (lib_transforms.cpp:46-120) */
+            for (int N1 = k; N1 > 1; N1 /= 2) {
+                const int N2 = N1 / 2;
+                if (on && i < N1 && j < N1) {
+                    const bool lo = j < N2; const int jj = lo ? j : j - N2;
+                    const float* f = lo ? tb->lpd : tb->hpd;
+                    float a = 0.0f;
+                    for (int t = 0; t < 10; t++) a += X[i * k + per_ext(t + 2 * jj, 4, N1)] * f[t];
+                    Tm[pq] = a;
+                }
+                __syncthreads();
+                if (on && i < N1 && j < N1) {
+                    const bool lo = i < N2; const int ii = lo ? i : i - N2;
+                    const float* f = lo ? tb->lpd : tb->hpd;
+                    float a = 0.0f;
+                    for (int t = 0; t < 10; t++) a += Tm[per_ext(t + 2 * ii, 4, N1) * k + j] * f[t];
+                    X[pq] = a;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+__device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, const GroupTables* tb) {
+    const int k2 = k * k, tid = threadIdx.x;
+    const int ppi = kThreads / k2 > 0 ? kThreads / k2 : 1;
+    for (int p0 = 0; p0 < np; p0 += ppi) {
+        const int slot = tid / k2, pq = tid % k2, patch = p0 + slot;
+        const bool on = slot < ppi && patch < np;
+        float* X = S + (size_t)patch * k2;
+        float* Tm = tmp + slot * k2;
+        const int i = pq / k, j = pq % k;
+        if (tau2 == 5) { /* bm3d.cpp:1039-1071 */
+            if (on) {
+                float a = 0.0f;
+                for (int v = 1; v < k; v++) a += X[i * k + v] * tb->cni2[i * k + v] * tb->cos2[v * k + j];
+                Tm[pq] = X[i * k] * tb->cni2[i * k] + 2.0f * a;
+            }
+            __syncthreads();
+            if (on) {
+                float a = 0.0f;
+                for (int u = 1; u < k; u++) a += Tm[u * k + j] * tb->cos2[u * k + i];
+                X[pq] = tb->coef2inv * (Tm[j] + 2.0f * a);
+            }
+            __syncthreads();
+        } else { /* lib_transforms.cpp:135-204 */
+            for (int N1 = 2; N1 <= k; N1 *= 2) {
+                const int N2 = N1 / 2;
+                if (on && i < N1 && j < N1) { /* columns: out[2m] = high, out[2m+1] = low */
+                    const int m = i / 2; const float* f = (i & 1) ? tb->lpr : tb->hpr;
+                    float a = 0.0f;
+                    for (int t = 0; t < 10; t++) a += f[t] * X[((t * N2 + m) % N1) * k + j];
+                    Tm[pq] = a;
+                }
+                __syncthreads();
+                if (on && i < N1 && j < N1) { /* rows */
+                    const int m = j / 2; const float* f = (j & 1) ? tb->lpr : tb->hpr;
+                    float a = 0.0f;
+                    for (int t = 0; t < 10; t++) a += f[t] * Tm[i * k + (t * N2 + m) % N1];
+                    X[pq] = a;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <int STEP>
+__global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ ShapeInfo sh;
+    __shared__ unsigned pos[kMaxN * kMaxA];
+    __shared__ float red[3][kThreads / 64];
+
+    const int tid = threadIdx.x;
+    const unsigned g = a.ref_begin + blockIdx.x;
+    const int c = blockIdx.y;
+    const int k = a.k, k2 = k * k, A = a.A, N = a.N;
+    const int nSx = (int)a.self_cnt[g];
+    const unsigned k_r = a.refs[g];
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const int stack = nSx * A * k2;
+    float* S0 = lds;
+    float* S1 = STEP == 2 ? lds + stack : nullptr;
+    float* tmp = lds + (STEP == 2 ? 2 : 1) * stack;
+    const GroupTables* tb = a.tb;
+
+    /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323) */
+    if (tid < nSx * A) {
+        const int n = tid / A, st = tid % A;
+        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
+        unsigned p = 0xffffffffu;
+        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+        pos[tid] = p;
+    }
+    if (tid == 0) {
+        int m[9];
+        for (int st = 0; st < 9; st++)
+            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
+        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
+    }
+    __syncthreads();
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+
+    /* gather (core:286-299).  Patches whose column equals Wb-k read the reference's never-filled
+     * table column, i.e. zeros (core:1697, bm3d.cpp:737) -- reproduce. */
+    for (int e = tid; e < stack; e += kThreads) {
+        const int pq = e % k2, ns = e / k2;
+        const int st = ns % A;
+        const unsigned p = pos[ns];
+        float v0 = 0.0f, v1 = 0.0f;
+        if (p != 0xffffffffu && (p % a.Wb) < a.Wb - k) {
+            const size_t off = ((size_t)st * a.C + c) * plane + p + (size_t)(pq / k) * a.Wb + pq % k;
+            v0 = a.noisy[off];
+            if (STEP == 2) v1 = a.basic[off];
+        }
+        S0[e] = v0;
+        if (STEP == 2) S1[e] = v1;
+    }
+    __syncthreads();
+
+    if (a.tau2 != 4) {
+        fwd2d(S0, tmp, nSx * A, k, a.tau2, tb);
+        if (STEP == 2) fwd2d(S1, tmp, nSx * A, k, a.tau2, tb);
+    }
+
+    /* 4-D forward (core:353-360): one (n, pq) fibre of A values per thread */
+    const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
+    const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < nSx * k2; f += kThreads) {
+            const int n = f / k2, pq = f % k2;
+            for (int s = 0; s < (STEP == 2 ? 2 : 1); s++) {
+                float* S = s ? S1 : S0;
+                float x[9];
+#pragma unroll
+                for (int st = 0; st < 9; st++) x[st] = S[(n * A + st) * k2 + pq];
+                if (do_dct4) dct9_fwd(x, tb); else sadct9_fwd(x, sh, tb);
+#pragma unroll
+                for (int st = 0; st < 9; st++) S[(n * A + st) * k2 + pq] = x[st];
+            }
+        }
+        __syncthreads();
+    }
+
+    /* 5th dimension + shrinkage (core:371-410): one (st, pq) fibre of nSx values per thread */
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    {
+        const float sig = a.sigma[c];
+        const float T = a.lambda * sig * 1.41421356237309505f; /* core:2431 */
+        const float sig2 = sig * sig;
+        for (int f = tid; f < A * k2; f += kThreads) {
+            const int st = f / k2, pq = f % k2;
+            const bool in_shape = !use_sadct || sh.mask_dct[st];
+            const int base = st * k2 + pq, stride = A * k2;
+            switch (nSx) {
+                case 1:  filter5<1, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 2:  filter5<2, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 4:  filter5<4, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 8:  filter5<8, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                default: filter5<16, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+            }
+        }
+    }
+    /* group weight (core:412-421, sd_weighting_5d core:3140-3173) */
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < kThreads / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(nSx * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)nSx);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
+    }
+    float* F = STEP == 2 ? S1 : S0;
+
+    /* 4-D inverse (core:431-451) */
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < nSx * k2; f += kThreads) {
+            const int n = f / k2, pq = f % k2;
+            float x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = F[(n * A + st) * k2 + pq];
+            if (do_dct4) dct9_inv(x, tb); else sadct9_inv(x, sh, tb);
+#pragma unroll
+            for (int st = 0; st < 9; st++) F[(n * A + st) * k2 + pq] = x[st];
+        }
+    }
+    __syncthreads();
+    if (a.tau2 != 4) inv2d(F, tmp, nSx * A, k, a.tau2, tb);
+
+    /* filtered patches out: [g][n][st][c][k2] */
+    float* out = a.filt + (size_t)g * N * A * a.C * k2;
+    for (int e = tid; e < stack; e += kThreads) {
+        const int pq = e % k2, ns = e / k2;
+        out[((size_t)ns * a.C + c) * k2 + pq] = F[e];
+    }
+}
+
+/* ================================ aggregation kernel ====================================== */
+
+constexpr int kTile = 16;
+
+/* Gather form of core:484-528.  Block = one kTile x kTile pixel tile of one SAI; candidates are the
+ * patch instances (reference patch in raster order, then match index n) of the reference patches
+ * whose search range can reach the tile; every pixel adds its contributions in that order, which
+ * is the reference's order for that pixel, starting from the value already in num/den. */
+__global__ __launch_bounds__(kTile * kTile) void k_aggregate(AggArgs a) {
+    __shared__ unsigned hit_pos[256];
+    __shared__ unsigned hit_inst[256];
+    __shared__ unsigned wave_cnt[4];
+    const int tid = threadIdx.x;
+    const int st = blockIdx.z;
+    if ((a.proc_bits >> st) & 1) return;      /* procSAI[st] != 0: skipped (core:486) */
+    if (!((a.mask_bits >> st) & 1)) return;
+    const int tx0 = blockIdx.x * kTile, ty0 = blockIdx.y * kTile;
+    const int x = tx0 + tid % kTile, y = ty0 + tid / kTile;
+    const bool inside = x < (int)a.Wb && y < (int)a.Hb;
+    const int k = a.k, k2 = k * k, C = a.C, N = a.N, A = a.A;
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const int reach = (st == (int)a.pst) ? (int)a.nSim : (int)a.nHW;
+
+    /* reference-grid index ranges that can reach this tile (grid = nHW + i*p, plus a forced last
+     * index, utilities.cpp:697-712) */
+    const int last_r = (int)a.Hb - k - (int)a.nHW, last_c = (int)a.Wb - k - (int)a.nHW;
+    auto lo_idx = [&](int v) { int d = v - (int)a.nHW; return d <= 0 ? 0 : (d + (int)a.p - 1) / (int)a.p; };
+    auto hi_idx = [&](int v, int n, int lastv) { /* largest index whose coordinate <= v */
+        if (v >= lastv) return n - 1;
+        int d = v - (int)a.nHW; if (d < 0) return -1;
+        int i = d / (int)a.p; return i > n - 2 ? n - 2 : i;
+    };
+    int r_lo = lo_idx(ty0 - k + 1 - reach), r_hi = hi_idx(ty0 + kTile - 1 + reach, (int)a.n_ref_rows, last_r);
+    int c_lo = lo_idx(tx0 - k + 1 - reach), c_hi = hi_idx(tx0 + kTile - 1 + reach, (int)a.n_ref_cols, last_c);
+    if (r_lo > (int)a.n_ref_rows - 1) r_lo = (int)a.n_ref_rows - 1; /* the forced last index may sit closer than p */
+    if (c_lo > (int)a.n_ref_cols - 1) c_lo = (int)a.n_ref_cols - 1;
+
+    float accn[3] = {0, 0, 0}, accd[3] = {0, 0, 0};
+    size_t pix = (size_t)st * C * plane + (size_t)y * a.Wb + x;
+    if (inside) for (int c = 0; c < C; c++) { accn[c] = a.num[pix + c * plane]; accd[c] = a.den[pix + c * plane]; }
+
+    const int ncols_span = c_hi - c_lo + 1;
+    const int n_cand = (r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span * N : 0;
+    const unsigned g_end = a.ref_begin + a.n_groups;
+    for (int c0 = 0; c0 < n_cand; c0 += 256) {
+        const int e = c0 + tid;
+        bool hit = false; unsigned p = 0, inst = 0;
+        if (e < n_cand) {
+            const int n = e % N, rr = e / N;
+            const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
+            const unsigned g = (unsigned)gr * a.n_ref_cols + gc;
+            if (g >= a.ref_begin && g < g_end && n < (int)a.self_cnt[g]) {
+                const unsigned k_r = a.refs[g];
+                const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r]; /* core:503 */
+                if (ok) {
+                    const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
+                    p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+                    const int py = p / a.Wb, px = p % a.Wb;
+                    hit = py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
+                    inst = g * N + n;
+                }
+            }
+        }
+        /* ordered compaction of the hits of this chunk */
+        const unsigned long long bal = __ballot(hit);
+        const int wv = tid >> 6, ln = tid & 63;
+        if (ln == 0) wave_cnt[wv] = __popcll(bal);
+        __syncthreads();
+        unsigned base = 0;
+        for (int w = 0; w < wv; w++) base += wave_cnt[w];
+        const unsigned total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (hit) {
+            const unsigned slot = base + __popcll(bal & ((1ull << ln) - 1ull));
+            hit_pos[slot] = p; hit_inst[slot] = inst;
+        }
+        __syncthreads();
+        if (inside) {
+            for (unsigned h = 0; h < total; h++) {
+                const unsigned hp = hit_pos[h];
+                const int dy = y - (int)(hp / a.Wb), dx = x - (int)(hp % a.Wb);
+                if (dy >= 0 && dy < k && dx >= 0 && dx < k) {
+                    const unsigned in = hit_inst[h];
+                    const float kz = a.tb->kaiser[dy * k + dx];
+                    const float* fp = a.filt + ((size_t)in * A + st) * C * k2 + dy * k + dx;
+                    const float* wp = a.wgt + (size_t)(in / N) * C;
+                    for (int c = 0; c < C; c++) {
+#pragma clang fp contract(off)
+                        const float kw = kz * wp[c];   /* core:516-520: (kaiser * w) * value */
+                        accn[c] += kw * fp[(size_t)c * k2];
+                        accd[c] += kw;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inside) for (int c = 0; c < C; c++) { a.num[pix + c * plane] = accn[c]; a.den[pix + c * plane] = accd[c]; }
+}
+
+} /* namespace */
+
+/* ================================== launchers ============================================= */
+
+static inline dim3 grid1d(size_t n, unsigned b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward) {
+    hipLaunchKernelGGL(k_color, grid1d(n_px), dim3(256), 0, s, img, cs, n_px, forward);
+    return hipGetLastError();
+}
+hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigned W, unsigned H, unsigned C, unsigned N) {
+    hipLaunchKernelGGL(k_symetrize, grid1d((size_t)(W + 2 * N) * (H + 2 * N) * C), dim3(256), 0, s, src, dst, (int)W, (int)H, (int)C, (int)N);
+    return hipGetLastError();
+}
+hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsigned W, unsigned H, unsigned C, unsigned N) {
+    hipLaunchKernelGGL(k_unsymetrize, grid1d((size_t)W * H * C), dim3(256), 0, s, dst, src, (int)W, (int)H, (int)C, (int)N);
+    return hipGetLastError();
+}
+hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t n) {
+    hipLaunchKernelGGL(k_estimate, grid1d(n), dim3(256), 0, s, num, den, sub, est, n);
+    return hipGetLastError();
+}
+hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n) {
+    hipLaunchKernelGGL(k_fill_f32, grid1d(n), dim3(256), 0, s, p, v, n);
+    return hipGetLastError();
+}
+hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n) {
+    hipLaunchKernelGGL(k_fill_i32, grid1d(n), dim3(256), 0, s, p, v, n);
+    return hipGetLastError();
+}
+hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsigned n_seg, unsigned* counts) {
+    unsigned gx = (unsigned)((seg + 256 * 8 - 1) / (256 * 8));
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(k_count_zeros, dim3(gx, n_seg), dim3(256), 0, s, den, seg, counts);
+    return hipGetLastError();
+}
+hipError_t launch_count_denoised(hipStream_t s, const float* den, unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count) {
+    hipLaunchKernelGGL(k_count_denoised, dim3(128), dim3(256), 0, s, den, (int)W, (int)H, (int)C, (int)N, (int)k, count);
+    return hipGetLastError();
+}
+
+size_t group_lds_bytes(const GroupArgs& a) {
+    const size_t stack = (size_t)a.N * a.A * a.k * a.k;
+    return ((a.step == 2 ? 2 : 1) * stack + 256) * sizeof(float);
+}
+hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
+    const size_t lds = group_lds_bytes(a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        attr_set = true;
+    }
+    if (a.step == 2) hipLaunchKernelGGL(k_group<2>, dim3(a.n_groups, a.C), dim3(kThreads), lds, s, a);
+    else             hipLaunchKernelGGL(k_group<1>, dim3(a.n_groups, a.C), dim3(kThreads), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
+    hipLaunchKernelGGL(k_aggregate, dim3((a.Wb + kTile - 1) / kTile, (a.Hb + kTile - 1) / kTile, a.A), dim3(kTile * kTile), 0, s, a);
+    return hipGetLastError();
+}
+
+} /* namespace lfbm5d */
