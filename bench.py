@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native LFBM5D core.
+
+Metric (BASELINE.json): SAI-megapixels/s of the full HT + Wiener denoise, sigma = 25, on the
+17x17x512x512 synthetic light field with the README "Stanford" parameters.
+One "step" = run_bm5d_1st_step + run_bm5d_2nd_step over the whole light field, inputs already
+resident in HBM.  N GPUs = one process per GPU (torchrun), reference-patch rows of every pass
+sharded over the ranks, window num/den summed with an RCCL all-reduce: fixed total work ->
+"scaling": "strong".
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the transform+aggregate kernels (k_group +
+k_aggregate: the SURVEY 8d algorithmic bytes cover exactly that pair), durations from HIP events
+recorded on the library's stream inside the timed region.  `cpu_baseline` times the CPU oracle
+(oracle/, a restatement of the reference: kind "port") on one centre-window pass of each step of
+the same noisy input and extrapolates by the pass count the GPU run reports.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+WORKLOADS = {
+    # README.md:60-61 "Stanford" parameters, aswSize 1, lambda 2.7, opp
+    "lf17x17x512x512_sigma25": dict(ah=17, aw=17, H=512, W=512, sigma=25.0,
+                                    p1=(8, 18, 6, 16, 4, "id", "sadct", "haar"),
+                                    p2=(16, 18, 6, 8, 4, "dct", "sadct", "haar")),
+    "lf9x9x512x512_sigma25": dict(ah=9, aw=9, H=512, W=512, sigma=25.0,
+                                  p1=(8, 18, 6, 16, 4, "id", "sadct", "haar"),
+                                  p2=(16, 18, 6, 8, 4, "dct", "sadct", "haar")),
+    "lf3x3x256x256_sigma25": dict(ah=3, aw=3, H=256, W=256, sigma=25.0,
+                                  p1=(8, 18, 6, 16, 4, "id", "sadct", "haar"),
+                                  p2=(16, 18, 6, 8, 4, "dct", "sadct", "haar")),
+}
+
+
+def cpu_baseline(wl, noisy_rgb_9, basic_rgb_9, passes1, passes2, total_mp):
+    """Oracle (CPU restatement) on one centre-window pass per step; checker code, timed only here."""
+    from oracle import oracle as O
+    lib = O.lib()
+    H, W = wl["H"], wl["W"]
+    out = {"unit": "SAI-megapixels/s", "kind": "port", "cores": int(lib.orc_get_threads())}
+    secs = []
+    for step, pk, src in ((1, wl["p1"], None), (2, wl["p2"], basic_rgb_9)):
+        P = O.make_params(wl["sigma"], 2.7, *pk)
+        nHW = pk[1] + pk[2]
+        Wb, Hb = W + 2 * nHW, H + 2 * nHW
+
+        def pad(arr):
+            o = np.zeros((9, 3 * Wb * Hb), np.float32)
+            for st in range(9):
+                im = np.ascontiguousarray(arr[st]).copy()
+                lib.orc_color_transform(im, O.OPP, W, H, 3, 1)
+                lib.orc_symetrize(im, o[st], W, H, 3, nHW)
+            return o
+        wn = pad(noisy_rgb_9)
+        wb = pad(src) if src is not None else None
+        num = np.zeros_like(wn)
+        den = np.zeros_like(wn)
+        mask = np.ones(9, np.uint32)
+        proc = np.zeros(9, np.uint32)
+        st = O.Stats()
+        t0 = time.time()
+        rc = lib.orc_pass(step, C.byref(P), 3, 3, Wb, Hb, 3, wn.reshape(-1), wb.ctypes.data if wb is not None else None,
+                          num.reshape(-1), den.reshape(-1), mask, proc, 4, 4, 0, -1, C.byref(st))
+        secs.append(time.time() - t0)
+        if rc:
+            raise RuntimeError("oracle pass failed")
+    est_total = secs[0] * passes1 + secs[1] * passes2
+    out["value"] = total_mp / est_total
+    out["sample"] = (f"one 3x3x{H}x{W} centre-window core pass per step on the same noisy input "
+                     f"(HT {secs[0]:.1f} s, Wiener {secs[1]:.1f} s), extrapolated to {passes1}+{passes2} passes")
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="lf17x17x512x512_sigma25", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    wl = WORKLOADS[args.workload]
+    ah, aw, H, W, sigma = wl["ah"], wl["aw"], wl["H"], wl["W"], wl["sigma"]
+    asize = ah * aw
+    ctx = L.Context(local)
+    if world > 1:
+        idt = torch.zeros(core.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(L.Context.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+
+    # synthetic input, identical on every rank (the read-only light field is replicated)
+    clean_u8 = synth.make_lf(ah, aw, H, W)
+    clean = torch.from_numpy(clean_u8.reshape(asize, -1)).cuda().float()
+    del clean_u8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    noisy0 = clean + sigma * torch.randn(clean.shape, generator=g, device="cuda")
+    noisy = torch.empty_like(noisy0)
+    basic = torch.zeros_like(noisy0)
+    den = torch.zeros_like(noisy0)
+    mask = np.ones(asize, np.uint32)
+    P1 = core.make_params(sigma, 2.7, *wl["p1"])
+    P2 = core.make_params(sigma, 2.7, *wl["p2"])
+
+    def one_step():
+        noisy.copy_(noisy0)
+        torch.cuda.synchronize()
+        ctx.step1(P1, noisy, mask, basic, L.ROWMAJOR, aw, ah, 1, W, H, 3)
+        ctx.step2(P2, noisy, mask, basic, den, L.ROWMAJOR, aw, ah, 1, W, H, 3)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    ctx.reset_stats()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    s = ctx.stats()
+
+    if rank == 0:
+        total_mp = asize * H * W / 1e6
+        ms_per_step = 1e3 * elapsed / max(1, args.steps)
+        value = total_mp * args.steps / elapsed
+        # quality: PSNR against the clean light field (mean over SAIs), this run
+        def psnr_lf(x):
+            mse = ((x - clean) ** 2).mean(dim=1)
+            return float((20 * torch.log10(255.0 / torch.sqrt(mse))).mean().item())
+        launches = max(1, int(s.launches_group))
+        pair_ms = (s.ms_group + s.ms_aggregate) / launches
+        # rank 0 processes 1/world of the groups; its bytes and its kernel time describe one GPU
+        alg_bytes = s.algorithmic_bytes / launches
+        achieved = alg_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == args.workload:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "SAI-megapixels/sec (HT+Wiener, sigma=25)",
+            "value": value, "unit": "SAI-megapixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "light_field": f"{ah}x{aw}x{H}x{W}x3", "sigma": sigma,
+                       "params_ht": list(map(str, wl["p1"])), "params_wiener": list(map(str, wl["p2"])),
+                       "asw": 1, "color_space": "opp", "parallelism": f"ref-row shards x{world} + RCCL all-reduce"},
+            "roofline": {"bound": "hbm", "kernel": "k_group+k_aggregate (transform + shrink + aggregate)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pair_ms,
+                         "launches": launches},
+            "kernel_ms_per_step": {"block_matching": s.ms_bm / args.steps, "group": s.ms_group / args.steps,
+                                   "aggregate": s.ms_aggregate / args.steps, "comm": s.ms_comm / args.steps},
+            "passes_per_step": s.passes / args.steps, "windows_per_step": s.windows / args.steps,
+            "psnr": {"noisy": psnr_lf(noisy0), "basic": psnr_lf(basic), "denoised": psnr_lf(den)},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                c = (ah // 2) * aw + aw // 2
+                idx = [c + ds * aw + dt for ds in (-1, 0, 1) for dt in (-1, 0, 1)]
+                n9 = noisy0[idx].cpu().numpy()
+                b9 = basic[idx].cpu().numpy()
+                half = s.passes / args.steps / 2
+                out["cpu_baseline"] = cpu_baseline(wl, n9, b9, int(round(half)), int(round(half)), total_mp)
+            except Exception as e:  # the baseline is a reported aside, never a reason to lose the bench line
+                out["cpu_baseline"] = {"value": None, "unit": "SAI-megapixels/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

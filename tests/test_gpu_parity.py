@@ -1,0 +1,282 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Every test drives the HIP path through the
+C-ABI (liblfbm5d_hip.so via lfbm5d_amd.core) and checks it against the CPU oracle on the same
+seeded inputs, or against size-independent properties at the benchmark's sizes.
+
+Tolerances (float32 path; BASELINE.json north_star: PSNR within +-0.01 dB of the CPU path):
+  * block-matching tables (indices, counts, shape flags): identical -- the kernels evaluate the
+    reference's integral-image recurrence in the reference's order;
+  * one core pass on identical inputs: coverage identical, estimate num/den within 2e-3 grey levels
+    (transforms accumulate in float32 on the GPU, in double in the oracle);
+  * whole steps: step 1 within 2e-3 grey levels, mean PSNR of either step within 0.01 dB.
+"""
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lfbm5d_amd as L
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, mask=None, proc=None, useSD=0):
+    from lfbm5d_amd import core
+    A = win.shape[0]
+    d_win = torch.from_numpy(win).cuda()
+    d_basic = torch.from_numpy(basic).cuda() if basic is not None else None
+    d_num = torch.zeros_like(d_win) if num is None else torch.from_numpy(num).cuda()
+    d_den = torch.zeros_like(d_win) if den is None else torch.from_numpy(den).cuda()
+    mask = np.ones(A, np.uint32) if mask is None else mask
+    proc = np.zeros(A, np.uint32) if proc is None else proc
+    torch.cuda.synchronize()
+    ctx.core_pass(step, core.make_params(sigma, 2.7, *pk, useSD=useSD), 3, 3, Wb, Hb, Cc, d_win, d_basic, d_num, d_den,
+                  mask, proc, 4, 4)
+    return d_num.cpu().numpy(), d_den.cpu().numpy()
+
+
+def window(sigma, pk, crop, grey=False):
+    lf = Hh.source_lf(crop=crop)
+    if grey:
+        lf = lf[:, :1]
+    clean, noisy = Hh.noisy_lf(lf, sigma)
+    Cc = lf.shape[1]
+    win, Wb, Hb = Hh.padded_window(noisy, crop, crop, Cc, pk[1] + pk[2])
+    return win, Wb, Hb, Cc
+
+
+PASS_CASES = [
+    # name, step, sigma, params, crop, useSD
+    ("ht-id-sadct-haar", 1, 25.0, (4, 6, 2, 8, 3, "id", "sadct", "haar"), 64, 0),
+    ("ht-bior-sadct-haar", 1, 25.0, (4, 6, 2, 8, 3, "bior", "sadct", "haar"), 64, 0),
+    ("ht-dct-dct-hw", 1, 25.0, (4, 6, 2, 8, 3, "dct", "dct", "hw"), 64, 0),
+    ("ht-id-dct-haar", 1, 25.0, (8, 6, 2, 8, 4, "id", "dct", "haar"), 64, 0),      # lambda /= sqrt2 (core:206)
+    ("ht-id-id-haar", 1, 25.0, (4, 6, 2, 8, 3, "id", "id", "haar"), 64, 0),
+    ("ht-k16-n8", 1, 25.0, (8, 8, 3, 16, 4, "id", "sadct", "haar"), 96, 0),
+    ("ht-k16-bior-n1", 1, 50.0, (1, 6, 2, 16, 3, "bior", "sadct", "haar"), 96, 0),   # sigma >= 35: tauMatch 5000
+    ("ht-k12", 1, 25.0, (4, 6, 2, 12, 4, "dct", "sadct", "haar"), 72, 0),
+    ("ht-usesd", 1, 25.0, (4, 6, 2, 8, 3, "id", "sadct", "haar"), 64, 1),
+    ("wien-dct-sadct-haar", 2, 25.0, (8, 6, 2, 8, 3, "dct", "sadct", "haar"), 64, 0),
+    ("wien-id-dct-hw", 2, 25.0, (8, 6, 2, 8, 3, "id", "dct", "hw"), 64, 0),
+    ("wien-bior-n16", 2, 10.0, (16, 6, 2, 8, 4, "bior", "sadct", "haar"), 64, 0),
+    ("wien-usesd", 2, 25.0, (8, 6, 2, 8, 3, "dct", "sadct", "haar"), 64, 1),
+]
+
+
+@pytest.mark.parametrize("case", PASS_CASES, ids=[c[0] for c in PASS_CASES])
+def test_core_pass_matches_oracle(ctx, case):
+    name, step, sigma, pk, crop, useSD = case
+    win, Wb, Hb, Cc = window(sigma, pk, crop)
+    basic = None
+    if step == 2:  # a plausible pilot: the oracle's own HT estimate of this window
+        n1, d1, _ = Hh.oracle_pass(1, sigma, (pk[0] // 2 or 1,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, Cc)
+        basic = np.ascontiguousarray(Hh.estimate(n1, d1, win).astype(np.float32))
+    num_o, den_o, st = Hh.oracle_pass(step, sigma, pk, win, basic, Wb, Hb, Cc, useSD=useSD)
+    ctx.reset_stats()
+    num_g, den_g = gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, useSD=useSD)
+    s = ctx.stats()
+    assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
+    # block matching: identical tables
+    N, nSim, nDisp, k = pk[0], pk[1], pk[2], pk[3]
+    refs, idx, cnt, best, shape = ctx.last_bm(N, 9, Wb * Hb)
+    est = (win if step == 1 else basic)[:, :Wb * Hb]
+    tau = Hh.tau_match(sigma, Cc, step)
+    o_idx = np.zeros((len(refs), max(N, 1)), np.uint32)
+    o_cnt = np.zeros(len(refs), np.uint32)
+    O.lib().orc_bm_self(np.ascontiguousarray(est[4]), Wb, Hb, k, N, nSim + nDisp, nSim, tau, refs, len(refs),
+                        o_idx.reshape(-1), o_cnt)
+    assert np.array_equal(o_cnt, cnt)
+    for r in range(len(refs)):
+        assert np.array_equal(o_idx[r, :o_cnt[r]], idx[r, :cnt[r]]), (name, r)
+    reg = slice(nDisp, Hb - k - nDisp + 1)
+    for st_i in (0, 5, 7):
+        ob, osh = np.zeros(Wb * Hb, np.uint32), np.zeros(Wb * Hb, np.uint8)
+        O.lib().orc_bm_stereo(np.ascontiguousarray(est[4]), np.ascontiguousarray(est[st_i]), Wb, Hb, k, nDisp, tau, ob, osh)
+        assert np.array_equal(ob.reshape(Hb, Wb)[reg, reg], best[st_i].reshape(Hb, Wb)[reg, reg])
+        assert np.array_equal(osh.reshape(Hb, Wb)[reg, reg], shape[st_i].reshape(Hb, Wb)[reg, reg])
+    # aggregation buffers
+    assert np.array_equal(den_o != 0, den_g != 0)
+    np.testing.assert_allclose(den_g, den_o, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(num_g, num_o, rtol=2e-5, atol=2e-2 * max(1.0, float(np.abs(den_o).max())))
+    eo, eg = Hh.estimate(num_o, den_o, win), Hh.estimate(num_g, den_g, win)
+    assert np.abs(eo - eg).max() < 2e-3
+
+
+def test_pass_accumulates_into_existing_buffers_and_skips_processed_sais(ctx):
+    pk = (4, 6, 2, 8, 3, "id", "sadct", "haar")
+    win, Wb, Hb, Cc = window(25.0, pk, 64)
+    rng = np.random.default_rng(5)
+    base_n = rng.uniform(0, 50, size=win.shape).astype(np.float32)
+    base_d = rng.uniform(0.1, 1, size=win.shape).astype(np.float32)
+    proc = np.zeros(9, np.uint32)
+    proc[[1, 6]] = 1
+    num_o, den_o, _ = Hh.oracle_pass(1, 25.0, pk, win, None, Wb, Hb, Cc, num=base_n.copy(), den=base_d.copy(), proc=proc)
+    num_g, den_g = gpu_pass(ctx, 1, 25.0, pk, win, None, Wb, Hb, Cc, num=base_n.copy(), den=base_d.copy(), proc=proc)
+    per = Cc * Wb * Hb
+    assert np.array_equal(num_g[1], base_n[1]) and np.array_equal(den_g[6], base_d[6])   # core:486
+    np.testing.assert_allclose(den_g, den_o, rtol=2e-5)
+    np.testing.assert_allclose(num_g, num_o, rtol=2e-5, atol=1e-2)
+
+
+def test_empty_sai_switches_to_sadct_like_the_reference(ctx):
+    """bm5d.cpp:276-280: an empty SAI in the window forces SADCT; its slot stays untouched."""
+    pk_dct = (4, 6, 2, 8, 3, "id", "dct", "haar")
+    pk_sa = (4, 6, 2, 8, 3, "id", "sadct", "haar")
+    win, Wb, Hb, Cc = window(25.0, pk_dct, 64)
+    mask = np.ones(9, np.uint32)
+    mask[2] = 0
+    win[2] = 0
+    proc = (1 - mask).astype(np.uint32)
+    num_o, den_o, st = Hh.oracle_pass(1, 25.0, pk_sa, win, None, Wb, Hb, Cc, mask=mask, proc=proc)
+    num_g, den_g = gpu_pass(ctx, 1, 25.0, pk_sa, win, None, Wb, Hb, Cc, mask=mask, proc=proc)
+    assert st.sadct_groups == st.groups
+    assert not den_g[2].any() and not num_g[2].any()
+    np.testing.assert_allclose(den_g, den_o, rtol=2e-5)
+    assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 2e-3
+
+
+def test_row_shards_sum_to_full_pass(ctx):
+    pk = (8, 6, 2, 8, 3, "dct", "sadct", "haar")
+    win, Wb, Hb, Cc = window(25.0, pk, 64)
+    basic = np.ascontiguousarray((0.5 * win + 0.5 * np.roll(win, 1, axis=1)).astype(np.float32))
+    full_n, full_d = gpu_pass(ctx, 2, 25.0, pk, win, basic, Wb, Hb, Cc)
+    parts = []
+    for r in range(3):
+        ctx.set_shard(r, 3)   # ranks > 0 start from zeroed buffers inside the pass
+        parts.append(gpu_pass(ctx, 2, 25.0, pk, win, basic, Wb, Hb, Cc))
+    ctx.set_shard(0, 1)
+    np.testing.assert_allclose(sum(p[0] for p in parts), full_n, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sum(p[1] for p in parts), full_d, rtol=1e-5, atol=1e-6)
+
+
+E2E = {
+    "readme": (25.0, Hh.README_HT, Hh.README_WIEN),
+    "config4": (10.0, Hh.C4_HT, Hh.README_WIEN),
+    "config5": (50.0, Hh.C5_HT, Hh.C5_WIEN),
+}
+
+
+@pytest.mark.parametrize("name", sorted(E2E))
+def test_whole_steps_match_oracle_psnr(ctx, name):
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    sigma, p1, p2 = E2E[name]
+    clean, noisy = Hh.noisy_lf(Hh.source_lf(), sigma)
+    mask = np.ones(9, np.uint32)
+    n1, b_o, _ = O.run_step1(O.make_params(sigma, 2.7, *p1), noisy.copy(), mask, O.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+    n2, b2_o, d_o, _ = O.run_step2(O.make_params(sigma, 2.7, *p2), n1.copy(), b_o.copy(), mask, O.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+    d_noisy = torch.from_numpy(noisy).cuda()
+    d_basic = torch.zeros_like(d_noisy)
+    d_den = torch.zeros_like(d_noisy)
+    torch.cuda.synchronize()
+    ctx.step1(core.make_params(sigma, 2.7, *p1), d_noisy, mask, d_basic, L.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+    b_g = d_basic.cpu().numpy()
+    n1_g = d_noisy.cpu().numpy()
+    assert np.abs(b_g - b_o).max() < 2e-3                       # step 1 on identical inputs
+    assert np.abs(n1_g - n1).max() < 1e-4                        # same in-place drift of LF_noisy (quirk 5)
+    assert abs(O.psnr_lf(b_g, clean) - O.psnr_lf(b_o, clean)) < 1e-4
+    # step 2 fed with the oracle's step-1 outputs: isolates the Wiener path
+    d_noisy.copy_(torch.from_numpy(n1))
+    d_basic.copy_(torch.from_numpy(b_o))
+    torch.cuda.synchronize()
+    ctx.step2(core.make_params(sigma, 2.7, *p2), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+    assert np.abs(d_den.cpu().numpy() - d_o).max() < 5e-3
+    assert np.abs(d_basic.cpu().numpy() - b2_o).max() < 1e-3   # LF_basic mutated in place like the reference
+    # the chained GPU run (its own step-1 output feeds step 2): north-star bar, +-0.01 dB
+    d_noisy.copy_(torch.from_numpy(n1_g))
+    d_basic.copy_(torch.from_numpy(b_g))
+    torch.cuda.synchronize()
+    ctx.step2(core.make_params(sigma, 2.7, *p2), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+    assert abs(O.psnr_lf(d_den.cpu().numpy(), clean) - O.psnr_lf(d_o, clean)) < 0.01
+
+
+def test_reference_named_wrappers_on_host_buffers(ctx):
+    """run_bm5d_1st_step / run_bm5d_2nd_step with the reference's argument list, numpy buffers."""
+    import lfbm5d_amd as L
+    clean, noisy = Hh.noisy_lf(Hh.source_lf(crop=96), 25.0)
+    mask = np.ones(9, np.uint32)
+    P1 = O.make_params(25.0, 2.7, 4, 8, 3, 8, 4, "bior", "sadct", "haar")
+    n1, b_o, _ = O.run_step1(P1, noisy.copy(), mask, O.ROWMAJOR, 3, 3, 1, 96, 96, 3)
+    h_noisy, h_basic = noisy.copy(), np.zeros_like(noisy)
+    assert L.run_bm5d_1st_step(25.0, 2.7, h_noisy, mask, h_basic, L.ROWMAJOR, 3, 3, 1, 96, 96, 3, 4, 8, 3, 8, 4,
+                               False, L.BIOR, L.SADCT, L.HAAR, L.OPP, 1, ctx=ctx) == 0
+    assert np.abs(h_basic - b_o).max() < 2e-3 and np.abs(h_noisy - n1).max() < 1e-4
+    h_den = np.zeros_like(noisy)
+    P2 = O.make_params(25.0, 2.7, 8, 8, 3, 8, 4, "dct", "sadct", "haar")
+    n2, b2, d_o, _ = O.run_step2(P2, n1.copy(), b_o.copy(), mask, O.ROWMAJOR, 3, 3, 1, 96, 96, 3)
+    h_n, h_b = n1.copy(), b_o.copy()
+    assert L.run_bm5d_2nd_step(25.0, h_n, mask, h_b, h_den, L.ROWMAJOR, 3, 3, 1, 96, 96, 3, 8, 8, 3, 8, 4, False,
+                               L.DCT, L.SADCT, L.HAAR, L.OPP, 1, ctx=ctx) == 0
+    assert np.abs(h_den - d_o).max() < 5e-3
+
+
+def test_window_schedule_5x5_and_colmajor(ctx):
+    """2^2+1 windows on a 5x5 LF, both angular orderings."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core, synth
+    lf = synth.make_lf(5, 5, 48, 48)
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(25, np.uint32)
+    for major_o, major_g in ((O.ROWMAJOR, L.ROWMAJOR), (O.COLMAJOR, L.COLMAJOR)):
+        P = O.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "sadct", "haar")
+        n1, b_o, st = O.run_step1(P, noisy.copy(), mask, major_o, 5, 5, 1, 48, 48, 3)
+        d_noisy = torch.from_numpy(noisy).cuda()
+        d_basic = torch.zeros_like(d_noisy)
+        ctx.reset_stats()
+        ctx.step1(core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "sadct", "haar"), d_noisy, mask, d_basic, major_g,
+                  5, 5, 1, 48, 48, 3)
+        s = ctx.stats()
+        assert (s.windows, s.passes) == (st.windows, st.passes) == (5, 5)
+        assert abs(O.psnr_lf(d_basic.cpu().numpy(), clean) - O.psnr_lf(b_o, clean)) < 0.01
+
+
+def test_unsupported_configurations_fail_loudly(ctx):
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    t = torch.zeros((25, 3 * 32 * 32), device="cuda")
+    with pytest.raises(L.LfBm5dError, match="angular search window"):
+        ctx.step1(core.make_params(25, 2.7, 4, 4, 2, 8, 4, "id", "sadct", "haar"), t, np.ones(25, np.uint32), t.clone(),
+                  L.ROWMAJOR, 5, 5, 2, 32, 32, 3)
+    with pytest.raises(L.LfBm5dError, match="tau_5D"):
+        ctx.step1(core.make_params(25, 2.7, 4, 4, 2, 8, 4, "id", "sadct", "dct"), t, np.ones(25, np.uint32), t.clone(),
+                  L.ROWMAJOR, 5, 5, 1, 32, 32, 3)
+
+
+def test_full_size_properties_9x9x512(ctx):
+    """BASELINE config 3 size (9x9x512x512, sigma 25, README params): properties that do not need
+    the oracle -- two runs are bit-identical (no float atomics anywhere), every pixel is covered,
+    both steps raise the PSNR, pass/window counts follow the greedy schedule (4^2+1 windows)."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core, synth
+    lf = synth.make_lf(9, 9, 512, 512)
+    clean = torch.from_numpy(lf.reshape(81, -1)).cuda().float()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    noisy0 = clean + 25.0 * torch.randn(clean.shape, generator=g, device="cuda")
+    mask = np.ones(81, np.uint32)
+    outs = []
+    for _ in range(2):
+        noisy = noisy0.clone()
+        basic, den = torch.zeros_like(noisy), torch.zeros_like(noisy)
+        torch.cuda.synchronize()
+        ctx.reset_stats()
+        ctx.step1(core.make_params(25.0, 2.7, *Hh.README_HT), noisy, mask, basic, L.ROWMAJOR, 9, 9, 1, 512, 512, 3)
+        b1 = basic.clone()
+        ctx.step2(core.make_params(25.0, 2.7, *Hh.README_WIEN), noisy, mask, basic, den, L.ROWMAJOR, 9, 9, 1, 512, 512, 3)
+        outs.append((b1, den.clone()))
+        s = ctx.stats()
+        assert s.windows == 2 * 17 and s.passes == 2 * 17
+
+    def psnr(x):
+        mse = ((x - clean) ** 2).mean(dim=1)
+        return float((20 * torch.log10(255.0 / torch.sqrt(mse))).mean())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert psnr(noisy0) + 8 < psnr(outs[0][0]) < psnr(outs[0][1])
+    assert torch.isfinite(outs[0][1]).all()
