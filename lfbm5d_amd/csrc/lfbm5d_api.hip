@@ -54,7 +54,7 @@ struct lfbm5d_ctx {
     ncclComm_t comm = nullptr;
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
-    DevBuf est, refs, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, counters, tb, small;
+    DevBuf est, refs, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, counters, tb, small;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
@@ -249,6 +249,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->shape.reserve(A * plane));
     HIPCK(c, c->filt.reserve((size_t)R * Nst * A * C * k2 * sizeof(float)));
     HIPCK(c, c->wgt.reserve((size_t)R * C * sizeof(float)));
+    HIPCK(c, c->aggpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->tb.reserve(sizeof(GroupTables)));
     if (!c->counters.p) {
         HIPCK(c, c->counters.reserve(4 * sizeof(unsigned long long)));
@@ -281,10 +282,9 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ScanArgs sa;
     std::memset(&sa, 0, sizeof(sa));
     sa.est = c->est.as<float>(); sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst; sa.two_thr = 2 * thr;
+    sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p; sa.nHW = nHW;
     if (N > 1) {
         HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
-        HIPCK(c, launch_fill_i32(s, c->refmap.as<int>(), -1, plane));
-        HIPCK(c, launch_refmap(s, c->refs.as<unsigned>(), R, c->refmap.as<int>()));
         sa.stereo = 0; sa.b = nHW; sa.trim = 0; sa.half = P->nSim;
         sa.refmap = c->refmap.as<int>(); sa.scores = c->scores.as<float>();
         sa.n_tables = (P->nSim + 1) * NsS;
@@ -300,9 +300,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
         sa.n_tables = n_slots * NsD * NsD;
         HIPCK(c, launch_bm_scan(s, sa));
-        for (unsigned i = 0; i < n_slots; i++)
-            HIPCK(c, launch_stereo_argmin(s, c->tables.as<float>(), i, slots[i], Wb, Hb, k, P->nDisp, thr,
-                                          c->best.as<unsigned>(), c->shape.as<unsigned char>()));
+        HIPCK(c, launch_stereo_argmin(s, c->tables.as<float>(), slots, n_slots, Wb, Hb, k, P->nDisp, thr,
+                                      c->best.as<unsigned>(), c->shape.as<unsigned char>()));
     }
     HIPCK(c, hipEventRecord(pe.e[1], s));
 
@@ -316,7 +315,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.noisy = d_noisy; ga.basic = d_basic; ga.num = d_num; ga.den = d_den;
     ga.refs = c->refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
     ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = c->tb.as<GroupTables>();
-    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.counters = c->counters.as<unsigned long long>();
+    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.n_refs_total = R; ga.counters = c->counters.as<unsigned long long>();
     ga.ref_begin = ref_begin; ga.n_groups = n_groups;
     ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
     ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;
@@ -329,7 +328,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
 
     AggArgs aa;
     std::memset(&aa, 0, sizeof(aa));
-    aa.num = d_num; aa.den = d_den; aa.filt = ga.filt; aa.wgt = ga.wgt; aa.refs = ga.refs;
+    aa.num = d_num; aa.den = d_den; aa.filt = ga.filt; aa.wgt = ga.wgt; aa.aggpos = ga.aggpos; aa.n_refs_total = R; aa.refs = ga.refs;
     aa.self_idx = ga.self_idx; aa.self_cnt = ga.self_cnt; aa.best = ga.best; aa.shape = ga.shape; aa.tb = ga.tb;
     aa.ref_begin = ref_begin; aa.n_groups = n_groups; aa.n_ref_rows = c->n_ref_rows; aa.n_ref_cols = c->n_ref_cols;
     aa.Wb = Wb; aa.Hb = Hb; aa.C = C; aa.A = A; aa.k = k; aa.N = Nst; aa.pst = pst; aa.p = P->p;
@@ -573,7 +572,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->shape, &c->filt, &c->wgt, &c->counters, &c->tb, &c->small, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->counters, &c->tb, &c->small, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

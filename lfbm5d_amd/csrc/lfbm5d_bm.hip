@@ -39,23 +39,43 @@ struct DiffImg {
     }
 };
 
+/* Reference-grid slot of a coordinate (utilities.cpp:697-712: nHW + i*p, plus a forced last index) */
+__device__ __forceinline__ int grid_index(int v, int n, int last, int nHW, int p) {
+    if (v == last) return n - 1;
+    const int d = v - nHW;
+    if (d < 0 || d % p) return -1;
+    const int i = d / p;
+    return i < n - 1 ? i : -1;
+}
+
+/*
+ * One wavefront per displacement table.  Lanes own 64 consecutive COLUMNS (a strip) and walk down
+ * the rows one step behind their left neighbour, so that
+ *   left    = the neighbour's value of the previous step (DPP wave shift),
+ *   upleft  = the neighbour's value of two steps ago,
+ *   up      = the lane's own previous value,
+ * and every global load is a coalesced row segment: the squared-difference image D of the strip is
+ * streamed through an LDS ring (RR rows x 64+K columns) that also provides the skew.  The first
+ * column of the table (a K-term chain per row) is computed up front; strips hand their last
+ * column to the next strip through `lcol`.
+ */
 template <int K>
 __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
+    constexpr int T = 8, RR = 96, CW = 64 + K;
     extern __shared__ float lds[];
+    float* ring = lds;              /* [RR][CW] D rows of the current strip; ring col 0 <-> x = cb-1 */
+    float* lcol = lds + RR * CW;    /* [nrows] column left of the current strip (strip 0: first column) */
     const int lane = threadIdx.x;
     const int W = a.W, H = a.H, b = a.b;
     const int Ns = 2 * (int)a.half + 1;
     const int ncand = Ns * Ns;
     const int nrows = H - 2 * b - (int)a.trim, ncols = W - 2 * b - (int)a.trim;
-    float* prow = lds;            /* [ncols] previous block's last row */
-    float* ebuf = lds + ncols;    /* [64*K] staging of difference terms */
 
-    int di, dj, slot = 0;
+    int di, dj;
     DiffImg D;
     const size_t WH = (size_t)W * H;
     if (a.stereo) {
-        slot = blockIdx.x / ncand;
-        const int ddk = blockIdx.x % ncand;
+        const int slot = blockIdx.x / ncand, ddk = blockIdx.x % ncand;
         di = ddk / Ns; dj = ddk % Ns;
         D.i1 = a.est + (size_t)a.pst * WH;
         D.i2 = a.est + (size_t)a.st_of_slot[slot] * WH;
@@ -71,81 +91,186 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
     const int nSim = (int)a.half;
     const int ord_fwd = dj * Ns + di;
     const int ord_bwd = (-djs + nSim) * Ns + (nSim + 1) + (nSim - di);
+    const int gR = a.n_ref_rows, gC = a.n_ref_cols, gP = a.p, gN = a.nHW;
+    const int lastR = H - (int)a.k - gN, lastC = W - (int)a.k - gN;
 
     auto emit = [&](int y, int x, float S) {
-        const int pos = y * W + x;
-        if (a.stereo) { table[pos] = S; return; }
-        const int r = a.refmap[pos];
-        if (r >= 0) a.scores[(size_t)r * ncand + ord_fwd] = S;
-        if (di > 0) { /* this entry is also the score of the mirrored candidate of ref pos + d */
-            const int yy = y + di, xx = x + djs;
-            if (yy < H && xx >= 0 && xx < W) {
-                const int r2 = a.refmap[yy * W + xx];
-                if (r2 >= 0) a.scores[(size_t)r2 * ncand + ord_bwd] = S;
+        if (a.stereo) { table[y * W + x] = S; return; }
+        /* forward candidate of the reference patch at (y,x) (core:3410-3413) */
+        const int cx = grid_index(x, gC, lastC, gN, gP);
+        if (cx >= 0) {
+            const int ry = grid_index(y, gR, lastR, gN, gP);
+            if (ry >= 0) a.scores[(size_t)(ry * gC + cx) * ncand + ord_fwd] = S;
+        }
+        if (di > 0) { /* ... and the score of the mirrored candidate of the reference at (y,x)+d (core:3416-3419) */
+            const int cx2 = grid_index(x + djs, gC, lastC, gN, gP);
+            if (cx2 >= 0) {
+                const int ry2 = grid_index(y + di, gR, lastR, gN, gP);
+                if (ry2 >= 0) a.scores[(size_t)(ry2 * gC + cx2) * ncand + ord_bwd] = S;
             }
         }
     };
 
-    /* ---- corner (core:3344-3352): K*K terms summed sequentially ---- */
-    for (int e = lane; e < K * K; e += 64) ebuf[e] = D(b + e / K, b + e % K);
+    /* ---- corner (core:3344-3352) and first column (core:3367-3372) -> lcol ---- */
+    for (int e = lane; e < K * K; e += 64) ring[e] = D(b + e / K, b + e % K);
     __syncthreads();
-    float v = 0.0f;
-    for (int e = 0; e < K * K; e++) v += ebuf[e];
+    float corner = 0.0f;
+    for (int e = 0; e < K * K; e++) corner += ring[e];
     __syncthreads();
-    if (lane == 0) { prow[0] = v; emit(b, b, v); }
-
-    /* ---- first row (core:3354-3362): S[b][j] = S[b][j-1] + sum_p (D(b+p, j-1+K) - D(b+p, j-1)) ---- */
-    for (int c0 = 1; c0 < ncols; c0 += 64) {
-        const int c = c0 + lane;
-        if (c < ncols)
-            for (int p = 0; p < K; p++) ebuf[lane * K + p] = D(b + p, b + c - 1 + K) - D(b + p, b + c - 1);
-        __syncthreads();
-        const int m = min(64, ncols - c0);
-        float mine = 0.0f;
-        for (int l = 0; l < m; l++) {
-            for (int p = 0; p < K; p++) v += ebuf[l * K + p];
-            if (l == lane) mine = v;
+    if (lane == 0) lcol[0] = corner;
+    {
+        float carry = corner;
+        for (int i0 = 1; i0 < nrows; i0 += 64) {
+            const int i = i0 + lane;
+            float e[K];
+#pragma unroll
+            for (int q = 0; q < K; q++) e[q] = i < nrows ? D(b + i - 1 + K, b + q) - D(b + i - 1, b + q) : 0.0f;
+            const int m = min(64, nrows - i0);
+            float mine = 0.0f;
+            for (int l = 0; l < m; l++) {
+                float cand = carry;
+#pragma unroll
+                for (int q = 0; q < K; q++) cand += e[q];
+                carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand), l));
+                if (lane == l) mine = carry;
+            }
+            if (i < nrows) lcol[i] = mine;
         }
-        __syncthreads();
-        if (c < ncols) { prow[c] = mine; emit(b, b + c, mine); }
     }
     __syncthreads();
 
-    /* ---- remaining rows, 64 at a time, skewed one column per lane ---- */
-    for (int r0 = 1; r0 < nrows; r0 += 64) {
-        const int r = r0 + lane;
-        const bool row_ok = r < nrows;
-        const int y = b + r;
-        const int last_lane = min(63, nrows - 1 - r0);
-        float prevS = 0.0f;   /* S[r][c-1] */
-        float up_prev = 0.0f; /* S[r-1][c-1] */
-        const int nsteps = ncols + last_lane;
-        for (int t = 0; t < nsteps; t++) {
-            const int c = t - lane;
-            /* value the lane above produced in the previous step == S[r-1][c] */
-            float up = __shfl_up(prevS, 1);
-            if (lane == 0) up = (t < ncols) ? prow[t] : 0.0f;
-            const bool act = row_ok && c >= 0 && c < ncols;
-            float S = prevS;
-            if (act) {
-                const int x = b + c;
-                if (c == 0) { /* first column (core:3367-3372) */
-                    S = up;
-                    for (int q = 0; q < K; q++) S += D(y - 1 + K, b + q) - D(y - 1, b + q);
-                } else {      /* general case (core:3377-3387), same association */
-                    S = prevS + up;
-                    S = S - up_prev;
-                    S = S + D(y + K - 1, x + K - 1);
-                    S = S - D(y + K - 1, x - 1);
-                    S = S - D(y - 1, x + K - 1);
-                    S = S + D(y - 1, x - 1);
-                }
-                emit(y, x, S);
-                if (lane == last_lane) prow[c] = S; /* hand-off row for the next block */
-            }
-            if (c >= 0) up_prev = up;
-            prevS = S;
+    /* reference-grid row slots of every table row (self mode): y and y + di */
+    int* ridx1 = reinterpret_cast<int*>(lcol + nrows);
+    int* ridx2 = ridx1 + nrows;
+    if (!a.stereo)
+        for (int i = lane; i < nrows; i += 64) {
+            ridx1[i] = grid_index(b + i, gR, lastR, gN, gP);
+            ridx2[i] = di > 0 ? grid_index(b + i + di, gR, lastR, gN, gP) : -1;
         }
+    __syncthreads();
+
+    float row0_left = corner; /* S[b][cb-1] */
+    const int nstrips = (ncols + 63) / 64;
+    for (int strip = 0; strip < nstrips; strip++) {
+        const int cb = b + 64 * strip;
+        const int x = cb + lane;
+        const bool col_ok = x < b + ncols;
+        const int last_lane = min(63, ncols - 1 - 64 * strip);
+        const bool first_col = strip == 0 && lane == 0;
+        /* column slots of this lane: constant over the strip */
+        const int cx = a.stereo ? -1 : grid_index(x, gC, lastC, gN, gP);
+        const int cx2 = (a.stereo || di == 0) ? -1 : grid_index(x + djs, gC, lastC, gN, gP);
+        float* sc1 = a.stereo ? nullptr : a.scores + (size_t)(cx < 0 ? 0 : cx) * ncand + ord_fwd;
+        float* sc2 = a.stereo ? nullptr : a.scores + (size_t)(cx2 < 0 ? 0 : cx2) * ncand + ord_bwd;
+        const size_t rstride = (size_t)gC * ncand;
+
+        auto load_row = [&](int R, float& m1, float& m2, float& e1, float& e2) {
+            const int yy = b + R;
+            const bool rin = yy < H - b;
+            const int xm = cb - 1 + lane, xe = cb + 63 + lane;
+            const bool inm = rin && xm >= b && xm < W - b;
+            const bool ine = rin && lane < K && xe < W - b;
+            const int qm = yy * W + xm, qe = yy * W + xe;
+            m1 = inm ? D.i1[qm] : 0.0f; m2 = inm ? D.i2[qm + D.dk] : 0.0f;
+            e1 = ine ? D.i1[qe] : 0.0f; e2 = ine ? D.i2[qe + D.dk] : 0.0f;
+        };
+        auto store_row = [&](int R, float m1, float m2, float e1, float e2) {
+            float* rr = ring + (R % RR) * CW;
+            const float dm = m2 - m1, de = e2 - e1;
+            rr[lane] = dm * dm;
+            if (lane < K) rr[64 + lane] = de * de;
+        };
+        int filled = 0;
+        for (int R0 = 0; R0 < K + T; R0 += T) {
+            float m1[T], m2[T], e1[T], e2[T];
+#pragma unroll
+            for (int s = 0; s < T; s++) load_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
+#pragma unroll
+            for (int s = 0; s < T; s++) store_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
+            filled += T;
+        }
+        __syncthreads();
+
+        /* first row of the strip (core:3354-3362): chain across the lanes */
+        float S0 = 0.0f;
+        {
+            float e[K];
+#pragma unroll
+            for (int p = 0; p < K; p++) e[p] = ring[p * CW + lane + K] - ring[p * CW + lane];
+            float carry = row0_left;
+            int l0 = 0;
+            if (strip == 0) { if (lane == 0) S0 = corner; l0 = 1; }
+            for (int l = l0; l <= last_lane; l++) {
+                float cand = carry;
+#pragma unroll
+                for (int p = 0; p < K; p++) cand += e[p];
+                carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cand), l));
+                if (lane == l) S0 = carry;
+            }
+            if (col_ok) emit(b, x, S0);
+        }
+
+        /* remaining rows: T steps per iteration -- loads, then the register-only chain, then stores */
+        float curS = S0;
+        float shifted_prev = 0.0f;
+        float left0_prev = row0_left;   /* lane 0: S[i-1][cb-1] */
+        const int nsteps = (nrows - 1) + last_lane;
+        for (int t0 = 0; t0 < nsteps; t0 += T) {
+            float m1[T], m2[T], e1[T], e2[T];
+#pragma unroll
+            for (int s = 0; s < T; s++) load_row(filled + s, m1[s], m2[s], e1[s], e2[s]);
+            const int i0 = 1 + t0 - lane;
+            int rA = (i0 + K - 1 + 64 * RR) % RR, rB = (i0 - 1 + 64 * RR) % RR;
+            float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
+            int r1[T], r2[T];
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                d1[s] = ring[rA * CW + lane + K]; d2[s] = ring[rA * CW + lane];
+                d3[s] = ring[rB * CW + lane + K]; d4[s] = ring[rB * CW + lane];
+                rA = rA + 1 == RR ? 0 : rA + 1;
+                rB = rB + 1 == RR ? 0 : rB + 1;
+                const int il = min(max(i0 + s, 0), nrows - 1);
+                lc[s] = lcol[il];
+                r1[s] = a.stereo ? -1 : ridx1[il];
+                r2[s] = a.stereo ? -1 : ridx2[il];
+            }
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                const int i = i0 + s;
+                const bool act = col_ok && i >= 1 && i < nrows;
+                const float shifted = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(curS), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+                const float left = lane == 0 ? lc[s] : shifted;
+                const float upleft = lane == 0 ? left0_prev : shifted_prev;
+                float S = left + curS;             /* core:3379-3386, same association */
+                S = S - upleft;
+                S = S + d1[s];
+                S = S - d2[s];
+                S = S - d3[s];
+                S = S + d4[s];
+                S = first_col ? left : S;          /* first column was computed up front */
+                Sout[s] = S;
+                curS = act ? S : curS;
+                left0_prev = left;
+                shifted_prev = shifted;
+            }
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                const int i = i0 + s;
+                const bool act = col_ok && i >= 1 && i < nrows;
+                if (act) {
+                    if (a.stereo) table[(b + i) * W + x] = Sout[s];
+                    else {
+                        if (cx >= 0 && r1[s] >= 0) sc1[(size_t)r1[s] * rstride] = Sout[s];
+                        if (cx2 >= 0 && r2[s] >= 0) sc2[(size_t)r2[s] * rstride] = Sout[s];
+                    }
+                    if (lane == last_lane) lcol[i] = Sout[s];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < T; s++) store_row(filled + s, m1[s], m2[s], e1[s], e2[s]);
+            filled += T;
+        }
+        row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
         __syncthreads();
     }
 }
@@ -221,30 +346,31 @@ __global__ void k_self_trivial(const unsigned* __restrict__ refs, unsigned n_ref
 }
 
 /* argmin over the (2 nDisp+1)^2 displacement tables (core:3581-3608); ties keep scan order
- * (dj outer, di inner), the order the reference pushes candidates in. */
-__global__ void k_stereo_argmin(const float* __restrict__ tables, unsigned slot, unsigned st, int W,
-                                int H, int k, int nDisp, float thr, unsigned* __restrict__ best,
-                                unsigned char* __restrict__ shape) {
-    const int span_c = W - 2 * nDisp - k + 1, span_r = H - 2 * nDisp - k + 1;
+ * (dj outer, di inner), the order the reference pushes candidates in.  grid.y = table slot. */
+struct ArgminArgs { const float* tables; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp; float thr; unsigned* best; unsigned char* shape; };
+__global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
+    const int W = a.W, H = a.H, nDisp = a.nDisp;
+    const int span_c = W - 2 * nDisp - a.k + 1, span_r = H - 2 * nDisp - a.k + 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= span_c * span_r) return;
+    const unsigned slot = blockIdx.y, st = a.st_of_slot[slot];
     const int y = nDisp + i / span_c, x = nDisp + i % span_c;
     const int Ns = 2 * nDisp + 1, ncand = Ns * Ns;
     const size_t WH = (size_t)W * H;
     const int pos = y * W + x;
-    const float* t = tables + (size_t)slot * ncand * WH + pos;
-    float bv = 0.0f; int bo = -1, bi = 0;
-    for (int ddk = 0; ddk < ncand; ddk++) {
-        const float v = t[(size_t)ddk * WH];
-        const int di = ddk / Ns, dj = ddk % Ns;
-        const int order = dj * Ns + di;
-        if (bo < 0 || v < bv || (v == bv && order < bo)) {
-            bv = v; bo = order;
-            bi = pos + (di - nDisp) * W + (dj - nDisp);
+    const float* t = a.tables + (size_t)slot * ncand * WH + pos;
+    float bv = t[0]; int bo = 0, bd = 0;
+    for (int di = 0; di < Ns; di++) {          /* one table row of displacements at a time: Ns independent loads */
+        const float* tr = t + (size_t)di * Ns * WH;
+        for (int dj = 0; dj < Ns; dj++) {
+            const float v = tr[(size_t)dj * WH];
+            const int order = dj * Ns + di;
+            if (v < bv || (v == bv && order < bo)) { bv = v; bo = order; bd = di * Ns + dj; }
         }
     }
-    best[(size_t)st * WH + pos] = (unsigned)bi;
-    shape[(size_t)st * WH + pos] = bv < thr ? 1 : 0;
+    const int di = bd / Ns, dj = bd % Ns;
+    a.best[(size_t)st * WH + pos] = (unsigned)(pos + (di - nDisp) * W + (dj - nDisp));
+    a.shape[(size_t)st * WH + pos] = bv < a.thr ? 1 : 0;
 }
 
 __global__ void k_refmap(const unsigned* __restrict__ refs, unsigned n_refs, int* __restrict__ refmap) {
@@ -260,8 +386,8 @@ hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, i
 }
 
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
-    const unsigned ncols = a.W - 2 * a.b - a.trim;
-    const size_t lds = (size_t)(ncols + 64 * a.k) * sizeof(float);
+    const unsigned nrows = a.H - 2 * a.b - a.trim;
+    const size_t lds = (size_t)(96 * (64 + a.k) + 3 * nrows) * sizeof(float);
     switch (a.k) {
         case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(a.n_tables), dim3(64), lds, s, a); break;
         case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(a.n_tables), dim3(64), lds, s, a); break;
@@ -286,12 +412,14 @@ hipError_t launch_self_trivial(hipStream_t s, const unsigned* refs, unsigned n_r
     return hipGetLastError();
 }
 
-hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, unsigned slot, unsigned st,
+hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,
                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
                                 unsigned* best, unsigned char* shape) {
     const unsigned n = (W - 2 * nDisp - k + 1) * (H - 2 * nDisp - k + 1);
-    hipLaunchKernelGGL(k_stereo_argmin, dim3((n + 255) / 256), dim3(256), 0, s, tables, slot, st, (int)W,
-                       (int)H, (int)k, (int)nDisp, thr, best, shape);
+    ArgminArgs a;
+    a.tables = tables; a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.thr = thr; a.best = best; a.shape = shape;
+    for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
+    hipLaunchKernelGGL(k_stereo_argmin, dim3((n + 255) / 256, n_slots), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -47,6 +47,8 @@ struct GroupArgs {
     const GroupTables* tb;
     float* filt;                /* [R][N][A][C][k2] filtered patches (pixel domain) */
     float* wgt;                 /* [R][C] aggregation weights */
+    unsigned* aggpos;           /* [A][R][N] where each filtered patch is aggregated (0xffffffff: nowhere) */
+    unsigned n_refs_total;
     unsigned long long* counters; /* [0] sum nSx, [1] sadct groups */
     unsigned ref_begin, n_groups;
     unsigned Wb, Hb, C, A, k, N, pst;
@@ -62,6 +64,8 @@ struct AggArgs {
     float* den;
     const float* filt;
     const float* wgt;
+    const unsigned* aggpos;     /* [A][R][N] */
+    unsigned n_refs_total;
     const unsigned* refs;
     const unsigned* self_idx;
     const unsigned* self_cnt;
@@ -81,8 +85,9 @@ struct ScanArgs {
     int stereo;                 /* 0: self similarity, 1: disparity */
     unsigned pst;
     float two_thr;
-    /* self */
-    const int* refmap;          /* [W*H] reference slot or -1 */
+    /* self: the regular reference grid (centre pass) */
+    unsigned n_ref_rows, n_ref_cols, p, nHW;
+    const int* refmap;          /* unused by the grid path; kept for the irregular (subset) path */
     float* scores;              /* [R][Ns*Ns], pre-filled with 2*threshold */
     /* stereo */
     float* tables;              /* [n_slots][Ns*Ns][W*H] */
@@ -113,7 +118,7 @@ hipError_t launch_self_select(hipStream_t s, const float* scores, const unsigned
                               unsigned* self_cnt);
 hipError_t launch_self_trivial(hipStream_t s, const unsigned* refs, unsigned n_refs, unsigned* self_idx,
                                unsigned* self_cnt);
-hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, unsigned slot, unsigned st,
+hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,
                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
                                 unsigned* best, unsigned char* shape);
 hipError_t launch_group(hipStream_t s, const GroupArgs& a);

@@ -452,21 +452,42 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     }
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
+     * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
+    if (c == 0 && tid < N * A) {
+        const int n = tid / A, st = tid % A;
+        unsigned p = 0xffffffffu;
+        if (n < nSx && ((a.mask_bits >> st) & 1)) {
+            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
+            if (ok) p = pos[n * A + st];
+        }
+        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
+    }
 
     /* gather (core:286-299).  Patches whose column equals Wb-k read the reference's never-filled
      * table column, i.e. zeros (core:1697, bm3d.cpp:737) -- reproduce. */
-    for (int e = tid; e < stack; e += kThreads) {
-        const int pq = e % k2, ns = e / k2;
-        const int st = ns % A;
-        const unsigned p = pos[ns];
-        float v0 = 0.0f, v1 = 0.0f;
-        if (p != 0xffffffffu && (p % a.Wb) < a.Wb - k) {
-            const size_t off = ((size_t)st * a.C + c) * plane + p + (size_t)(pq / k) * a.Wb + pq % k;
-            v0 = a.noisy[off];
-            if (STEP == 2) v1 = a.basic[off];
+    for (int e0 = tid; e0 < stack; e0 += kThreads * 8) {
+        float v0[8], v1[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * kThreads;
+            v0[u] = 0.0f; v1[u] = 0.0f;
+            if (e < stack) {
+                const int pq = e % k2, ns = e / k2;
+                const int st = ns % A;
+                const unsigned p = pos[ns];
+                if (p != 0xffffffffu && (p % a.Wb) < a.Wb - k) {
+                    const size_t off = ((size_t)st * a.C + c) * plane + p + (size_t)(pq / k) * a.Wb + pq % k;
+                    v0[u] = a.noisy[off];
+                    if (STEP == 2) v1[u] = a.basic[off];
+                }
+            }
         }
-        S0[e] = v0;
-        if (STEP == 2) S1[e] = v1;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * kThreads;
+            if (e < stack) { S0[e] = v0[u]; if (STEP == 2) S1[e] = v1[u]; }
+        }
     }
     __syncthreads();
 
@@ -569,8 +590,9 @@ constexpr int kTile = 16;
  * whose search range can reach the tile; every pixel adds its contributions in that order, which
  * is the reference's order for that pixel, starting from the value already in num/den. */
 __global__ __launch_bounds__(kTile * kTile) void k_aggregate(AggArgs a) {
-    __shared__ unsigned hit_pos[256];
-    __shared__ unsigned hit_inst[256];
+    __shared__ unsigned hit_pk[256];   /* (py << 16) | px */
+    __shared__ unsigned hit_base[256]; /* offset of the patch in filt */
+    __shared__ unsigned hit_w[256];    /* offset of the group's weights */
     __shared__ unsigned wave_cnt[4];
     const int tid = threadIdx.x;
     const int st = blockIdx.z;
@@ -606,20 +628,19 @@ __global__ __launch_bounds__(kTile * kTile) void k_aggregate(AggArgs a) {
     const unsigned g_end = a.ref_begin + a.n_groups;
     for (int c0 = 0; c0 < n_cand; c0 += 256) {
         const int e = c0 + tid;
-        bool hit = false; unsigned p = 0, inst = 0;
+        bool hit = false; unsigned pk = 0, fbase = 0, woff = 0;
         if (e < n_cand) {
             const int n = e % N, rr = e / N;
             const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
             const unsigned g = (unsigned)gr * a.n_ref_cols + gc;
-            if (g >= a.ref_begin && g < g_end && n < (int)a.self_cnt[g]) {
-                const unsigned k_r = a.refs[g];
-                const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r]; /* core:503 */
-                if (ok) {
-                    const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
-                    p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+            if (g >= a.ref_begin && g < g_end) {
+                const unsigned p = a.aggpos[((size_t)st * a.n_refs_total + g) * N + n];
+                if (p != 0xffffffffu) {
                     const int py = p / a.Wb, px = p % a.Wb;
                     hit = py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
-                    inst = g * N + n;
+                    pk = ((unsigned)py << 16) | (unsigned)px;
+                    fbase = ((g * N + n) * A + st) * C * k2;
+                    woff = g * C;
                 }
             }
         }
@@ -633,25 +654,44 @@ __global__ __launch_bounds__(kTile * kTile) void k_aggregate(AggArgs a) {
         const unsigned total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         if (hit) {
             const unsigned slot = base + __popcll(bal & ((1ull << ln) - 1ull));
-            hit_pos[slot] = p; hit_inst[slot] = inst;
+            hit_pk[slot] = pk; hit_base[slot] = fbase; hit_w[slot] = woff;
         }
         __syncthreads();
         if (inside) {
-            for (unsigned h = 0; h < total; h++) {
-                const unsigned hp = hit_pos[h];
-                const int dy = y - (int)(hp / a.Wb), dx = x - (int)(hp % a.Wb);
-                if (dy >= 0 && dy < k && dx >= 0 && dx < k) {
-                    const unsigned in = hit_inst[h];
-                    const float kz = a.tb->kaiser[dy * k + dx];
-                    const float* fp = a.filt + ((size_t)in * A + st) * C * k2 + dy * k + dx;
-                    const float* wp = a.wgt + (size_t)(in / N) * C;
-                    for (int c = 0; c < C; c++) {
-#pragma clang fp contract(off)
-                        const float kw = kz * wp[c];   /* core:516-520: (kaiser * w) * value */
-                        accn[c] += kw * fp[(size_t)c * k2];
-                        accd[c] += kw;
+            constexpr int U = 4; /* hits per batch: loads of a batch are issued together, adds stay in hit order */
+            for (unsigned h0 = 0; h0 < total; h0 += U) {
+                float val[U][3], kw[U][3];
+                bool on[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned h = h0 + u;
+                    on[u] = false;
+                    if (h < total) {
+                        const unsigned hp = hit_pk[h];
+                        const unsigned dy = (unsigned)(y - (int)(hp >> 16)), dx = (unsigned)(x - (int)(hp & 0xffffu));
+                        if (dy < (unsigned)k && dx < (unsigned)k) {
+                            on[u] = true;
+                            const unsigned o = dy * k + dx;
+                            const float kz = a.tb->kaiser[o];
+                            const float* fp = a.filt + hit_base[h] + o;
+                            const float* wp = a.wgt + hit_w[h];
+#pragma unroll
+                            for (int c = 0; c < 3; c++)
+                                if (c < C) { val[u][c] = fp[(size_t)c * k2]; kw[u][c] = kz * wp[c]; } /* core:516-520 */
+                        }
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (on[u]) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++)
+                            if (c < C) {
+#pragma clang fp contract(off)
+                                accn[c] += kw[u][c] * val[u][c];
+                                accd[c] += kw[u][c];
+                            }
+                    }
             }
         }
         __syncthreads();
