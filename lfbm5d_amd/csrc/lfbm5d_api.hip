@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -239,7 +240,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     unsigned slots[kMaxA]; unsigned n_slots = 0;
     for (unsigned st = 0; st < A; st++) if (st != pst && ((mask_bits >> st) & 1)) slots[n_slots++] = st;
     const unsigned Nst = N > 1 ? N : 1;
-    HIPCK(c, c->est.reserve(A * plane * sizeof(float)));
+    HIPCK(c, c->est.reserve((A * plane + 256) * sizeof(float)));   /* slack: strip loads may overrun a row end by <= nHW */
     HIPCK(c, c->refmap.reserve(plane * sizeof(int)));
     if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
     HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * plane * sizeof(float)));
@@ -282,6 +283,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ScanArgs sa;
     std::memset(&sa, 0, sizeof(sa));
     sa.est = c->est.as<float>(); sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst; sa.two_thr = 2 * thr;
+    { const char* dbg = getenv("LFBM5D_SCAN_DEBUG"); sa.debug = dbg ? (unsigned)atoi(dbg) : 0u; }
     sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p; sa.nHW = nHW;
     if (N > 1) {
         HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));

@@ -139,18 +139,23 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
     }
     __syncthreads();
 
-    /* reference-grid row slots of every table row (self mode): y and y + di */
-    int* ridx1 = reinterpret_cast<int*>(lcol + nrows);
-    int* ridx2 = ridx1 + nrows;
+    /* reference-grid row slots of every table row (self mode): y and y + di; 64 entries of front
+     * padding and T+1 of back padding (-1) so the skewed lanes can index them without clamping */
+    int* ridx1 = reinterpret_cast<int*>(lcol + nrows + T + 1) + 64;
+    int* ridx2 = ridx1 + nrows + T + 1 + 64;
     if (!a.stereo)
-        for (int i = lane; i < nrows; i += 64) {
-            ridx1[i] = grid_index(b + i, gR, lastR, gN, gP);
-            ridx2[i] = di > 0 ? grid_index(b + i + di, gR, lastR, gN, gP) : -1;
+        for (int i = lane - 64; i < nrows + T + 1; i += 64) {
+            const bool in = i >= 0 && i < nrows;
+            ridx1[i] = in ? grid_index(b + i, gR, lastR, gN, gP) : -1;
+            ridx2[i] = (in && di > 0) ? grid_index(b + i + di, gR, lastR, gN, gP) : -1;
         }
+    for (int i = nrows + lane; i < nrows + T + 1; i += 64) lcol[i] = 0.0f;
     __syncthreads();
 
     float row0_left = corner; /* S[b][cb-1] */
-    const int nstrips = (ncols + 63) / 64;
+    const int nstrips = (a.debug & 8) ? 0 : (ncols + 63) / 64;
+    const float* i1 = D.i1;
+    const float* i2 = D.i2 + D.dk;
     for (int strip = 0; strip < nstrips; strip++) {
         const int cb = b + 64 * strip;
         const int x = cb + lane;
@@ -164,21 +169,27 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
         float* sc2 = a.stereo ? nullptr : a.scores + (size_t)(cx2 < 0 ? 0 : cx2) * ncand + ord_bwd;
         const size_t rstride = (size_t)gC * ncand;
 
+        /* D-row loads of the strip: ring column 0 <-> x = cb-1; columns are clamped into the row
+         * (loads stay inside the plane, est has slack) and out-of-band entries zeroed afterwards */
+        const int xm0 = cb - 1 + lane;
+        const int xm = min(max(xm0, b), W - 1), xe = min(cb + 63 + lane, W - 1);
+        const bool inm = xm0 >= b && xm0 < W - b;
+        const bool ine = lane < K && cb + 63 + lane < W - b;
         auto load_row = [&](int R, float& m1, float& m2, float& e1, float& e2) {
-            const int yy = b + R;
-            const bool rin = yy < H - b;
-            const int xm = cb - 1 + lane, xe = cb + 63 + lane;
-            const bool inm = rin && xm >= b && xm < W - b;
-            const bool ine = rin && lane < K && xe < W - b;
-            const int qm = yy * W + xm, qe = yy * W + xe;
-            m1 = inm ? D.i1[qm] : 0.0f; m2 = inm ? D.i2[qm + D.dk] : 0.0f;
-            e1 = ine ? D.i1[qe] : 0.0f; e2 = ine ? D.i2[qe + D.dk] : 0.0f;
+            const int yy = b + R;            /* uniform */
+            m1 = m2 = e1 = e2 = 0.0f;
+            if (yy < H - b && !(a.debug & 1)) {
+                const float* p1 = i1 + (size_t)yy * W;
+                const float* p2 = i2 + (size_t)yy * W;
+                m1 = p1[xm]; m2 = p2[xm];
+                if (lane < K) { e1 = p1[xe]; e2 = p2[xe]; }
+            }
         };
         auto store_row = [&](int R, float m1, float m2, float e1, float e2) {
-            float* rr = ring + (R % RR) * CW;
+            float* rr = ring + (R % RR) * CW;   /* uniform */
             const float dm = m2 - m1, de = e2 - e1;
-            rr[lane] = dm * dm;
-            if (lane < K) rr[64 + lane] = de * de;
+            rr[lane] = inm ? dm * dm : 0.0f;
+            if (lane < K) rr[64 + lane] = ine ? de * de : 0.0f;
         };
         int filled = 0;
         for (int R0 = 0; R0 < K + T; R0 += T) {
@@ -210,39 +221,42 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
             if (col_ok) emit(b, x, S0);
         }
 
-        /* remaining rows: T steps per iteration -- loads, then the register-only chain, then stores */
+        /* remaining rows: T steps per iteration -- loads, then the register-only chain, then stores.
+         * Lane l works on table row i = 1 + t - l at step t. */
         float curS = S0;
-        float shifted_prev = 0.0f;
-        float left0_prev = row0_left;   /* lane 0: S[i-1][cb-1] */
+        float left_prev = row0_left;    /* lane 0: S[0][cb-1]; other lanes: overwritten before use */
         const int nsteps = (nrows - 1) + last_lane;
-        for (int t0 = 0; t0 < nsteps; t0 += T) {
+        /* per-lane constants of the skewed LDS addressing: ring row (u - lane) mod RR, column lane */
+        const int offA0 = lane - lane * CW, offA1 = offA0 + RR * CW;
+        const int xoff = x - lane * W;
+        for (int t0 = 0; t0 < ((a.debug & 4) ? 0 : nsteps); t0 += T) {
             float m1[T], m2[T], e1[T], e2[T];
 #pragma unroll
             for (int s = 0; s < T; s++) load_row(filled + s, m1[s], m2[s], e1[s], e2[s]);
-            const int i0 = 1 + t0 - lane;
-            int rA = (i0 + K - 1 + 64 * RR) % RR, rB = (i0 - 1 + 64 * RR) % RR;
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
             int r1[T], r2[T];
+            int uA = (t0 + K) % RR, uB = t0 % RR;       /* uniform */
 #pragma unroll
             for (int s = 0; s < T; s++) {
-                d1[s] = ring[rA * CW + lane + K]; d2[s] = ring[rA * CW + lane];
-                d3[s] = ring[rB * CW + lane + K]; d4[s] = ring[rB * CW + lane];
-                rA = rA + 1 == RR ? 0 : rA + 1;
-                rB = rB + 1 == RR ? 0 : rB + 1;
-                const int il = min(max(i0 + s, 0), nrows - 1);
-                lc[s] = lcol[il];
-                r1[s] = a.stereo ? -1 : ridx1[il];
-                r2[s] = a.stereo ? -1 : ridx2[il];
+                const float* pa = ring + uA * CW + (uA < lane ? offA1 : offA0);
+                const float* pb = ring + uB * CW + (uB < lane ? offA1 : offA0);
+                d1[s] = pa[K]; d2[s] = pa[0];
+                d3[s] = pb[K]; d4[s] = pb[0];
+                uA = uA + 1 == RR ? 0 : uA + 1;
+                uB = uB + 1 == RR ? 0 : uB + 1;
+                lc[s] = lcol[min(1 + t0 + s, nrows + T)];   /* uniform address: lane 0's left neighbour */
+                if (!a.stereo) { r1[s] = ridx1[1 + t0 + s - lane]; r2[s] = ridx2[1 + t0 + s - lane]; }
             }
 #pragma unroll
             for (int s = 0; s < T; s++) {
-                const int i = i0 + s;
-                const bool act = col_ok && i >= 1 && i < nrows;
-                const float shifted = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(curS), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-                const float left = lane == 0 ? lc[s] : shifted;
-                const float upleft = lane == 0 ? left0_prev : shifted_prev;
+                const int t = t0 + s;
+                const int lo = t + 2 - nrows, hi = min(t, last_lane);            /* uniform */
+                const bool act = lane >= lo && lane <= hi;
+                /* left neighbour's value of the previous step; lane 0 takes the hand-off column */
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lc[s]), __float_as_int(curS),
+                                                                              0x138 /* wave_shr:1 */, 0xf, 0xf, false));
                 float S = left + curS;             /* core:3379-3386, same association */
-                S = S - upleft;
+                S = S - left_prev;
                 S = S + d1[s];
                 S = S - d2[s];
                 S = S - d3[s];
@@ -250,21 +264,23 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 S = first_col ? left : S;          /* first column was computed up front */
                 Sout[s] = S;
                 curS = act ? S : curS;
-                left0_prev = left;
-                shifted_prev = shifted;
+                left_prev = left;
             }
 #pragma unroll
             for (int s = 0; s < T; s++) {
-                const int i = i0 + s;
-                const bool act = col_ok && i >= 1 && i < nrows;
-                if (act) {
-                    if (a.stereo) table[(b + i) * W + x] = Sout[s];
-                    else {
-                        if (cx >= 0 && r1[s] >= 0) sc1[(size_t)r1[s] * rstride] = Sout[s];
-                        if (cx2 >= 0 && r2[s] >= 0) sc2[(size_t)r2[s] * rstride] = Sout[s];
-                    }
-                    if (lane == last_lane) lcol[i] = Sout[s];
+                const int t = t0 + s;
+                const int lo = t + 2 - nrows, hi = min(t, last_lane);
+                const bool act = lane >= lo && lane <= hi;
+                if (a.stereo) {
+                    float* trow = table + (size_t)(b + 1 + t) * W;                /* uniform */
+                    if (act && !(a.debug & 2)) trow[xoff] = Sout[s];
+                } else if (act) {
+                    if (cx >= 0 && r1[s] >= 0) sc1[(size_t)r1[s] * rstride] = Sout[s];
+                    if (cx2 >= 0 && r2[s] >= 0) sc2[(size_t)r2[s] * rstride] = Sout[s];
                 }
+                const int il = 1 + t - last_lane;                                 /* uniform */
+                const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
+                if (il >= 1 && il < nrows && lane == 0) lcol[il] = hv;            /* hand-off column for the next strip */
             }
 #pragma unroll
             for (int s = 0; s < T; s++) store_row(filled + s, m1[s], m2[s], e1[s], e2[s]);
@@ -387,7 +403,7 @@ hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, i
 
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
     const unsigned nrows = a.H - 2 * a.b - a.trim;
-    const size_t lds = (size_t)(96 * (64 + a.k) + 3 * nrows) * sizeof(float);
+    const size_t lds = (size_t)(96 * (64 + a.k) + 3 * (nrows + 9) + 2 * 64) * sizeof(float);
     switch (a.k) {
         case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(a.n_tables), dim3(64), lds, s, a); break;
         case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(a.n_tables), dim3(64), lds, s, a); break;

@@ -93,6 +93,7 @@ struct ScanArgs {
     float* tables;              /* [n_slots][Ns*Ns][W*H] */
     unsigned st_of_slot[kMaxA];
     unsigned n_tables;          /* grid size */
+    unsigned debug;             /* timing experiments only (LFBM5D_SCAN_DEBUG); 0 in production */
 };
 
 hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward);

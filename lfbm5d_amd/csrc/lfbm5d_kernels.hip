@@ -281,16 +281,12 @@ template <int NS> __device__ __forceinline__ void hadamard(float* v) {
 
 /* 5th-dimension filter of one (st, pq) fibre held in registers.
  * HT: core:2408-2505 / :2281-2391; Wiener: core:2826-2925 / :2706-2810. */
+/* 5th-dimension transform + shrinkage + inverse of one (st, pq) fibre held in registers.
+ * o: noisy fibre, e: pilot fibre (Wiener); the filtered fibre is returned in o (HT) / e (Wiener).
+ * HT: core:2408-2505 / :2281-2391; Wiener: core:2826-2925 / :2706-2810. */
 template <int NS, int STEP>
-__device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stride, unsigned tau5,
-                                        float T, float sig2, bool in_shape, float& wacc, float& s1, float& s2) {
-    float o[NS], e[NS];
-#pragma unroll
-    for (int n = 0; n < NS; n++) o[n] = S0[base + n * stride];
-    if (STEP == 2) {
-#pragma unroll
-        for (int n = 0; n < NS; n++) e[n] = S1[base + n * stride];
-    }
+__device__ __forceinline__ void shrink_fibre(float* o, float* e, unsigned tau5, float T, float sig2,
+                                             bool in_shape, float& wacc) {
     const bool haar = tau5 == 9;
     if (NS > 1) {
         if (haar) { haar_fwd<NS>(o); if (STEP == 2) haar_fwd<NS>(e); }
@@ -326,6 +322,21 @@ __device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stri
             }
         }
     }
+}
+
+/* the same on a fibre stored in the LDS stack */
+template <int NS, int STEP>
+__device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stride, unsigned tau5,
+                                        float T, float sig2, bool in_shape, float& wacc, float& s1, float& s2) {
+    float o[NS], e[NS];
+#pragma unroll
+    for (int n = 0; n < NS; n++) o[n] = S0[base + n * stride];
+    if (STEP == 2) {
+#pragma unroll
+        for (int n = 0; n < NS; n++) e[n] = S1[base + n * stride];
+    }
+    shrink_fibre<NS, STEP>(o, e, tau5, T, sig2, in_shape, wacc);
+    float* r = STEP == 1 ? o : e;
     float* dst = STEP == 1 ? S0 : S1;
 #pragma unroll
     for (int n = 0; n < NS; n++) { dst[base + n * stride] = r[n]; s1 += r[n]; s2 += r[n] * r[n]; }
@@ -335,8 +346,81 @@ __device__ __forceinline__ int per_ext(int j, int L, int N) { int m = (j - L) % 
 
 /* 2-D forward transform of `np` patches stored back to back at S (k*k floats each).  All threads
  * of the workgroup call this. */
+
+/* barrier between the two passes of a patch: when a patch is exactly one wavefront (k = 8) the LDS
+ * traffic of a patch stays inside that wave, whose DS operations execute in order -- no workgroup
+ * barrier needed */
+#define PATCH_SYNC() do { if (wave_local) __builtin_amdgcn_wave_barrier(); else __syncthreads(); } while (0)
+
+/* 2-D DCT of all patches with the per-thread table entries held in registers (thread = coefficient
+ * (i,j) of a patch; its cosine rows never change from patch to patch) */
+template <int K>
+__device__ void fwd2d_dct(float* S, float* tmp, int np, const GroupTables* tb) {
+    constexpr int K2 = K * K;
+    const int tid = threadIdx.x;
+    const bool wave_local = K2 == 64;
+    constexpr int ppi = kThreads / K2 > 0 ? kThreads / K2 : 1;
+    const int slot = tid / K2, pq = tid % K2, i = pq / K, j = pq % K;
+    float cj[K], ci[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) { cj[t] = tb->cos2[j * K + t]; ci[t] = tb->cos2[i * K + t]; }
+    const float cn = tb->cn2[pq];
+    float* Tm = tmp + slot * K2;
+    for (int p0 = 0; p0 < np; p0 += ppi) {
+        const int patch = p0 + slot;
+        const bool on = slot < ppi && patch < np;
+        float* X = S + (size_t)patch * K2;
+        if (on) { float a = 0.0f;
+#pragma unroll
+            for (int t = 0; t < K; t++) a += X[i * K + t] * cj[t];
+            Tm[pq] = 2.0f * a; }
+        PATCH_SYNC();
+        if (on) { float a = 0.0f;
+#pragma unroll
+            for (int t = 0; t < K; t++) a += Tm[t * K + j] * ci[t];
+            X[pq] = 2.0f * a * cn; }
+        PATCH_SYNC();
+    }
+    __syncthreads();
+}
+template <int K>
+__device__ void inv2d_dct(float* S, float* tmp, int np, const GroupTables* tb) {
+    constexpr int K2 = K * K;
+    const int tid = threadIdx.x;
+    const bool wave_local = K2 == 64;
+    constexpr int ppi = kThreads / K2 > 0 ? kThreads / K2 : 1;
+    const int slot = tid / K2, pq = tid % K2, i = pq / K, j = pq % K;
+    float cc[K], ni[K], cu[K];
+#pragma unroll
+    for (int t = 0; t < K; t++) { cc[t] = tb->cos2[t * K + j]; ni[t] = tb->cni2[i * K + t]; cu[t] = tb->cos2[t * K + i]; }
+    const float c2 = tb->coef2inv;
+    float* Tm = tmp + slot * K2;
+    for (int p0 = 0; p0 < np; p0 += ppi) {
+        const int patch = p0 + slot;
+        const bool on = slot < ppi && patch < np;
+        float* X = S + (size_t)patch * K2;
+        if (on) { float a = 0.0f;
+#pragma unroll
+            for (int v = 1; v < K; v++) a += X[i * K + v] * ni[v] * cc[v];
+            Tm[pq] = X[i * K] * ni[0] + 2.0f * a; }
+        PATCH_SYNC();
+        if (on) { float a = 0.0f;
+#pragma unroll
+            for (int u = 1; u < K; u++) a += Tm[u * K + j] * cu[u];
+            X[pq] = c2 * (Tm[j] + 2.0f * a); }
+        PATCH_SYNC();
+    }
+    __syncthreads();
+}
+
 __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const GroupTables* tb) {
+    if (tau2 == 5) {
+        if (k == 8) return fwd2d_dct<8>(S, tmp, np, tb);
+        if (k == 12) return fwd2d_dct<12>(S, tmp, np, tb);
+        return fwd2d_dct<16>(S, tmp, np, tb);
+    }
     const int k2 = k * k, tid = threadIdx.x;
+    const bool wave_local = k2 == 64;
     const int ppi = kThreads / k2 > 0 ? kThreads / k2 : 1; /* patches per iteration */
     for (int p0 = 0; p0 < np; p0 += ppi) {
         const int slot = tid / k2, pq = tid % k2, patch = p0 + slot;
@@ -346,9 +430,9 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
         const int i = pq / k, j = pq % k;
         if (tau2 == 5) { /* DCT: REDFT10 rows, REDFT10 columns, * coef_norm (bm3d.cpp:745-757) */
             if (on) { float a = 0.0f; for (int t = 0; t < k; t++) a += X[i * k + t] * tb->cos2[j * k + t]; Tm[pq] = 2.0f * a; }
-            __syncthreads();
+            PATCH_SYNC();
             if (on) { float a = 0.0f; for (int t = 0; t < k; t++) a += Tm[t * k + j] * tb->cos2[i * k + t]; X[pq] = 2.0f * a * tb->cn2[pq]; }
-            __syncthreads();
+            PATCH_SYNC();
         } else {         /* bior1.5 (lib_transforms.cpp:46-120) */
             for (int N1 = k; N1 > 1; N1 /= 2) {
                 const int N2 = N1 / 2;
@@ -359,7 +443,7 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
                     for (int t = 0; t < 10; t++) a += X[i * k + per_ext(t + 2 * jj, 4, N1)] * f[t];
                     Tm[pq] = a;
                 }
-                __syncthreads();
+                PATCH_SYNC();
                 if (on && i < N1 && j < N1) {
                     const bool lo = i < N2; const int ii = lo ? i : i - N2;
                     const float* f = lo ? tb->lpd : tb->hpd;
@@ -367,13 +451,20 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
                     for (int t = 0; t < 10; t++) a += Tm[per_ext(t + 2 * ii, 4, N1) * k + j] * f[t];
                     X[pq] = a;
                 }
-                __syncthreads();
+                PATCH_SYNC();
             }
         }
     }
+    __syncthreads();
 }
 __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, const GroupTables* tb) {
+    if (tau2 == 5) {
+        if (k == 8) return inv2d_dct<8>(S, tmp, np, tb);
+        if (k == 12) return inv2d_dct<12>(S, tmp, np, tb);
+        return inv2d_dct<16>(S, tmp, np, tb);
+    }
     const int k2 = k * k, tid = threadIdx.x;
+    const bool wave_local = k2 == 64;
     const int ppi = kThreads / k2 > 0 ? kThreads / k2 : 1;
     for (int p0 = 0; p0 < np; p0 += ppi) {
         const int slot = tid / k2, pq = tid % k2, patch = p0 + slot;
@@ -387,13 +478,13 @@ __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
                 for (int v = 1; v < k; v++) a += X[i * k + v] * tb->cni2[i * k + v] * tb->cos2[v * k + j];
                 Tm[pq] = X[i * k] * tb->cni2[i * k] + 2.0f * a;
             }
-            __syncthreads();
+            PATCH_SYNC();
             if (on) {
                 float a = 0.0f;
                 for (int u = 1; u < k; u++) a += Tm[u * k + j] * tb->cos2[u * k + i];
                 X[pq] = tb->coef2inv * (Tm[j] + 2.0f * a);
             }
-            __syncthreads();
+            PATCH_SYNC();
         } else { /* lib_transforms.cpp:135-204 */
             for (int N1 = 2; N1 <= k; N1 *= 2) {
                 const int N2 = N1 / 2;
@@ -403,17 +494,18 @@ __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
                     for (int t = 0; t < 10; t++) a += f[t] * X[((t * N2 + m) % N1) * k + j];
                     Tm[pq] = a;
                 }
-                __syncthreads();
+                PATCH_SYNC();
                 if (on && i < N1 && j < N1) { /* rows */
                     const int m = j / 2; const float* f = (j & 1) ? tb->lpr : tb->hpr;
                     float a = 0.0f;
                     for (int t = 0; t < 10; t++) a += f[t] * Tm[i * k + (t * N2 + m) % N1];
                     X[pq] = a;
                 }
-                __syncthreads();
+                PATCH_SYNC();
             }
         }
     }
+    __syncthreads();
 }
 
 template <int STEP>
@@ -466,27 +558,30 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
 
     /* gather (core:286-299).  Patches whose column equals Wb-k read the reference's never-filled
      * table column, i.e. zeros (core:1697, bm3d.cpp:737) -- reproduce. */
-    for (int e0 = tid; e0 < stack; e0 += kThreads * 8) {
-        float v0[8], v1[8];
+    {
+        constexpr int G = 12; /* loads in flight per thread and stack */
+        for (int e0 = tid; e0 < stack; e0 += kThreads * G) {
+            float v0[G], v1[G];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int e = e0 + u * kThreads;
-            v0[u] = 0.0f; v1[u] = 0.0f;
-            if (e < stack) {
-                const int pq = e % k2, ns = e / k2;
-                const int st = ns % A;
-                const unsigned p = pos[ns];
-                if (p != 0xffffffffu && (p % a.Wb) < a.Wb - k) {
-                    const size_t off = ((size_t)st * a.C + c) * plane + p + (size_t)(pq / k) * a.Wb + pq % k;
-                    v0[u] = a.noisy[off];
-                    if (STEP == 2) v1[u] = a.basic[off];
+            for (int u = 0; u < G; u++) {
+                const int e = e0 + u * kThreads;
+                v0[u] = 0.0f; v1[u] = 0.0f;
+                if (e < stack) {
+                    const int pq = e % k2, ns = e / k2;
+                    const int st = ns % A;
+                    const unsigned p = pos[ns];
+                    if (p != 0xffffffffu && (p % a.Wb) < a.Wb - k) {
+                        const size_t off = ((size_t)st * a.C + c) * plane + p + (size_t)(pq / k) * a.Wb + pq % k;
+                        v0[u] = a.noisy[off];
+                        if (STEP == 2) v1[u] = a.basic[off];
+                    }
                 }
             }
-        }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int e = e0 + u * kThreads;
-            if (e < stack) { S0[e] = v0[u]; if (STEP == 2) S1[e] = v1[u]; }
+            for (int u = 0; u < G; u++) {
+                const int e = e0 + u * kThreads;
+                if (e < stack) { S0[e] = v0[u]; if (STEP == 2) S1[e] = v1[u]; }
+            }
         }
     }
     __syncthreads();
@@ -578,6 +673,158 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     for (int e = tid; e < stack; e += kThreads) {
         const int pq = e % k2, ns = e / k2;
         out[((size_t)ns * a.C + c) * k2 + pq] = F[e];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Register-resident variant for tau_2D = id (the README hard-thresholding configuration): with no
+ * 2-D transform, pixel pq of the group never mixes with other pixels, so one thread owns pixel pq
+ * of all nSx * A patches (72 registers for N = 8), loads them straight from the window images and
+ * runs the 3x3 angular DCT / SADCT, the Haar/Hadamard fibre transforms, the shrinkage and the
+ * inverses without touching LDS (only the group weight is reduced through it).  No LDS stack means
+ * occupancy is set by registers, not by the 72 KiB stack of k_group.
+ * ------------------------------------------------------------------------------------------ */
+template <int STEP, int NS>
+__device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const unsigned* pos,
+                                              const ShapeInfo& sh, bool use_sadct, float& wacc, float& s1, float& s2) {
+    const int k = a.k, k2 = k * k, A = 9;
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const GroupTables* tb = a.tb;
+    float v[NS][9];
+    float w[STEP == 2 ? NS : 1][9];
+    const unsigned poff = (unsigned)(pq / k) * a.Wb + pq % k;
+#pragma unroll
+    for (int n = 0; n < NS; n++)
+#pragma unroll
+        for (int st = 0; st < 9; st++) {
+            const unsigned p = pos[n * A + st];
+            const bool ok = p != 0xffffffffu && (p % a.Wb) < a.Wb - k;  /* never-filled table column (core:1697) */
+            const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u) + poff;
+            const float x0 = a.noisy[off];
+            v[n][st] = ok ? x0 : 0.0f;
+            if (STEP == 2) { const float x1 = a.basic[off]; w[n][st] = ok ? x1 : 0.0f; }
+        }
+    const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
+    const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    if (do_dct4) {
+#pragma unroll
+        for (int n = 0; n < NS; n++) { dct9_fwd(v[n], tb); if (STEP == 2) dct9_fwd(w[n], tb); }
+    } else if (do_sa4) { /* rare: staged through a small scratch vector so v[][] stays in registers */
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            float t9[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) t9[i] = v[n][i];
+            sadct9_fwd(t9, sh, tb);
+#pragma unroll
+            for (int i = 0; i < 9; i++) v[n][i] = t9[i];
+            if (STEP == 2) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) t9[i] = w[n][i];
+                sadct9_fwd(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) w[n][i] = t9[i];
+            }
+        }
+    }
+    const float sig = a.sigma[c];
+    const float T = a.lambda * sig * 1.41421356237309505f;
+    const float sig2 = sig * sig;
+#pragma unroll
+    for (int st = 0; st < 9; st++) {
+        float o[NS], e[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) { o[n] = v[n][st]; e[n] = STEP == 2 ? w[n][st] : 0.0f; }
+        shrink_fibre<NS, STEP>(o, e, a.tau5, T, sig2, !use_sadct || sh.mask_dct[st], wacc);
+#pragma unroll
+        for (int n = 0; n < NS; n++) { const float r = STEP == 1 ? o[n] : e[n]; v[n][st] = r; s1 += r; s2 += r * r; }
+    }
+    if (do_dct4) {
+#pragma unroll
+        for (int n = 0; n < NS; n++) dct9_inv(v[n], tb);
+    } else if (do_sa4) {
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            float t9[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) t9[i] = v[n][i];
+            sadct9_inv(t9, sh, tb);
+#pragma unroll
+            for (int i = 0; i < 9; i++) v[n][i] = t9[i];
+        }
+    }
+    float* out = a.filt + (size_t)g * a.N * A * a.C * k2;
+#pragma unroll
+    for (int n = 0; n < NS; n++)
+#pragma unroll
+        for (int st = 0; st < 9; st++) out[((size_t)(n * A + st) * a.C + c) * k2 + pq] = v[n][st];
+}
+
+template <int STEP>
+__global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
+    __shared__ ShapeInfo sh;
+    __shared__ unsigned pos[kMaxN * kMaxA];
+    __shared__ float red[3][4];
+    const int tid = threadIdx.x;
+    const unsigned g = a.ref_begin + blockIdx.x;
+    const int c = blockIdx.y;
+    const int A = 9, N = a.N;
+    const int nSx = (int)a.self_cnt[g];
+    const unsigned k_r = a.refs[g];
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    if (tid < nSx * A) {
+        const int n = tid / A, st = tid % A;
+        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
+        unsigned p = 0xffffffffu;
+        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+        pos[tid] = p;
+    }
+    if (tid == 0) {
+        int m[9];
+        for (int st = 0; st < 9; st++)
+            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
+        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
+    }
+    __syncthreads();
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    if (c == 0 && tid < N * A) {
+        const int n = tid / A, st = tid % A;
+        unsigned p = 0xffffffffu;
+        if (n < nSx && ((a.mask_bits >> st) & 1)) {
+            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
+            if (ok) p = pos[n * A + st];
+        }
+        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
+    }
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (tid < (int)(a.k * a.k)) {
+        switch (nSx) {
+            case 1:  group_id_body<STEP, 1>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 2:  group_id_body<STEP, 2>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 4:  group_id_body<STEP, 4>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            default: group_id_body<STEP, 8>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (unsigned i = 0; i < (blockDim.x + 63) / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(nSx * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)nSx);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
     }
 }
 
@@ -745,6 +992,12 @@ size_t group_lds_bytes(const GroupArgs& a) {
     return ((a.step == 2 ? 2 : 1) * stack + 256) * sizeof(float);
 }
 hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
+    /* no 2-D transform and a stack small enough for registers: register-resident kernel */
+    if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) {
+        const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
+        hipLaunchKernelGGL(k_group_id<1>, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        return hipGetLastError();
+    }
     const size_t lds = group_lds_bytes(a);
     static bool attr_set = false;
     if (!attr_set) {
