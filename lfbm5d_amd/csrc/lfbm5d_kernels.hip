@@ -772,12 +772,12 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     const int nSx = (int)a.self_cnt[g];
     const unsigned k_r = a.refs[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
-    if (tid < nSx * A) {
-        const int n = tid / A, st = tid % A;
+    for (int i = tid; i < nSx * A; i += (int)blockDim.x) {   /* the block may be narrower than N*A (k = 8) */
+        const int n = i / A, st = i % A;
         const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
         unsigned p = 0xffffffffu;
         if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
-        pos[tid] = p;
+        pos[i] = p;
     }
     if (tid == 0) {
         int m[9];
@@ -787,8 +787,8 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     }
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
-    if (c == 0 && tid < N * A) {
-        const int n = tid / A, st = tid % A;
+    for (int i = tid; c == 0 && i < N * A; i += (int)blockDim.x) {
+        const int n = i / A, st = i % A;
         unsigned p = 0xffffffffu;
         if (n < nSx && ((a.mask_bits >> st) & 1)) {
             const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
