@@ -1,0 +1,287 @@
+/*
+ * lfbm5d_cli.cpp -- `LFBM5Ddenoising`, the reference's command line (src/main.cpp:60-309,
+ * argument order of get_params, utilities_LF.cpp:1181-1309 / README.md:83) on the GPU backend:
+ *
+ *   LFBM5Ddenoising LFSourceDir|none SAIName sep awidth aheight sIdxStart tIdxStart aswSizeHard
+ *       aswSizeWien row|col sigma lambda LFNoisyDir LFBasicDir LFDenoisedDir LFDiffDir
+ *       NHard nSimHard nDispHard kHard pHard id|dct|bior id|dct|sadct hw|haar|dct useSDHard
+ *       NWien nSimWien nDispWien kWien pWien id|dct|bior id|dct|sadct hw|haar|dct useSDWien
+ *       rgb|yuv|ycbcr|opp nbThreads resultsFile
+ *
+ * Same files in and out (<dir>/<name><sep><ss><sep><tt>.png), same PSNR report format.
+ * Differences, all opt-in through the environment so the argument list stays a drop-in:
+ *   LFBM5D_SEED=<n>   seed MT19937 once with n and draw the noise SAI by SAI in st order
+ *                     (reproducible); unset = time + pid seeding like the reference;
+ *   LFBM5D_DEVICE=<i> HIP device index.
+ * nbThreads is parsed and ignored: the GPU path has the reference's untiled (nb_threads == 1)
+ * semantics.
+ */
+#include <sys/time.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/lfbm5d.h"
+#include "png_min.h"
+#include "run_bm5d.h"
+
+using namespace std;
+
+namespace {
+
+double now_s() { timeval tp; gettimeofday(&tp, nullptr); return tp.tv_sec + tp.tv_usec * 1e-6; }
+
+/* mt19937ar genrand_res53 on std::mt19937 (identical generator and seeding recurrence) */
+struct Mt {
+    std::mt19937 g;
+    explicit Mt(unsigned long s) : g((uint32_t)s) {}
+    double res53() { const unsigned long a = g() >> 5, b = g() >> 6; return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0); }
+};
+
+string sai_path(const char* dir, const char* name, const char* sep, unsigned s, unsigned t) {
+    ostringstream o;
+    o << dir << "/" << name << sep << setfill('0') << setw(2) << s << sep << setfill('0') << setw(2) << t << ".png";
+    return o.str();
+}
+
+/* load_LF, utilities_LF.cpp:72-167 */
+int load_LF(const char* dir, const char* name, const char* sep, vector<vector<float> >& LF, vector<unsigned>& mask,
+            unsigned ang_major, unsigned aw, unsigned ah, unsigned s0, unsigned t0, unsigned& W, unsigned& H, unsigned& C) {
+    mask.assign(aw * ah, 0u);
+    LF.assign(aw * ah, vector<float>());
+    bool first = true;
+    cout << endl;
+    for (unsigned s = 0; s < ah; s++)
+        for (unsigned t = 0; t < aw; t++) {
+            const string p = sai_path(dir, name, sep, s + s0, t + t0);
+            cout << "\rRead input image " << p << flush;
+            vector<float> img;
+            size_t w, h, c;
+            if (!png_read_planar_f32(p, img, w, h, c)) {
+                cout << endl << "error :: " << p << " not found or not a correct png image." << endl;
+                return EXIT_FAILURE;
+            }
+            if (c == 2) c = 1; /* drop alpha */
+            if (c > 2) {       /* really colour? (utilities_LF.cpp:118-125) */
+                size_t k = 0; float acc = 0.0f;
+                while (k < w * h && img[k] == img[w * h + k] && img[k] == img[2 * w * h + k]) { acc += img[k] + img[w * h + k] + img[2 * w * h + k]; k++; }
+                c = (k == w * h && acc > 0.0f) ? 1 : 3;
+            }
+            if (first) { W = (unsigned)w; H = (unsigned)h; C = (unsigned)c; first = false; }
+            if (w != W || h != H || c != C) { cout << endl << "error :: SAIs of different sizes" << endl; return EXIT_FAILURE; }
+            const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah;
+            LF[st].assign(img.begin(), img.begin() + w * h * c);
+            for (float v : LF[st]) if (v) { mask[st] = 1; break; }
+        }
+    cout << endl << " Light field size :" << endl << " - awidth         = " << aw << endl << " - aheight        = " << ah << endl
+         << " - width          = " << W << endl << " - height         = " << H << endl << " - nb of channels = " << C << endl;
+    return EXIT_SUCCESS;
+}
+
+/* save_LF + save_image, utilities_LF.cpp:182-231, utilities.cpp:118-142 */
+int save_LF(const char* dir, const char* name, const char* sep, const vector<vector<float> >& LF, unsigned ang_major,
+            unsigned aw, unsigned ah, unsigned s0, unsigned t0, unsigned W, unsigned H, unsigned C) {
+    vector<float> tmp((size_t)W * H * C);
+    for (unsigned s = 0; s < ah; s++)
+        for (unsigned t = 0; t < aw; t++) {
+            const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah;
+            const string p = sai_path(dir, name, sep, s + s0, t + t0);
+            cout << "\rWrite image " << p << flush;
+            if (LF[st].size() != tmp.size()) { std::fill(tmp.begin(), tmp.end(), 0.0f); }
+            else for (size_t k = 0; k < tmp.size(); k++) tmp[k] = LF[st][k] > 255.0f ? 255.0f : (LF[st][k] < 0.0f ? 0.0f : LF[st][k]);
+            if (!png_write_planar_f32(p, tmp.data(), W, H, C)) { cout << "... failed to save png image " << p << endl; return EXIT_FAILURE; }
+        }
+    cout << endl;
+    return EXIT_SUCCESS;
+}
+
+/* compute_psnr(_LF), utilities.cpp:412-435, utilities_LF.cpp:639-692 */
+void psnr_LF(const vector<vector<float> >& A, const vector<vector<float> >& B, const vector<unsigned>& mask, vector<float>& psnr,
+             float& avg_p, float& std_p, vector<float>& rmse, float& avg_r, float& std_r) {
+    const size_t n = mask.size();
+    psnr.assign(n, 0.0f); rmse.assign(n, 0.0f);
+    float cnt = 0, sp = 0, sr = 0;
+    for (size_t st = 0; st < n; st++) {
+        if (!mask[st]) continue;
+        float tmp = 0.0f;
+        for (size_t k = 0; k < A[st].size(); k++) tmp += (A[st][k] - B[st][k]) * (A[st][k] - B[st][k]);
+        rmse[st] = sqrtf(tmp / (float)A[st].size());
+        psnr[st] = 20.0f * log10f(255.0f / rmse[st]);
+        cnt++; sp += psnr[st]; sr += rmse[st];
+    }
+    avg_p = sp / cnt; avg_r = sr / cnt;
+    float vp = 0, vr = 0;
+    for (size_t st = 0; st < n; st++) if (mask[st]) { vp += (psnr[st] - avg_p) * (psnr[st] - avg_p); vr += (rmse[st] - avg_r) * (rmse[st] - avg_r); }
+    std_p = sqrtf(vp / cnt); std_r = sqrtf(vr / cnt);
+}
+
+/* write_psnr_LF, utilities_LF.cpp:782-869 */
+void write_psnr(const char* file, const char* what, const vector<unsigned>& mask, unsigned ang_major, unsigned aw, unsigned ah,
+                const vector<float>& psnr, float avg_p, float std_p, const vector<float>& rmse, float avg_r, float std_r) {
+    ofstream f(file, ios::out | ios::app);
+    if (!f) { cout << "Can't open " << file << endl; return; }
+    f << endl << "******************************************" << endl;
+    f << "-> Average PSNR " << what << " = " << avg_p << endl << "-> Standard deviation PSNR " << what << " = " << std_p << endl;
+    f << "PSNR for all " << what << " SAIs:" << endl;
+    for (unsigned s = 0; s < ah; s++) { for (unsigned t = 0; t < aw; t++) { const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah; if (mask[st]) f << psnr[st] << " "; else f << "No SAI "; } f << endl; }
+    f << endl << "-> Average RMSE " << what << " = " << avg_r << endl << "-> Standard deviation RMSE " << what << " = " << std_r << endl;
+    f << "RMSE for all " << what << " SAIs:" << endl;
+    for (unsigned s = 0; s < ah; s++) { for (unsigned t = 0; t < aw; t++) { const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah; f << rmse[st] << " "; } f << endl; }
+    f << "******************************************" << endl;
+}
+
+/* compute_diff, utilities.cpp:440-468 */
+void diff_LF(const vector<vector<float> >& A, const vector<vector<float> >& B, const vector<unsigned>& mask, vector<vector<float> >& D, float sigma) {
+    const float s = 4.0f * sigma;
+    for (size_t st = 0; st < mask.size(); st++) {
+        if (!mask[st]) continue;
+        D[st].resize(A[st].size());
+        for (size_t k = 0; k < A[st].size(); k++) {
+            const float v = s > 0.0 ? (A[st][k] - B[st][k] + s) * 255.0f / (2.0f * s) : fabsf(A[st][k] - B[st][k]);
+            D[st][k] = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        }
+    }
+}
+
+int tau(const char* s, int which) {
+    if (!strcmp(s, "id")) return LFBM5D_ID;
+    if (!strcmp(s, "dct")) return LFBM5D_DCT;
+    if (which == 2 && !strcmp(s, "bior")) return LFBM5D_BIOR;
+    if (which == 4 && !strcmp(s, "sadct")) return LFBM5D_SADCT;
+    if (which == 5 && !strcmp(s, "hw")) return LFBM5D_HADAMARD;
+    if (which == 5 && !strcmp(s, "haar")) return LFBM5D_HAAR;
+    return -1;
+}
+
+void usage(const char* a0) {
+    cout << "usage: " << a0 << " LFSourceDir|none SAIName sep awidth aheight sIdxStart tIdxStart aswSizeHard aswSizeWien row|col "
+            "sigma lambda LFNoisyDir LFBasicDir LFDenoisedDir LFDiffDir NHard nSimHard nDispHard kHard pHard id|dct|bior id|dct|sadct "
+            "hw|haar|dct useSDHard NWien nSimWien nDispWien kWien pWien id|dct|bior id|dct|sadct hw|haar|dct useSDWien "
+            "rgb|yuv|ycbcr|opp nbThreads resultsFile" << endl;
+}
+
+} // namespace
+
+int main(int argc, char** argv) {
+    cout << "*********************************************************************************************************************" << endl;
+    cout << "********************************************              START               ***************************************" << endl;
+    cout << "*********************************************************************************************************************" << endl;
+    if (argc == 4 && !strcmp(argv[1], "--png-roundtrip")) { /* codec self-check (no GPU): read, rewrite */
+        vector<float> img; size_t w, h, c;
+        if (!png_read_planar_f32(argv[2], img, w, h, c)) { cout << "cannot read " << argv[2] << endl; return EXIT_FAILURE; }
+        if (c == 2) c = 1;
+        if (c == 4) c = 3;
+        return png_write_planar_f32(argv[3], img.data(), w, h, c) ? EXIT_SUCCESS : EXIT_FAILURE;
+    }
+    if (argc < 38) { usage(argv[0]); cout << "Problem while reading parameters from command line !" << endl; return EXIT_FAILURE; }
+    int a = 1;
+    const char* src = argv[a++]; const char* name = argv[a++]; const char* sep_in = argv[a++];
+    const bool gt = strcmp(src, "none") != 0;
+    const char* sep = strcmp(sep_in, "none") ? sep_in : "";
+    if (!strcmp(name, "none")) name = "";
+    const unsigned aw = atoi(argv[a++]), ah = atoi(argv[a++]), s0 = atoi(argv[a++]), t0 = atoi(argv[a++]);
+    const unsigned anH = atoi(argv[a++]), anW = atoi(argv[a++]);
+    const char* maj = argv[a++];
+    const unsigned ang_major = !strcmp(maj, "row") ? LFBM5D_ROWMAJOR : !strcmp(maj, "col") ? LFBM5D_COLMAJOR : 0;
+    const float sigma = (float)atof(argv[a++]), lambda = (float)atof(argv[a++]);
+    const char* d_noisy = argv[a++]; const char* d_basic = argv[a++]; const char* d_den = argv[a++]; const char* d_diff = argv[a++];
+    unsigned N[2], nSim[2], nDisp[2], k[2], p[2], sd[2]; int t2[2], t4[2], t5[2];
+    for (int i = 0; i < 2; i++) {
+        N[i] = atoi(argv[a++]); nSim[i] = atoi(argv[a++]); nDisp[i] = atoi(argv[a++]); k[i] = atoi(argv[a++]); p[i] = atoi(argv[a++]);
+        t2[i] = tau(argv[a++], 2); t4[i] = tau(argv[a++], 4); t5[i] = tau(argv[a++], 5); sd[i] = atoi(argv[a++]);
+        if (t2[i] < 0 || t4[i] < 0 || t5[i] < 0) { cout << "unknown transform name" << endl; usage(argv[0]); return EXIT_FAILURE; }
+    }
+    const char* csn = argv[a++];
+    const int cs = !strcmp(csn, "rgb") ? LFBM5D_RGB : !strcmp(csn, "yuv") ? LFBM5D_YUV : !strcmp(csn, "ycbcr") ? LFBM5D_YCBCR : !strcmp(csn, "opp") ? LFBM5D_OPP : -1;
+    const unsigned nb_threads = atoi(argv[a++]);
+    const char* results = argv[a++];
+    if (!ang_major || cs < 0) { cout << "Problem while reading parameters from command line !" << endl; usage(argv[0]); return EXIT_FAILURE; }
+
+    vector<vector<float> > LF, LF_noisy, LF_basic, LF_den, LF_diff;
+    vector<unsigned> mask;
+    unsigned W = 0, H = 0, C = 0;
+    const unsigned awh = aw * ah;
+    if (gt) {
+        double t = now_s();
+        if (load_LF(src, name, sep, LF, mask, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+        cout << "Loading LF elapsed time = " << now_s() - t << "s." << endl;
+        /* add_noise_LF, utilities_LF.cpp:244-263 + add_noise, utilities.cpp:154-185 */
+        LF_noisy.assign(awh, vector<float>((size_t)W * H * C, 0.0f));
+        cout << endl << "Add noise [sigma = " << sigma << "] ... " << flush;
+        t = now_s();
+        const char* seed = getenv("LFBM5D_SEED");
+        Mt fixed(seed ? strtoul(seed, nullptr, 10) : 0);
+        for (unsigned st = 0; st < awh; st++) {
+            if (!mask[st]) continue;
+            timeval tp; gettimeofday(&tp, nullptr);
+            Mt per(tp.tv_sec * 1000 + tp.tv_usec / 1000 + (unsigned long)getpid());
+            Mt& g = seed ? fixed : per;
+            for (size_t q = 0; q < LF[st].size(); q++) {
+                const double x = g.res53(), y = g.res53();
+                LF_noisy[st][q] = LF[st][q] + (float)((double)sigma * sqrt(-2.0 * log(x)) * cos(2.0 * M_PI * y));
+            }
+        }
+        cout << "done in " << now_s() - t << "s." << endl << endl << "Save noisy light field..." << endl;
+        if (save_LF(d_noisy, name, sep, LF_noisy, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    } else {
+        if (load_LF(d_noisy, name, sep, LF_noisy, mask, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    }
+    LF_basic.assign(awh, vector<float>((size_t)W * H * C, 0.0f));
+    LF_den = LF_basic; LF_diff = LF_basic;
+    vector<float> ps, rm; float ap_n = 0, sp = 0, ar = 0, sr = 0, ap_b = 0;
+    if (gt) {
+        psnr_LF(LF, LF_noisy, mask, ps, ap_n, sp, rm, ar, sr);
+        cout << endl << "Average PSNR:" << endl << "- Noisy light field: " << ap_n << endl;
+        write_psnr(results, "noisy", mask, ang_major, aw, ah, ps, ap_n, sp, rm, ar, sr);
+    }
+    cout << endl << " ---> Running LFBM5D filter <--- " << endl << endl << "Step 1 running..." << endl;
+    const double tb = now_s();
+    double t1 = now_s();
+    if (run_bm5d_1st_step(sigma, lambda, LF_noisy, mask, LF_basic, ang_major, aw, ah, anH, W, H, C, N[0], nSim[0], nDisp[0], k[0], p[0],
+                          sd[0] != 0, t2[0], t4[0], t5[0], cs, nb_threads) != EXIT_SUCCESS) return EXIT_FAILURE;
+    const double step1 = now_s() - t1;
+    cout << endl << "Step 1 done in " << step1 << " secs." << endl << endl;
+    if (gt) {
+        psnr_LF(LF, LF_basic, mask, ps, ap_b, sp, rm, ar, sr);
+        cout << endl << "Average PSNR:" << endl << "- Noisy light field: " << ap_n << endl << "- Basic light field: " << ap_b << endl;
+        write_psnr(results, "basic", mask, ang_major, aw, ah, ps, ap_b, sp, rm, ar, sr);
+        diff_LF(LF, LF_basic, mask, LF_diff, sigma);
+    }
+    cout << endl << "Save basic light field..." << endl;
+    if (save_LF(d_basic, name, sep, LF_basic, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    cout << endl << endl << "Step 2 running..." << endl;
+    t1 = now_s();
+    if (run_bm5d_2nd_step(sigma, LF_noisy, mask, LF_basic, LF_den, ang_major, aw, ah, anW, W, H, C, N[1], nSim[1], nDisp[1], k[1], p[1],
+                          sd[1] != 0, t2[1], t4[1], t5[1], cs, nb_threads) != EXIT_SUCCESS) return EXIT_FAILURE;
+    const double step2 = now_s() - t1;
+    cout << endl << "Step 2 done in " << step2 << " secs." << endl << endl;
+    if (gt) {
+        float ap_d;
+        psnr_LF(LF, LF_den, mask, ps, ap_d, sp, rm, ar, sr);
+        cout << endl << "Average PSNR:" << endl << "- Noisy light field: " << ap_n << endl << "- Basic light field: " << ap_b << endl
+             << "- Denoised light field: " << ap_d << endl << endl;
+        write_psnr(results, "denoised", mask, ang_major, aw, ah, ps, ap_d, sp, rm, ar, sr);
+        diff_LF(LF, LF_den, mask, LF_diff, sigma);
+    }
+    cout << endl << "Save denoised light field..." << endl;
+    if (save_LF(d_den, name, sep, LF_den, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (gt) {
+        cout << endl << "Save diff light field..." << endl;
+        if (save_LF(d_diff, name, sep, LF_diff, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    }
+    cout << "Total LFBM5D computing time = " << step1 + step2 << "s." << endl;
+    cout << "Total elapsed time = " << now_s() - tb << "s." << endl << endl;
+    cout << "*********************************************************************************************************************" << endl;
+    cout << "********************************************         THIS IS THE END          ***************************************" << endl;
+    cout << "*********************************************************************************************************************" << endl;
+    return EXIT_SUCCESS;
+}

@@ -1,0 +1,112 @@
+/*
+ * run_bm5d.cpp -- the reference's outer seam (src/bm5d.h:11-62) on top of the C-ABI.
+ * Host side only: flattens the vector-of-vectors light field, calls lfbm5d_step{1,2}_host
+ * (which stages through HBM and runs every kernel on the GPU), copies the results back.
+ * Error behaviour follows the reference: message on stdout, EXIT_FAILURE.
+ */
+#include "run_bm5d.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "../../include/lfbm5d.h"
+
+namespace {
+
+lfbm5d_ctx* context() {
+    static lfbm5d_ctx* ctx = nullptr;
+    if (!ctx) {
+        const char* dev = std::getenv("LFBM5D_DEVICE");
+        if (lfbm5d_create(&ctx, dev ? std::atoi(dev) : 0) != 0) {
+            std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(nullptr) << std::endl;
+            ctx = nullptr;
+        }
+    }
+    return ctx;
+}
+
+void flatten(const std::vector<std::vector<float> >& LF, const std::vector<unsigned>& mask, size_t img,
+             std::vector<float>& flat) {
+    flat.assign(LF.size() * img, 0.0f);
+    for (size_t st = 0; st < LF.size(); st++)
+        if (mask[st] && LF[st].size() == img) std::memcpy(&flat[st * img], LF[st].data(), img * sizeof(float));
+}
+void unflatten(std::vector<std::vector<float> >& LF, const std::vector<unsigned>& mask, size_t img,
+               const std::vector<float>& flat) {
+    for (size_t st = 0; st < LF.size(); st++) {
+        if (!mask[st]) continue;
+        if (LF[st].size() != img) LF[st].resize(img);
+        std::memcpy(LF[st].data(), &flat[st * img], img * sizeof(float));
+    }
+}
+
+lfbm5d_params make(float sigma, float lambda, unsigned N, unsigned nSim, unsigned nDisp, unsigned k, unsigned p,
+                   bool useSD, unsigned t2, unsigned t4, unsigned t5, unsigned cs) {
+    lfbm5d_params P;
+    P.sigma = sigma; P.lambda = lambda; P.N = N; P.nSim = nSim; P.nDisp = nDisp; P.k = k; P.p = p;
+    P.useSD = useSD ? 1u : 0u; P.tau_2D = t2; P.tau_4D = t4; P.tau_5D = t5; P.color_space = cs;
+    return P;
+}
+
+} // namespace
+
+int run_bm5d_1st_step(const float sigma, const float lambdaHard5D, std::vector<std::vector<float> >& LF_noisy,
+                      std::vector<unsigned>& LF_SAI_mask, std::vector<std::vector<float> >& LF_basic,
+                      const unsigned ang_major, const unsigned awidth, const unsigned aheight, const unsigned anHard,
+                      const unsigned width, const unsigned height, const unsigned chnls, const unsigned NHard,
+                      const unsigned nSim, const unsigned nDisp, const unsigned kHard, const unsigned pHard,
+                      const bool useSD, const unsigned tau_2D, unsigned tau_4D, const unsigned tau_5D,
+                      const unsigned color_space, const unsigned /*nb_threads*/) {
+    const unsigned asize = awidth * aheight;
+    if (LF_noisy.size() != asize || LF_SAI_mask.size() != asize) {
+        std::cout << "run_bm5d_1st_step: light field and mask must hold awidth*aheight SAIs" << std::endl;
+        return EXIT_FAILURE;
+    }
+    lfbm5d_ctx* ctx = context();
+    if (!ctx) return EXIT_FAILURE;
+    if (LF_basic.size() != asize) LF_basic.resize(asize); /* bm5d.cpp:129-130 */
+    const size_t img = (size_t)width * height * chnls;
+    std::vector<float> noisy, basic(asize * img, 0.0f);
+    flatten(LF_noisy, LF_SAI_mask, img, noisy);
+    const lfbm5d_params P = make(sigma, lambdaHard5D, NHard, nSim, nDisp, kHard, pHard, useSD, tau_2D, tau_4D, tau_5D, color_space);
+    if (lfbm5d_step1_host(ctx, &P, noisy.data(), LF_SAI_mask.data(), basic.data(), ang_major, awidth, aheight, anHard,
+                          width, height, chnls) != 0) {
+        std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
+        return EXIT_FAILURE;
+    }
+    unflatten(LF_noisy, LF_SAI_mask, img, noisy);
+    unflatten(LF_basic, LF_SAI_mask, img, basic);
+    return EXIT_SUCCESS;
+}
+
+int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_noisy, std::vector<unsigned>& LF_SAI_mask,
+                      std::vector<std::vector<float> >& LF_basic, std::vector<std::vector<float> >& LF_denoised,
+                      const unsigned ang_major, const unsigned awidth, const unsigned aheight, const unsigned anWien,
+                      const unsigned width, const unsigned height, const unsigned chnls, const unsigned NWien,
+                      const unsigned nSim, const unsigned nDisp, const unsigned kWien, const unsigned pWien,
+                      const bool useSD, const unsigned tau_2D, unsigned tau_4D, const unsigned tau_5D,
+                      const unsigned color_space, const unsigned /*nb_threads*/) {
+    const unsigned asize = awidth * aheight;
+    if (LF_noisy.size() != asize || LF_basic.size() != asize || LF_SAI_mask.size() != asize) {
+        std::cout << "run_bm5d_2nd_step: light fields and mask must hold awidth*aheight SAIs" << std::endl;
+        return EXIT_FAILURE;
+    }
+    lfbm5d_ctx* ctx = context();
+    if (!ctx) return EXIT_FAILURE;
+    if (LF_denoised.size() != asize) LF_denoised.resize(asize); /* bm5d.cpp:823-824 */
+    const size_t img = (size_t)width * height * chnls;
+    std::vector<float> noisy, basic, den(asize * img, 0.0f);
+    flatten(LF_noisy, LF_SAI_mask, img, noisy);
+    flatten(LF_basic, LF_SAI_mask, img, basic);
+    const lfbm5d_params P = make(sigma, 0.0f, NWien, nSim, nDisp, kWien, pWien, useSD, tau_2D, tau_4D, tau_5D, color_space);
+    if (lfbm5d_step2_host(ctx, &P, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), ang_major, awidth, aheight,
+                          anWien, width, height, chnls) != 0) {
+        std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
+        return EXIT_FAILURE;
+    }
+    unflatten(LF_noisy, LF_SAI_mask, img, noisy);
+    unflatten(LF_basic, LF_SAI_mask, img, basic);
+    unflatten(LF_denoised, LF_SAI_mask, img, den);
+    return EXIT_SUCCESS;
+}

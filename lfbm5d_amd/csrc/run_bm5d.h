@@ -1,0 +1,69 @@
+/*
+ * run_bm5d.h -- drop-in declarations with the reference's exact signatures
+ * (V-Sense/LFBM5D src/bm5d.h:11-35 and :38-62).  A program written against the reference's bm5d.h
+ * links against liblfbm5d_dropin.so instead of the reference's bm5d.cpp / bm5d_core_processing.cpp
+ * and runs the whole path on the GPU through the C-ABI of include/lfbm5d.h.
+ */
+#ifndef LFBM5D_RUN_BM5D_H
+#define LFBM5D_RUN_BM5D_H
+
+#include <vector>
+
+//! Main function (hard-thresholding step) -- same argument list as the reference.  LF_noisy is
+//! colour-transformed and transformed back in place (lossy for OPP, like the reference),
+//! LF_basic is (re)sized and filled.  nb_threads is accepted for source compatibility; the GPU path
+//! always has the semantics of nb_threads == 1 (no tile-halo discard).
+int run_bm5d_1st_step(
+    const float sigma
+,   const float lambdaHard5D
+,   std::vector<std::vector<float> > &LF_noisy
+,   std::vector<unsigned> &LF_SAI_mask
+,   std::vector<std::vector<float> > &LF_basic
+,   const unsigned ang_major
+,   const unsigned awidth
+,   const unsigned aheight
+,   const unsigned anHard
+,   const unsigned width
+,   const unsigned height
+,   const unsigned chnls
+,   const unsigned NHard
+,   const unsigned nSim
+,   const unsigned nDisp
+,   const unsigned kHard
+,   const unsigned pHard
+,   const bool     useSD
+,   const unsigned tau_2D
+,         unsigned tau_4D
+,   const unsigned tau_5D
+,   const unsigned color_space
+,   const unsigned nb_threads
+);
+
+//! Main function (Wiener step)
+int run_bm5d_2nd_step(
+    const float sigma
+,   std::vector<std::vector<float> > &LF_noisy
+,   std::vector<unsigned> &LF_SAI_mask
+,   std::vector<std::vector<float> > &LF_basic
+,   std::vector<std::vector<float> > &LF_denoised
+,   const unsigned ang_major
+,   const unsigned awidth
+,   const unsigned aheight
+,   const unsigned anWien
+,   const unsigned width
+,   const unsigned height
+,   const unsigned chnls
+,   const unsigned NWien
+,   const unsigned nSim
+,   const unsigned nDisp
+,   const unsigned kWien
+,   const unsigned pWien
+,   const bool     useSD
+,   const unsigned tau_2D
+,         unsigned tau_4D
+,   const unsigned tau_5D
+,   const unsigned color_space
+,   const unsigned nb_threads
+);
+
+#endif

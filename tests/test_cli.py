@@ -1,0 +1,61 @@
+"""The drop-in command line: PNG codec self-check on CPU, the README test command on the GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "lfbm5d_amd", "LFBM5Ddenoising")
+
+
+def write_source_lf(tmp):
+    from PIL import Image
+    lf = np.load(os.path.join(ROOT, "tests", "golden", "sourceLF_3x3_256_u8.npy"))
+    src = os.path.join(tmp, "sourceLF")
+    os.makedirs(src)
+    for s in range(3):
+        for t in range(3):
+            Image.fromarray(lf[s * 3 + t].transpose(1, 2, 0)).save(f"{src}/SAI_{s + 1:02d}_{t + 1:02d}.png")
+    return src, lf
+
+
+def test_png_codec_round_trip(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for shape, mode in (((37, 53, 3), "RGB"), ((20, 31), "L"), ((16, 16, 4), "RGBA")):
+        a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+        src, dst = str(tmp_path / f"in_{mode}.png"), str(tmp_path / f"out_{mode}.png")
+        Image.fromarray(a, mode).save(src)   # PIL picks per-row filters: exercises all unfilter paths
+        subprocess.check_call([CLI, "--png-roundtrip", src, dst], stdout=subprocess.DEVNULL)
+        b = np.asarray(Image.open(dst))
+        assert np.array_equal(b, a[..., :3] if mode == "RGBA" else a)
+
+
+def test_usage_on_missing_arguments():
+    r = subprocess.run([CLI, "a", "b"], capture_output=True, text=True)
+    assert r.returncode != 0 and "usage:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_readme_command_matches_oracle(tmp_path):
+    """README.md:50 test command with LFBM5D_SEED=1: same noise as the oracle harness, PSNR report
+    within the north-star tolerance of the oracle's (and of the reference-run numbers of SURVEY 6)."""
+    tmp = str(tmp_path)
+    src, lf = write_source_lf(tmp)
+    for d in ("noisy", "basic", "denoised", "diff"):
+        os.makedirs(os.path.join(tmp, d))
+    res = os.path.join(tmp, "measures.txt")
+    args = [CLI, src, "SAI", "_", "3", "3", "1", "1", "1", "1", "row", "25", "2.7", f"{tmp}/noisy", f"{tmp}/basic",
+            f"{tmp}/denoised", f"{tmp}/diff", "8", "18", "6", "16", "4", "id", "sadct", "haar", "0", "16", "18", "6", "8", "4",
+            "dct", "sadct", "haar", "0", "opp", "0", res]
+    out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, LFBM5D_SEED="1"))
+    assert out.returncode == 0, out.stdout[-2000:]
+    txt = open(res).read()
+    vals = {k: float(txt.split(f"-> Average PSNR {k} = ")[1].split()[0]) for k in ("noisy", "basic", "denoised")}
+    assert abs(vals["noisy"] - 20.1672) < 1e-3
+    assert abs(vals["basic"] - 34.2073) < 0.01 and abs(vals["denoised"] - 35.7082) < 0.01
+    from PIL import Image
+    im = np.asarray(Image.open(f"{tmp}/denoised/SAI_02_02.png")).astype(np.float32).transpose(2, 0, 1)
+    mse = ((im - lf[4].astype(np.float32)) ** 2).mean()
+    assert 20 * np.log10(255 / np.sqrt(mse)) > 36.0
