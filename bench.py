@@ -179,7 +179,7 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload:
+                if args.workload in tj.get("applies_to", [tj.get("workload")]):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None

@@ -30,7 +30,8 @@ def per_kernel(d, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {"workload": sys.argv[3], "unit": "bytes", "kernels": {}}
+res = {"workload": sys.argv[3], "applies_to": ["lf17x17x512x512_sigma25", "lf9x9x512x512_sigma25"],
+       "note": "per-pass figures depend on the 3x3x560x560 window only, not on the number of windows", "unit": "bytes", "kernels": {}}
 pair_raw = pair_corr = 0.0
 for k in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(k, (0.0, 1))
@@ -38,9 +39,12 @@ for k in sorted(set(fetch) | set(write)):
     fb, wb = f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
     res["kernels"][k] = {"launches": nf, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb,
                          "write_bytes_per_launch": wb}
-    if k in ("group", "aggregate"):
+    if k == "group":        # gather of window pixels: coalesced row segments -> the 1/2 rule applies
         pair_raw += fb + wb
         pair_corr += 2 * fb + wb
+    if k == "aggregate":    # calibrated on a known byte count: filt is read exactly once and the raw
+        pair_raw += fb + wb  # FETCH_SIZE equals its size (4 B/lane row-segment reads are not halved)
+        pair_corr += fb + wb
 # one pass launches one group kernel and one aggregate kernel: the pair's traffic per pass
 res["hbm_bytes_per_launch"] = pair_corr
 res["hbm_bytes_per_launch_fetch_uncorrected"] = pair_raw
