@@ -55,7 +55,7 @@ struct lfbm5d_ctx {
     ncclComm_t comm = nullptr;
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
-    DevBuf est, refs, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, counters, tb, small;
+    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, counters, tb, small;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
@@ -229,6 +229,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         c->last_refs_host.resize(rows.size() * cols.size());
         for (size_t i = 0; i < rows.size(); i++)
             for (size_t j = 0; j < cols.size(); j++) c->last_refs_host[i * cols.size() + j] = rows[i] * Wb + cols[j];
+        std::vector<int> rslot(Hb + 64, -1);   /* 64 slots of padding: the scan reads rslot[y + di] unclamped */
+        for (size_t i = 0; i < rows.size(); i++) rslot[rows[i]] = (int)i;
+        HIPCK(c, c->rslot.reserve(rslot.size() * sizeof(int)));
+        HIPCK(c, hipMemcpyAsync(c->rslot.p, rslot.data(), rslot.size() * sizeof(int), hipMemcpyHostToDevice, s));
         HIPCK(c, c->refs.reserve(c->last_refs_host.size() * sizeof(unsigned)));
         HIPCK(c, hipMemcpyAsync(c->refs.p, c->last_refs_host.data(), c->last_refs_host.size() * sizeof(unsigned), hipMemcpyHostToDevice, s));
         HIPCK(c, hipStreamSynchronize(s));
@@ -279,32 +283,26 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     }
 
     HIPCK(c, hipEventRecord(pe.e[0], s));
-    /* block matching (core:209-236) */
+    /* block matching (core:209-236): all distance tables in one launch, then the two selections */
     ScanArgs sa;
     std::memset(&sa, 0, sizeof(sa));
-    sa.est = c->est.as<float>(); sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst; sa.two_thr = 2 * thr;
-    { const char* dbg = getenv("LFBM5D_SCAN_DEBUG"); sa.debug = dbg ? (unsigned)atoi(dbg) : 0u; }
-    sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p; sa.nHW = nHW;
-    if (N > 1) {
-        HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
-        sa.stereo = 0; sa.b = nHW; sa.trim = 0; sa.half = P->nSim;
-        sa.refmap = c->refmap.as<int>(); sa.scores = c->scores.as<float>();
-        sa.n_tables = (P->nSim + 1) * NsS;
-        HIPCK(c, launch_bm_scan(s, sa));
+    sa.est = c->est.as<float>(); sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
+    sa.nSim = P->nSim; sa.nDisp = P->nDisp; sa.nHW = nHW;
+    sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p;
+    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = c->rslot.as<int>(); sa.scores_bytes = (unsigned)std::min<size_t>((size_t)R * NsS * NsS * sizeof(float), 0x7fffffffu);
+    sa.n_self = N > 1 ? (P->nSim + 1) * NsS : 0;
+    sa.n_stereo = n_slots * NsD * NsD;
+    for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
+    if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
+    HIPCK(c, launch_bm_scan(s, sa));
+    if (N > 1)
         HIPCK(c, launch_self_select(s, c->scores.as<float>(), c->refs.as<unsigned>(), R, Wb, P->nSim, N, thr,
                                     c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
-    } else {
+    else
         HIPCK(c, launch_self_trivial(s, c->refs.as<unsigned>(), R, c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
-    }
-    if (n_slots) {
-        sa.stereo = 1; sa.b = P->nDisp; sa.trim = k - 1; sa.half = P->nDisp;
-        sa.tables = c->tables.as<float>();
-        for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
-        sa.n_tables = n_slots * NsD * NsD;
-        HIPCK(c, launch_bm_scan(s, sa));
+    if (n_slots)
         HIPCK(c, launch_stereo_argmin(s, c->tables.as<float>(), slots, n_slots, Wb, Hb, k, P->nDisp, thr,
                                       c->best.as<unsigned>(), c->shape.as<unsigned char>()));
-    }
     HIPCK(c, hipEventRecord(pe.e[1], s));
 
     /* shard of reference-patch rows owned by this rank */
@@ -573,7 +571,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
-    DevBuf* bufs[] = {&c->est, &c->refs, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
+    DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
                       &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->counters, &c->tb, &c->small, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out};
     for (DevBuf* b : bufs) b->release();

@@ -61,41 +61,57 @@ __device__ __forceinline__ int grid_index(int v, int n, int last, int nHW, int p
  */
 template <int K>
 __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
-    constexpr int T = 8, RR = 96, CW = 64 + K;
+    /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows.  Sized so that five waves fit a CU
+     * at 560-wide windows (32 KiB each): the launch then takes two rounds of resident waves, not three */
+    constexpr int T = K >= 12 ? 4 : 8, RR = 64 + K + 2 * T, CW = 64 + K;
     extern __shared__ float lds[];
     float* ring = lds;              /* [RR][CW] D rows of the current strip; ring col 0 <-> x = cb-1 */
     float* lcol = lds + RR * CW;    /* [nrows] column left of the current strip (strip 0: first column) */
     const int lane = threadIdx.x;
-    const int W = a.W, H = a.H, b = a.b;
-    const int Ns = 2 * (int)a.half + 1;
+    /* one launch covers both searches: blocks [0, n_self) are self-similarity tables, the rest
+     * disparity tables (fewer, fuller rounds of resident waves than two launches) */
+    const bool stereo = blockIdx.x >= a.n_self;
+    const int bid = stereo ? (int)(blockIdx.x - a.n_self) : (int)blockIdx.x;
+    const int half = stereo ? (int)a.nDisp : (int)a.nSim;
+    const int trim = stereo ? (int)a.k - 1 : 0;
+    const int W = a.W, H = a.H, b = stereo ? (int)a.nDisp : (int)a.nHW;
+    const int Ns = 2 * half + 1;
     const int ncand = Ns * Ns;
-    const int nrows = H - 2 * b - (int)a.trim, ncols = W - 2 * b - (int)a.trim;
+    const int nrows = H - 2 * b - trim, ncols = W - 2 * b - trim;
 
     int di, dj;
     DiffImg D;
     const size_t WH = (size_t)W * H;
-    if (a.stereo) {
-        const int slot = blockIdx.x / ncand, ddk = blockIdx.x % ncand;
+    if (stereo) {
+        const int slot = bid / ncand, ddk = bid % ncand;
         di = ddk / Ns; dj = ddk % Ns;
         D.i1 = a.est + (size_t)a.pst * WH;
         D.i2 = a.est + (size_t)a.st_of_slot[slot] * WH;
-        D.dk = di * W + dj - (int)a.half * (1 + W);
+        D.dk = di * W + dj - half * (1 + W);
     } else {
-        di = blockIdx.x / Ns; dj = blockIdx.x % Ns;
+        di = bid / Ns; dj = bid % Ns;
         D.i1 = D.i2 = a.est + (size_t)a.pst * WH;
-        D.dk = di * W + dj - (int)a.half;
+        D.dk = di * W + dj - half;
     }
     D.W = W; D.H = H; D.b = b;
-    float* table = a.stereo ? a.tables + (size_t)blockIdx.x * WH : nullptr;
-    const int djs = dj - (int)a.half;
-    const int nSim = (int)a.half;
+    float* table = stereo ? a.tables + (size_t)bid * WH : nullptr;
+    const int djs = dj - half;
+    const int nSim = half;
     const int ord_fwd = dj * Ns + di;
     const int ord_bwd = (-djs + nSim) * Ns + (nSim + 1) + (nSim - di);
+    /* buffer resources: 32-bit offsets (scalar row base + per-lane column offset) instead of 64-bit
+     * flat addressing, and stores that are dropped by setting the lane offset out of range */
+    const unsigned kRsrcFlags = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)D.i1, 0, (int)(WH * 4 + 1024), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(D.i2 + D.dk), 0, (int)(WH * 4 + 1024), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)(WH * 4), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (int)a.scores_bytes, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.rslot, 0, (int)((H + 64) * 4), kRsrcFlags);
     const int gR = a.n_ref_rows, gC = a.n_ref_cols, gP = a.p, gN = a.nHW;
     const int lastR = H - (int)a.k - gN, lastC = W - (int)a.k - gN;
 
     auto emit = [&](int y, int x, float S) {
-        if (a.stereo) { table[y * W + x] = S; return; }
+        if (stereo) { table[y * W + x] = S; return; }
         /* forward candidate of the reference patch at (y,x) (core:3410-3413) */
         const int cx = grid_index(x, gC, lastC, gN, gP);
         if (cx >= 0) {
@@ -139,23 +155,11 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
     }
     __syncthreads();
 
-    /* reference-grid row slots of every table row (self mode): y and y + di; 64 entries of front
-     * padding and T+1 of back padding (-1) so the skewed lanes can index them without clamping */
-    int* ridx1 = reinterpret_cast<int*>(lcol + nrows + T + 1) + 64;
-    int* ridx2 = ridx1 + nrows + T + 1 + 64;
-    if (!a.stereo)
-        for (int i = lane - 64; i < nrows + T + 1; i += 64) {
-            const bool in = i >= 0 && i < nrows;
-            ridx1[i] = in ? grid_index(b + i, gR, lastR, gN, gP) : -1;
-            ridx2[i] = (in && di > 0) ? grid_index(b + i + di, gR, lastR, gN, gP) : -1;
-        }
     for (int i = nrows + lane; i < nrows + T + 1; i += 64) lcol[i] = 0.0f;
     __syncthreads();
 
     float row0_left = corner; /* S[b][cb-1] */
-    const int nstrips = (a.debug & 8) ? 0 : (ncols + 63) / 64;
-    const float* i1 = D.i1;
-    const float* i2 = D.i2 + D.dk;
+    const int nstrips = (ncols + 63) / 64;
     for (int strip = 0; strip < nstrips; strip++) {
         const int cb = b + 64 * strip;
         const int x = cb + lane;
@@ -163,11 +167,8 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
         const int last_lane = min(63, ncols - 1 - 64 * strip);
         const bool first_col = strip == 0 && lane == 0;
         /* column slots of this lane: constant over the strip */
-        const int cx = a.stereo ? -1 : grid_index(x, gC, lastC, gN, gP);
-        const int cx2 = (a.stereo || di == 0) ? -1 : grid_index(x + djs, gC, lastC, gN, gP);
-        float* sc1 = a.stereo ? nullptr : a.scores + (size_t)(cx < 0 ? 0 : cx) * ncand + ord_fwd;
-        float* sc2 = a.stereo ? nullptr : a.scores + (size_t)(cx2 < 0 ? 0 : cx2) * ncand + ord_bwd;
-        const size_t rstride = (size_t)gC * ncand;
+        const int cx = stereo ? -1 : grid_index(x, gC, lastC, gN, gP);
+        const int cx2 = (stereo || di == 0) ? -1 : grid_index(x + djs, gC, lastC, gN, gP);
 
         /* D-row loads of the strip: ring column 0 <-> x = cb-1; columns are clamped into the row
          * (loads stay inside the plane, est has slack) and out-of-band entries zeroed afterwards */
@@ -175,31 +176,34 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
         const int xm = min(max(xm0, b), W - 1), xe = min(cb + 63 + lane, W - 1);
         const bool inm = xm0 >= b && xm0 < W - b;
         const bool ine = lane < K && cb + 63 + lane < W - b;
+        const int vm = xm * 4, ve = xe * 4;                 /* per-lane byte offsets inside a row */
         auto load_row = [&](int R, float& m1, float& m2, float& e1, float& e2) {
-            const int yy = b + R;            /* uniform */
-            m1 = m2 = e1 = e2 = 0.0f;
-            if (yy < H - b && !(a.debug & 1)) {
-                const float* p1 = i1 + (size_t)yy * W;
-                const float* p2 = i2 + (size_t)yy * W;
-                m1 = p1[xm]; m2 = p2[xm];
-                if (lane < K) { e1 = p1[xe]; e2 = p2[xe]; }
-            }
+            const int yy = min(b + R, H - b - 1);        /* uniform; rows past the band are zeroed in store_row */
+            const int so = yy * W * 4;
+            m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vm, so, 0));
+            m2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vm, so, 0));
+            e1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ve, so, 0));
+            e2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, ve, so, 0));
         };
         auto store_row = [&](int R, float m1, float m2, float e1, float e2) {
             float* rr = ring + (R % RR) * CW;   /* uniform */
+            const bool rin = b + R < H - b;     /* uniform */
             const float dm = m2 - m1, de = e2 - e1;
-            rr[lane] = inm ? dm * dm : 0.0f;
-            if (lane < K) rr[64 + lane] = ine ? de * de : 0.0f;
+            rr[lane] = (rin && inm) ? dm * dm : 0.0f;
+            if (lane < K) rr[64 + lane] = (rin && ine) ? de * de : 0.0f;
         };
-        int filled = 0;
         for (int R0 = 0; R0 < K + T; R0 += T) {
             float m1[T], m2[T], e1[T], e2[T];
 #pragma unroll
             for (int s = 0; s < T; s++) load_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
 #pragma unroll
             for (int s = 0; s < T; s++) store_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
-            filled += T;
         }
+        /* rows K+T .. K+2T-1 wait in registers: loads run one chunk ahead of the ring writes */
+        float p1[T], p2[T], q1[T], q2[T];
+#pragma unroll
+        for (int s = 0; s < T; s++) load_row(K + T + s, p1[s], p2[s], q1[s], q2[s]);
+        int filled = K + T;   /* rows [0, filled) are in the ring; the next T rows wait in p1..q2 */
         __syncthreads();
 
         /* first row of the strip (core:3354-3362): chain across the lanes */
@@ -229,10 +233,10 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
         /* per-lane constants of the skewed LDS addressing: ring row (u - lane) mod RR, column lane */
         const int offA0 = lane - lane * CW, offA1 = offA0 + RR * CW;
         const int xoff = x - lane * W;
-        for (int t0 = 0; t0 < ((a.debug & 4) ? 0 : nsteps); t0 += T) {
+        for (int t0 = 0; t0 < nsteps; t0 += T) {
             float m1[T], m2[T], e1[T], e2[T];
 #pragma unroll
-            for (int s = 0; s < T; s++) load_row(filled + s, m1[s], m2[s], e1[s], e2[s]);
+            for (int s = 0; s < T; s++) load_row(filled + T + s, m1[s], m2[s], e1[s], e2[s]);
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
             int r1[T], r2[T];
             int uA = (t0 + K) % RR, uB = t0 % RR;       /* uniform */
@@ -245,7 +249,12 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 uA = uA + 1 == RR ? 0 : uA + 1;
                 uB = uB + 1 == RR ? 0 : uB + 1;
                 lc[s] = lcol[min(1 + t0 + s, nrows + T)];   /* uniform address: lane 0's left neighbour */
-                if (!a.stereo) { r1[s] = ridx1[1 + t0 + s - lane]; r2[s] = ridx2[1 + t0 + s - lane]; }
+                r1[s] = -1; r2[s] = -1;
+                if (!stereo) {   /* uniform */
+                    const int vy = max(b + 1 + t0 + s - lane, 0) * 4;
+                    r1[s] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, 0, 0);
+                    r2[s] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, di * 4, 0);   /* table has 64 slots of -1 padding */
+                }
             }
 #pragma unroll
             for (int s = 0; s < T; s++) {
@@ -271,19 +280,24 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 const int t = t0 + s;
                 const int lo = t + 2 - nrows, hi = min(t, last_lane);
                 const bool act = lane >= lo && lane <= hi;
-                if (a.stereo) {
-                    float* trow = table + (size_t)(b + 1 + t) * W;                /* uniform */
-                    if (act && !(a.debug & 2)) trow[xoff] = Sout[s];
-                } else if (act) {
-                    if (cx >= 0 && r1[s] >= 0) sc1[(size_t)r1[s] * rstride] = Sout[s];
-                    if (cx2 >= 0 && r2[s] >= 0) sc2[(size_t)r2[s] * rstride] = Sout[s];
+                if (stereo) {   /* uniform */
+                    const int vo = act ? ((b + 1 + t) * W + xoff) * 4 : -1;       /* -1: out of range, store dropped */
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, vo, 0, 0);
+                } else {
+                    const int v1 = (act && cx >= 0 && r1[s] >= 0) ? (int)(((unsigned)(r1[s] * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
+                    const int v2 = (act && cx2 >= 0 && r2[s] >= 0 && di > 0) ? (int)(((unsigned)(r2[s] * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
                 }
                 const int il = 1 + t - last_lane;                                 /* uniform */
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
-                if (il >= 1 && il < nrows && lane == 0) lcol[il] = hv;            /* hand-off column for the next strip */
+                lcol[(il >= 1 && il < nrows) ? il : nrows + T] = hv;   /* hand-off column for the next strip (uniform; dump slot otherwise) */
             }
 #pragma unroll
-            for (int s = 0; s < T; s++) store_row(filled + s, m1[s], m2[s], e1[s], e2[s]);
+            for (int s = 0; s < T; s++) {
+                store_row(filled + s, p1[s], p2[s], q1[s], q2[s]);
+                p1[s] = m1[s]; p2[s] = m2[s]; q1[s] = e1[s]; q2[s] = e2[s];
+            }
             filled += T;
         }
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
@@ -402,12 +416,16 @@ hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, i
 }
 
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
-    const unsigned nrows = a.H - 2 * a.b - a.trim;
-    const size_t lds = (size_t)(96 * (64 + a.k) + 3 * (nrows + 9) + 2 * 64) * sizeof(float);
+    const unsigned rows_self = a.n_self ? a.H - 2 * a.nHW : 0, rows_st = a.n_stereo ? a.H - 2 * a.nDisp - (a.k - 1) : 0;
+    const unsigned nrows = rows_self > rows_st ? rows_self : rows_st;
+    const unsigned T = a.k >= 12 ? 4 : 8;
+    const size_t lds = (size_t)((64 + a.k + 2 * T) * (64 + a.k) + nrows + T + 1) * sizeof(float);
+    const unsigned n = a.n_self + a.n_stereo;
+    if (!n) return hipSuccess;
     switch (a.k) {
-        case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(a.n_tables), dim3(64), lds, s, a); break;
-        case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(a.n_tables), dim3(64), lds, s, a); break;
-        case 16: hipLaunchKernelGGL(k_bm_scan<16>, dim3(a.n_tables), dim3(64), lds, s, a); break;
+        case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(n), dim3(64), lds, s, a); break;
+        case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(n), dim3(64), lds, s, a); break;
+        case 16: hipLaunchKernelGGL(k_bm_scan<16>, dim3(n), dim3(64), lds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

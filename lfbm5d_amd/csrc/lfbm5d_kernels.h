@@ -79,21 +79,20 @@ struct AggArgs {
 };
 
 struct ScanArgs {
-    const float* est;           /* [A][Wb*Hb] channel-0 estimates */
-    unsigned W, H, k, b, trim;
-    unsigned half;              /* nSim (self) or nDisp (stereo) */
-    int stereo;                 /* 0: self similarity, 1: disparity */
+    const float* est;           /* [A][Wb*Hb] channel-0 estimates (+ slack) */
+    unsigned W, H, k;
+    unsigned nSim, nDisp, nHW;  /* self search: band nHW, half window nSim; disparity: band and half window nDisp */
     unsigned pst;
-    float two_thr;
+    unsigned n_self;            /* (nSim+1)*(2nSim+1) self tables (0 when N == 1) */
+    unsigned n_stereo;          /* n_slots * (2nDisp+1)^2 disparity tables */
     /* self: the regular reference grid (centre pass) */
-    unsigned n_ref_rows, n_ref_cols, p, nHW;
-    const int* refmap;          /* unused by the grid path; kept for the irregular (subset) path */
+    unsigned n_ref_rows, n_ref_cols, p;
+    const int* rslot;           /* [H] reference-grid row slot of each image row, -1 off the grid */
     float* scores;              /* [R][Ns*Ns], pre-filled with 2*threshold */
+    unsigned scores_bytes;
     /* stereo */
     float* tables;              /* [n_slots][Ns*Ns][W*H] */
     unsigned st_of_slot[kMaxA];
-    unsigned n_tables;          /* grid size */
-    unsigned debug;             /* timing experiments only (LFBM5D_SCAN_DEBUG); 0 in production */
 };
 
 hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward);
