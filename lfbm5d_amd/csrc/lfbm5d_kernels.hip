@@ -830,27 +830,31 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
 
 /* ================================ aggregation kernel ====================================== */
 
-constexpr int kTile = 16;
+constexpr int kTile = 8;
 
-/* Gather form of core:484-528.  Block = one kTile x kTile pixel tile of one SAI; candidates are the
- * patch instances (reference patch in raster order, then match index n) of the reference patches
- * whose search range can reach the tile; every pixel adds its contributions in that order, which
- * is the reference's order for that pixel, starting from the value already in num/den. */
-__global__ __launch_bounds__(kTile * kTile) void k_aggregate(AggArgs a) {
-    __shared__ unsigned hit_pk[256];   /* (py << 16) | px */
-    __shared__ unsigned hit_base[256]; /* offset of the patch in filt */
-    __shared__ unsigned hit_w[256];    /* offset of the group's weights */
-    __shared__ unsigned wave_cnt[4];
-    const int tid = threadIdx.x;
+/* Gather form of core:484-528.  One wavefront = one 8x8 pixel tile of one SAI (thread = pixel).
+ * Candidates are the patch instances (reference patch in raster order, then match index n) of the
+ * reference patches whose search range can reach the tile; every pixel adds its contributions in
+ * that order -- the reference's order for that pixel -- starting from the value already in num/den.
+ * Everything is wave-synchronous: hits of a 64-candidate chunk are compacted in order with a ballot
+ * into LDS (position, patch offset, the group's three weights), then consumed by all lanes. */
+__global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
+    __shared__ unsigned hit_pk[64];    /* (py << 16) | px */
+    __shared__ unsigned hit_base[64];  /* offset of the patch in filt */
+    __shared__ float hit_w[64][3];     /* the group's aggregation weights */
+    __shared__ float kai[kMaxK * kMaxK];
+    const int lane = threadIdx.x;
     const int st = blockIdx.z;
     if ((a.proc_bits >> st) & 1) return;      /* procSAI[st] != 0: skipped (core:486) */
     if (!((a.mask_bits >> st) & 1)) return;
     const int tx0 = blockIdx.x * kTile, ty0 = blockIdx.y * kTile;
-    const int x = tx0 + tid % kTile, y = ty0 + tid / kTile;
+    const int x = tx0 + lane % kTile, y = ty0 + lane / kTile;
     const bool inside = x < (int)a.Wb && y < (int)a.Hb;
     const int k = a.k, k2 = k * k, C = a.C, N = a.N, A = a.A;
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int reach = (st == (int)a.pst) ? (int)a.nSim : (int)a.nHW;
+    const bool windowed = k == 8 || k == 12;  /* any other size: all-ones window (bm3d.cpp:1144-1146) */
+    if (windowed) for (int i = lane; i < k2; i += 64) kai[i] = a.tb->kaiser[i];
 
     /* reference-grid index ranges that can reach this tile (grid = nHW + i*p, plus a forced last
      * index, utilities.cpp:697-712) */
@@ -867,81 +871,75 @@ __global__ __launch_bounds__(kTile * kTile) void k_aggregate(AggArgs a) {
     if (c_lo > (int)a.n_ref_cols - 1) c_lo = (int)a.n_ref_cols - 1;
 
     float accn[3] = {0, 0, 0}, accd[3] = {0, 0, 0};
-    size_t pix = (size_t)st * C * plane + (size_t)y * a.Wb + x;
+    const size_t pix = (size_t)st * C * plane + (size_t)y * a.Wb + x;
     if (inside) for (int c = 0; c < C; c++) { accn[c] = a.num[pix + c * plane]; accd[c] = a.den[pix + c * plane]; }
 
     const int ncols_span = c_hi - c_lo + 1;
     const int n_cand = (r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span * N : 0;
     const unsigned g_end = a.ref_begin + a.n_groups;
-    for (int c0 = 0; c0 < n_cand; c0 += 256) {
-        const int e = c0 + tid;
-        bool hit = false; unsigned pk = 0, fbase = 0, woff = 0;
+    const unsigned* apos = a.aggpos + (size_t)st * a.n_refs_total * N;
+    __builtin_amdgcn_wave_barrier();
+    for (int c0 = 0; c0 < n_cand; c0 += 64) {
+        const int e = c0 + lane;
+        bool hit = false; unsigned pk = 0, fbase = 0, g = 0;
         if (e < n_cand) {
             const int n = e % N, rr = e / N;
             const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
-            const unsigned g = (unsigned)gr * a.n_ref_cols + gc;
+            g = (unsigned)gr * a.n_ref_cols + gc;
             if (g >= a.ref_begin && g < g_end) {
-                const unsigned p = a.aggpos[((size_t)st * a.n_refs_total + g) * N + n];
+                const unsigned p = apos[(size_t)g * N + n];
                 if (p != 0xffffffffu) {
                     const int py = p / a.Wb, px = p % a.Wb;
                     hit = py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
                     pk = ((unsigned)py << 16) | (unsigned)px;
                     fbase = ((g * N + n) * A + st) * C * k2;
-                    woff = g * C;
                 }
             }
         }
-        /* ordered compaction of the hits of this chunk */
+        /* ordered compaction of this chunk's hits */
         const unsigned long long bal = __ballot(hit);
-        const int wv = tid >> 6, ln = tid & 63;
-        if (ln == 0) wave_cnt[wv] = __popcll(bal);
-        __syncthreads();
-        unsigned base = 0;
-        for (int w = 0; w < wv; w++) base += wave_cnt[w];
-        const unsigned total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        const unsigned total = __popcll(bal);
         if (hit) {
-            const unsigned slot = base + __popcll(bal & ((1ull << ln) - 1ull));
-            hit_pk[slot] = pk; hit_base[slot] = fbase; hit_w[slot] = woff;
+            const unsigned slot = __popcll(bal & ((1ull << lane) - 1ull));
+            hit_pk[slot] = pk; hit_base[slot] = fbase;
+            for (int c = 0; c < C; c++) hit_w[slot][c] = a.wgt[(size_t)g * C + c];
         }
-        __syncthreads();
-        if (inside) {
-            constexpr int U = 4; /* hits per batch: loads of a batch are issued together, adds stay in hit order */
-            for (unsigned h0 = 0; h0 < total; h0 += U) {
-                float val[U][3], kw[U][3];
-                bool on[U];
+        __builtin_amdgcn_wave_barrier();
+        constexpr int U = 4; /* loads of U hits are issued together; the adds stay in hit order */
+        for (unsigned h0 = 0; h0 < total; h0 += U) {
+            float val[U][3], kw[U][3];
+            bool on[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned h = h0 + u;
-                    on[u] = false;
-                    if (h < total) {
-                        const unsigned hp = hit_pk[h];
-                        const unsigned dy = (unsigned)(y - (int)(hp >> 16)), dx = (unsigned)(x - (int)(hp & 0xffffu));
-                        if (dy < (unsigned)k && dx < (unsigned)k) {
-                            on[u] = true;
-                            const unsigned o = dy * k + dx;
-                            const float kz = a.tb->kaiser[o];
-                            const float* fp = a.filt + hit_base[h] + o;
-                            const float* wp = a.wgt + hit_w[h];
-#pragma unroll
-                            for (int c = 0; c < 3; c++)
-                                if (c < C) { val[u][c] = fp[(size_t)c * k2]; kw[u][c] = kz * wp[c]; } /* core:516-520 */
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++)
-                    if (on[u]) {
+            for (int u = 0; u < U; u++) {
+                const unsigned h = h0 + u;
+                on[u] = false;
+                if (h < total) {
+                    const unsigned hp = hit_pk[h];
+                    const unsigned dy = (unsigned)(y - (int)(hp >> 16)), dx = (unsigned)(x - (int)(hp & 0xffffu));
+                    if (dy < (unsigned)k && dx < (unsigned)k) {
+                        on[u] = true;
+                        const unsigned o = dy * k + dx;
+                        const float kz = windowed ? kai[o] : 1.0f;
+                        const float* fp = a.filt + hit_base[h] + o;
 #pragma unroll
                         for (int c = 0; c < 3; c++)
-                            if (c < C) {
-#pragma clang fp contract(off)
-                                accn[c] += kw[u][c] * val[u][c];
-                                accd[c] += kw[u][c];
-                            }
+                            if (c < C) { val[u][c] = fp[(size_t)c * k2]; kw[u][c] = kz * hit_w[h][c]; } /* core:516-520 */
                     }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (on[u]) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        if (c < C) {
+#pragma clang fp contract(off)
+                            accn[c] += kw[u][c] * val[u][c];
+                            accd[c] += kw[u][c];
+                        }
+                }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
     }
     if (inside) for (int c = 0; c < C; c++) { a.num[pix + c * plane] = accn[c]; a.den[pix + c * plane] = accd[c]; }
 }
