@@ -828,6 +828,232 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * 8x8 2-D DCT variant (the README Wiener configuration: k = 8, tau_2D = dct).  The 2-D transform
+ * is done with ONE THREAD PER PATCH entirely in registers: the thread loads its 8x8 patch from the
+ * window image, runs 8 row + 8 column 8-point DCTs (even/odd factorisation, orthonormal scaling
+ * = REDFT10 x REDFT10 x coef_norm of bm3d.cpp:745-757,1148-1168) and scatters the 64 coefficients
+ * into an LDS stack laid out [coefficient pq][patch] (+1 padding, conflict-free for every phase).
+ * That replaces the gather + per-coefficient LDS matrix products of k_group (about 20 LDS
+ * operations per stacked pixel) by one LDS write per pixel.  4-D / 5th-dimension phases work on
+ * fibres of that stack as in k_group; the inverse 2-D DCT is again one thread per patch, reading
+ * its 64 coefficients and storing the 64 pixels of the filtered patch as four-float vectors.
+ * ------------------------------------------------------------------------------------------ */
+constexpr int kDct8Threads = 320;
+
+__device__ __forceinline__ void dct8_fwd(float* x) {
+    const float a0 = 0.35355339059327376f;   /* 1/sqrt(8) */
+    const float h = 0.5f;
+    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
+                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
+    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
+    const float d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+    const float p0 = s0 + s3, p1 = s1 + s2, m0 = s0 - s3, m1 = s1 - s2;
+    x[0] = a0 * (p0 + p1);
+    x[4] = (h * c4) * (p0 - p1);
+    x[2] = h * (c2 * m0 + c6 * m1);
+    x[6] = h * (c6 * m0 - c2 * m1);
+    x[1] = h * (c1 * d0 + c3 * d1 + c5 * d2 + c7 * d3);
+    x[3] = h * (c3 * d0 - c7 * d1 - c1 * d2 - c5 * d3);
+    x[5] = h * (c5 * d0 - c1 * d1 + c7 * d2 + c3 * d3);
+    x[7] = h * (c7 * d0 - c5 * d1 + c3 * d2 - c1 * d3);
+}
+__device__ __forceinline__ void dct8_inv(float* X) {
+    const float a0 = 0.35355339059327376f;
+    const float h = 0.5f;
+    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
+                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
+    const float e0 = a0 * X[0] + (h * c4) * X[4], e1 = a0 * X[0] - (h * c4) * X[4];
+    const float f0 = h * (c2 * X[2] + c6 * X[6]), f1 = h * (c6 * X[2] - c2 * X[6]);
+    const float E0 = e0 + f0, E1 = e1 + f1, E2 = e1 - f1, E3 = e0 - f0;
+    const float O0 = h * (c1 * X[1] + c3 * X[3] + c5 * X[5] + c7 * X[7]);
+    const float O1 = h * (c3 * X[1] - c7 * X[3] - c1 * X[5] - c5 * X[7]);
+    const float O2 = h * (c5 * X[1] - c1 * X[3] + c7 * X[5] + c3 * X[7]);
+    const float O3 = h * (c7 * X[1] - c5 * X[3] + c3 * X[5] - c1 * X[7]);
+    X[0] = E0 + O0; X[7] = E0 - O0;
+    X[1] = E1 + O1; X[6] = E1 - O1;
+    X[2] = E2 + O2; X[5] = E2 - O2;
+    X[3] = E3 + O3; X[4] = E3 - O3;
+}
+
+template <int STEP>
+__global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ ShapeInfo sh;
+    __shared__ unsigned pos[kMaxN * kMaxA];
+    __shared__ float red[3][kDct8Threads / 64];
+    const int tid = threadIdx.x;
+    const unsigned g = a.ref_begin + blockIdx.x;
+    const int c = blockIdx.y;
+    constexpr int A = 9, K2 = 64;
+    const int N = a.N;
+    const int nSx = (int)a.self_cnt[g];
+    const unsigned k_r = a.refs[g];
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const int NP = nSx * A;               /* patches per stack */
+    const int NPp = (N * A) | 1;          /* row stride of the [pq][patch] stack, odd */
+    float* S0 = lds;
+    float* S1 = lds + K2 * NPp;
+    const GroupTables* tb = a.tb;
+    constexpr int S = STEP == 2 ? 2 : 1;
+
+    for (int i = tid; i < NP; i += kDct8Threads) {
+        const int n = i / A, st = i % A;
+        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
+        unsigned p = 0xffffffffu;
+        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+        pos[i] = p;
+    }
+    if (tid == 0) {
+        int m[9];
+        for (int st = 0; st < 9; st++)
+            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
+        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
+    }
+    __syncthreads();
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    for (int i = tid; c == 0 && i < N * A; i += kDct8Threads) {
+        const int n = i / A, st = i % A;
+        unsigned p = 0xffffffffu;
+        if (n < nSx && ((a.mask_bits >> st) & 1)) {
+            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
+            if (ok) p = pos[n * A + st];
+        }
+        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
+    }
+
+    /* gather + forward 2-D DCT, one thread per patch */
+    for (int task = tid; task < S * NP; task += kDct8Threads) {
+        const int s = task / NP, patch = task % NP, st = patch % A;
+        const unsigned p = pos[patch];
+        const bool ok = p != 0xffffffffu && (p % a.Wb) < a.Wb - 8;   /* never-filled table column (core:1697) */
+        const float* img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
+        float x[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float v = img[(size_t)i * a.Wb + j]; x[i][j] = ok ? v : 0.0f; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) dct8_fwd(x[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float col[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) col[i] = x[i][j];
+            dct8_fwd(col);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i][j] = col[i];
+        }
+        float* dst = (s ? S1 : S0) + patch;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) dst[(i * 8 + j) * NPp] = x[i][j];
+    }
+    __syncthreads();
+
+    /* 4-D forward: one (n, pq) fibre of 9 values per thread */
+    const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
+    const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < S * nSx * K2; f += kDct8Threads) {
+            const int s = f / (nSx * K2), r = f % (nSx * K2), n = r / K2, pq = r % K2;
+            float* base = (s ? S1 : S0) + pq * NPp + n * A;
+            float x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = base[st];
+            if (do_dct4) dct9_fwd(x, tb); else sadct9_fwd(x, sh, tb);
+#pragma unroll
+            for (int st = 0; st < 9; st++) base[st] = x[st];
+        }
+        __syncthreads();
+    }
+
+    /* 5th dimension + shrinkage: one (st, pq) fibre of nSx values per thread */
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    {
+        const float sig = a.sigma[c];
+        const float T = a.lambda * sig * 1.41421356237309505f;
+        const float sig2 = sig * sig;
+        for (int f = tid; f < A * K2; f += kDct8Threads) {
+            const int st = f / K2, pq = f % K2;
+            const bool in_shape = !use_sadct || sh.mask_dct[st];
+            const int base = pq * NPp + st;
+            switch (nSx) {
+                case 1:  filter5<1, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 2:  filter5<2, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 4:  filter5<4, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 8:  filter5<8, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                default: filter5<16, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < kDct8Threads / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(nSx * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)nSx);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
+    }
+    float* F = STEP == 2 ? S1 : S0;
+
+    /* 4-D inverse */
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < nSx * K2; f += kDct8Threads) {
+            const int n = f / K2, pq = f % K2;
+            float* base = F + pq * NPp + n * A;
+            float x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = base[st];
+            if (do_dct4) dct9_inv(x, tb); else sadct9_inv(x, sh, tb);
+#pragma unroll
+            for (int st = 0; st < 9; st++) base[st] = x[st];
+        }
+    }
+    __syncthreads();
+
+    /* inverse 2-D DCT + store, one thread per patch: filt[g][n][st][c][64] */
+    for (int patch = tid; patch < NP; patch += kDct8Threads) {
+        float x[8][8];
+        const float* src = F + patch;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[i][j] = src[(i * 8 + j) * NPp];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float col[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) col[i] = x[i][j];
+            dct8_inv(col);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i][j] = col[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) dct8_inv(x[i]);
+        float4* out = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + patch) * a.C * K2 + (size_t)c * K2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            out[2 * i] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+            out[2 * i + 1] = make_float4(x[i][4], x[i][5], x[i][6], x[i][7]);
+        }
+    }
+}
+
 /* ================================ aggregation kernel ====================================== */
 
 constexpr int kTile = 8;
@@ -994,6 +1220,18 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
         hipLaunchKernelGGL(k_group_id<1>, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.tau2 == 5 && a.k == 8 && a.A == 9) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
+        const size_t l8 = (size_t)(a.step == 2 ? 2 : 1) * 64 * ((a.N * 9) | 1) * sizeof(float);
+        static bool attr8 = false;
+        if (!attr8) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            attr8 = true;
+        }
+        if (a.step == 2) hipLaunchKernelGGL(k_group_dct8<2>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);
+        else             hipLaunchKernelGGL(k_group_dct8<1>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);
         return hipGetLastError();
     }
     const size_t lds = group_lds_bytes(a);
