@@ -420,7 +420,8 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     float* w_noisy = c->w_noisy.as<float>(); float* w_basic = c->w_basic.as<float>();
     float* w_num = c->w_num.as<float>(); float* w_den = c->w_den.as<float>();
     unsigned* d_small = c->small.as<unsigned>();
-    std::vector<unsigned> h_cnt(asize + 8);
+    std::vector<unsigned> h_cnt(asize + 8, (unsigned)img), h_tmp(asize + 8), h_one(8);   /* den starts all zero */
+    std::vector<unsigned> dirty;
 
     std::vector<unsigned> proc(asize);
     for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
@@ -429,11 +430,16 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     unsigned ps = 0, pt = 0, pst = 0;
     while (remaining) {
         if (remaining == total && h_mask[cst]) { ps = cs; pt = ct; }
-        else { /* bm5d.cpp:187-213: SAI with most exact-zero weights, last index wins ties */
-            HIPCK(c, hipMemsetAsync(d_small, 0, asize * sizeof(unsigned), s));
-            HIPCK(c, launch_count_zeros(s, g_den, img, asize, d_small));
-            HIPCK(c, hipMemcpyAsync(h_cnt.data(), d_small, asize * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            HIPCK(c, hipStreamSynchronize(s));
+        else { /* bm5d.cpp:187-213: SAI with most exact-zero weights, last index wins ties.  Counts
+                * only change for the SAIs of the window just processed: recount those. */
+            if (!dirty.empty()) {
+                HIPCK(c, hipMemsetAsync(d_small, 0, asize * sizeof(unsigned), s));
+                for (unsigned st : dirty) HIPCK(c, launch_count_zeros(s, g_den + st * img, img, 1, d_small + st));
+                HIPCK(c, hipMemcpyAsync(h_tmp.data(), d_small, asize * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                HIPCK(c, hipStreamSynchronize(s));
+                for (unsigned st : dirty) h_cnt[st] = h_tmp[st];
+                dirty.clear();
+            }
             long best_cnt = -1;
             for (unsigned st = 0; st < asize; st++) {
                 if (proc[st]) continue;
@@ -474,12 +480,12 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             else {
                 HIPCK(c, hipMemsetAsync(d_small, 0, Aw * sizeof(unsigned), s));
                 HIPCK(c, launch_count_zeros(s, w_den, imgb, Aw, d_small));
-                HIPCK(c, hipMemcpyAsync(h_cnt.data(), d_small, Aw * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                HIPCK(c, hipMemcpyAsync(h_tmp.data(), d_small, Aw * sizeof(unsigned), hipMemcpyDeviceToHost, s));
                 HIPCK(c, hipStreamSynchronize(s));
                 long best_cnt = -1;
                 for (unsigned i = 0; i < Aw; i++) {
                     if (proc_w[i]) continue;
-                    if ((long)h_cnt[i] >= best_cnt) { pst_w = i; best_cnt = (long)h_cnt[i]; }
+                    if ((long)h_tmp[i] >= best_cnt) { pst_w = i; best_cnt = (long)h_tmp[i]; }
                 }
                 if (ang_major == LFBM5D_ROWMAJOR) { ps_w = pst_w / asw; pt_w = pst_w - ps_w * asw; }
                 else { pt_w = pst_w / asw; ps_w = pst_w - pt_w * asw; }
@@ -498,9 +504,9 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
                 n_mask++;
                 HIPCK(c, launch_count_denoised(s, w_den + i * imgb, W, H, C, nHW, P->k, d_small));
             }
-            HIPCK(c, hipMemcpyAsync(h_cnt.data(), d_small, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIPCK(c, hipMemcpyAsync(h_one.data(), d_small, sizeof(unsigned), hipMemcpyDeviceToHost, s));
             HIPCK(c, hipStreamSynchronize(s));
-            const float pct = (float)h_cnt[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
+            const float pct = (float)h_one[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
             if (pct >= 100.0f)
                 for (unsigned i = 0; i < Aw; i++)
                     if (proc_w[i] == 0) { proc_w[i] += 1; proc[st_idx[i]] += 1; }
@@ -511,6 +517,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             if (!h_mask[st]) continue;
             HIPCK(c, launch_unsymetrize(s, g_num + st * img, w_num + i * imgb, W, H, C, nHW));
             HIPCK(c, launch_unsymetrize(s, g_den + st * img, w_den + i * imgb, W, H, C, nHW));
+            dirty.push_back(st);
         }
         remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
         c->stats.windows += 1;

@@ -17,6 +17,8 @@
  */
 #include "lfbm5d_kernels.h"
 
+#include <type_traits>
+
 #pragma clang fp contract(off)
 
 namespace lfbm5d {
@@ -233,7 +235,11 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
         /* per-lane constants of the skewed LDS addressing: ring row (u - lane) mod RR, column lane */
         const int offA0 = lane - lane * CW, offA1 = offA0 + RR * CW;
         const int xoff = x - lane * W;
-        for (int t0 = 0; t0 < nsteps; t0 += T) {
+        /* store offsets of the steady state: lane-constant part (>= 0) + scalar row part; lanes past
+         * the last column get an out-of-range offset, which drops their stores */
+        const int voT = col_ok ? (x + (last_lane - lane) * W) * 4 : 0x7fffff00;
+        auto do_chunk = [&](int t0, auto steady_tag) {
+            constexpr bool STEADY = decltype(steady_tag)::value;   /* every lane 0..last_lane active for all T steps */
             float m1[T], m2[T], e1[T], e2[T];
 #pragma unroll
             for (int s = 0; s < T; s++) load_row(filled + T + s, m1[s], m2[s], e1[s], e2[s]);
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 d3[s] = pb[K]; d4[s] = pb[0];
                 uA = uA + 1 == RR ? 0 : uA + 1;
                 uB = uB + 1 == RR ? 0 : uB + 1;
-                lc[s] = lcol[min(1 + t0 + s, nrows + T)];   /* uniform address: lane 0's left neighbour */
+                lc[s] = lcol[STEADY ? 1 + t0 + s : min(1 + t0 + s, nrows + T)];   /* uniform address: lane 0's left neighbour */
                 r1[s] = -1; r2[s] = -1;
                 if (!stereo) {   /* uniform */
                     const int vy = max(b + 1 + t0 + s - lane, 0) * 4;
@@ -259,8 +265,6 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 const int t = t0 + s;
-                const int lo = t + 2 - nrows, hi = min(t, last_lane);            /* uniform */
-                const bool act = lane >= lo && lane <= hi;
                 /* left neighbour's value of the previous step; lane 0 takes the hand-off column */
                 const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lc[s]), __float_as_int(curS),
                                                                               0x138 /* wave_shr:1 */, 0xf, 0xf, false));
@@ -272,17 +276,24 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 S = S + d4[s];
                 S = first_col ? left : S;          /* first column was computed up front */
                 Sout[s] = S;
-                curS = act ? S : curS;
+                if (STEADY) curS = S;              /* lanes past the last column carry garbage nobody reads */
+                else {
+                    const int lo = t + 2 - nrows, hi = min(t, last_lane);        /* uniform */
+                    curS = (lane >= lo && lane <= hi) ? S : curS;
+                }
                 left_prev = left;
             }
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 const int t = t0 + s;
                 const int lo = t + 2 - nrows, hi = min(t, last_lane);
-                const bool act = lane >= lo && lane <= hi;
+                const bool act = STEADY ? col_ok : (lane >= lo && lane <= hi);
                 if (stereo) {   /* uniform */
-                    const int vo = act ? ((b + 1 + t) * W + xoff) * 4 : -1;       /* -1: out of range, store dropped */
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, vo, 0, 0);
+                    if (STEADY) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, voT, (b + 1 + t - last_lane) * W * 4, 0);
+                    else {
+                        const int vo = act ? ((b + 1 + t) * W + xoff) * 4 : -1;   /* -1: out of range, store dropped */
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, vo, 0, 0);
+                    }
                 } else {
                     const int v1 = (act && cx >= 0 && r1[s] >= 0) ? (int)(((unsigned)(r1[s] * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
                     const int v2 = (act && cx2 >= 0 && r2[s] >= 0 && di > 0) ? (int)(((unsigned)(r2[s] * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
@@ -291,7 +302,8 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 }
                 const int il = 1 + t - last_lane;                                 /* uniform */
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
-                lcol[(il >= 1 && il < nrows) ? il : nrows + T] = hv;   /* hand-off column for the next strip (uniform; dump slot otherwise) */
+                if (STEADY) lcol[il] = hv;         /* hand-off column for the next strip (uniform address and value) */
+                else lcol[(il >= 1 && il < nrows) ? il : nrows + T] = hv;
             }
 #pragma unroll
             for (int s = 0; s < T; s++) {
@@ -299,7 +311,14 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 p1[s] = m1[s]; p2[s] = m2[s]; q1[s] = e1[s]; q2[s] = e2[s];
             }
             filled += T;
-        }
+        };
+        /* ramp-up (lanes start one step apart), steady state, ramp-down */
+        const int t_steady0 = ((last_lane + T - 1) / T) * T;               /* first chunk with t0 >= last_lane */
+        const int t_steady1 = nrows - T - 1 >= 0 ? ((nrows - T - 1) / T) * T + T : 0;   /* chunks with t0 <= nrows-T-1 */
+        int t0 = 0;
+        for (; t0 < nsteps && t0 < t_steady0; t0 += T) do_chunk(t0, std::false_type{});
+        for (; t0 < nsteps && t0 < t_steady1; t0 += T) do_chunk(t0, std::true_type{});
+        for (; t0 < nsteps; t0 += T) do_chunk(t0, std::false_type{});
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
         __syncthreads();
     }
@@ -390,12 +409,18 @@ __global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
     const int pos = y * W + x;
     const float* t = a.tables + (size_t)slot * ncand * WH + pos;
     float bv = t[0]; int bo = 0, bd = 0;
-    for (int di = 0; di < Ns; di++) {          /* one table row of displacements at a time: Ns independent loads */
-        const float* tr = t + (size_t)di * Ns * WH;
-        for (int dj = 0; dj < Ns; dj++) {
-            const float v = tr[(size_t)dj * WH];
-            const int order = dj * Ns + di;
-            if (v < bv || (v == bv && order < bo)) { bv = v; bo = order; bd = di * Ns + dj; }
+    for (int d0 = 0; d0 < ncand; d0 += 8) {   /* eight independent table reads in flight */
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = t[(size_t)min(d0 + u, ncand - 1) * WH];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int ddk = d0 + u;
+            if (ddk < ncand) {
+                const int di = ddk / Ns, dj = ddk - di * Ns;
+                const int order = dj * Ns + di;
+                if (v[u] < bv || (v[u] == bv && order < bo)) { bv = v[u]; bo = order; bd = ddk; }
+            }
         }
     }
     const int di = bd / Ns, dj = bd % Ns;
