@@ -169,6 +169,14 @@ void build_tables(GroupTables& t, unsigned k, unsigned aw, unsigned ah) {
         for (unsigned i = 1; i < n; i++) { t.cn1[n][i] = c1; t.cni1[n][i] = 1.0f; }
         t.c1inv[n] = 0.5f * (float)kSqrt2Inv / std::sqrt((float)n);
     }
+    for (unsigned l = 0; l < 5; l++) {
+        const unsigned n = 1u << l;
+        for (unsigned uu = 0; uu < n; uu++)
+            for (unsigned j = 0; j < n; j++) t.cos5[l][uu * n + j] = (float)std::cos(kPi * (j + 0.5) * uu / n);
+        const float c5 = (float)((float)kSqrt2 / std::sqrt((double)n));
+        t.cn5_0[l] = (float)(kSqrt2Inv * c5); t.cn5[l] = c5;
+        t.c5inv[l] = 0.5f * (float)kSqrt2Inv / std::sqrt((float)n);
+    }
     const float cn = 1.f / (std::sqrt(2.f) * 128.f), s = 1.f / std::sqrt(2.f);
     const float a1[10] = {3.f, -3.f, -22.f, 22.f, 128.f, 128.f, 22.f, -22.f, -3.f, 3.f};
     const float b1[10] = {3.f, 3.f, -22.f, -22.f, 128.f, -128.f, 22.f, 22.f, -3.f, -3.f};
@@ -187,8 +195,7 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
     if (P->tau_2D == LFBM5D_BIOR && !is_pow2(P->k)) return fail(c, "bior1.5 needs a power-of-two patch size");
     if (P->tau_2D != LFBM5D_ID && P->tau_2D != LFBM5D_DCT && P->tau_2D != LFBM5D_BIOR) return fail(c, "bad tau_2D");
     if (P->tau_4D != LFBM5D_ID && P->tau_4D != LFBM5D_DCT && P->tau_4D != LFBM5D_SADCT) return fail(c, "bad tau_4D");
-    if (P->tau_5D != LFBM5D_HAAR && P->tau_5D != LFBM5D_HADAMARD)
-        return fail(c, "unsupported: tau_5D must be haar or hw (5th-dimension DCT is not built yet)");
+    if (P->tau_5D != LFBM5D_HAAR && P->tau_5D != LFBM5D_HADAMARD && P->tau_5D != LFBM5D_DCT) return fail(c, "bad tau_5D");
     if (!is_pow2(P->N) || P->N > (unsigned)kMaxN) return fail(c, "unsupported: N must be a power of two <= 16");
     if (P->nSim < 1 || P->nDisp < 1 || P->p < 1) return fail(c, "bad search window / step");
     (void)step;

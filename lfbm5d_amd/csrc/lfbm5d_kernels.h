@@ -29,6 +29,9 @@ struct GroupTables {
     float cn1[4][3];            /* SADCT 1-D norms for length n (core:3229-3252) */
     float cni1[4][3];
     float c1inv[4];             /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
+    float cos5[5][256];         /* 5th-dimension DCT: cos(pi (j+1/2) u / n) at [log2 n][u*n + j], n = 1..16 */
+    float cn5_0[5], cn5[5];     /* coef_norm of preProcess_5d (core:3262-3276) */
+    float c5inv[5];             /* 0.5 * SQRT2_INV / sqrt(n) (core:2591) */
     float lpd[10], hpd[10], lpr[10], hpr[10];
     float coef2inv;             /* 1 / (2k)                       (bm3d.cpp:1064) */
     float coef4inv;             /* 1 / (2 sqrt(aw) sqrt(ah))      (core:1945)     */

@@ -281,37 +281,72 @@ template <int NS> __device__ __forceinline__ void hadamard(float* v) {
 
 /* 5th-dimension filter of one (st, pq) fibre held in registers.
  * HT: core:2408-2505 / :2281-2391; Wiener: core:2826-2925 / :2706-2810. */
+/* 5th-dimension DCT of a fibre (tau_5D = dct): REDFT10 * coef_norm / coef_norm_inv * REDFT01 * coef
+ * (core:2546-2593, norms preProcess_5d core:3262-3276) */
+template <int NS> __device__ __forceinline__ int log2c() { return NS == 1 ? 0 : NS == 2 ? 1 : NS == 4 ? 2 : NS == 8 ? 3 : 4; }
+template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, const GroupTables* tb) {
+    const float* ct = tb->cos5[log2c<NS>()];
+    float y[NS];
+#pragma unroll
+    for (int u = 0; u < NS; u++) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NS; j++) a += v[j] * ct[u * NS + j];
+        y[u] = 2.0f * a * (u == 0 ? tb->cn5_0[log2c<NS>()] : tb->cn5[log2c<NS>()]);
+    }
+#pragma unroll
+    for (int u = 0; u < NS; u++) v[u] = y[u];
+}
+template <int NS> __device__ __forceinline__ void dct5_inv(float* v, const GroupTables* tb) {
+    const float* ct = tb->cos5[log2c<NS>()];
+    float y[NS];
+    const float x0 = v[0] * 1.41421356237309505f;   /* coef_norm_inv[0] = sqrt2, others 1 */
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        float a = 0.0f;
+#pragma unroll
+        for (int u = 1; u < NS; u++) a += v[u] * ct[u * NS + j];
+        y[j] = (x0 + 2.0f * a) * tb->c5inv[log2c<NS>()];
+    }
+#pragma unroll
+    for (int j = 0; j < NS; j++) v[j] = y[j];
+}
+
 /* 5th-dimension transform + shrinkage + inverse of one (st, pq) fibre held in registers.
  * o: noisy fibre, e: pilot fibre (Wiener); the filtered fibre is returned in o (HT) / e (Wiener).
  * HT: core:2408-2505 / :2281-2391; Wiener: core:2826-2925 / :2706-2810. */
 template <int NS, int STEP>
 __device__ __forceinline__ void shrink_fibre(float* o, float* e, unsigned tau5, float T, float sig2,
-                                             bool in_shape, float& wacc) {
-    const bool haar = tau5 == 9;
-    if (NS > 1) {
+                                             bool in_shape, float& wacc, const GroupTables* tb) {
+    const bool haar = tau5 == 9, dct = tau5 == 5;
+    if (dct) { dct5_fwd<NS>(o, tb); if (STEP == 2) dct5_fwd<NS>(e, tb); }
+    else if (NS > 1) {
         if (haar) { haar_fwd<NS>(o); if (STEP == 2) haar_fwd<NS>(e); }
         else      { hadamard<NS>(o); if (STEP == 2) hadamard<NS>(e); }
     }
     if (in_shape) {
         if (STEP == 1) {
-            const float Th = haar ? T : T * sqrtf((float)NS);
+            /* T = lambda*sigma*sqrt2; Hadamard: * sqrt(nSx) (core:2306); DCT: * 2 (core:2567) */
+            const float Th = haar ? T : (dct ? T * 2.0f : T * sqrtf((float)NS));
 #pragma unroll
             for (int n = 0; n < NS; n++) {
                 if (fabsf(o[n]) > Th) wacc += 1.0f; else o[n] = 0.0f;
             }
         } else {
             const float hc = 1.0f / (float)NS;
+            const bool plain = haar || dct;
 #pragma unroll
             for (int n = 0; n < NS; n++) {
-                float value = haar ? e[n] * e[n] : e[n] * e[n] * hc;
+                float value = plain ? e[n] * e[n] : e[n] * e[n] * hc;
                 value = __fdiv_rn(value, value + sig2);
-                e[n] = haar ? o[n] * value : o[n] * value * hc;
+                e[n] = plain ? o[n] * value : o[n] * value * hc;
                 wacc += value;
             }
         }
     }
     float* r = STEP == 1 ? o : e;
-    if (NS > 1) {
+    if (dct) dct5_inv<NS>(r, tb);
+    else if (NS > 1) {
         if (haar) haar_inv<NS>(r);
         else {
             hadamard<NS>(r);
@@ -327,7 +362,8 @@ __device__ __forceinline__ void shrink_fibre(float* o, float* e, unsigned tau5, 
 /* the same on a fibre stored in the LDS stack */
 template <int NS, int STEP>
 __device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stride, unsigned tau5,
-                                        float T, float sig2, bool in_shape, float& wacc, float& s1, float& s2) {
+                                        float T, float sig2, bool in_shape, float& wacc, float& s1, float& s2,
+                                        const GroupTables* tb) {
     float o[NS], e[NS];
 #pragma unroll
     for (int n = 0; n < NS; n++) o[n] = S0[base + n * stride];
@@ -335,7 +371,7 @@ __device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stri
 #pragma unroll
         for (int n = 0; n < NS; n++) e[n] = S1[base + n * stride];
     }
-    shrink_fibre<NS, STEP>(o, e, tau5, T, sig2, in_shape, wacc);
+    shrink_fibre<NS, STEP>(o, e, tau5, T, sig2, in_shape, wacc, tb);
     float* r = STEP == 1 ? o : e;
     float* dst = STEP == 1 ? S0 : S1;
 #pragma unroll
@@ -621,11 +657,11 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
             const bool in_shape = !use_sadct || sh.mask_dct[st];
             const int base = st * k2 + pq, stride = A * k2;
             switch (nSx) {
-                case 1:  filter5<1, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                case 2:  filter5<2, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                case 4:  filter5<4, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                case 8:  filter5<8, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                default: filter5<16, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 1:  filter5<1, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                case 2:  filter5<2, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                case 4:  filter5<4, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                case 8:  filter5<8, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                default: filter5<16, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
             }
         }
     }
@@ -735,7 +771,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
         float o[NS], e[NS];
 #pragma unroll
         for (int n = 0; n < NS; n++) { o[n] = v[n][st]; e[n] = STEP == 2 ? w[n][st] : 0.0f; }
-        shrink_fibre<NS, STEP>(o, e, a.tau5, T, sig2, !use_sadct || sh.mask_dct[st], wacc);
+        shrink_fibre<NS, STEP>(o, e, a.tau5, T, sig2, !use_sadct || sh.mask_dct[st], wacc, tb);
 #pragma unroll
         for (int n = 0; n < NS; n++) { const float r = STEP == 1 ? o[n] : e[n]; v[n][st] = r; s1 += r; s2 += r * r; }
     }
@@ -980,11 +1016,11 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
             const bool in_shape = !use_sadct || sh.mask_dct[st];
             const int base = pq * NPp + st;
             switch (nSx) {
-                case 1:  filter5<1, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                case 2:  filter5<2, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                case 4:  filter5<4, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                case 8:  filter5<8, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
-                default: filter5<16, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2); break;
+                case 1:  filter5<1, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                case 2:  filter5<2, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                case 4:  filter5<4, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                case 8:  filter5<8, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                default: filter5<16, STEP>(S0, S1, base, A, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
             }
         }
     }

@@ -67,6 +67,9 @@ PASS_CASES = [
     ("wien-id-dct-hw", 2, 25.0, (8, 6, 2, 8, 3, "id", "dct", "hw"), 64, 0),
     ("wien-bior-n16", 2, 10.0, (16, 6, 2, 8, 4, "bior", "sadct", "haar"), 64, 0),
     ("wien-usesd", 2, 25.0, (8, 6, 2, 8, 3, "dct", "sadct", "haar"), 64, 1),
+    ("ht-dct-sadct-dct5", 1, 25.0, (4, 6, 2, 8, 3, "dct", "sadct", "dct"), 64, 0),
+    ("ht-id-dct-dct5", 1, 25.0, (8, 6, 2, 8, 4, "id", "dct", "dct"), 64, 0),
+    ("wien-dct-sadct-dct5", 2, 25.0, (8, 6, 2, 8, 3, "dct", "sadct", "dct"), 64, 0),
 ]
 
 
@@ -248,8 +251,8 @@ def test_unsupported_configurations_fail_loudly(ctx):
     with pytest.raises(L.LfBm5dError, match="angular search window"):
         ctx.step1(core.make_params(25, 2.7, 4, 4, 2, 8, 4, "id", "sadct", "haar"), t, np.ones(25, np.uint32), t.clone(),
                   L.ROWMAJOR, 5, 5, 2, 32, 32, 3)
-    with pytest.raises(L.LfBm5dError, match="tau_5D"):
-        ctx.step1(core.make_params(25, 2.7, 4, 4, 2, 8, 4, "id", "sadct", "dct"), t, np.ones(25, np.uint32), t.clone(),
+    with pytest.raises(L.LfBm5dError, match="power of two"):
+        ctx.step1(core.make_params(25, 2.7, 6, 4, 2, 8, 4, "id", "sadct", "haar"), t, np.ones(25, np.uint32), t.clone(),
                   L.ROWMAJOR, 5, 5, 1, 32, 32, 3)
 
 
