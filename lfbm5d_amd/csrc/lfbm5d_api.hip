@@ -210,7 +210,6 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
               float* d_den, const unsigned* h_mask, const unsigned* h_proc, unsigned cst, unsigned pst) {
     if (validate(c, step, P, aw, ah, C)) return 1;
     if (step == 2 && !d_basic) return fail(c, "step 2 needs the basic estimate");
-    if (pst != cst) return fail(c, "unsupported: non-centre pass (greyscale subset path, core:531-821) is not built yet");
     const unsigned A = aw * ah, k = P->k, k2 = k * k, N = P->N, nHW = P->nSim + P->nDisp;
     const size_t plane = (size_t)Wb * Hb;
     hipStream_t s = c->stream;
@@ -227,8 +226,9 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     if (!((mask_bits >> pst) & 1)) return fail(c, "processed SAI is empty");
 
     /* reference grid (core:149-156); cached while the geometry is unchanged */
+    const bool centre = pst == cst;
     const unsigned key[5] = {Wb, Hb, k, nHW, P->p};
-    if (std::memcmp(key, c->grid_key, sizeof(key)) != 0 || c->last_refs_host.empty()) {
+    if (centre && (std::memcmp(key, c->grid_key, sizeof(key)) != 0 || c->last_refs_host.empty())) {
         std::vector<unsigned> rows, cols;
         ind_init(rows, Hb - k + 1, nHW, P->p);
         ind_init(cols, Wb - k + 1, nHW, P->p);
@@ -245,14 +245,55 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         HIPCK(c, hipStreamSynchronize(s));
         std::memcpy(c->grid_key, key, sizeof(key));
     }
-    const unsigned R = c->n_ref_rows * c->n_ref_cols;
+    unsigned R = c->n_ref_rows * c->n_ref_cols;
+    std::vector<unsigned> row_start;   /* subset path: first reference of every listed row (+ end) */
+    if (!centre) {
+        /* Subset path (core:157-158, utilities_LF.cpp:1000-1099): only reference patches whose k x k
+         * footprint still holds an exactly-zero weight in channel 0 of den[pst]; one extra column /
+         * row at the far border like ind_initialize.  The list is built on the host from a copy of
+         * that plane (1.2 MB at 560^2; this path only runs for greyscale light fields). */
+        std::vector<float> den0(plane);
+        HIPCK(c, hipMemcpyAsync(den0.data(), d_den + (size_t)pst * C * plane, plane * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCK(c, hipStreamSynchronize(s));
+        auto denoised = [&](unsigned p_idx) {
+            for (unsigned pp = 0; pp < k; pp++)
+                for (unsigned q = 0; q < k; q++)
+                    if (den0[p_idx + pp * Wb + q] == 0.0f) return false;
+            return true;
+        };
+        const unsigned max_h = Hb - k + 1, max_w = Wb - k + 1;
+        std::vector<unsigned> refs, tmp;
+        row_start.clear();
+        auto scan_row = [&](unsigned i) {
+            tmp.clear();
+            for (unsigned j = nHW; j < max_w - nHW; j += P->p)
+                if (!denoised(i * Wb + j)) tmp.push_back(j);
+            const bool border = tmp.empty() ? true : (tmp.back() < max_w - nHW - 1);
+            if (border && !denoised(i * Wb + max_w - nHW - 1)) tmp.push_back(max_w - nHW - 1);
+            if (!tmp.empty()) { row_start.push_back((unsigned)refs.size()); for (unsigned j : tmp) refs.push_back(i * Wb + j); return true; }
+            return false;
+        };
+        unsigned last_row = 0; bool any = false;
+        for (unsigned i = nHW; i < max_h - nHW; i += P->p) if (scan_row(i)) { last_row = i; any = true; }
+        if (!any || last_row < max_h - nHW - 1) scan_row(max_h - nHW - 1);
+        row_start.push_back((unsigned)refs.size());
+        c->last_refs_host = refs;
+        std::memset(c->grid_key, 0, sizeof(c->grid_key));   /* the cached regular grid is gone */
+        R = (unsigned)refs.size();
+        if (R == 0) { c->last_n_refs = 0; return 0; }   /* nothing left to denoise (core:160-165) */
+        HIPCK(c, c->refs.reserve(R * sizeof(unsigned)));
+        HIPCK(c, hipMemcpyAsync(c->refs.p, refs.data(), R * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        HIPCK(c, c->refmap.reserve(plane * sizeof(int)));
+        HIPCK(c, launch_fill_i32(s, c->refmap.as<int>(), -1, plane));
+        HIPCK(c, launch_refmap(s, c->refs.as<unsigned>(), R, c->refmap.as<int>()));
+        HIPCK(c, hipStreamSynchronize(s));   /* refs is a stack vector */
+    }
 
     const unsigned NsS = 2 * P->nSim + 1, NsD = 2 * P->nDisp + 1;
     unsigned slots[kMaxA]; unsigned n_slots = 0;
     for (unsigned st = 0; st < A; st++) if (st != pst && ((mask_bits >> st) & 1)) slots[n_slots++] = st;
     const unsigned Nst = N > 1 ? N : 1;
     HIPCK(c, c->est.reserve((A * plane + 256) * sizeof(float)));   /* slack: strip loads may overrun a row end by <= nHW */
-    HIPCK(c, c->refmap.reserve(plane * sizeof(int)));
     if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
     HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * plane * sizeof(float)));
     HIPCK(c, c->self_idx.reserve((size_t)R * Nst * sizeof(unsigned)));
@@ -296,7 +337,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     sa.est = c->est.as<float>(); sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
     sa.nSim = P->nSim; sa.nDisp = P->nDisp; sa.nHW = nHW;
     sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p;
-    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = c->rslot.as<int>(); sa.scores_bytes = (unsigned)std::min<size_t>((size_t)R * NsS * NsS * sizeof(float), 0x7fffffffu);
+    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = c->rslot.as<int>(); sa.refmap = centre ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)std::min<size_t>((size_t)R * NsS * NsS * sizeof(float), 0x7fffffffu);
     sa.n_self = N > 1 ? (P->nSim + 1) * NsS : 0;
     sa.n_stereo = n_slots * NsD * NsD;
     for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
@@ -313,9 +354,16 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, hipEventRecord(pe.e[1], s));
 
     /* shard of reference-patch rows owned by this rank */
-    unsigned rb = 0, re = c->n_ref_rows;
-    lfbm5d_shard_rows(c->n_ref_rows, c->rank, c->world, &rb, &re);
-    const unsigned ref_begin = rb * c->n_ref_cols, n_groups = (re - rb) * c->n_ref_cols;
+    unsigned ref_begin, n_groups;
+    if (centre) {
+        unsigned rb = 0, re = c->n_ref_rows;
+        lfbm5d_shard_rows(c->n_ref_rows, c->rank, c->world, &rb, &re);
+        ref_begin = rb * c->n_ref_cols; n_groups = (re - rb) * c->n_ref_cols;
+    } else {
+        unsigned rb = 0, re = (unsigned)row_start.size() - 1;
+        lfbm5d_shard_rows((unsigned)row_start.size() - 1, c->rank, c->world, &rb, &re);
+        ref_begin = row_start[rb]; n_groups = row_start[re] - row_start[rb];
+    }
 
     GroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
@@ -327,7 +375,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
     ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;
     ga.tau2 = P->tau_2D; ga.tau4 = P->tau_4D; ga.tau5 = P->tau_5D; ga.useSD = P->useSD;
-    ga.step = step; ga.lambda = lambda;
+    ga.step = step; ga.lambda = lambda; ga.fill_quirk = centre ? 1u : 0u;
     for (int i = 0; i < 3; i++) ga.sigma[i] = sig[i];
     if (group_lds_bytes(ga) > 160 * 1024 - 4096) return fail(c, "unsupported: N*k*k stack does not fit the 160 KiB LDS");
     if (n_groups) HIPCK(c, launch_group(s, ga));
@@ -340,7 +388,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     aa.ref_begin = ref_begin; aa.n_groups = n_groups; aa.n_ref_rows = c->n_ref_rows; aa.n_ref_cols = c->n_ref_cols;
     aa.Wb = Wb; aa.Hb = Hb; aa.C = C; aa.A = A; aa.k = k; aa.N = Nst; aa.pst = pst; aa.p = P->p;
     aa.nHW = nHW; aa.nSim = P->nSim; aa.nDisp = P->nDisp;
-    aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D;
+    aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D; aa.irregular = centre ? 0u : 1u;
     if (n_groups) HIPCK(c, launch_aggregate(s, aa));
     HIPCK(c, hipEventRecord(pe.e[3], s));
 

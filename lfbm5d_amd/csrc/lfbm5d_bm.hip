@@ -109,11 +109,23 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
     const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)(WH * 4), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (int)a.scores_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.rslot, 0, (int)((H + 64) * 4), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.refmap, 0, a.refmap ? (int)(WH * 4) : 0, kRsrcFlags);
+    const bool irregular = a.refmap != nullptr;
     const int gR = a.n_ref_rows, gC = a.n_ref_cols, gP = a.p, gN = a.nHW;
     const int lastR = H - (int)a.k - gN, lastC = W - (int)a.k - gN;
 
     auto emit = [&](int y, int x, float S) {
         if (stereo) { table[y * W + x] = S; return; }
+        if (a.refmap) { /* irregular reference list (subset path, core:3631-3788): slots come from a position map */
+            const int r = a.refmap[y * W + x];
+            if (r >= 0) a.scores[(size_t)r * ncand + ord_fwd] = S;
+            const int yy = y + di, xx = x + djs;
+            if (di > 0 && yy < H && xx >= 0 && xx < W) {
+                const int r2 = a.refmap[yy * W + xx];
+                if (r2 >= 0) a.scores[(size_t)r2 * ncand + ord_bwd] = S;
+            }
+            return;
+        }
         /* forward candidate of the reference patch at (y,x) (core:3410-3413) */
         const int cx = grid_index(x, gC, lastC, gN, gP);
         if (cx >= 0) {
@@ -256,10 +268,17 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                 uB = uB + 1 == RR ? 0 : uB + 1;
                 lc[s] = lcol[STEADY ? 1 + t0 + s : min(1 + t0 + s, nrows + T)];   /* uniform address: lane 0's left neighbour */
                 r1[s] = -1; r2[s] = -1;
-                if (!stereo) {   /* uniform */
+                if (!stereo && !irregular) {   /* uniform */
                     const int vy = max(b + 1 + t0 + s - lane, 0) * 4;
                     r1[s] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, 0, 0);
                     r2[s] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, di * 4, 0);   /* table has 64 slots of -1 padding */
+                } else if (!stereo) {          /* irregular list: whole-slot lookups (out-of-range offsets read 0) */
+                    const int yy = b + 1 + t0 + s - lane;
+                    const bool in1 = yy >= 0 && yy < H && col_ok;
+                    const int xx = x + djs, y2 = yy + di;
+                    const bool in2 = in1 && di > 0 && y2 < H && xx >= 0 && xx < W;
+                    r1[s] = in1 ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (yy * W + x) * 4, 0, 0) : -1;
+                    r2[s] = in2 ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (y2 * W + xx) * 4, 0, 0) : -1;
                 }
             }
 #pragma unroll
@@ -295,8 +314,14 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, vo, 0, 0);
                     }
                 } else {
-                    const int v1 = (act && cx >= 0 && r1[s] >= 0) ? (int)(((unsigned)(r1[s] * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
-                    const int v2 = (act && cx2 >= 0 && r2[s] >= 0 && di > 0) ? (int)(((unsigned)(r2[s] * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                    int v1, v2;
+                    if (irregular) {   /* uniform */
+                        v1 = (act && r1[s] >= 0) ? (int)(((unsigned)r1[s] * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
+                        v2 = (act && r2[s] >= 0) ? (int)(((unsigned)r2[s] * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                    } else {
+                        v1 = (act && cx >= 0 && r1[s] >= 0) ? (int)(((unsigned)(r1[s] * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
+                        v2 = (act && cx2 >= 0 && r2[s] >= 0 && di > 0) ? (int)(((unsigned)(r2[s] * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
                 }

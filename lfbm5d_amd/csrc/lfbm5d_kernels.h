@@ -57,6 +57,7 @@ struct GroupArgs {
     unsigned Wb, Hb, C, A, k, N, pst;
     unsigned mask_bits, proc_bits;
     unsigned tau2, tau4, tau5, useSD;
+    unsigned fill_quirk;        /* 1 on the centre path: patches at column Wb-k read as zeros (core:1697) */
     int step;
     float lambda;
     float sigma[3];
@@ -79,6 +80,7 @@ struct AggArgs {
     unsigned n_ref_rows, n_ref_cols;
     unsigned Wb, Hb, C, A, k, N, pst, p, nHW, nSim, nDisp;
     unsigned mask_bits, proc_bits, tau4;
+    unsigned irregular;         /* reference list is not the regular grid (subset path): scan every reference */
 };
 
 struct ScanArgs {
@@ -91,6 +93,7 @@ struct ScanArgs {
     /* self: the regular reference grid (centre pass) */
     unsigned n_ref_rows, n_ref_cols, p;
     const int* rslot;           /* [H] reference-grid row slot of each image row, -1 off the grid */
+    const int* refmap;          /* [W*H] slot of the reference patch at a position or -1: irregular lists only, else NULL */
     float* scores;              /* [R][Ns*Ns], pre-filled with 2*threshold */
     unsigned scores_bytes;
     /* stereo */

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
                     const int pq = e % k2, ns = e / k2;
                     const int st = ns % A;
                     const unsigned p = pos[ns];
-                    if (p != 0xffffffffu && (p % a.Wb) < a.Wb - k) {
+                    if (p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - k)) {
                         const size_t off = ((size_t)st * a.C + c) * plane + p + (size_t)(pq / k) * a.Wb + pq % k;
                         v0[u] = a.noisy[off];
                         if (STEP == 2) v1[u] = a.basic[off];
@@ -734,7 +734,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
 #pragma unroll
         for (int st = 0; st < 9; st++) {
             const unsigned p = pos[n * A + st];
-            const bool ok = p != 0xffffffffu && (p % a.Wb) < a.Wb - k;  /* never-filled table column (core:1697) */
+            const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - k);  /* never-filled table column (core:1697) */
             const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u) + poff;
             const float x0 = a.noisy[off];
             v[n][st] = ok ? x0 : 0.0f;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     for (int task = tid; task < S * NP; task += kDct8Threads) {
         const int s = task / NP, patch = task % NP, st = patch % A;
         const unsigned p = pos[patch];
-        const bool ok = p != 0xffffffffu && (p % a.Wb) < a.Wb - 8;   /* never-filled table column (core:1697) */
+        const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - 8);   /* never-filled table column (core:1697) */
         const float* img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
         float x[8][8];
 #pragma unroll
@@ -1137,7 +1137,8 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     if (inside) for (int c = 0; c < C; c++) { accn[c] = a.num[pix + c * plane]; accd[c] = a.den[pix + c * plane]; }
 
     const int ncols_span = c_hi - c_lo + 1;
-    const int n_cand = (r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span * N : 0;
+    const int n_cand = a.irregular ? (int)a.n_refs_total * N
+                                   : ((r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span * N : 0);
     const unsigned g_end = a.ref_begin + a.n_groups;
     const unsigned* apos = a.aggpos + (size_t)st * a.n_refs_total * N;
     __builtin_amdgcn_wave_barrier();
@@ -1146,8 +1147,11 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
         bool hit = false; unsigned pk = 0, fbase = 0, g = 0;
         if (e < n_cand) {
             const int n = e % N, rr = e / N;
-            const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
-            g = (unsigned)gr * a.n_ref_cols + gc;
+            if (a.irregular) g = (unsigned)rr;   /* the list is in raster order too (row lists, then columns) */
+            else {
+                const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
+                g = (unsigned)gr * a.n_ref_cols + gc;
+            }
             if (g >= a.ref_begin && g < g_end) {
                 const unsigned p = apos[(size_t)g * N + n];
                 if (p != 0xffffffffu) {

@@ -694,6 +694,7 @@ struct PassCtx {
     float sigma[4];
     const float* noisy; const float* basic;
     const unsigned* mask; unsigned pst;
+    bool centre; /* pst == cst: the row-band tables of the centre path leave column Wb-k unfilled */
     Norms2D n2; Norms4D n4;
     const unsigned* self_idx; const unsigned* self_cnt;       /* per ref */
     std::vector<std::vector<unsigned> >* best;                /* [st][Wb*Hb] */
@@ -734,10 +735,12 @@ void process_group(const PassCtx& cx, unsigned ref_slot, unsigned k_r, GroupOut&
         for (unsigned n = 0; n < nSx; n++)
             for (unsigned st = 0; st < A; st++) {
                 if (!cx.mask[st]) continue;
-                /* The reference gathers from per-row tables filled only for columns j < Wb - k
-                 * (core:1697, bm3d.cpp:737/:857): a patch at column Wb - k reads the table's zero
-                 * initialisation.  Reachable when self and disparity offsets both max out. */
-                if (pos[n * A + st] % cx.Wb >= cx.Wb - cx.k) continue;
+                /* Centre path: the reference gathers from per-row tables filled only for columns
+                 * j < Wb - k (core:1697, bm3d.cpp:737/:857): a patch at column Wb - k reads the table's
+                 * zero initialisation.  Reachable when self and disparity offsets both max out.  The
+                 * subset path fills a (2nHW+1)^2 block around each reference patch (core:1733-1738,
+                 * :1782-1803, :1842-1848), which includes that column. */
+                if (cx.centre && pos[n * A + st] % cx.Wb >= cx.Wb - cx.k) continue;
                 for (unsigned c = 0; c < C; c++) {
                     transform_patch_2d(cx, src + ((size_t)st * C + c) * plane, pos[n * A + st], tmp.data());
                     float* dst = &T[(((size_t)s * nSx + n) * C + c) * k2 * A];
@@ -834,7 +837,7 @@ int pass_impl(int step, const orc_params* P, unsigned aw, unsigned ah, unsigned 
     PassCtx cx;
     cx.step = step; cx.P = P; cx.aw = aw; cx.ah = ah; cx.A = aw * ah; cx.Wb = Wb; cx.Hb = Hb; cx.C = C;
     cx.k = P->k; cx.k2 = P->k * P->k; cx.N = P->N ? P->N : 1; cx.nHW = P->nSim + P->nDisp;
-    cx.noisy = noisy; cx.basic = basic; cx.mask = mask; cx.pst = pst;
+    cx.noisy = noisy; cx.basic = basic; cx.mask = mask; cx.pst = pst; cx.centre = pst == cst;
     const unsigned A = cx.A, k = cx.k, nHW = cx.nHW;
     const size_t plane = (size_t)Wb * Hb;
     if (sigma_table(P->sigma, C, P->color_space, cx.sigma)) return 1;

@@ -27,7 +27,7 @@ def ctx():
     c.close()
 
 
-def gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, mask=None, proc=None, useSD=0):
+def gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, mask=None, proc=None, useSD=0, cst=4, pst=4):
     from lfbm5d_amd import core
     A = win.shape[0]
     d_win = torch.from_numpy(win).cuda()
@@ -38,7 +38,7 @@ def gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, m
     proc = np.zeros(A, np.uint32) if proc is None else proc
     torch.cuda.synchronize()
     ctx.core_pass(step, core.make_params(sigma, 2.7, *pk, useSD=useSD), 3, 3, Wb, Hb, Cc, d_win, d_basic, d_num, d_den,
-                  mask, proc, 4, 4)
+                  mask, proc, cst, pst)
     return d_num.cpu().numpy(), d_den.cpu().numpy()
 
 
@@ -157,6 +157,50 @@ def test_row_shards_sum_to_full_pass(ctx):
     ctx.set_shard(0, 1)
     np.testing.assert_allclose(sum(p[0] for p in parts), full_n, rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(sum(p[1] for p in parts), full_d, rtol=1e-5, atol=1e-6)
+
+
+def test_subset_pass_matches_oracle(ctx):
+    """pst != cst (core:531-821): greyscale window, centre pass first, then a pass for another SAI that
+    only takes the reference patches whose footprint still has a zero weight (den-aware list,
+    utilities_LF.cpp:1031-1099), matched with the irregular-list block matching (core:3631-3945)."""
+    pk = (4, 6, 2, 8, 4, "dct", "sadct", "haar")
+    win, Wb, Hb, Cc = window(20.0, pk, 72, grey=True)
+    num0, den0, st0 = Hh.oracle_pass(1, 20.0, pk, win, None, Wb, Hb, Cc)
+    proc = np.zeros(9, np.uint32)
+    proc[4] = 1
+    for pst in (8, 1):
+        num_o, den_o, st = Hh.oracle_pass(1, 20.0, pk, win, None, Wb, Hb, Cc, num=num0.copy(), den=den0.copy(), proc=proc, pst=pst)
+        assert 0 < st.groups < st0.groups
+        ctx.reset_stats()
+        num_g, den_g = gpu_pass(ctx, 1, 20.0, pk, win, None, Wb, Hb, Cc, num=num0.copy(), den=den0.copy(), proc=proc, pst=pst)
+        s = ctx.stats()
+        assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
+        assert np.array_equal(den_o != 0, den_g != 0)
+        np.testing.assert_allclose(den_g, den_o, rtol=2e-5, atol=1e-7)
+        assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 2e-3
+        assert np.array_equal(num_g[4], num0[4])   # the processed centre SAI is not aggregated into again
+
+
+def test_greyscale_light_field_whole_steps(ctx):
+    """C == 1: windows are not finished by their centre pass, the subset path runs."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    lf = Hh.source_lf(crop=96)[:, :1]
+    clean, noisy = Hh.noisy_lf(lf, 20.0)
+    mask = np.ones(9, np.uint32)
+    p1 = (4, 6, 2, 8, 4, "dct", "sadct", "haar")
+    p2 = (8, 6, 2, 8, 4, "dct", "sadct", "haar")
+    n1, b_o, st1 = O.run_step1(O.make_params(20.0, 2.7, *p1, cs="rgb"), noisy.copy(), mask, O.ROWMAJOR, 3, 3, 1, 96, 96, 1)
+    n2, b2, d_o, st2 = O.run_step2(O.make_params(20.0, 2.7, *p2, cs="rgb"), n1.copy(), b_o.copy(), mask, O.ROWMAJOR, 3, 3, 1, 96, 96, 1)
+    d_noisy = torch.from_numpy(noisy).cuda()
+    d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+    ctx.reset_stats()
+    ctx.step1(core.make_params(20.0, 2.7, *p1, color_space="rgb"), d_noisy, mask, d_basic, L.ROWMAJOR, 3, 3, 1, 96, 96, 1)
+    s = ctx.stats()
+    assert s.passes == st1.passes and s.passes > 1
+    assert abs(O.psnr_lf(d_basic.cpu().numpy(), clean) - O.psnr_lf(b_o, clean)) < 0.01
+    ctx.step2(core.make_params(20.0, 2.7, *p2, color_space="rgb"), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, 3, 3, 1, 96, 96, 1)
+    assert abs(O.psnr_lf(d_den.cpu().numpy(), clean) - O.psnr_lf(d_o, clean)) < 0.01
 
 
 E2E = {
