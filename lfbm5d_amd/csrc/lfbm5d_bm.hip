@@ -61,19 +61,17 @@ __device__ __forceinline__ int grid_index(int v, int n, int last, int nHW, int p
  * column of the table (a K-term chain per row) is computed up front; strips hand their last
  * column to the next strip through `lcol`.
  */
-template <int K>
-__global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
+template <int K, int MODE>   /* MODE 0: self search on the regular grid, 1: self search on an irregular list, 2: disparity */
+__device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, float* lds) {
     /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows.  Sized so that five waves fit a CU
      * at 560-wide windows (32 KiB each): the launch then takes two rounds of resident waves, not three */
     constexpr int T = K >= 12 ? 4 : 8, RR = 64 + K + 2 * T, CW = 64 + K;
-    extern __shared__ float lds[];
+    constexpr bool stereo = MODE == 2;
+    constexpr bool irregular = MODE == 1;
     float* ring = lds;              /* [RR][CW] D rows of the current strip; ring col 0 <-> x = cb-1 */
-    float* lcol = lds + RR * CW;    /* [nrows] column left of the current strip (strip 0: first column) */
+    /* rows RR .. RR+T-2 mirror rows 0 .. T-2, so T consecutive ring rows can be read without wrapping */
+    float* lcol = lds + (RR + T - 1) * CW;   /* [nrows] column left of the current strip (strip 0: first column) */
     const int lane = threadIdx.x;
-    /* one launch covers both searches: blocks [0, n_self) are self-similarity tables, the rest
-     * disparity tables (fewer, fuller rounds of resident waves than two launches) */
-    const bool stereo = blockIdx.x >= a.n_self;
-    const int bid = stereo ? (int)(blockIdx.x - a.n_self) : (int)blockIdx.x;
     const int half = stereo ? (int)a.nDisp : (int)a.nSim;
     const int trim = stereo ? (int)a.k - 1 : 0;
     const int W = a.W, H = a.H, b = stereo ? (int)a.nDisp : (int)a.nHW;
@@ -109,14 +107,13 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
     const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)(WH * 4), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (int)a.scores_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.rslot, 0, (int)((H + 64) * 4), kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.refmap, 0, a.refmap ? (int)(WH * 4) : 0, kRsrcFlags);
-    const bool irregular = a.refmap != nullptr;
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.refmap, 0, irregular ? (int)(WH * 4) : 0, kRsrcFlags);
     const int gR = a.n_ref_rows, gC = a.n_ref_cols, gP = a.p, gN = a.nHW;
     const int lastR = H - (int)a.k - gN, lastC = W - (int)a.k - gN;
 
     auto emit = [&](int y, int x, float S) {
         if (stereo) { table[y * W + x] = S; return; }
-        if (a.refmap) { /* irregular reference list (subset path, core:3631-3788): slots come from a position map */
+        if (irregular) { /* irregular reference list (subset path, core:3631-3788): slots come from a position map */
             const int r = a.refmap[y * W + x];
             if (r >= 0) a.scores[(size_t)r * ncand + ord_fwd] = S;
             const int yy = y + di, xx = x + djs;
@@ -200,11 +197,17 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
             e2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, ve, so, 0));
         };
         auto store_row = [&](int R, float m1, float m2, float e1, float e2) {
-            float* rr = ring + (R % RR) * CW;   /* uniform */
-            const bool rin = b + R < H - b;     /* uniform */
+            const int rw = R % RR;               /* uniform */
+            float* rr = ring + rw * CW;
+            const bool rin = b + R < H - b;      /* uniform */
             const float dm = m2 - m1, de = e2 - e1;
-            rr[lane] = (rin && inm) ? dm * dm : 0.0f;
-            if (lane < K) rr[64 + lane] = (rin && ine) ? de * de : 0.0f;
+            const float vmain = (rin && inm) ? dm * dm : 0.0f, vext = (rin && ine) ? de * de : 0.0f;
+            rr[lane] = vmain;
+            if (lane < K) rr[64 + lane] = vext;
+            if (rw < T - 1) {                    /* mirror row (uniform, rare) */
+                rr[RR * CW + lane] = vmain;
+                if (lane < K) rr[RR * CW + 64 + lane] = vext;
+            }
         };
         for (int R0 = 0; R0 < K + T; R0 += T) {
             float m1[T], m2[T], e1[T], e2[T];
@@ -337,16 +340,116 @@ __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
             }
             filled += T;
         };
+        /* Lean steady-state chunk: every lane 0..last_lane active for all T steps and every loaded row
+         * inside the band, so nothing is predicated; ring rows are addressed through running
+         * pointers (mirror rows make T consecutive rows wrap-free), the row-load offset and the ring
+         * write row advance incrementally, and two chunks are issued back to back with the staging
+         * registers swapped instead of copied. */
+        const int offE = lane < K ? 64 + lane : lane;   /* extra-column slot; lanes >= K rewrite their own main slot */
+        auto lean_chunk = [&](int t0, int& rA, int& rB, int& wrow, int& soff,
+                              float* ld1, float* ld2, float* le1, float* le2,          /* receive rows filled+T .. */
+                              const float* st1, const float* st2, const float* se1, const float* se2) { /* rows filled .. go to the ring */
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                ld1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vm, soff, 0));
+                ld2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vm, soff, 0));
+                le1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ve, soff, 0));
+                le2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, ve, soff, 0));
+                soff += W * 4;
+            }
+            const float* pa = ring + rA * CW + lane;
+            const float* pb = ring + rB * CW + lane;
+            float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
+                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
+                lc[s] = lcol[1 + t0 + s];
+            }
+            rA += T; rA = rA >= RR ? rA - RR : rA;
+            rB += T; rB = rB >= RR ? rB - RR : rB;
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lc[s]), __float_as_int(curS),
+                                                                              0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+                float S = left + curS;             /* core:3379-3386, same association */
+                S = S - left_prev;
+                S = S + d1[s];
+                S = S - d2[s];
+                S = S - d3[s];
+                S = S + d4[s];
+                S = first_col ? left : S;
+                Sout[s] = S;
+                curS = S;
+                left_prev = left;
+            }
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                const int t = t0 + s;
+                if (stereo) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, voT, (b + 1 + t - last_lane) * W * 4, 0);
+                else {
+                    const int vy = (b + 1 + t - lane) * 4;   /* >= 0 in the steady state */
+                    int v1, v2;
+                    if (irregular) {
+                        const int q = (b + 1 + t - lane) * W + x;
+                        const int r1 = __builtin_amdgcn_raw_buffer_load_b32(rsM, q * 4, 0, 0);
+                        const int r2 = (di > 0 && x + djs >= 0 && x + djs < W) ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (q + di * W + djs) * 4, 0, 0) : -1;
+                        v1 = (col_ok && r1 >= 0) ? (int)(((unsigned)r1 * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
+                        v2 = (col_ok && r2 >= 0) ? (int)(((unsigned)r2 * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                    } else {
+                        const int r1 = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, 0, 0);
+                        const int r2 = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, di * 4, 0);
+                        v1 = (col_ok && cx >= 0 && r1 >= 0) ? (int)(((unsigned)(r1 * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
+                        v2 = (col_ok && cx2 >= 0 && r2 >= 0 && di > 0) ? (int)(((unsigned)(r2 * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
+                }
+                lcol[1 + t - last_lane] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
+            }
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                float* rr = ring + wrow * CW;       /* uniform */
+                const float dm = st2[s] - st1[s], de = se2[s] - se1[s];
+                const float vmain = inm ? dm * dm : 0.0f, vext = ine ? de * de : 0.0f;
+                rr[lane] = vmain;
+                rr[offE] = lane < K ? vext : vmain;
+                if (wrow < T - 1) { rr[RR * CW + lane] = vmain; rr[RR * CW + offE] = lane < K ? vext : vmain; }
+                wrow = wrow + 1 == RR ? 0 : wrow + 1;
+            }
+        };
         /* ramp-up (lanes start one step apart), steady state, ramp-down */
+        const int band_rows = H - 2 * b;
         const int t_steady0 = ((last_lane + T - 1) / T) * T;               /* first chunk with t0 >= last_lane */
-        const int t_steady1 = nrows - T - 1 >= 0 ? ((nrows - T - 1) / T) * T + T : 0;   /* chunks with t0 <= nrows-T-1 */
+        int t_steady1 = nrows - T - 1 >= 0 ? ((nrows - T - 1) / T) * T + T : 0;   /* chunks with t0 <= nrows-T-1 ... */
+        t_steady1 = min(t_steady1, ((band_rows - K - 3 * T) / T) * T + T);        /* ... whose loaded rows are all in the band */
         int t0 = 0;
         for (; t0 < nsteps && t0 < t_steady0; t0 += T) do_chunk(t0, std::false_type{});
-        for (; t0 < nsteps && t0 < t_steady1; t0 += T) do_chunk(t0, std::true_type{});
+        if (t0 + 2 * T <= t_steady1 && t0 + 2 * T <= nsteps) {
+            int rA = (t0 + K - lane + 64 * RR) % RR, rB = (t0 - lane + 64 * RR) % RR;
+            int wrow = filled % RR;
+            int soff = (b + filled + T) * W * 4;
+            float u1[T], u2[T], g1[T], g2[T];
+            for (; t0 + 2 * T <= t_steady1 && t0 + 2 * T <= nsteps; t0 += 2 * T) {
+                lean_chunk(t0, rA, rB, wrow, soff, u1, u2, g1, g2, p1, p2, q1, q2);
+                lean_chunk(t0 + T, rA, rB, wrow, soff, p1, p2, q1, q2, u1, u2, g1, g2);
+                filled += 2 * T;
+            }
+        }
         for (; t0 < nsteps; t0 += T) do_chunk(t0, std::false_type{});
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
         __syncthreads();
     }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
+    extern __shared__ float lds[];
+    /* one launch covers both searches: blocks [0, n_self) are self-similarity tables, the rest
+     * disparity tables (fewer, fuller rounds of resident waves than two launches) */
+    if (blockIdx.x >= a.n_self) scan_body<K, 2>(a, (int)(blockIdx.x - a.n_self), lds);
+    else if (a.refmap) scan_body<K, 1>(a, (int)blockIdx.x, lds);
+    else scan_body<K, 0>(a, (int)blockIdx.x, lds);
 }
 
 /* order-preserving float -> uint map (scores can be slightly negative after cancellation) */
@@ -469,7 +572,7 @@ hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
     const unsigned rows_self = a.n_self ? a.H - 2 * a.nHW : 0, rows_st = a.n_stereo ? a.H - 2 * a.nDisp - (a.k - 1) : 0;
     const unsigned nrows = rows_self > rows_st ? rows_self : rows_st;
     const unsigned T = a.k >= 12 ? 4 : 8;
-    const size_t lds = (size_t)((64 + a.k + 2 * T) * (64 + a.k) + nrows + T + 1) * sizeof(float);
+    const size_t lds = (size_t)((64 + a.k + 2 * T + T - 1) * (64 + a.k) + nrows + T + 1) * sizeof(float);
     const unsigned n = a.n_self + a.n_stereo;
     if (!n) return hipSuccess;
     switch (a.k) {
