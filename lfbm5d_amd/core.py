@@ -64,7 +64,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = library_path()
+    # LFBM5D_HIP_LIB: an alternative build of the same library (kernel A/B experiments, tools/build_variant.sh)
+    path = os.environ.get("LFBM5D_HIP_LIB") or library_path()
     if not os.path.exists(path):
         raise LfBm5dError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950).  lfbm5d_amd has no CPU fallback.")

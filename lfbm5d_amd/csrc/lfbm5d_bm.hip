@@ -351,6 +351,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                               const float* st1, const float* st2, const float* se1, const float* se2) { /* rows filled .. go to the ring */
 #pragma unroll
             for (int s = 0; s < T; s++) {
+#ifdef LFBM5D_EXP
+                if (LFBM5D_EXP & 4) { ld1[s] = st1[s]; ld2[s] = st2[s]; le1[s] = se1[s]; le2[s] = se2[s]; continue; }
+#endif
                 ld1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vm, soff, 0));
                 ld2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vm, soff, 0));
                 le1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ve, soff, 0));
@@ -362,6 +365,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
 #pragma unroll
             for (int s = 0; s < T; s++) {
+#ifdef LFBM5D_EXP
+                if (LFBM5D_EXP & 8) { d1[s] = st1[s]; d2[s] = st2[s]; d3[s] = se1[s]; d4[s] = se2[s]; lc[s] = lcol[1 + t0 + s]; continue; }
+#endif
                 d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
                 d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
                 lc[s] = lcol[1 + t0 + s];
@@ -386,6 +392,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 const int t = t0 + s;
+#ifdef LFBM5D_EXP
+                if (LFBM5D_EXP & 2) { lcol[1 + t - last_lane] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane)); continue; }
+                if (stereo && (LFBM5D_EXP & 1)) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, x * 4, (b + 1 + t - last_lane) * W * 4, 0); }
+                else
+#endif
                 if (stereo) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, voT, (b + 1 + t - last_lane) * W * 4, 0);
                 else {
                     const int vy = (b + 1 + t - lane) * 4;   /* >= 0 in the steady state */

@@ -964,6 +964,9 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
         const unsigned p = pos[patch];
         const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - 8);   /* never-filled table column (core:1697) */
         const float* img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
+#ifdef LFBM5D_EXP
+        if (LFBM5D_EXP & 16) img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (tid & 63) * 8;
+#endif
         float x[8][8];
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -991,6 +994,9 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     /* 4-D forward: one (n, pq) fibre of 9 values per thread */
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+#ifdef LFBM5D_EXP
+    if (!(LFBM5D_EXP & 32))
+#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < S * nSx * K2; f += kDct8Threads) {
             const int s = f / (nSx * K2), r = f % (nSx * K2), n = r / K2, pq = r % K2;
@@ -1011,6 +1017,9 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
         const float sig = a.sigma[c];
         const float T = a.lambda * sig * 1.41421356237309505f;
         const float sig2 = sig * sig;
+#ifdef LFBM5D_EXP
+        if (!(LFBM5D_EXP & 64))
+#endif
         for (int f = tid; f < A * K2; f += kDct8Threads) {
             const int st = f / K2, pq = f % K2;
             const bool in_shape = !use_sadct || sh.mask_dct[st];
@@ -1048,6 +1057,9 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     float* F = STEP == 2 ? S1 : S0;
 
     /* 4-D inverse */
+#ifdef LFBM5D_EXP
+    if (!(LFBM5D_EXP & 32))
+#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * K2; f += kDct8Threads) {
             const int n = f / K2, pq = f % K2;
@@ -1063,6 +1075,9 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     __syncthreads();
 
     /* inverse 2-D DCT + store, one thread per patch: filt[g][n][st][c][64] */
+#ifdef LFBM5D_EXP
+    if (!(LFBM5D_EXP & 128))
+#endif
     for (int patch = tid; patch < NP; patch += kDct8Threads) {
         float x[8][8];
         const float* src = F + patch;
@@ -1086,6 +1101,353 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
         for (int i = 0; i < 8; i++) {
             out[2 * i] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
             out[2 * i + 1] = make_float4(x[i][4], x[i][5], x[i][6], x[i][7]);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Wiener step of the 8x8 DCT configuration (step 2, k = 8, tau_2D = dct): packed-fp32 variant.
+ * The noisy and the pilot (basic) stacks go through identical forward transforms, so they are kept
+ * as the two halves of a float2 everywhere: one LDS stack of float2 laid out [coefficient pq][patch],
+ * 64-bit LDS accesses, and v_pk_{add,mul,fma}_f32 arithmetic that transforms both stacks at once.
+ * Where only the filtered stack remains (inverse transforms) two fibres / two patches are paired
+ * instead.  The arithmetic per element is the same sequence as in k_group_dct8<2>.
+ * Phases (256 threads, barriers between them):
+ *   1  thread = patch: 16-byte loads of the 8 rows from both images, 16 packed 8-point DCTs, 64 LDS writes
+ *   2  thread = (n, pq) fibre over the 9 SAIs: packed 3x3 DCT (shape-adaptive variant on the scalar path)
+ *   3  thread = (st, pq) fibre over the nSx patches: packed Haar, Wiener shrinkage, inverse Haar
+ *   4  thread = two (n, pq) fibres of the filtered stack: packed inverse 3x3 DCT
+ *   5  thread = two patches: packed inverse 8x8 DCT, 16-byte stores of the filtered patches
+ * ------------------------------------------------------------------------------------------ */
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };   /* 16-byte load at 4-byte alignment */
+
+template <class T> __device__ __forceinline__ void dct8_fwd_t(T* x) {
+    const float a0 = 0.35355339059327376f, h = 0.5f;
+    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
+                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
+    const T s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
+    const T d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+    const T p0 = s0 + s3, p1 = s1 + s2, m0 = s0 - s3, m1 = s1 - s2;
+    x[0] = a0 * (p0 + p1);
+    x[4] = (h * c4) * (p0 - p1);
+    x[2] = h * (c2 * m0 + c6 * m1);
+    x[6] = h * (c6 * m0 - c2 * m1);
+    x[1] = h * (c1 * d0 + c3 * d1 + c5 * d2 + c7 * d3);
+    x[3] = h * (c3 * d0 - c7 * d1 - c1 * d2 - c5 * d3);
+    x[5] = h * (c5 * d0 - c1 * d1 + c7 * d2 + c3 * d3);
+    x[7] = h * (c7 * d0 - c5 * d1 + c3 * d2 - c1 * d3);
+}
+template <class T> __device__ __forceinline__ void dct8_inv_t(T* X) {
+    const float a0 = 0.35355339059327376f, h = 0.5f;
+    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
+                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
+    const T e0 = a0 * X[0] + (h * c4) * X[4], e1 = a0 * X[0] - (h * c4) * X[4];
+    const T f0 = h * (c2 * X[2] + c6 * X[6]), f1 = h * (c6 * X[2] - c2 * X[6]);
+    const T E0 = e0 + f0, E1 = e1 + f1, E2 = e1 - f1, E3 = e0 - f0;
+    const T O0 = h * (c1 * X[1] + c3 * X[3] + c5 * X[5] + c7 * X[7]);
+    const T O1 = h * (c3 * X[1] - c7 * X[3] - c1 * X[5] - c5 * X[7]);
+    const T O2 = h * (c5 * X[1] - c1 * X[3] + c7 * X[5] + c3 * X[7]);
+    const T O3 = h * (c7 * X[1] - c5 * X[3] + c3 * X[5] - c1 * X[7]);
+    X[0] = E0 + O0; X[7] = E0 - O0;
+    X[1] = E1 + O1; X[6] = E1 - O1;
+    X[2] = E2 + O2; X[5] = E2 - O2;
+    X[3] = E3 + O3; X[4] = E3 - O3;
+}
+/* dct9_fwd / dct9_inv on a pair of fibres */
+__device__ __forceinline__ void dct9_fwd2(v2f* x, const GroupTables* tb) {
+    v2f t[9];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            t[s * 3 + u] = 2.0f * (x[s * 3] * tb->cos3[u * 3] + x[s * 3 + 1] * tb->cos3[u * 3 + 1] + x[s * 3 + 2] * tb->cos3[u * 3 + 2]);
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            x[v * 3 + u] = 2.0f * (t[u] * tb->cos3[v * 3] + t[3 + u] * tb->cos3[v * 3 + 1] + t[6 + u] * tb->cos3[v * 3 + 2]) * tb->cn4[v * 3 + u];
+}
+__device__ __forceinline__ void dct9_inv2(v2f* x, const GroupTables* tb) {
+    v2f t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[i] *= tb->cni4[i];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            t[s * 3 + j] = x[s * 3] + 2.0f * (x[s * 3 + 1] * tb->cos3[3 + j] + x[s * 3 + 2] * tb->cos3[6 + j]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
+}
+template <int NS> __device__ __forceinline__ void haar_fwd2(v2f* v) {
+    const float s = 0.70710678118654752f;
+#pragma unroll
+    for (int n = NS; n > 1; n /= 2) {
+        v2f t[NS > 1 ? NS : 1];
+#pragma unroll
+        for (int i = 0; i < n / 2; i++) { t[i] = (v[2 * i] + v[2 * i + 1]) * s; t[n / 2 + i] = (v[2 * i] - v[2 * i + 1]) * s; }
+#pragma unroll
+        for (int i = 0; i < n; i++) v[i] = t[i];
+    }
+}
+
+/* phase 3 of k_group_dct8w on one (st, pq) fibre of nSx = NS float2 entries (x: noisy, y: pilot) */
+template <int NS, bool HAAR>
+__device__ __forceinline__ void wiener_fibre2(v2f* stack, int base, int stride, unsigned tau5, float sig2, bool in_shape,
+                                              bool useSD, float& wacc, float& s1, float& s2, const GroupTables* tb) {
+    v2f f[NS];
+#pragma unroll
+    for (int n = 0; n < NS; n++) f[n] = stack[base + n * stride];
+    float o[NS], e[NS];
+    if (HAAR) {
+        if (NS > 1) haar_fwd2<NS>(f);
+#pragma unroll
+        for (int n = 0; n < NS; n++) { o[n] = f[n].x; e[n] = f[n].y; }
+        if (in_shape) {
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                float value = e[n] * e[n];
+                value = __fdiv_rn(value, value + sig2);
+                e[n] = o[n] * value;
+                wacc += value;
+            }
+        }
+        if (NS > 1) haar_inv<NS>(e);
+    } else {
+#pragma unroll
+        for (int n = 0; n < NS; n++) { o[n] = f[n].x; e[n] = f[n].y; }
+        shrink_fibre<NS, 2>(o, e, tau5, 0.0f, sig2, in_shape, wacc, tb);
+    }
+    float* dst = reinterpret_cast<float*>(stack);
+#pragma unroll
+    for (int n = 0; n < NS; n++) dst[2 * (base + n * stride) + 1] = e[n];
+    if (useSD) {
+#pragma unroll
+        for (int n = 0; n < NS; n++) { s1 += e[n]; s2 += e[n] * e[n]; }
+    }
+}
+
+constexpr int kDct8wThreads = 256;
+
+template <bool HAAR>
+__global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ ShapeInfo sh;
+    __shared__ unsigned pos[kMaxN * kMaxA];
+    __shared__ float red[3][kDct8wThreads / 64];
+    const int tid = threadIdx.x;
+    const unsigned g = a.ref_begin + blockIdx.x;
+    const int c = blockIdx.y;
+    constexpr int A = 9, K2 = 64;
+    const int N = a.N;
+    const int nSx = (int)a.self_cnt[g];
+    const unsigned k_r = a.refs[g];
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const int NP = nSx * A;               /* patches per stack */
+    const int NPp = (N * A) | 1;          /* row stride of the [pq][patch] stack (float2 units), odd */
+    v2f* stack = reinterpret_cast<v2f*>(lds);
+    float* stackf = lds;
+    const GroupTables* tb = a.tb;
+
+    for (int i = tid; i < NP; i += kDct8wThreads) {
+        const int n = i / A, st = i % A;
+        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
+        unsigned p = 0xffffffffu;
+        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+        pos[i] = p;
+    }
+    if (tid == 0) {
+        int m[9];
+        for (int st = 0; st < 9; st++)
+            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
+        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
+    }
+    __syncthreads();
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    for (int i = tid; c == 0 && i < N * A; i += kDct8wThreads) {
+        const int n = i / A, st = i % A;
+        unsigned p = 0xffffffffu;
+        if (n < nSx && ((a.mask_bits >> st) & 1)) {
+            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
+            if (ok) p = pos[n * A + st];
+        }
+        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
+    }
+
+    /* 1: gather + forward 2-D DCT of both images, one thread per patch */
+    for (int patch = tid; patch < NP; patch += kDct8wThreads) {
+        const int st = patch % A;
+        const unsigned p = pos[patch];
+        const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - 8);   /* never-filled table column (core:1697) */
+        const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
+        const float* in0 = a.noisy + off;
+        const float* in1 = a.basic + off;
+        v2f x[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const f4u l0 = *reinterpret_cast<const f4u*>(in0 + (size_t)i * a.Wb), l1 = *reinterpret_cast<const f4u*>(in0 + (size_t)i * a.Wb + 4);
+            const f4u r0 = *reinterpret_cast<const f4u*>(in1 + (size_t)i * a.Wb), r1 = *reinterpret_cast<const f4u*>(in1 + (size_t)i * a.Wb + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                x[i][j] = ok ? v2f{l0.v[j], r0.v[j]} : v2f{0.0f, 0.0f};
+                x[i][4 + j] = ok ? v2f{l1.v[j], r1.v[j]} : v2f{0.0f, 0.0f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) dct8_fwd_t(x[i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            v2f col[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) col[i] = x[i][j];
+            dct8_fwd_t(col);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i][j] = col[i];
+        }
+        v2f* dst = stack + patch;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) dst[(i * 8 + j) * NPp] = x[i][j];
+    }
+    __syncthreads();
+
+    /* 2: 4-D forward, one (n, pq) fibre of 9 float2 per thread */
+    const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
+    const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < nSx * K2; f += kDct8wThreads) {
+            const int n = f / K2, pq = f % K2;
+            v2f* base = stack + pq * NPp + n * A;
+            v2f x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = base[st];
+            if (do_dct4) dct9_fwd2(x, tb);
+            else {   /* rare: shape-adaptive transform on the scalar path */
+                float t9[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) t9[i] = x[i].x;
+                sadct9_fwd(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
+                sadct9_fwd(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) x[i].y = t9[i];
+            }
+#pragma unroll
+            for (int st = 0; st < 9; st++) base[st] = x[st];
+        }
+        __syncthreads();
+    }
+
+    /* 3: 5th dimension + Wiener shrinkage, one (st, pq) fibre of nSx float2 per thread; result -> .y */
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    {
+        const float sig = a.sigma[c];
+        const float sig2 = sig * sig;
+        const bool useSD = a.useSD != 0;
+        for (int f = tid; f < A * K2; f += kDct8wThreads) {
+            const int st = f / K2, pq = f % K2;
+            const bool in_shape = !use_sadct || sh.mask_dct[st];
+            const int base = pq * NPp + st;
+            switch (nSx) {
+                case 1:  wiener_fibre2<1, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                case 2:  wiener_fibre2<2, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                case 4:  wiener_fibre2<4, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                case 8:  wiener_fibre2<8, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                default: wiener_fibre2<16, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < kDct8wThreads / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(nSx * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)nSx);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
+    }
+
+    /* 4: 4-D inverse of the filtered stack (.y), two (n, pq) fibres per thread: pq and pq + 32 */
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < nSx * (K2 / 2); f += kDct8wThreads) {
+            const int n = f / (K2 / 2), pq = f % (K2 / 2);
+            float* b0 = stackf + 2 * (pq * NPp + n * A) + 1;
+            float* b1 = stackf + 2 * ((pq + K2 / 2) * NPp + n * A) + 1;
+            v2f x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = v2f{b0[2 * st], b1[2 * st]};
+            if (do_dct4) dct9_inv2(x, tb);
+            else {
+                float t9[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) t9[i] = x[i].x;
+                sadct9_inv(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
+                sadct9_inv(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) x[i].y = t9[i];
+            }
+#pragma unroll
+            for (int st = 0; st < 9; st++) { b0[2 * st] = x[st].x; b1[2 * st] = x[st].y; }
+        }
+    }
+    __syncthreads();
+
+    /* 5: inverse 2-D DCT + store, two patches per thread (patch, patch + NPh): filt[g][n][st][c][64] */
+    const int NPh = (NP + 1) / 2;
+    for (int pa = tid; pa < NPh; pa += kDct8wThreads) {
+        const int pb = pa + NPh;
+        const bool has_b = pb < NP;
+        const float* sa = stackf + 2 * pa + 1;
+        const float* sb = stackf + 2 * (has_b ? pb : pa) + 1;
+        v2f x[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[i][j] = v2f{sa[2 * (i * 8 + j) * NPp], sb[2 * (i * 8 + j) * NPp]};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            v2f col[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) col[i] = x[i][j];
+            dct8_inv_t(col);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i][j] = col[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) dct8_inv_t(x[i]);
+        float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            oa[2 * i] = make_float4(x[i][0].x, x[i][1].x, x[i][2].x, x[i][3].x);
+            oa[2 * i + 1] = make_float4(x[i][4].x, x[i][5].x, x[i][6].x, x[i][7].x);
+        }
+        if (has_b) {
+            float4* ob = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pb) * a.C * K2 + (size_t)c * K2);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                ob[2 * i] = make_float4(x[i][0].y, x[i][1].y, x[i][2].y, x[i][3].y);
+                ob[2 * i + 1] = make_float4(x[i][4].y, x[i][5].y, x[i][6].y, x[i][7].y);
+            }
         }
     }
 }
@@ -1269,6 +1631,17 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
             attr8 = true;
+        }
+        if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* packed noisy/pilot pair */
+            static bool attrw = false;
+            if (!attrw) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+                attrw = true;
+            }
+            if (a.tau5 == 9) hipLaunchKernelGGL(k_group_dct8w<true>, dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
+            else             hipLaunchKernelGGL(k_group_dct8w<false>, dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
+            return hipGetLastError();
         }
         if (a.step == 2) hipLaunchKernelGGL(k_group_dct8<2>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);
         else             hipLaunchKernelGGL(k_group_dct8<1>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);

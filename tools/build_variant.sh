@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build an experimental variant of liblfbm5d_hip.so with extra compiler flags (kernel A/B tests):
+#   tools/build_variant.sh <name> "<extra hipcc flags>"   ->  lfbm5d_amd/variants/lib_<name>.so
+# Select it at run time with LFBM5D_HIP_LIB=lfbm5d_amd/variants/lib_<name>.so.
+set -e
+cd "$(dirname "$0")/../lfbm5d_amd/csrc"
+name=$1; extra=$2
+out=../variants; mkdir -p $out/obj_$name
+F="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-result $extra"
+hipcc $F -ffp-contract=off -c lfbm5d_bm.hip -o $out/obj_$name/bm.o &
+hipcc $F -c lfbm5d_kernels.hip -o $out/obj_$name/kernels.o &
+hipcc $F -c lfbm5d_api.hip -o $out/obj_$name/api.o &
+wait
+hipcc --offload-arch=gfx950 -shared -o $out/lib_$name.so $out/obj_$name/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo built $out/lib_$name.so
