@@ -55,7 +55,7 @@ struct lfbm5d_ctx {
     ncclComm_t comm = nullptr;
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
-    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, counters, tb, small;
+    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
@@ -303,6 +303,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->filt.reserve((size_t)R * Nst * A * C * k2 * sizeof(float)));
     HIPCK(c, c->wgt.reserve((size_t)R * C * sizeof(float)));
     HIPCK(c, c->aggpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
+    HIPCK(c, c->gpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
+    HIPCK(c, c->gshape.reserve((size_t)R * sizeof(unsigned)));
     HIPCK(c, c->tb.reserve(sizeof(GroupTables)));
     if (!c->counters.p) {
         HIPCK(c, c->counters.reserve(4 * sizeof(unsigned long long)));
@@ -370,7 +372,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.noisy = d_noisy; ga.basic = d_basic; ga.num = d_num; ga.den = d_den;
     ga.refs = c->refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
     ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = c->tb.as<GroupTables>();
-    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.n_refs_total = R; ga.counters = c->counters.as<unsigned long long>();
+    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gshape = c->gshape.as<unsigned>(); ga.n_refs_total = R; ga.counters = c->counters.as<unsigned long long>();
     ga.ref_begin = ref_begin; ga.n_groups = n_groups;
     ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
     ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;
@@ -634,7 +636,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->counters, &c->tb, &c->small, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

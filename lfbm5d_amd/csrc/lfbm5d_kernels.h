@@ -51,6 +51,8 @@ struct GroupArgs {
     float* filt;                /* [R][N][A][C][k2] filtered patches (pixel domain) */
     float* wgt;                 /* [R][C] aggregation weights */
     unsigned* aggpos;           /* [A][R][N] where each filtered patch is aggregated (0xffffffff: nowhere) */
+    unsigned* gpos;             /* [R][N][A] window position of every patch of every group (pre-pass output) */
+    unsigned* gshape;           /* [R] 9-bit angular shape of the group (pre-pass output) */
     unsigned n_refs_total;
     unsigned long long* counters; /* [0] sum nSx, [1] sadct groups */
     unsigned ref_begin, n_groups;

@@ -544,6 +544,56 @@ __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
     __syncthreads();
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Group geometry pre-pass (core:286-323, :503): for every group of the launch, the window position
+ * of each of its N x A patches (0xffffffff: no patch), the positions the aggregation kernel adds
+ * them at, and the 9-bit angular shape.  Doing this once, fully parallel, takes the
+ * self_idx -> best -> patch dependent-load chain out of every group workgroup.
+ * ------------------------------------------------------------------------------------------ */
+__global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
+    const int A = a.A, N = a.N, NA = N * A;
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)a.n_groups * NA) return;
+    const unsigned g = a.ref_begin + (unsigned)(idx / NA);
+    const int i = (int)(idx % NA), n = i / A, st = i % A;
+    const int nSx = (int)a.self_cnt[g];
+    const unsigned k_r = a.refs[g];
+    const bool masked = (a.mask_bits >> st) & 1;
+    unsigned p = 0xffffffffu;
+    if (n < nSx && masked) {
+        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
+        p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+    }
+    a.gpos[(size_t)g * NA + i] = p;
+    const bool in_shape = st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r]);
+    /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
+     * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
+    a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = (a.tau4 != 6 || in_shape) ? p : 0xffffffffu;
+}
+__global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_groups) return;
+    const unsigned g = a.ref_begin + i;
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const unsigned k_r = a.refs[g];
+    unsigned bits = 0;
+    for (int st = 0; st < (int)a.A; st++) {
+        const bool masked = (a.mask_bits >> st) & 1;
+        if (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) bits |= 1u << st;
+    }
+    a.gshape[g] = bits;
+}
+/* SADCT shape of the group from its 9-bit mask (thread 0 of the workgroup) */
+__device__ __forceinline__ void group_shape(ShapeInfo& sh, const GroupArgs& a, unsigned g) {
+    if (a.tau4 == 6) {
+        const unsigned bits = a.gshape[g];
+        int m[9];
+        for (int st = 0; st < 9; st++) m[st] = (bits >> st) & 1;
+        build_shape(sh, m);
+    } else sh.use_sadct = 0;
+}
+
 template <int STEP>
 __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     extern __shared__ float lds[];
@@ -556,7 +606,6 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     const int c = blockIdx.y;
     const int k = a.k, k2 = k * k, A = a.A, N = a.N;
     const int nSx = (int)a.self_cnt[g];
-    const unsigned k_r = a.refs[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int stack = nSx * A * k2;
     float* S0 = lds;
@@ -564,33 +613,11 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     float* tmp = lds + (STEP == 2 ? 2 : 1) * stack;
     const GroupTables* tb = a.tb;
 
-    /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323) */
-    if (tid < nSx * A) {
-        const int n = tid / A, st = tid % A;
-        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
-        unsigned p = 0xffffffffu;
-        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
-        pos[tid] = p;
-    }
-    if (tid == 0) {
-        int m[9];
-        for (int st = 0; st < 9; st++)
-            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
-        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
-    }
+    /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323): from the pre-pass */
+    if (tid < nSx * A) pos[tid] = a.gpos[(size_t)g * N * A + tid];
+    if (tid == 0) group_shape(sh, a, g);
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
-    /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
-     * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
-    if (c == 0 && tid < N * A) {
-        const int n = tid / A, st = tid % A;
-        unsigned p = 0xffffffffu;
-        if (n < nSx && ((a.mask_bits >> st) & 1)) {
-            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
-            if (ok) p = pos[n * A + st];
-        }
-        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
-    }
 
     /* gather (core:286-299).  Patches whose column equals Wb-k read the reference's never-filled
      * table column, i.e. zeros (core:1697, bm3d.cpp:737) -- reproduce. */
@@ -806,32 +833,10 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     const int c = blockIdx.y;
     const int A = 9, N = a.N;
     const int nSx = (int)a.self_cnt[g];
-    const unsigned k_r = a.refs[g];
-    const size_t plane = (size_t)a.Wb * a.Hb;
-    for (int i = tid; i < nSx * A; i += (int)blockDim.x) {   /* the block may be narrower than N*A (k = 8) */
-        const int n = i / A, st = i % A;
-        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
-        unsigned p = 0xffffffffu;
-        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
-        pos[i] = p;
-    }
-    if (tid == 0) {
-        int m[9];
-        for (int st = 0; st < 9; st++)
-            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
-        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
-    }
+    for (int i = tid; i < nSx * A; i += (int)blockDim.x) pos[i] = a.gpos[(size_t)g * N * A + i];   /* the block may be narrower than N*A (k = 8) */
+    if (tid == 0) group_shape(sh, a, g);
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
-    for (int i = tid; c == 0 && i < N * A; i += (int)blockDim.x) {
-        const int n = i / A, st = i % A;
-        unsigned p = 0xffffffffu;
-        if (n < nSx && ((a.mask_bits >> st) & 1)) {
-            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
-            if (ok) p = pos[n * A + st];
-        }
-        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
-    }
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (tid < (int)(a.k * a.k)) {
         switch (nSx) {
@@ -924,7 +929,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     constexpr int A = 9, K2 = 64;
     const int N = a.N;
     const int nSx = (int)a.self_cnt[g];
-    const unsigned k_r = a.refs[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int NP = nSx * A;               /* patches per stack */
     const int NPp = (N * A) | 1;          /* row stride of the [pq][patch] stack, odd */
@@ -933,30 +937,10 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     const GroupTables* tb = a.tb;
     constexpr int S = STEP == 2 ? 2 : 1;
 
-    for (int i = tid; i < NP; i += kDct8Threads) {
-        const int n = i / A, st = i % A;
-        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
-        unsigned p = 0xffffffffu;
-        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
-        pos[i] = p;
-    }
-    if (tid == 0) {
-        int m[9];
-        for (int st = 0; st < 9; st++)
-            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
-        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
-    }
+    for (int i = tid; i < NP; i += kDct8Threads) pos[i] = a.gpos[(size_t)g * N * A + i];
+    if (tid == 0) group_shape(sh, a, g);
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
-    for (int i = tid; c == 0 && i < N * A; i += kDct8Threads) {
-        const int n = i / A, st = i % A;
-        unsigned p = 0xffffffffu;
-        if (n < nSx && ((a.mask_bits >> st) & 1)) {
-            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
-            if (ok) p = pos[n * A + st];
-        }
-        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
-    }
 
     /* gather + forward 2-D DCT, one thread per patch */
     for (int task = tid; task < S * NP; task += kDct8Threads) {
@@ -1237,7 +1221,6 @@ template <bool HAAR>
 __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     extern __shared__ float lds[];
     __shared__ ShapeInfo sh;
-    __shared__ unsigned pos[kMaxN * kMaxA];
     __shared__ float red[3][kDct8wThreads / 64];
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x;
@@ -1245,7 +1228,6 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     constexpr int A = 9, K2 = 64;
     const int N = a.N;
     const int nSx = (int)a.self_cnt[g];
-    const unsigned k_r = a.refs[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int NP = nSx * A;               /* patches per stack */
     const int NPp = (N * A) | 1;          /* row stride of the [pq][patch] stack (float2 units), odd */
@@ -1253,39 +1235,19 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     float* stackf = lds;
     const GroupTables* tb = a.tb;
 
-    for (int i = tid; i < NP; i += kDct8wThreads) {
-        const int n = i / A, st = i % A;
-        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
-        unsigned p = 0xffffffffu;
-        if ((a.mask_bits >> st) & 1) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
-        pos[i] = p;
-    }
-    if (tid == 0) {
-        int m[9];
-        for (int st = 0; st < 9; st++)
-            m[st] = (st == (int)a.pst) ? 1 : (((a.mask_bits >> st) & 1) ? (int)a.shape[(size_t)st * plane + k_r] : 0);
-        if (a.tau4 == 6) build_shape(sh, m); else sh.use_sadct = 0;
-    }
-    __syncthreads();
-    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
-    for (int i = tid; c == 0 && i < N * A; i += kDct8wThreads) {
-        const int n = i / A, st = i % A;
-        unsigned p = 0xffffffffu;
-        if (n < nSx && ((a.mask_bits >> st) & 1)) {
-            const bool ok = a.tau4 != 6 || st == (int)a.pst || a.shape[(size_t)st * plane + k_r];
-            if (ok) p = pos[n * A + st];
-        }
-        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = p;
-    }
+    if (tid == kDct8wThreads - 1) group_shape(sh, a, g);   /* read after the phase-1 barrier */
 
     /* 1: gather + forward 2-D DCT of both images, one thread per patch */
     for (int patch = tid; patch < NP; patch += kDct8wThreads) {
         const int st = patch % A;
-        const unsigned p = pos[patch];
+        const unsigned p = a.gpos[(size_t)g * N * A + patch];
         const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - 8);   /* never-filled table column (core:1697) */
         const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
         const float* in0 = a.noisy + off;
         const float* in1 = a.basic + off;
+#ifdef LFBM5D_EXP
+        if (LFBM5D_EXP & 16) { in0 = a.noisy + ((size_t)st * a.C + c) * plane + (tid & 63) * 8; in1 = a.basic + ((size_t)st * a.C + c) * plane + (tid & 63) * 8; }
+#endif
         v2f x[8][8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -1317,8 +1279,12 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     __syncthreads();
 
     /* 2: 4-D forward, one (n, pq) fibre of 9 float2 per thread */
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+#ifdef LFBM5D_EXP
+    if (!(LFBM5D_EXP & 32))
+#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * K2; f += kDct8wThreads) {
             const int n = f / K2, pq = f % K2;
@@ -1350,6 +1316,9 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         const float sig = a.sigma[c];
         const float sig2 = sig * sig;
         const bool useSD = a.useSD != 0;
+#ifdef LFBM5D_EXP
+        if (!(LFBM5D_EXP & 64))
+#endif
         for (int f = tid; f < A * K2; f += kDct8wThreads) {
             const int st = f / K2, pq = f % K2;
             const bool in_shape = !use_sadct || sh.mask_dct[st];
@@ -1386,6 +1355,9 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     }
 
     /* 4: 4-D inverse of the filtered stack (.y), two (n, pq) fibres per thread: pq and pq + 32 */
+#ifdef LFBM5D_EXP
+    if (!(LFBM5D_EXP & 32))
+#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * (K2 / 2); f += kDct8wThreads) {
             const int n = f / (K2 / 2), pq = f % (K2 / 2);
@@ -1414,6 +1386,9 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
 
     /* 5: inverse 2-D DCT + store, two patches per thread (patch, patch + NPh): filt[g][n][st][c][64] */
     const int NPh = (NP + 1) / 2;
+#ifdef LFBM5D_EXP
+    if (!(LFBM5D_EXP & 128))
+#endif
     for (int pa = tid; pa < NPh; pa += kDct8wThreads) {
         const int pb = pa + NPh;
         const bool has_b = pb < NP;
@@ -1618,6 +1593,9 @@ size_t group_lds_bytes(const GroupArgs& a) {
     return ((a.step == 2 ? 2 : 1) * stack + 256) * sizeof(float);
 }
 hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
+    /* geometry pre-pass: patch positions, aggregation positions, angular shapes */
+    hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N * a.A), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_group_shape, grid1d(a.n_groups), dim3(256), 0, s, a);
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
     if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
