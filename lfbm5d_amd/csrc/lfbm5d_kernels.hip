@@ -20,6 +20,10 @@ namespace lfbm5d {
 
 namespace {
 
+/* transform tables are constant during a kernel: constant address space, so uniform reads become scalar loads */
+typedef const __attribute__((address_space(4))) GroupTables* TbPtr;
+typedef const __attribute__((address_space(4))) float* TbFloats;
+
 /* ============================== elementwise helpers ======================================= */
 
 __global__ void k_color(float* __restrict__ img, unsigned cs, unsigned n, int fwd) {
@@ -148,7 +152,7 @@ __device__ void build_shape(ShapeInfo& sh, const int* m) {
 }
 
 /* orthonormalised 3x3 angular DCT as the reference applies it (core:1862-1954) */
-__device__ __forceinline__ void dct9_fwd(float* x, const GroupTables* tb) {
+__device__ __forceinline__ void dct9_fwd(float* x, TbPtr tb) {
     float t[9];
 #pragma unroll
     for (int s = 0; s < 3; s++)
@@ -161,7 +165,7 @@ __device__ __forceinline__ void dct9_fwd(float* x, const GroupTables* tb) {
         for (int u = 0; u < 3; u++)
             x[v * 3 + u] = 2.0f * (t[u] * tb->cos3[v * 3] + t[3 + u] * tb->cos3[v * 3 + 1] + t[6 + u] * tb->cos3[v * 3 + 2]) * tb->cn4[v * 3 + u];
 }
-__device__ __forceinline__ void dct9_inv(float* x, const GroupTables* tb) {
+__device__ __forceinline__ void dct9_inv(float* x, TbPtr tb) {
     float t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) x[i] *= tb->cni4[i];
@@ -178,14 +182,14 @@ __device__ __forceinline__ void dct9_inv(float* x, const GroupTables* tb) {
 }
 
 /* 1-D REDFT10 / REDFT01 of runtime length n <= 3 (SADCT rows / columns) */
-__device__ void r10_small(const float* x, float* y, int n, const GroupTables* tb) {
+__device__ void r10_small(const float* x, float* y, int n, TbPtr tb) {
     for (int u = 0; u < n; u++) {
         float a = 0.0f;
         for (int j = 0; j < n; j++) a += x[j] * tb->cos1[n][u * n + j];
         y[u] = 2.0f * a;
     }
 }
-__device__ void r01_small(const float* x, float* y, int n, const GroupTables* tb) {
+__device__ void r01_small(const float* x, float* y, int n, TbPtr tb) {
     for (int j = 0; j < n; j++) {
         float a = 0.0f;
         for (int u = 1; u < n; u++) a += x[u] * tb->cos1[n][u * n + j];
@@ -193,7 +197,7 @@ __device__ void r01_small(const float* x, float* y, int n, const GroupTables* tb
     }
 }
 /* core:1969-2116 on one 3x3 vector */
-__device__ __noinline__ void sadct9_fwd(float* v, const ShapeInfo& sh, const GroupTables* tb) {
+__device__ __noinline__ void sadct9_fwd(float* v, const ShapeInfo& sh, TbPtr tb) {
     float x[3], y[3];
     for (int s = 0; s < 3; s++) {
         const int n = sh.row_n[s];
@@ -217,7 +221,7 @@ __device__ __noinline__ void sadct9_fwd(float* v, const ShapeInfo& sh, const Gro
     for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask_dct[i] * coef;
 }
 /* core:2131-2264 */
-__device__ __noinline__ void sadct9_inv(float* v, const ShapeInfo& sh, const GroupTables* tb) {
+__device__ __noinline__ void sadct9_inv(float* v, const ShapeInfo& sh, TbPtr tb) {
     float x[3], y[3];
     const float coef = 2.0f * 1.41421356237309505f;
     for (int t = 0; t < 3; t++) {
@@ -284,8 +288,8 @@ template <int NS> __device__ __forceinline__ void hadamard(float* v) {
 /* 5th-dimension DCT of a fibre (tau_5D = dct): REDFT10 * coef_norm / coef_norm_inv * REDFT01 * coef
  * (core:2546-2593, norms preProcess_5d core:3262-3276) */
 template <int NS> __device__ __forceinline__ int log2c() { return NS == 1 ? 0 : NS == 2 ? 1 : NS == 4 ? 2 : NS == 8 ? 3 : 4; }
-template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, const GroupTables* tb) {
-    const float* ct = tb->cos5[log2c<NS>()];
+template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, TbPtr tb) {
+    TbFloats ct = tb->cos5[log2c<NS>()];
     float y[NS];
 #pragma unroll
     for (int u = 0; u < NS; u++) {
@@ -297,8 +301,8 @@ template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, const Group
 #pragma unroll
     for (int u = 0; u < NS; u++) v[u] = y[u];
 }
-template <int NS> __device__ __forceinline__ void dct5_inv(float* v, const GroupTables* tb) {
-    const float* ct = tb->cos5[log2c<NS>()];
+template <int NS> __device__ __forceinline__ void dct5_inv(float* v, TbPtr tb) {
+    TbFloats ct = tb->cos5[log2c<NS>()];
     float y[NS];
     const float x0 = v[0] * 1.41421356237309505f;   /* coef_norm_inv[0] = sqrt2, others 1 */
 #pragma unroll
@@ -317,7 +321,7 @@ template <int NS> __device__ __forceinline__ void dct5_inv(float* v, const Group
  * HT: core:2408-2505 / :2281-2391; Wiener: core:2826-2925 / :2706-2810. */
 template <int NS, int STEP>
 __device__ __forceinline__ void shrink_fibre(float* o, float* e, unsigned tau5, float T, float sig2,
-                                             bool in_shape, float& wacc, const GroupTables* tb) {
+                                             bool in_shape, float& wacc, TbPtr tb) {
     const bool haar = tau5 == 9, dct = tau5 == 5;
     if (dct) { dct5_fwd<NS>(o, tb); if (STEP == 2) dct5_fwd<NS>(e, tb); }
     else if (NS > 1) {
@@ -363,7 +367,7 @@ __device__ __forceinline__ void shrink_fibre(float* o, float* e, unsigned tau5, 
 template <int NS, int STEP>
 __device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stride, unsigned tau5,
                                         float T, float sig2, bool in_shape, float& wacc, float& s1, float& s2,
-                                        const GroupTables* tb) {
+                                        TbPtr tb) {
     float o[NS], e[NS];
 #pragma unroll
     for (int n = 0; n < NS; n++) o[n] = S0[base + n * stride];
@@ -391,7 +395,7 @@ __device__ __forceinline__ int per_ext(int j, int L, int N) { int m = (j - L) % 
 /* 2-D DCT of all patches with the per-thread table entries held in registers (thread = coefficient
  * (i,j) of a patch; its cosine rows never change from patch to patch) */
 template <int K>
-__device__ void fwd2d_dct(float* S, float* tmp, int np, const GroupTables* tb) {
+__device__ void fwd2d_dct(float* S, float* tmp, int np, TbPtr tb) {
     constexpr int K2 = K * K;
     const int tid = threadIdx.x;
     const bool wave_local = K2 == 64;
@@ -420,7 +424,7 @@ __device__ void fwd2d_dct(float* S, float* tmp, int np, const GroupTables* tb) {
     __syncthreads();
 }
 template <int K>
-__device__ void inv2d_dct(float* S, float* tmp, int np, const GroupTables* tb) {
+__device__ void inv2d_dct(float* S, float* tmp, int np, TbPtr tb) {
     constexpr int K2 = K * K;
     const int tid = threadIdx.x;
     const bool wave_local = K2 == 64;
@@ -449,7 +453,7 @@ __device__ void inv2d_dct(float* S, float* tmp, int np, const GroupTables* tb) {
     __syncthreads();
 }
 
-__device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const GroupTables* tb) {
+__device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr tb) {
     if (tau2 == 5) {
         if (k == 8) return fwd2d_dct<8>(S, tmp, np, tb);
         if (k == 12) return fwd2d_dct<12>(S, tmp, np, tb);
@@ -474,7 +478,7 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
                 const int N2 = N1 / 2;
                 if (on && i < N1 && j < N1) {
                     const bool lo = j < N2; const int jj = lo ? j : j - N2;
-                    const float* f = lo ? tb->lpd : tb->hpd;
+                    TbFloats f = lo ? tb->lpd : tb->hpd;
                     float a = 0.0f;
                     for (int t = 0; t < 10; t++) a += X[i * k + per_ext(t + 2 * jj, 4, N1)] * f[t];
                     Tm[pq] = a;
@@ -482,7 +486,7 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
                 PATCH_SYNC();
                 if (on && i < N1 && j < N1) {
                     const bool lo = i < N2; const int ii = lo ? i : i - N2;
-                    const float* f = lo ? tb->lpd : tb->hpd;
+                    TbFloats f = lo ? tb->lpd : tb->hpd;
                     float a = 0.0f;
                     for (int t = 0; t < 10; t++) a += Tm[per_ext(t + 2 * ii, 4, N1) * k + j] * f[t];
                     X[pq] = a;
@@ -493,7 +497,7 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
     }
     __syncthreads();
 }
-__device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, const GroupTables* tb) {
+__device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr tb) {
     if (tau2 == 5) {
         if (k == 8) return inv2d_dct<8>(S, tmp, np, tb);
         if (k == 12) return inv2d_dct<12>(S, tmp, np, tb);
@@ -525,14 +529,14 @@ __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, const 
             for (int N1 = 2; N1 <= k; N1 *= 2) {
                 const int N2 = N1 / 2;
                 if (on && i < N1 && j < N1) { /* columns: out[2m] = high, out[2m+1] = low */
-                    const int m = i / 2; const float* f = (i & 1) ? tb->lpr : tb->hpr;
+                    const int m = i / 2; TbFloats f = (i & 1) ? tb->lpr : tb->hpr;
                     float a = 0.0f;
                     for (int t = 0; t < 10; t++) a += f[t] * X[((t * N2 + m) % N1) * k + j];
                     Tm[pq] = a;
                 }
                 PATCH_SYNC();
                 if (on && i < N1 && j < N1) { /* rows */
-                    const int m = j / 2; const float* f = (j & 1) ? tb->lpr : tb->hpr;
+                    const int m = j / 2; TbFloats f = (j & 1) ? tb->lpr : tb->hpr;
                     float a = 0.0f;
                     for (int t = 0; t < 10; t++) a += f[t] * Tm[i * k + (t * N2 + m) % N1];
                     X[pq] = a;
@@ -565,7 +569,10 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
         const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
         p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
     }
-    a.gpos[(size_t)g * NA + i] = p;
+    /* gather position: patches whose column equals Wb-k read the reference's never-filled table
+     * column, i.e. zeros (core:1697, bm3d.cpp:737) on the centre path -- they are still aggregated */
+    const bool zero_patch = a.fill_quirk && p != 0xffffffffu && (p % a.Wb) >= a.Wb - a.k;
+    a.gpos[(size_t)g * NA + i] = zero_patch ? 0xffffffffu : p;
     const bool in_shape = st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r]);
     /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
      * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     float* S0 = lds;
     float* S1 = STEP == 2 ? lds + stack : nullptr;
     float* tmp = lds + (STEP == 2 ? 2 : 1) * stack;
-    const GroupTables* tb = a.tb;
+    const TbPtr tb = (TbPtr)a.tb;
 
     /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323): from the pre-pass */
     if (tid < nSx * A) pos[tid] = a.gpos[(size_t)g * N * A + tid];
@@ -633,7 +640,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
                     const int pq = e % k2, ns = e / k2;
                     const int st = ns % A;
                     const unsigned p = pos[ns];
-                    if (p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - k)) {
+                    if (p != 0xffffffffu) {   /* the pre-pass folds the never-filled table column in */
                         const size_t off = ((size_t)st * a.C + c) * plane + p + (size_t)(pq / k) * a.Wb + pq % k;
                         v0[u] = a.noisy[off];
                         if (STEP == 2) v1[u] = a.basic[off];
@@ -748,11 +755,11 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
  * occupancy is set by registers, not by the 72 KiB stack of k_group.
  * ------------------------------------------------------------------------------------------ */
 template <int STEP, int NS>
-__device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const unsigned* pos,
+__device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
                                               const ShapeInfo& sh, bool use_sadct, float& wacc, float& s1, float& s2) {
     const int k = a.k, k2 = k * k, A = 9;
     const size_t plane = (size_t)a.Wb * a.Hb;
-    const GroupTables* tb = a.tb;
+    const TbPtr tb = (TbPtr)a.tb;
     float v[NS][9];
     float w[STEP == 2 ? NS : 1][9];
     const unsigned poff = (unsigned)(pq / k) * a.Wb + pq % k;
@@ -760,8 +767,8 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
     for (int n = 0; n < NS; n++)
 #pragma unroll
         for (int st = 0; st < 9; st++) {
-            const unsigned p = pos[n * A + st];
-            const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - k);  /* never-filled table column (core:1697) */
+            const unsigned p = pos[n * A + st];       /* uniform: scalar load, scalar patch base + one per-lane offset */
+            const bool ok = p != 0xffffffffu;
             const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u) + poff;
             const float x0 = a.noisy[off];
             v[n][st] = ok ? x0 : 0.0f;
@@ -826,14 +833,15 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
 template <int STEP>
 __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     __shared__ ShapeInfo sh;
-    __shared__ unsigned pos[kMaxN * kMaxA];
     __shared__ float red[3][4];
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x;
     const int c = blockIdx.y;
     const int A = 9, N = a.N;
     const int nSx = (int)a.self_cnt[g];
-    for (int i = tid; i < nSx * A; i += (int)blockDim.x) pos[i] = a.gpos[(size_t)g * N * A + i];   /* the block may be narrower than N*A (k = 8) */
+    /* positions are uniform per workgroup and constant during this kernel: constant address space -> scalar loads */
+    typedef const __attribute__((address_space(4))) unsigned* cuptr;
+    const cuptr pos = (cuptr)(a.gpos + (size_t)g * N * A);
     if (tid == 0) group_shape(sh, a, g);
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
@@ -934,7 +942,7 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     const int NPp = (N * A) | 1;          /* row stride of the [pq][patch] stack, odd */
     float* S0 = lds;
     float* S1 = lds + K2 * NPp;
-    const GroupTables* tb = a.tb;
+    const TbPtr tb = (TbPtr)a.tb;
     constexpr int S = STEP == 2 ? 2 : 1;
 
     for (int i = tid; i < NP; i += kDct8Threads) pos[i] = a.gpos[(size_t)g * N * A + i];
@@ -946,7 +954,7 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     for (int task = tid; task < S * NP; task += kDct8Threads) {
         const int s = task / NP, patch = task % NP, st = patch % A;
         const unsigned p = pos[patch];
-        const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - 8);   /* never-filled table column (core:1697) */
+        const bool ok = p != 0xffffffffu;
         const float* img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
 #ifdef LFBM5D_EXP
         if (LFBM5D_EXP & 16) img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (tid & 63) * 8;
@@ -1139,7 +1147,7 @@ template <class T> __device__ __forceinline__ void dct8_inv_t(T* X) {
     X[3] = E3 + O3; X[4] = E3 - O3;
 }
 /* dct9_fwd / dct9_inv on a pair of fibres */
-__device__ __forceinline__ void dct9_fwd2(v2f* x, const GroupTables* tb) {
+__device__ __forceinline__ void dct9_fwd2(v2f* x, TbPtr tb) {
     v2f t[9];
 #pragma unroll
     for (int s = 0; s < 3; s++)
@@ -1152,7 +1160,7 @@ __device__ __forceinline__ void dct9_fwd2(v2f* x, const GroupTables* tb) {
         for (int u = 0; u < 3; u++)
             x[v * 3 + u] = 2.0f * (t[u] * tb->cos3[v * 3] + t[3 + u] * tb->cos3[v * 3 + 1] + t[6 + u] * tb->cos3[v * 3 + 2]) * tb->cn4[v * 3 + u];
 }
-__device__ __forceinline__ void dct9_inv2(v2f* x, const GroupTables* tb) {
+__device__ __forceinline__ void dct9_inv2(v2f* x, TbPtr tb) {
     v2f t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) x[i] *= tb->cni4[i];
@@ -1182,7 +1190,7 @@ template <int NS> __device__ __forceinline__ void haar_fwd2(v2f* v) {
 /* phase 3 of k_group_dct8w on one (st, pq) fibre of nSx = NS float2 entries (x: noisy, y: pilot) */
 template <int NS, bool HAAR>
 __device__ __forceinline__ void wiener_fibre2(v2f* stack, int base, int stride, unsigned tau5, float sig2, bool in_shape,
-                                              bool useSD, float& wacc, float& s1, float& s2, const GroupTables* tb) {
+                                              bool useSD, float& wacc, float& s1, float& s2, TbPtr tb) {
     v2f f[NS];
 #pragma unroll
     for (int n = 0; n < NS; n++) f[n] = stack[base + n * stride];
@@ -1233,7 +1241,7 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     const int NPp = (N * A) | 1;          /* row stride of the [pq][patch] stack (float2 units), odd */
     v2f* stack = reinterpret_cast<v2f*>(lds);
     float* stackf = lds;
-    const GroupTables* tb = a.tb;
+    const TbPtr tb = (TbPtr)a.tb;
 
     if (tid == kDct8wThreads - 1) group_shape(sh, a, g);   /* read after the phase-1 barrier */
 
@@ -1241,7 +1249,7 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     for (int patch = tid; patch < NP; patch += kDct8wThreads) {
         const int st = patch % A;
         const unsigned p = a.gpos[(size_t)g * N * A + patch];
-        const bool ok = p != 0xffffffffu && (!a.fill_quirk || (p % a.Wb) < a.Wb - 8);   /* never-filled table column (core:1697) */
+        const bool ok = p != 0xffffffffu;
         const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
         const float* in0 = a.noisy + off;
         const float* in1 = a.basic + off;
