@@ -304,7 +304,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->wgt.reserve((size_t)R * C * sizeof(float)));
     HIPCK(c, c->aggpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
-    HIPCK(c, c->gshape.reserve((size_t)R * sizeof(unsigned)));
+    HIPCK(c, c->gshape.reserve((size_t)R * kShapeInfoBytes));
     HIPCK(c, c->tb.reserve(sizeof(GroupTables)));
     if (!c->counters.p) {
         HIPCK(c, c->counters.reserve(4 * sizeof(unsigned long long)));
@@ -372,7 +372,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.noisy = d_noisy; ga.basic = d_basic; ga.num = d_num; ga.den = d_den;
     ga.refs = c->refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
     ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = c->tb.as<GroupTables>();
-    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gshape = c->gshape.as<unsigned>(); ga.n_refs_total = R; ga.counters = c->counters.as<unsigned long long>();
+    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gshape = c->gshape.p; ga.n_refs_total = R; ga.counters = c->counters.as<unsigned long long>();
     ga.ref_begin = ref_begin; ga.n_groups = n_groups;
     ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
     ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;

@@ -37,6 +37,8 @@ struct GroupTables {
     float coef4inv;             /* 1 / (2 sqrt(aw) sqrt(ah))      (core:1945)     */
 };
 
+constexpr unsigned kShapeInfoBytes = 208;
+
 struct GroupArgs {
     const float* noisy;         /* [A][C][Hb][Wb] */
     const float* basic;         /* step 2 only */
@@ -52,7 +54,7 @@ struct GroupArgs {
     float* wgt;                 /* [R][C] aggregation weights */
     unsigned* aggpos;           /* [A][R][N] where each filtered patch is aggregated (0xffffffff: nowhere) */
     unsigned* gpos;             /* [R][N][A] window position of every patch of every group (pre-pass output) */
-    unsigned* gshape;           /* [R] 9-bit angular shape of the group (pre-pass output) */
+    void* gshape;               /* [R] kShapeInfoBytes each: SADCT bookkeeping of the group (pre-pass output) */
     unsigned n_refs_total;
     unsigned long long* counters; /* [0] sum nSx, [1] sadct groups */
     unsigned ref_begin, n_groups;

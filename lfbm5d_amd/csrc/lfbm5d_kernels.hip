@@ -132,6 +132,9 @@ struct ShapeInfo {           /* SADCT bookkeeping of one group (core:302-323, :2
     int row_n[3], col_n[3];
     int use_sadct;
 };
+static_assert(sizeof(ShapeInfo) == kShapeInfoBytes, "GroupArgs::gshape stride");
+/* the per-group ShapeInfo written by the pre-pass is constant during the group kernels: scalar loads */
+typedef const __attribute__((address_space(4))) ShapeInfo& ShRef;
 
 __device__ void build_shape(ShapeInfo& sh, const int* m) {
     int size = 0;
@@ -197,7 +200,7 @@ __device__ void r01_small(const float* x, float* y, int n, TbPtr tb) {
     }
 }
 /* core:1969-2116 on one 3x3 vector */
-__device__ __noinline__ void sadct9_fwd(float* v, const ShapeInfo& sh, TbPtr tb) {
+__device__ __noinline__ void sadct9_fwd(float* v, ShRef sh, TbPtr tb) {
     float x[3], y[3];
     for (int s = 0; s < 3; s++) {
         const int n = sh.row_n[s];
@@ -221,7 +224,7 @@ __device__ __noinline__ void sadct9_fwd(float* v, const ShapeInfo& sh, TbPtr tb)
     for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask_dct[i] * coef;
 }
 /* core:2131-2264 */
-__device__ __noinline__ void sadct9_inv(float* v, const ShapeInfo& sh, TbPtr tb) {
+__device__ __noinline__ void sadct9_inv(float* v, ShRef sh, TbPtr tb) {
     float x[3], y[3];
     const float coef = 2.0f * 1.41421356237309505f;
     for (int t = 0; t < 3; t++) {
@@ -584,27 +587,28 @@ __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     const unsigned g = a.ref_begin + i;
     const size_t plane = (size_t)a.Wb * a.Hb;
     const unsigned k_r = a.refs[g];
-    unsigned bits = 0;
-    for (int st = 0; st < (int)a.A; st++) {
-        const bool masked = (a.mask_bits >> st) & 1;
-        if (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) bits |= 1u << st;
-    }
-    a.gshape[g] = bits;
-}
-/* SADCT shape of the group from its 9-bit mask (thread 0 of the workgroup) */
-__device__ __forceinline__ void group_shape(ShapeInfo& sh, const GroupArgs& a, unsigned g) {
+    ShapeInfo sh;
     if (a.tau4 == 6) {
-        const unsigned bits = a.gshape[g];
         int m[9];
-        for (int st = 0; st < 9; st++) m[st] = (bits >> st) & 1;
+        for (int st = 0; st < 9; st++) {
+            const bool masked = (a.mask_bits >> st) & 1;
+            m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
+        }
         build_shape(sh, m);
-    } else sh.use_sadct = 0;
+    } else {
+        for (int q = 0; q < (int)(sizeof(ShapeInfo) / sizeof(int)); q++) reinterpret_cast<int*>(&sh)[q] = 0;
+    }
+    reinterpret_cast<ShapeInfo*>(a.gshape)[g] = sh;
+}
+/* SADCT bookkeeping of group g (pre-pass output) */
+__device__ __forceinline__ ShRef group_shape(const GroupArgs& a, unsigned g) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) ShapeInfo*>(
+        (const __attribute__((address_space(4))) char*)a.gshape + (size_t)g * sizeof(ShapeInfo));
 }
 
 template <int STEP>
 __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     extern __shared__ float lds[];
-    __shared__ ShapeInfo sh;
     __shared__ unsigned pos[kMaxN * kMaxA];
     __shared__ float red[3][kThreads / 64];
 
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
 
     /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323): from the pre-pass */
     if (tid < nSx * A) pos[tid] = a.gpos[(size_t)g * N * A + tid];
-    if (tid == 0) group_shape(sh, a, g);
+    ShRef sh = group_shape(a, g);
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
 
@@ -756,7 +760,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
  * ------------------------------------------------------------------------------------------ */
 template <int STEP, int NS>
 __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
-                                              const ShapeInfo& sh, bool use_sadct, float& wacc, float& s1, float& s2) {
+                                              ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2) {
     const int k = a.k, k2 = k * k, A = 9;
     const size_t plane = (size_t)a.Wb * a.Hb;
     const TbPtr tb = (TbPtr)a.tb;
@@ -832,7 +836,6 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
 
 template <int STEP>
 __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
-    __shared__ ShapeInfo sh;
     __shared__ float red[3][4];
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x;
@@ -842,8 +845,7 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     /* positions are uniform per workgroup and constant during this kernel: constant address space -> scalar loads */
     typedef const __attribute__((address_space(4))) unsigned* cuptr;
     const cuptr pos = (cuptr)(a.gpos + (size_t)g * N * A);
-    if (tid == 0) group_shape(sh, a, g);
-    __syncthreads();
+    ShRef sh = group_shape(a, g);
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (tid < (int)(a.k * a.k)) {
@@ -928,7 +930,6 @@ __device__ __forceinline__ void dct8_inv(float* X) {
 template <int STEP>
 __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     extern __shared__ float lds[];
-    __shared__ ShapeInfo sh;
     __shared__ unsigned pos[kMaxN * kMaxA];
     __shared__ float red[3][kDct8Threads / 64];
     const int tid = threadIdx.x;
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     constexpr int S = STEP == 2 ? 2 : 1;
 
     for (int i = tid; i < NP; i += kDct8Threads) pos[i] = a.gpos[(size_t)g * N * A + i];
-    if (tid == 0) group_shape(sh, a, g);
+    ShRef sh = group_shape(a, g);
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
 
@@ -1228,7 +1229,6 @@ constexpr int kDct8wThreads = 256;
 template <bool HAAR>
 __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     extern __shared__ float lds[];
-    __shared__ ShapeInfo sh;
     __shared__ float red[3][kDct8wThreads / 64];
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x;
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     float* stackf = lds;
     const TbPtr tb = (TbPtr)a.tb;
 
-    if (tid == kDct8wThreads - 1) group_shape(sh, a, g);   /* read after the phase-1 barrier */
+    ShRef sh = group_shape(a, g);
 
     /* 1: gather + forward 2-D DCT of both images, one thread per patch */
     for (int patch = tid; patch < NP; patch += kDct8wThreads) {
