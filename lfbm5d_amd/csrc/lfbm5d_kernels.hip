@@ -184,6 +184,36 @@ __device__ __forceinline__ void dct9_inv(float* x, TbPtr tb) {
             x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));   /* two values per lane: v_pk_{add,mul,fma}_f32 */
+/* dct9_fwd / dct9_inv on a pair of fibres */
+__device__ __forceinline__ void dct9_fwd2(v2f* x, TbPtr tb) {
+    v2f t[9];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            t[s * 3 + u] = 2.0f * (x[s * 3] * tb->cos3[u * 3] + x[s * 3 + 1] * tb->cos3[u * 3 + 1] + x[s * 3 + 2] * tb->cos3[u * 3 + 2]);
+#pragma unroll
+    for (int v = 0; v < 3; v++)
+#pragma unroll
+        for (int u = 0; u < 3; u++)
+            x[v * 3 + u] = 2.0f * (t[u] * tb->cos3[v * 3] + t[3 + u] * tb->cos3[v * 3 + 1] + t[6 + u] * tb->cos3[v * 3 + 2]) * tb->cn4[v * 3 + u];
+}
+__device__ __forceinline__ void dct9_inv2(v2f* x, TbPtr tb) {
+    v2f t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) x[i] *= tb->cni4[i];
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            t[s * 3 + j] = x[s * 3] + 2.0f * (x[s * 3 + 1] * tb->cos3[3 + j] + x[s * 3 + 2] * tb->cos3[6 + j]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
+}
 /* 1-D REDFT10 / REDFT01 of runtime length n <= 3 (SADCT rows / columns) */
 __device__ void r10_small(const float* x, float* y, int n, TbPtr tb) {
     for (int u = 0; u < n; u++) {
@@ -758,31 +788,57 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
  * inverses without touching LDS (only the group weight is reduced through it).  No LDS stack means
  * occupancy is set by registers, not by the 72 KiB stack of k_group.
  * ------------------------------------------------------------------------------------------ */
-template <int STEP, int NS>
+/* One pixel of all NS * 9 patches of the group (hard-thresholding step).  Loads and stores go
+ * through buffer resources with the per-patch part of the address in a scalar register (the patch
+ * positions are uniform), so none of the 2 * NS * 9 memory operations needs address VGPRs; the
+ * 3x3 angular DCTs run on pairs of patches (n, n + 1) with packed fp32 arithmetic. */
+template <int NS, bool HAAR>
 __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
                                               ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2) {
     const int k = a.k, k2 = k * k, A = 9;
-    const size_t plane = (size_t)a.Wb * a.Hb;
+    const unsigned plane = a.Wb * a.Hb;
     const TbPtr tb = (TbPtr)a.tb;
+    const unsigned kRsrcFlags = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)((size_t)a.A * a.C * plane * 4), kRsrcFlags);
+    float* const out = a.filt + (size_t)g * a.N * A * a.C * k2;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((size_t)a.N * A * a.C * k2 * 4), kRsrcFlags);
+    constexpr int NH = NS > 1 ? NS / 2 : 1;
     float v[NS][9];
-    float w[STEP == 2 ? NS : 1][9];
-    const unsigned poff = (unsigned)(pq / k) * a.Wb + pq % k;
+    const int voff = (int)(((unsigned)(pq / k) * a.Wb + pq % k) * 4u);
+    unsigned okbits[NS];
 #pragma unroll
-    for (int n = 0; n < NS; n++)
+    for (int n = 0; n < NS; n++) {
+        okbits[n] = 0;
 #pragma unroll
         for (int st = 0; st < 9; st++) {
-            const unsigned p = pos[n * A + st];       /* uniform: scalar load, scalar patch base + one per-lane offset */
+            const unsigned p = pos[n * A + st];       /* uniform: scalar load */
             const bool ok = p != 0xffffffffu;
-            const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u) + poff;
-            const float x0 = a.noisy[off];
-            v[n][st] = ok ? x0 : 0.0f;
-            if (STEP == 2) { const float x1 = a.basic[off]; w[n][st] = ok ? x1 : 0.0f; }
+            okbits[n] |= ok ? 1u << st : 0u;
+            const unsigned so = (((unsigned)st * a.C + c) * plane + (ok ? p : 0u)) * 4u;
+            v[n][st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NS; n++)
+        if (okbits[n] != 0x1ffu) {   /* uniform, rare: patches of empty SAIs / never-filled table column read as zeros */
+#pragma unroll
+            for (int st = 0; st < 9; st++) v[n][st] = ((okbits[n] >> st) & 1) ? v[n][st] : 0.0f;
         }
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
     if (do_dct4) {
+        if (NS == 1) dct9_fwd(v[0], tb);
+        else {
 #pragma unroll
-        for (int n = 0; n < NS; n++) { dct9_fwd(v[n], tb); if (STEP == 2) dct9_fwd(w[n], tb); }
+            for (int h = 0; h < NH; h++) {
+                v2f x[9];
+#pragma unroll
+                for (int st = 0; st < 9; st++) x[st] = v2f{v[2 * h][st], v[(2 * h + 1) % NS][st]};
+                dct9_fwd2(x, tb);
+#pragma unroll
+                for (int st = 0; st < 9; st++) { v[2 * h][st] = x[st].x; v[(2 * h + 1) % NS][st] = x[st].y; }
+            }
+        }
     } else if (do_sa4) { /* rare: staged through a small scratch vector so v[][] stays in registers */
 #pragma unroll
         for (int n = 0; n < NS; n++) {
@@ -792,30 +848,46 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
             sadct9_fwd(t9, sh, tb);
 #pragma unroll
             for (int i = 0; i < 9; i++) v[n][i] = t9[i];
-            if (STEP == 2) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) t9[i] = w[n][i];
-                sadct9_fwd(t9, sh, tb);
-#pragma unroll
-                for (int i = 0; i < 9; i++) w[n][i] = t9[i];
-            }
         }
     }
     const float sig = a.sigma[c];
     const float T = a.lambda * sig * 1.41421356237309505f;
-    const float sig2 = sig * sig;
 #pragma unroll
     for (int st = 0; st < 9; st++) {
-        float o[NS], e[NS];
+        float o[NS], e[1] = {0.0f};
 #pragma unroll
-        for (int n = 0; n < NS; n++) { o[n] = v[n][st]; e[n] = STEP == 2 ? w[n][st] : 0.0f; }
-        shrink_fibre<NS, STEP>(o, e, a.tau5, T, sig2, !use_sadct || sh.mask_dct[st], wacc, tb);
+        for (int n = 0; n < NS; n++) o[n] = v[n][st];
+        const bool in_shape = !use_sadct || sh.mask_dct[st];
+        if (HAAR) {
+            if (NS > 1) haar_fwd<NS>(o);
+            if (in_shape) {
 #pragma unroll
-        for (int n = 0; n < NS; n++) { const float r = STEP == 1 ? o[n] : e[n]; v[n][st] = r; s1 += r; s2 += r * r; }
+                for (int n = 0; n < NS; n++) { const bool keep = fabsf(o[n]) > T; wacc += keep ? 1.0f : 0.0f; o[n] = keep ? o[n] : 0.0f; }
+            }
+            if (NS > 1) haar_inv<NS>(o);
+        } else shrink_fibre<NS, 1>(o, e, a.tau5, T, sig * sig, in_shape, wacc, tb);
+#pragma unroll
+        for (int n = 0; n < NS; n++) v[n][st] = o[n];
+    }
+    if (a.useSD) {
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+#pragma unroll
+            for (int st = 0; st < 9; st++) { s1 += v[n][st]; s2 += v[n][st] * v[n][st]; }
     }
     if (do_dct4) {
+        if (NS == 1) dct9_inv(v[0], tb);
+        else {
 #pragma unroll
-        for (int n = 0; n < NS; n++) dct9_inv(v[n], tb);
+            for (int h = 0; h < NH; h++) {
+                v2f x[9];
+#pragma unroll
+                for (int st = 0; st < 9; st++) x[st] = v2f{v[2 * h][st], v[(2 * h + 1) % NS][st]};
+                dct9_inv2(x, tb);
+#pragma unroll
+                for (int st = 0; st < 9; st++) { v[2 * h][st] = x[st].x; v[(2 * h + 1) % NS][st] = x[st].y; }
+            }
+        }
     } else if (do_sa4) {
 #pragma unroll
         for (int n = 0; n < NS; n++) {
@@ -827,14 +899,15 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
             for (int i = 0; i < 9; i++) v[n][i] = t9[i];
         }
     }
-    float* out = a.filt + (size_t)g * a.N * A * a.C * k2;
+    const int vout = pq * 4;
 #pragma unroll
     for (int n = 0; n < NS; n++)
 #pragma unroll
-        for (int st = 0; st < 9; st++) out[((size_t)(n * A + st) * a.C + c) * k2 + pq] = v[n][st];
+        for (int st = 0; st < 9; st++)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[n][st]), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
 }
 
-template <int STEP>
+template <bool HAAR>
 __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     __shared__ float red[3][4];
     const int tid = threadIdx.x;
@@ -850,10 +923,10 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (tid < (int)(a.k * a.k)) {
         switch (nSx) {
-            case 1:  group_id_body<STEP, 1>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            case 2:  group_id_body<STEP, 2>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            case 4:  group_id_body<STEP, 4>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            default: group_id_body<STEP, 8>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 1:  group_id_body<1, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 2:  group_id_body<2, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 4:  group_id_body<4, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            default: group_id_body<8, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
         }
     }
     for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
@@ -1112,7 +1185,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
  *   4  thread = two (n, pq) fibres of the filtered stack: packed inverse 3x3 DCT
  *   5  thread = two patches: packed inverse 8x8 DCT, 16-byte stores of the filtered patches
  * ------------------------------------------------------------------------------------------ */
-typedef float v2f __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(4))) f4u { float v[4]; };   /* 16-byte load at 4-byte alignment */
 
 template <class T> __device__ __forceinline__ void dct8_fwd_t(T* x) {
@@ -1146,35 +1218,6 @@ template <class T> __device__ __forceinline__ void dct8_inv_t(T* X) {
     X[1] = E1 + O1; X[6] = E1 - O1;
     X[2] = E2 + O2; X[5] = E2 - O2;
     X[3] = E3 + O3; X[4] = E3 - O3;
-}
-/* dct9_fwd / dct9_inv on a pair of fibres */
-__device__ __forceinline__ void dct9_fwd2(v2f* x, TbPtr tb) {
-    v2f t[9];
-#pragma unroll
-    for (int s = 0; s < 3; s++)
-#pragma unroll
-        for (int u = 0; u < 3; u++)
-            t[s * 3 + u] = 2.0f * (x[s * 3] * tb->cos3[u * 3] + x[s * 3 + 1] * tb->cos3[u * 3 + 1] + x[s * 3 + 2] * tb->cos3[u * 3 + 2]);
-#pragma unroll
-    for (int v = 0; v < 3; v++)
-#pragma unroll
-        for (int u = 0; u < 3; u++)
-            x[v * 3 + u] = 2.0f * (t[u] * tb->cos3[v * 3] + t[3 + u] * tb->cos3[v * 3 + 1] + t[6 + u] * tb->cos3[v * 3 + 2]) * tb->cn4[v * 3 + u];
-}
-__device__ __forceinline__ void dct9_inv2(v2f* x, TbPtr tb) {
-    v2f t[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) x[i] *= tb->cni4[i];
-#pragma unroll
-    for (int s = 0; s < 3; s++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            t[s * 3 + j] = x[s * 3] + 2.0f * (x[s * 3 + 1] * tb->cos3[3 + j] + x[s * 3 + 2] * tb->cos3[6 + j]);
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-            x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
 }
 template <int NS> __device__ __forceinline__ void haar_fwd2(v2f* v) {
     const float s = 0.70710678118654752f;
@@ -1607,7 +1650,8 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
     if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
-        hipLaunchKernelGGL(k_group_id<1>, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id<true>, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        else             hipLaunchKernelGGL(k_group_id<false>, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
         return hipGetLastError();
     }
     if (a.tau2 == 5 && a.k == 8 && a.A == 9) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
