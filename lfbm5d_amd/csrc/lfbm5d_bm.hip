@@ -61,11 +61,15 @@ __device__ __forceinline__ int grid_index(int v, int n, int last, int nHW, int p
  * column of the table (a K-term chain per row) is computed up front; strips hand their last
  * column to the next strip through `lcol`.
  */
+#ifndef LFBM5D_SCAN_DEPTH
+#define LFBM5D_SCAN_DEPTH(T) ((T) == 4 ? 4 : 3)
+#endif
 template <int K, int MODE>   /* MODE 0: self search on the regular grid, 1: self search on an irregular list, 2: disparity */
 __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, float* lds) {
     /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows.  Sized so that five waves fit a CU
      * at 560-wide windows (32 KiB each): the launch then takes two rounds of resident waves, not three */
     constexpr int T = K >= 12 ? 4 : 8, RR = 64 + K + 2 * T, CW = 64 + K;
+    constexpr int DEP = LFBM5D_SCAN_DEPTH(T);   /* row-load pipeline depth in chunks */
     constexpr bool stereo = MODE == 2;
     constexpr bool irregular = MODE == 1;
     float* ring = lds;              /* [RR][CW] D rows of the current strip; ring col 0 <-> x = cb-1 */
@@ -104,7 +108,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     const unsigned kRsrcFlags = 0x00020000u;
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)D.i1, 0, (int)(WH * 4 + 1024), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(D.i2 + D.dk), 0, (int)(WH * 4 + 1024), kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)(WH * 4), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (int)a.scores_bytes, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.rslot, 0, (int)((H + 64) * 4), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.refmap, 0, irregular ? (int)(WH * 4) : 0, kRsrcFlags);
@@ -216,11 +219,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
 #pragma unroll
             for (int s = 0; s < T; s++) store_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
         }
-        /* rows K+T .. K+2T-1 wait in registers: loads run one chunk ahead of the ring writes */
-        float p1[T], p2[T], q1[T], q2[T];
+        /* the next (DEP-1)*T rows wait in registers: row loads run DEP-1 chunks ahead of the ring writes, far
+         * enough that a chunk never waits on the memory latency (vmcnt also counts the table stores) */
+        float B1[DEP][T], B2[DEP][T], E1[DEP][T], E2[DEP][T];
 #pragma unroll
-        for (int s = 0; s < T; s++) load_row(K + T + s, p1[s], p2[s], q1[s], q2[s]);
-        int filled = K + T;   /* rows [0, filled) are in the ring; the next T rows wait in p1..q2 */
+        for (int j = 0; j < DEP - 1; j++)
+#pragma unroll
+            for (int s = 0; s < T; s++) load_row(K + T + j * T + s, B1[j][s], B2[j][s], E1[j][s], E2[j][s]);
+        int filled = K + T;   /* rows [0, filled) are in the ring; rows [filled, filled + (DEP-1)T) wait in registers */
         __syncthreads();
 
         /* first row of the strip (core:3354-3362): chain across the lanes */
@@ -242,51 +248,57 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             if (col_ok) emit(b, x, S0);
         }
 
-        /* remaining rows: T steps per iteration -- loads, then the register-only chain, then stores.
-         * Lane l works on table row i = 1 + t - l at step t. */
+        /* remaining rows: T steps per chunk -- loads, then the register-only chain, then stores.
+         * Lane l works on table row i = 1 + t - l at step t, i.e. it is active for t in [l, nrows-2+l].
+         * Two flavours of the same chunk:
+         *   steady: every lane 0..last_lane is active for all T steps and every loaded row lies in the band,
+         *           so nothing is predicated;
+         *   edge:   ramp-up / ramp-down (and the whole strip of small windows): stores of inactive lanes are
+         *           dropped through an out-of-range offset, a lane's row-0 value is injected on the step it
+         *           becomes active, row loads are clamped to the band and rows past it written as zeros.
+         * Inactive lanes compute on garbage that no active lane ever reads.  Ring rows are addressed through
+         * running pointers (mirror rows make T consecutive rows wrap-free); chunks are issued in pairs with
+         * the two sets of staging registers swapped instead of copied. */
         float curS = S0;
         float left_prev = row0_left;    /* lane 0: S[0][cb-1]; other lanes: overwritten before use */
         const int nsteps = (nrows - 1) + last_lane;
-        /* per-lane constants of the skewed LDS addressing: ring row (u - lane) mod RR, column lane */
-        const int offA0 = lane - lane * CW, offA1 = offA0 + RR * CW;
-        const int xoff = x - lane * W;
-        /* store offsets of the steady state: lane-constant part (>= 0) + scalar row part; lanes past
-         * the last column get an out-of-range offset, which drops their stores */
-        const int voT = col_ok ? (x + (last_lane - lane) * W) * 4 : 0x7fffff00;
-        auto do_chunk = [&](int t0, auto steady_tag) {
-            constexpr bool STEADY = decltype(steady_tag)::value;   /* every lane 0..last_lane active for all T steps */
-            float m1[T], m2[T], e1[T], e2[T];
-#pragma unroll
-            for (int s = 0; s < T; s++) load_row(filled + T + s, m1[s], m2[s], e1[s], e2[s]);
-            float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
-            int r1[T], r2[T];
-            int uA = (t0 + K) % RR, uB = t0 % RR;       /* uniform */
+        const int lane_eff = col_ok ? lane : 0x40000000;   /* lanes past the last column are never active */
+        /* table stores: lane-constant offset (>= 0) + scalar row offset; the resource starts 64 rows above the
+         * table so that the scalar part stays non-negative during the ramp-up */
+        const __amdgpu_buffer_rsrc_t rsTb = __builtin_amdgcn_make_buffer_rsrc((void*)(table - 64 * W), 0, (int)((WH + 64 * (size_t)W) * 4), kRsrcFlags);
+        const int voT = col_ok ? (x + (last_lane - lane) * W) * 4 : -1;
+        const int offE = lane < K ? 64 + lane : lane;   /* extra-column slot; lanes >= K rewrite their own main slot */
+        const int soff_max = (H - b - 1) * W * 4;
+        int rA = (K - lane + 64 * RR) % RR, rB = (64 * RR - lane) % RR;   /* ring rows of (t + K - lane) and (t - lane) */
+        int wrow = filled % RR;
+        int soff = (b + filled + (DEP - 1) * T) * W * 4;
+        auto chunk = [&](auto edge_tag, int t0,
+                         float* ld1, float* ld2, float* le1, float* le2,                                 /* receive rows filled+(DEP-1)T .. */
+                         const float* st1, const float* st2, const float* se1, const float* se2) {     /* rows filled .. go to the ring */
+            constexpr bool EDGE = decltype(edge_tag)::value;
 #pragma unroll
             for (int s = 0; s < T; s++) {
-                const float* pa = ring + uA * CW + (uA < lane ? offA1 : offA0);
-                const float* pb = ring + uB * CW + (uB < lane ? offA1 : offA0);
-                d1[s] = pa[K]; d2[s] = pa[0];
-                d3[s] = pb[K]; d4[s] = pb[0];
-                uA = uA + 1 == RR ? 0 : uA + 1;
-                uB = uB + 1 == RR ? 0 : uB + 1;
-                lc[s] = lcol[STEADY ? 1 + t0 + s : min(1 + t0 + s, nrows + T)];   /* uniform address: lane 0's left neighbour */
-                r1[s] = -1; r2[s] = -1;
-                if (!stereo && !irregular) {   /* uniform */
-                    const int vy = max(b + 1 + t0 + s - lane, 0) * 4;
-                    r1[s] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, 0, 0);
-                    r2[s] = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, di * 4, 0);   /* table has 64 slots of -1 padding */
-                } else if (!stereo) {          /* irregular list: whole-slot lookups (out-of-range offsets read 0) */
-                    const int yy = b + 1 + t0 + s - lane;
-                    const bool in1 = yy >= 0 && yy < H && col_ok;
-                    const int xx = x + djs, y2 = yy + di;
-                    const bool in2 = in1 && di > 0 && y2 < H && xx >= 0 && xx < W;
-                    r1[s] = in1 ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (yy * W + x) * 4, 0, 0) : -1;
-                    r2[s] = in2 ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (y2 * W + xx) * 4, 0, 0) : -1;
-                }
+                const int so = EDGE ? min(soff, soff_max) : soff;    /* uniform */
+                ld1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vm, so, 0));
+                ld2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vm, so, 0));
+                le1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ve, so, 0));
+                le2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, ve, so, 0));
+                soff += W * 4;
             }
+            const float* pa = ring + rA * CW + lane;
+            const float* pb = ring + rB * CW + lane;
+            float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
 #pragma unroll
             for (int s = 0; s < T; s++) {
-                const int t = t0 + s;
+                d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
+                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
+                lc[s] = lcol[EDGE ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
+            }
+            rA += T; rA = rA >= RR ? rA - RR : rA;
+            rB += T; rB = rB >= RR ? rB - RR : rB;
+#pragma unroll
+            for (int s = 0; s < T; s++) {
+                if (EDGE) curS = (lane_eff == t0 + s) ? S0 : curS;      /* becomes active: start from its row-0 value */
                 /* left neighbour's value of the previous step; lane 0 takes the hand-off column */
                 const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lc[s]), __float_as_int(curS),
                                                                               0x138 /* wave_shr:1 */, 0xf, 0xf, false));
@@ -298,156 +310,80 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 S = S + d4[s];
                 S = first_col ? left : S;          /* first column was computed up front */
                 Sout[s] = S;
-                if (STEADY) curS = S;              /* lanes past the last column carry garbage nobody reads */
-                else {
-                    const int lo = t + 2 - nrows, hi = min(t, last_lane);        /* uniform */
-                    curS = (lane >= lo && lane <= hi) ? S : curS;
-                }
-                left_prev = left;
-            }
-#pragma unroll
-            for (int s = 0; s < T; s++) {
-                const int t = t0 + s;
-                const int lo = t + 2 - nrows, hi = min(t, last_lane);
-                const bool act = STEADY ? col_ok : (lane >= lo && lane <= hi);
-                if (stereo) {   /* uniform */
-                    if (STEADY) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, voT, (b + 1 + t - last_lane) * W * 4, 0);
-                    else {
-                        const int vo = act ? ((b + 1 + t) * W + xoff) * 4 : -1;   /* -1: out of range, store dropped */
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, vo, 0, 0);
-                    }
-                } else {
-                    int v1, v2;
-                    if (irregular) {   /* uniform */
-                        v1 = (act && r1[s] >= 0) ? (int)(((unsigned)r1[s] * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
-                        v2 = (act && r2[s] >= 0) ? (int)(((unsigned)r2[s] * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
-                    } else {
-                        v1 = (act && cx >= 0 && r1[s] >= 0) ? (int)(((unsigned)(r1[s] * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
-                        v2 = (act && cx2 >= 0 && r2[s] >= 0 && di > 0) ? (int)(((unsigned)(r2[s] * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
-                    }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
-                }
-                const int il = 1 + t - last_lane;                                 /* uniform */
-                const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
-                if (STEADY) lcol[il] = hv;         /* hand-off column for the next strip (uniform address and value) */
-                else lcol[(il >= 1 && il < nrows) ? il : nrows + T] = hv;
-            }
-#pragma unroll
-            for (int s = 0; s < T; s++) {
-                store_row(filled + s, p1[s], p2[s], q1[s], q2[s]);
-                p1[s] = m1[s]; p2[s] = m2[s]; q1[s] = e1[s]; q2[s] = e2[s];
-            }
-            filled += T;
-        };
-        /* Lean steady-state chunk: every lane 0..last_lane active for all T steps and every loaded row
-         * inside the band, so nothing is predicated; ring rows are addressed through running
-         * pointers (mirror rows make T consecutive rows wrap-free), the row-load offset and the ring
-         * write row advance incrementally, and two chunks are issued back to back with the staging
-         * registers swapped instead of copied. */
-        const int offE = lane < K ? 64 + lane : lane;   /* extra-column slot; lanes >= K rewrite their own main slot */
-        auto lean_chunk = [&](int t0, int& rA, int& rB, int& wrow, int& soff,
-                              float* ld1, float* ld2, float* le1, float* le2,          /* receive rows filled+T .. */
-                              const float* st1, const float* st2, const float* se1, const float* se2) { /* rows filled .. go to the ring */
-#pragma unroll
-            for (int s = 0; s < T; s++) {
-#ifdef LFBM5D_EXP
-                if (LFBM5D_EXP & 4) { ld1[s] = st1[s]; ld2[s] = st2[s]; le1[s] = se1[s]; le2[s] = se2[s]; continue; }
-#endif
-                ld1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vm, soff, 0));
-                ld2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vm, soff, 0));
-                le1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ve, soff, 0));
-                le2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, ve, soff, 0));
-                soff += W * 4;
-            }
-            const float* pa = ring + rA * CW + lane;
-            const float* pb = ring + rB * CW + lane;
-            float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
-#pragma unroll
-            for (int s = 0; s < T; s++) {
-#ifdef LFBM5D_EXP
-                if (LFBM5D_EXP & 8) { d1[s] = st1[s]; d2[s] = st2[s]; d3[s] = se1[s]; d4[s] = se2[s]; lc[s] = lcol[1 + t0 + s]; continue; }
-#endif
-                d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
-                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
-                lc[s] = lcol[1 + t0 + s];
-            }
-            rA += T; rA = rA >= RR ? rA - RR : rA;
-            rB += T; rB = rB >= RR ? rB - RR : rB;
-#pragma unroll
-            for (int s = 0; s < T; s++) {
-                const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lc[s]), __float_as_int(curS),
-                                                                              0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-                float S = left + curS;             /* core:3379-3386, same association */
-                S = S - left_prev;
-                S = S + d1[s];
-                S = S - d2[s];
-                S = S - d3[s];
-                S = S + d4[s];
-                S = first_col ? left : S;
-                Sout[s] = S;
                 curS = S;
                 left_prev = left;
             }
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 const int t = t0 + s;
-#ifdef LFBM5D_EXP
-                if (LFBM5D_EXP & 2) { lcol[1 + t - last_lane] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane)); continue; }
-                if (stereo && (LFBM5D_EXP & 1)) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, x * 4, (b + 1 + t - last_lane) * W * 4, 0); }
-                else
-#endif
-                if (stereo) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsT, voT, (b + 1 + t - last_lane) * W * 4, 0);
-                else {
-                    const int vy = (b + 1 + t - lane) * 4;   /* >= 0 in the steady state */
+                const bool act = EDGE ? (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2) : col_ok;
+                if (stereo) {
+                    const int vo = EDGE ? (act ? voT : -1) : voT;    /* -1: out of range, store dropped */
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsTb, vo, (b + 1 + t - last_lane + 64) * W * 4, 0);
+                } else {
                     int v1, v2;
-                    if (irregular) {
+                    if (irregular) {   /* irregular list: whole-slot lookups (out-of-range offsets read 0, masked by act) */
                         const int q = (b + 1 + t - lane) * W + x;
                         const int r1 = __builtin_amdgcn_raw_buffer_load_b32(rsM, q * 4, 0, 0);
                         const int r2 = (di > 0 && x + djs >= 0 && x + djs < W) ? __builtin_amdgcn_raw_buffer_load_b32(rsM, (q + di * W + djs) * 4, 0, 0) : -1;
-                        v1 = (col_ok && r1 >= 0) ? (int)(((unsigned)r1 * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
-                        v2 = (col_ok && r2 >= 0) ? (int)(((unsigned)r2 * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                        v1 = (act && r1 >= 0) ? (int)(((unsigned)r1 * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
+                        v2 = (act && r2 >= 0) ? (int)(((unsigned)r2 * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
                     } else {
+                        const int vy = (b + 1 + t - lane) * 4;   /* negative for lanes not yet started: reads 0, masked by act */
                         const int r1 = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, 0, 0);
-                        const int r2 = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, di * 4, 0);
-                        v1 = (col_ok && cx >= 0 && r1 >= 0) ? (int)(((unsigned)(r1 * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
-                        v2 = (col_ok && cx2 >= 0 && r2 >= 0 && di > 0) ? (int)(((unsigned)(r2 * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                        const int r2 = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, di * 4, 0);   /* table has 64 slots of -1 padding */
+                        v1 = (act && cx >= 0 && r1 >= 0) ? (int)(((unsigned)(r1 * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
+                        v2 = (act && cx2 >= 0 && r2 >= 0 && di > 0) ? (int)(((unsigned)(r2 * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
                     }
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
                 }
-                lcol[1 + t - last_lane] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
+                /* hand-off column for the next strip (uniform address and value) */
+                const int il = 1 + t - last_lane;
+                const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
+                lcol[EDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : il] = hv;
             }
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 float* rr = ring + wrow * CW;       /* uniform */
+                const bool rin = !EDGE || b + filled + s < H - b;   /* uniform; rows past the band are zeros */
                 const float dm = st2[s] - st1[s], de = se2[s] - se1[s];
-                const float vmain = inm ? dm * dm : 0.0f, vext = ine ? de * de : 0.0f;
+                const float vmain = (rin && inm) ? dm * dm : 0.0f, vext = (rin && ine) ? de * de : 0.0f;
+                const float vsec = lane < K ? vext : vmain;
                 rr[lane] = vmain;
-                rr[offE] = lane < K ? vext : vmain;
-                if (wrow < T - 1) { rr[RR * CW + lane] = vmain; rr[RR * CW + offE] = lane < K ? vext : vmain; }
+                rr[offE] = vsec;
+                if (wrow < T - 1) { rr[RR * CW + lane] = vmain; rr[RR * CW + offE] = vsec; }   /* mirror row (uniform, rare) */
                 wrow = wrow + 1 == RR ? 0 : wrow + 1;
             }
+            filled += T;
         };
-        /* ramp-up (lanes start one step apart), steady state, ramp-down */
-        const int band_rows = H - 2 * b;
-        const int t_steady0 = ((last_lane + T - 1) / T) * T;               /* first chunk with t0 >= last_lane */
-        int t_steady1 = nrows - T - 1 >= 0 ? ((nrows - T - 1) / T) * T + T : 0;   /* chunks with t0 <= nrows-T-1 ... */
-        t_steady1 = min(t_steady1, ((band_rows - K - 3 * T) / T) * T + T);        /* ... whose loaded rows are all in the band */
-        int t0 = 0;
-        for (; t0 < nsteps && t0 < t_steady0; t0 += T) do_chunk(t0, std::false_type{});
-        if (t0 + 2 * T <= t_steady1 && t0 + 2 * T <= nsteps) {
-            int rA = (t0 + K - lane + 64 * RR) % RR, rB = (t0 - lane + 64 * RR) % RR;
-            int wrow = filled % RR;
-            int soff = (b + filled + T) * W * 4;
-            float u1[T], u2[T], g1[T], g2[T];
-            for (; t0 + 2 * T <= t_steady1 && t0 + 2 * T <= nsteps; t0 += 2 * T) {
-                lean_chunk(t0, rA, rB, wrow, soff, u1, u2, g1, g2, p1, p2, q1, q2);
-                lean_chunk(t0 + T, rA, rB, wrow, soff, p1, p2, q1, q2, u1, u2, g1, g2);
-                filled += 2 * T;
+        {
+            /* [0, tS0): ramp-up, [tS0, tS1): steady, [tS1, nsteps): ramp-down; all in groups of DEP chunks (the
+             * register buffers rotate with the chunk index).  The edge flavour is valid anywhere, so the
+             * ranges are simply rounded to whole groups. */
+            const int band_rows = H - 2 * b;
+            constexpr int G = DEP * T;
+            int tS0 = ((last_lane + G - 1) / G) * G;
+            int tS1 = min(nrows - 1, band_rows - K - DEP * T);   /* chunks [t0, t0+T) with t0+T <= tS1 are steady */
+            tS1 = tS1 > tS0 ? tS0 + ((tS1 - tS0) / G) * G : tS0;
+            int t0 = 0;
+            for (int ph = 0; ph < 2; ph++) {
+                const int te = ph == 0 ? min(tS0, nsteps) : nsteps;
+                for (; t0 < te; t0 += G) {
+#pragma unroll
+                    for (int j = 0; j < DEP; j++)
+                        chunk(std::true_type{}, t0 + j * T, B1[(j + DEP - 1) % DEP], B2[(j + DEP - 1) % DEP], E1[(j + DEP - 1) % DEP], E2[(j + DEP - 1) % DEP],
+                              B1[j], B2[j], E1[j], E2[j]);
+                }
+                if (ph == 0)
+                    for (; t0 < tS1; t0 += G) {
+#pragma unroll
+                        for (int j = 0; j < DEP; j++)
+                            chunk(std::false_type{}, t0 + j * T, B1[(j + DEP - 1) % DEP], B2[(j + DEP - 1) % DEP], E1[(j + DEP - 1) % DEP], E2[(j + DEP - 1) % DEP],
+                                  B1[j], B2[j], E1[j], E2[j]);
+                    }
             }
         }
-        for (; t0 < nsteps; t0 += T) do_chunk(t0, std::false_type{});
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
         __syncthreads();
     }

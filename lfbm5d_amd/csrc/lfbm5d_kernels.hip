@@ -815,6 +815,9 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
             const bool ok = p != 0xffffffffu;
             okbits[n] |= ok ? 1u << st : 0u;
             const unsigned so = (((unsigned)st * a.C + c) * plane + (ok ? p : 0u)) * 4u;
+#ifdef LFBM5D_EXP
+            if (LFBM5D_EXP & 512) { v[n][st] = (float)(pq + so); continue; }
+#endif
             v[n][st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
         }
     }
@@ -904,6 +907,9 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
     for (int n = 0; n < NS; n++)
 #pragma unroll
         for (int st = 0; st < 9; st++)
+#ifdef LFBM5D_EXP
+            if ((LFBM5D_EXP & 256) && v[n][st] != 1234.5f) continue; else
+#endif
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[n][st]), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
 }
 
