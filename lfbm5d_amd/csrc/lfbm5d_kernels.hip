@@ -1492,18 +1492,32 @@ constexpr int kTile = 8;
  * Candidates are the patch instances (reference patch in raster order, then match index n) of the
  * reference patches whose search range can reach the tile; every pixel adds its contributions in
  * that order -- the reference's order for that pixel -- starting from the value already in num/den.
- * Everything is wave-synchronous: hits of a 64-candidate chunk are compacted in order with a ballot
- * into LDS (position, patch offset, the group's three weights), then consumed by all lanes. */
+ * Everything is wave-synchronous and built to keep many loads in flight (the kernel is a chain of
+ * dependent gathers, so latency, not bandwidth, is what has to be hidden):
+ *   scan     kAggPF chunks of 64 candidates at a time: their aggregation positions are loaded
+ *            together, then the group weights of the hits, then the hits are appended in candidate
+ *            order (ballot prefix) to a hit list in LDS: position, patch offset in filt, weights;
+ *   consume  once the list holds enough hits (or at the end) all lanes walk it in order, kAggU hits
+ *            per round: the loads of a round are issued together, the adds stay in list order.
+ * Workgroups are renumbered so that the tiles one XCD works on at a time are neighbours: the
+ * filtered patches they share are then fetched into that XCD's L2 once. */
+constexpr int kAggPF = 4, kAggU = 8, kAggFlush = 64, kAggCap = kAggFlush + kAggPF * 64;
 __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
-    __shared__ unsigned hit_pk[64];    /* (py << 16) | px */
-    __shared__ unsigned hit_base[64];  /* offset of the patch in filt */
-    __shared__ float hit_w[64][3];     /* the group's aggregation weights */
+    __shared__ unsigned hit_pk[kAggCap];    /* (py << 16) | px */
+    __shared__ unsigned hit_base[kAggCap];  /* offset of the patch in filt */
+    __shared__ float hit_w[kAggCap][3];     /* the group's aggregation weights */
     __shared__ float kai[kMaxK * kMaxK];
     const int lane = threadIdx.x;
-    const int st = blockIdx.z;
+    /* XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs */
+    const unsigned gx = (a.Wb + kTile - 1) / kTile, gy = (a.Hb + kTile - 1) / kTile, total_wg = gx * gy * a.A;
+    const unsigned per_xcd = gridDim.x / 8;          /* the launch is rounded up to a multiple of 8 workgroups */
+    const unsigned lin2 = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (lin2 >= total_wg) return;
+    const int st = (int)(lin2 / (gx * gy));
+    const int tile_y = (int)((lin2 / gx) % gy), tile_x = (int)(lin2 % gx);
     if ((a.proc_bits >> st) & 1) return;      /* procSAI[st] != 0: skipped (core:486) */
     if (!((a.mask_bits >> st) & 1)) return;
-    const int tx0 = blockIdx.x * kTile, ty0 = blockIdx.y * kTile;
+    const int tx0 = tile_x * kTile, ty0 = tile_y * kTile;
     const int x = tx0 + lane % kTile, y = ty0 + lane / kTile;
     const bool inside = x < (int)a.Wb && y < (int)a.Hb;
     const int k = a.k, k2 = k * k, C = a.C, N = a.N, A = a.A;
@@ -1535,45 +1549,17 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
                                    : ((r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span * N : 0);
     const unsigned g_end = a.ref_begin + a.n_groups;
     const unsigned* apos = a.aggpos + (size_t)st * a.n_refs_total * N;
-    __builtin_amdgcn_wave_barrier();
-    for (int c0 = 0; c0 < n_cand; c0 += 64) {
-        const int e = c0 + lane;
-        bool hit = false; unsigned pk = 0, fbase = 0, g = 0;
-        if (e < n_cand) {
-            const int n = e % N, rr = e / N;
-            if (a.irregular) g = (unsigned)rr;   /* the list is in raster order too (row lists, then columns) */
-            else {
-                const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
-                g = (unsigned)gr * a.n_ref_cols + gc;
-            }
-            if (g >= a.ref_begin && g < g_end) {
-                const unsigned p = apos[(size_t)g * N + n];
-                if (p != 0xffffffffu) {
-                    const int py = p / a.Wb, px = p % a.Wb;
-                    hit = py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
-                    pk = ((unsigned)py << 16) | (unsigned)px;
-                    fbase = ((g * N + n) * A + st) * C * k2;
-                }
-            }
-        }
-        /* ordered compaction of this chunk's hits */
-        const unsigned long long bal = __ballot(hit);
-        const unsigned total = __popcll(bal);
-        if (hit) {
-            const unsigned slot = __popcll(bal & ((1ull << lane) - 1ull));
-            hit_pk[slot] = pk; hit_base[slot] = fbase;
-            for (int c = 0; c < C; c++) hit_w[slot][c] = a.wgt[(size_t)g * C + c];
-        }
-        __builtin_amdgcn_wave_barrier();
-        constexpr int U = 4; /* loads of U hits are issued together; the adds stay in hit order */
-        for (unsigned h0 = 0; h0 < total; h0 += U) {
-            float val[U][3], kw[U][3];
-            bool on[U];
+    unsigned nh = 0;   /* hits in the list (uniform) */
+
+    auto consume = [&]() {
+        for (unsigned h0 = 0; h0 < nh; h0 += kAggU) {
+            float val[kAggU][3], kw[kAggU][3];
+            bool on[kAggU];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
+            for (int u = 0; u < kAggU; u++) {
                 const unsigned h = h0 + u;
                 on[u] = false;
-                if (h < total) {
+                if (h < nh) {
                     const unsigned hp = hit_pk[h];
                     const unsigned dy = (unsigned)(y - (int)(hp >> 16)), dx = (unsigned)(x - (int)(hp & 0xffffu));
                     if (dy < (unsigned)k && dx < (unsigned)k) {
@@ -1588,7 +1574,7 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < U; u++)
+            for (int u = 0; u < kAggU; u++)
                 if (on[u]) {
 #pragma unroll
                     for (int c = 0; c < 3; c++)
@@ -1599,8 +1585,57 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
                         }
                 }
         }
+        nh = 0;
         __builtin_amdgcn_wave_barrier();
+    };
+
+    __builtin_amdgcn_wave_barrier();
+    for (int c0 = 0; c0 < n_cand; c0 += 64 * kAggPF) {
+        unsigned g[kAggPF], p[kAggPF], nn[kAggPF];
+#pragma unroll
+        for (int u = 0; u < kAggPF; u++) {
+            const int e = c0 + u * 64 + lane;
+            p[u] = 0xffffffffu; g[u] = 0; nn[u] = 0;
+            if (e < n_cand) {
+                const int n = e % N, rr = e / N;
+                nn[u] = (unsigned)n;
+                if (a.irregular) g[u] = (unsigned)rr;   /* the list is in raster order too (row lists, then columns) */
+                else {
+                    const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
+                    g[u] = (unsigned)gr * a.n_ref_cols + gc;
+                }
+                if (g[u] >= a.ref_begin && g[u] < g_end) p[u] = apos[(size_t)g[u] * N + n];
+            }
+        }
+        bool hit[kAggPF];
+        float w[kAggPF][3];
+#pragma unroll
+        for (int u = 0; u < kAggPF; u++) {
+            hit[u] = false;
+            if (p[u] != 0xffffffffu) {
+                const int py = p[u] / a.Wb, px = p[u] % a.Wb;
+                hit[u] = py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
+                p[u] = ((unsigned)py << 16) | (unsigned)px;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) w[u][c] = (hit[u] && c < C) ? a.wgt[(size_t)g[u] * C + c] : 0.0f;
+        }
+        /* ordered append of the hits of these chunks */
+#pragma unroll
+        for (int u = 0; u < kAggPF; u++) {
+            const unsigned long long bal = __ballot(hit[u]);
+            if (hit[u]) {
+                const unsigned slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
+                hit_pk[slot] = p[u];
+                hit_base[slot] = ((g[u] * N + nn[u]) * A + st) * C * k2;
+                hit_w[slot][0] = w[u][0]; hit_w[slot][1] = w[u][1]; hit_w[slot][2] = w[u][2];
+            }
+            nh += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (nh >= kAggFlush) consume();
     }
+    if (nh) consume();
     if (inside) for (int c = 0; c < C; c++) { a.num[pix + c * plane] = accn[c]; a.den[pix + c * plane] = accd[c]; }
 }
 
@@ -1695,7 +1730,8 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     return hipGetLastError();
 }
 hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
-    hipLaunchKernelGGL(k_aggregate, dim3((a.Wb + kTile - 1) / kTile, (a.Hb + kTile - 1) / kTile, a.A), dim3(kTile * kTile), 0, s, a);
+    const unsigned tiles = ((a.Wb + kTile - 1) / kTile) * ((a.Hb + kTile - 1) / kTile) * a.A;
+    hipLaunchKernelGGL(k_aggregate, dim3(((tiles + 7) / 8) * 8), dim3(kTile * kTile), 0, s, a);
     return hipGetLastError();
 }
 
