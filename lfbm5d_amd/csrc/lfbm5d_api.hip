@@ -214,6 +214,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     const size_t plane = (size_t)Wb * Hb;
     hipStream_t s = c->stream;
     if (Hb < 2 * nHW + k + 1 || Wb < 2 * nHW + k + 1) return fail(c, "window smaller than the search range");
+    if (Hb > 65535 || Wb > 65535) return fail(c, "unsupported: window larger than 65535 pixels a side");
 
     float sig[3] = {0, 0, 0};
     if (sigma_table(P->sigma, C, P->color_space, sig)) return fail(c, "bad color space");

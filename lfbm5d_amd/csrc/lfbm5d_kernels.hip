@@ -609,7 +609,8 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
     const bool in_shape = st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r]);
     /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
      * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
-    a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = (a.tau4 != 6 || in_shape) ? p : 0xffffffffu;
+    /* stored as (row << 16) | column: the aggregation kernel tests each position against many tiles */
+    a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = ((a.tau4 != 6 || in_shape) && p != 0xffffffffu) ? ((p / a.Wb) << 16) | (p % a.Wb) : 0xffffffffu;
 }
 __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1497,16 +1498,25 @@ constexpr int kTile = 8;
  *   scan     kAggPF chunks of 64 candidates at a time: their aggregation positions are loaded
  *            together, then the group weights of the hits, then the hits are appended in candidate
  *            order (ballot prefix) to a hit list in LDS: position, patch offset in filt, weights;
- *   consume  once the list holds enough hits (or at the end) all lanes walk it in order, kAggU hits
+ *   consume  once the list holds enough hits (or is full, or at the end) all lanes walk it in order, kAggU hits
  *            per round: the loads of a round are issued together, the adds stay in list order.
  * Workgroups are renumbered so that the tiles one XCD works on at a time are neighbours: the
  * filtered patches they share are then fetched into that XCD's L2 once. */
-constexpr int kAggPF = 4, kAggU = 8, kAggFlush = 64, kAggCap = kAggFlush + kAggPF * 64;
+#ifndef LFBM5D_AGG_PF
+#define LFBM5D_AGG_PF 4
+#endif
+#ifndef LFBM5D_AGG_U
+#define LFBM5D_AGG_U 8
+#endif
+#ifndef LFBM5D_AGG_FLUSH
+#define LFBM5D_AGG_FLUSH 64
+#endif
+constexpr int kAggPF = LFBM5D_AGG_PF, kAggU = LFBM5D_AGG_U, kAggFlush = LFBM5D_AGG_FLUSH, kAggCap = kAggFlush + kAggPF * 64;
+template <bool WINDOWED>   /* Kaiser window (k = 8, 12); any other size has an all-ones window (bm3d.cpp:1144-1146) */
 __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
-    __shared__ unsigned hit_pk[kAggCap];    /* (py << 16) | px */
-    __shared__ unsigned hit_base[kAggCap];  /* offset of the patch in filt */
-    __shared__ float hit_w[kAggCap][3];     /* the group's aggregation weights */
-    __shared__ float kai[kMaxK * kMaxK];
+    __shared__ uint4 hit_a[kAggCap];       /* (py << 16) | px, offset of the patch in filt, weights of channels 0 and 1 */
+    __shared__ float hit_w2[kAggCap];      /* weight of channel 2 */
+    __shared__ float kai[WINDOWED ? kMaxK * kMaxK : 1];
     const int lane = threadIdx.x;
     /* XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs */
     const unsigned gx = (a.Wb + kTile - 1) / kTile, gy = (a.Hb + kTile - 1) / kTile, total_wg = gx * gy * a.A;
@@ -1521,10 +1531,10 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     const int x = tx0 + lane % kTile, y = ty0 + lane / kTile;
     const bool inside = x < (int)a.Wb && y < (int)a.Hb;
     const int k = a.k, k2 = k * k, C = a.C, N = a.N, A = a.A;
+    const int logN = 31 - __builtin_clz((unsigned)N);   /* N is a power of two (lfbm5d_api.hip validate) */
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int reach = (st == (int)a.pst) ? (int)a.nSim : (int)a.nHW;
-    const bool windowed = k == 8 || k == 12;  /* any other size: all-ones window (bm3d.cpp:1144-1146) */
-    if (windowed) for (int i = lane; i < k2; i += 64) kai[i] = a.tb->kaiser[i];
+    if (WINDOWED) for (int i = lane; i < k2; i += 64) kai[i] = a.tb->kaiser[i];
 
     /* reference-grid index ranges that can reach this tile (grid = nHW + i*p, plus a forced last
      * index, utilities.cpp:697-712) */
@@ -1545,44 +1555,45 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     if (inside) for (int c = 0; c < C; c++) { accn[c] = a.num[pix + c * plane]; accd[c] = a.den[pix + c * plane]; }
 
     const int ncols_span = c_hi - c_lo + 1;
-    const int n_cand = a.irregular ? (int)a.n_refs_total * N
-                                   : ((r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span * N : 0);
+    const int n_rr = a.irregular ? (int)a.n_refs_total : ((r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span : 0);
+    const int n_cand = n_rr << logN;
+    /* rr / ncols_span by multiplication: exact while rr < 2^20 / ncols_span (rr is a few hundred) */
+    const bool mul_div = !a.irregular && (long long)n_rr * ncols_span < (1 << 20);
+    const unsigned div_m = ((1u << 20) + (unsigned)max(ncols_span, 1) - 1) / (unsigned)max(ncols_span, 1);
     const unsigned g_end = a.ref_begin + a.n_groups;
     const unsigned* apos = a.aggpos + (size_t)st * a.n_refs_total * N;
+    const unsigned cstride = (unsigned)k2 * 4u;       /* channel stride inside a filtered patch, bytes */
     unsigned nh = 0;   /* hits in the list (uniform) */
 
     auto consume = [&]() {
         for (unsigned h0 = 0; h0 < nh; h0 += kAggU) {
             float val[kAggU][3], kw[kAggU][3];
-            bool on[kAggU];
 #pragma unroll
             for (int u = 0; u < kAggU; u++) {
-                const unsigned h = h0 + u;
-                on[u] = false;
-                if (h < nh) {
-                    const unsigned hp = hit_pk[h];
-                    const unsigned dy = (unsigned)(y - (int)(hp >> 16)), dx = (unsigned)(x - (int)(hp & 0xffffu));
-                    if (dy < (unsigned)k && dx < (unsigned)k) {
-                        on[u] = true;
-                        const unsigned o = dy * k + dx;
-                        const float kz = windowed ? kai[o] : 1.0f;
-                        const float* fp = a.filt + hit_base[h] + o;
-#pragma unroll
-                        for (int c = 0; c < 3; c++)
-                            if (c < C) { val[u][c] = fp[(size_t)c * k2]; kw[u][c] = kz * hit_w[h][c]; } /* core:516-520 */
-                    }
-                }
+                const unsigned h = min(h0 + u, nh - 1);          /* rounds are padded with the last hit at zero weight */
+                const uint4 ha = hit_a[h];
+                const float w2 = hit_w2[h];
+                const int dy = y - (int)(ha.x >> 16), dx = x - (int)(ha.x & 0xffffu);
+                const bool on = (unsigned)dy < (unsigned)k && (unsigned)dx < (unsigned)k && h0 + u < nh;
+                /* pixels the patch does not cover read the nearest pixel it does cover -- a pixel of this tile,
+                 * so no extra cache line is touched ... */
+                const unsigned o = (unsigned)(min(max(dy, 0), k - 1) * k + min(max(dx, 0), k - 1));
+                const float kz = WINDOWED ? kai[o] : 1.0f;
+                const char* fp = reinterpret_cast<const char*>(a.filt) + ((size_t)ha.y + o) * 4;
+                val[u][0] = *reinterpret_cast<const float*>(fp);
+                val[u][1] = C > 1 ? *reinterpret_cast<const float*>(fp + cstride) : 0.0f;
+                val[u][2] = C > 2 ? *reinterpret_cast<const float*>(fp + 2 * cstride) : 0.0f;
+                kw[u][0] = on ? kz * __uint_as_float(ha.z) : 0.0f;   /* ... and add it with weight zero */
+                kw[u][1] = on ? kz * __uint_as_float(ha.w) : 0.0f;
+                kw[u][2] = on ? kz * w2 : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < kAggU; u++)
-                if (on[u]) {
 #pragma unroll
-                    for (int c = 0; c < 3; c++)
-                        if (c < C) {
+                for (int c = 0; c < 3; c++) {
 #pragma clang fp contract(off)
-                            accn[c] += kw[u][c] * val[u][c];
-                            accd[c] += kw[u][c];
-                        }
+                    accn[c] += kw[u][c] * val[u][c];   /* core:516-520 */
+                    accd[c] += kw[u][c];
                 }
         }
         nh = 0;
@@ -1597,26 +1608,22 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
             const int e = c0 + u * 64 + lane;
             p[u] = 0xffffffffu; g[u] = 0; nn[u] = 0;
             if (e < n_cand) {
-                const int n = e % N, rr = e / N;
-                nn[u] = (unsigned)n;
-                if (a.irregular) g[u] = (unsigned)rr;   /* the list is in raster order too (row lists, then columns) */
+                const unsigned n = (unsigned)e & (unsigned)(N - 1), rr = (unsigned)e >> logN;
+                nn[u] = n;
+                if (a.irregular) g[u] = rr;   /* the list is in raster order too (row lists, then columns) */
                 else {
-                    const int gr = r_lo + rr / ncols_span, gc = c_lo + rr % ncols_span;
-                    g[u] = (unsigned)gr * a.n_ref_cols + gc;
+                    const unsigned q = mul_div ? (rr * div_m) >> 20 : rr / (unsigned)ncols_span;
+                    g[u] = ((unsigned)r_lo + q) * a.n_ref_cols + (unsigned)c_lo + (rr - q * (unsigned)ncols_span);
                 }
-                if (g[u] >= a.ref_begin && g[u] < g_end) p[u] = apos[(size_t)g[u] * N + n];
+                if (g[u] >= a.ref_begin && g[u] < g_end) p[u] = apos[((size_t)g[u] << logN) + n];
             }
         }
         bool hit[kAggPF];
         float w[kAggPF][3];
 #pragma unroll
         for (int u = 0; u < kAggPF; u++) {
-            hit[u] = false;
-            if (p[u] != 0xffffffffu) {
-                const int py = p[u] / a.Wb, px = p[u] % a.Wb;
-                hit[u] = py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
-                p[u] = ((unsigned)py << 16) | (unsigned)px;
-            }
+            const int py = (int)(p[u] >> 16), px = (int)(p[u] & 0xffffu);
+            hit[u] = p[u] != 0xffffffffu && py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
 #pragma unroll
             for (int c = 0; c < 3; c++) w[u][c] = (hit[u] && c < C) ? a.wgt[(size_t)g[u] * C + c] : 0.0f;
         }
@@ -1626,9 +1633,8 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
             const unsigned long long bal = __ballot(hit[u]);
             if (hit[u]) {
                 const unsigned slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
-                hit_pk[slot] = p[u];
-                hit_base[slot] = ((g[u] * N + nn[u]) * A + st) * C * k2;
-                hit_w[slot][0] = w[u][0]; hit_w[slot][1] = w[u][1]; hit_w[slot][2] = w[u][2];
+                hit_a[slot] = make_uint4(p[u], (((g[u] << logN) + nn[u]) * A + st) * C * k2, __float_as_uint(w[u][0]), __float_as_uint(w[u][1]));
+                hit_w2[slot] = w[u][2];
             }
             nh += __popcll(bal);
         }
@@ -1731,7 +1737,8 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
 }
 hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
     const unsigned tiles = ((a.Wb + kTile - 1) / kTile) * ((a.Hb + kTile - 1) / kTile) * a.A;
-    hipLaunchKernelGGL(k_aggregate, dim3(((tiles + 7) / 8) * 8), dim3(kTile * kTile), 0, s, a);
+    if (a.k == 8 || a.k == 12) hipLaunchKernelGGL(k_aggregate<true>, dim3(((tiles + 7) / 8) * 8), dim3(kTile * kTile), 0, s, a);
+    else                       hipLaunchKernelGGL(k_aggregate<false>, dim3(((tiles + 7) / 8) * 8), dim3(kTile * kTile), 0, s, a);
     return hipGetLastError();
 }
 
