@@ -1487,7 +1487,6 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
 
 /* ================================ aggregation kernel ====================================== */
 
-constexpr int kTile = 8;
 
 /* Gather form of core:484-528.  One wavefront = one 8x8 pixel tile of one SAI (thread = pixel).
  * Candidates are the patch instances (reference patch in raster order, then match index n) of the
@@ -1512,14 +1511,17 @@ constexpr int kTile = 8;
 #define LFBM5D_AGG_FLUSH 64
 #endif
 constexpr int kAggPF = LFBM5D_AGG_PF, kAggU = LFBM5D_AGG_U, kAggFlush = LFBM5D_AGG_FLUSH, kAggCap = kAggFlush + kAggPF * 64;
-template <bool WINDOWED>   /* Kaiser window (k = 8, 12); any other size has an all-ones window (bm3d.cpp:1144-1146) */
+/* WINDOWED: Kaiser window (k = 8, 12); any other size has an all-ones window (bm3d.cpp:1144-1146).
+ * TW x TH: tile shape (64 pixels).  A filtered patch row is k floats, so wide flat tiles read longer
+ * contiguous runs of it: 16x4 for k >= 12 (64-byte rows), 8x8 for k = 8 (a whole patch is two cache lines). */
+template <bool WINDOWED, int TW, int TH>
 __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     __shared__ uint4 hit_a[kAggCap];       /* (py << 16) | px, offset of the patch in filt, weights of channels 0 and 1 */
     __shared__ float hit_w2[kAggCap];      /* weight of channel 2 */
     __shared__ float kai[WINDOWED ? kMaxK * kMaxK : 1];
     const int lane = threadIdx.x;
     /* XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs */
-    const unsigned gx = (a.Wb + kTile - 1) / kTile, gy = (a.Hb + kTile - 1) / kTile, total_wg = gx * gy * a.A;
+    const unsigned gx = (a.Wb + TW - 1) / TW, gy = (a.Hb + TH - 1) / TH, total_wg = gx * gy * a.A;
     const unsigned per_xcd = gridDim.x / 8;          /* the launch is rounded up to a multiple of 8 workgroups */
     const unsigned lin2 = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (lin2 >= total_wg) return;
@@ -1527,8 +1529,8 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     const int tile_y = (int)((lin2 / gx) % gy), tile_x = (int)(lin2 % gx);
     if ((a.proc_bits >> st) & 1) return;      /* procSAI[st] != 0: skipped (core:486) */
     if (!((a.mask_bits >> st) & 1)) return;
-    const int tx0 = tile_x * kTile, ty0 = tile_y * kTile;
-    const int x = tx0 + lane % kTile, y = ty0 + lane / kTile;
+    const int tx0 = tile_x * TW, ty0 = tile_y * TH;
+    const int x = tx0 + lane % TW, y = ty0 + lane / TW;
     const bool inside = x < (int)a.Wb && y < (int)a.Hb;
     const int k = a.k, k2 = k * k, C = a.C, N = a.N, A = a.A;
     const int logN = 31 - __builtin_clz((unsigned)N);   /* N is a power of two (lfbm5d_api.hip validate) */
@@ -1545,8 +1547,8 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
         int d = v - (int)a.nHW; if (d < 0) return -1;
         int i = d / (int)a.p; return i > n - 2 ? n - 2 : i;
     };
-    int r_lo = lo_idx(ty0 - k + 1 - reach), r_hi = hi_idx(ty0 + kTile - 1 + reach, (int)a.n_ref_rows, last_r);
-    int c_lo = lo_idx(tx0 - k + 1 - reach), c_hi = hi_idx(tx0 + kTile - 1 + reach, (int)a.n_ref_cols, last_c);
+    int r_lo = lo_idx(ty0 - k + 1 - reach), r_hi = hi_idx(ty0 + TH - 1 + reach, (int)a.n_ref_rows, last_r);
+    int c_lo = lo_idx(tx0 - k + 1 - reach), c_hi = hi_idx(tx0 + TW - 1 + reach, (int)a.n_ref_cols, last_c);
     if (r_lo > (int)a.n_ref_rows - 1) r_lo = (int)a.n_ref_rows - 1; /* the forced last index may sit closer than p */
     if (c_lo > (int)a.n_ref_cols - 1) c_lo = (int)a.n_ref_cols - 1;
 
@@ -1623,7 +1625,7 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
 #pragma unroll
         for (int u = 0; u < kAggPF; u++) {
             const int py = (int)(p[u] >> 16), px = (int)(p[u] & 0xffffu);
-            hit[u] = p[u] != 0xffffffffu && py < ty0 + kTile && py + k > ty0 && px < tx0 + kTile && px + k > tx0;
+            hit[u] = p[u] != 0xffffffffu && py < ty0 + TH && py + k > ty0 && px < tx0 + TW && px + k > tx0;
 #pragma unroll
             for (int c = 0; c < 3; c++) w[u][c] = (hit[u] && c < C) ? a.wgt[(size_t)g[u] * C + c] : 0.0f;
         }
@@ -1736,9 +1738,14 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     return hipGetLastError();
 }
 hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
-    const unsigned tiles = ((a.Wb + kTile - 1) / kTile) * ((a.Hb + kTile - 1) / kTile) * a.A;
-    if (a.k == 8 || a.k == 12) hipLaunchKernelGGL(k_aggregate<true>, dim3(((tiles + 7) / 8) * 8), dim3(kTile * kTile), 0, s, a);
-    else                       hipLaunchKernelGGL(k_aggregate<false>, dim3(((tiles + 7) / 8) * 8), dim3(kTile * kTile), 0, s, a);
+    const bool wide = a.k >= 12;
+    const unsigned tw = wide ? 16 : 8, th = wide ? 4 : 8;
+    const unsigned tiles = ((a.Wb + tw - 1) / tw) * ((a.Hb + th - 1) / th) * a.A;
+    const dim3 grid(((tiles + 7) / 8) * 8), block(64);
+    if (a.k == 12)      hipLaunchKernelGGL((k_aggregate<true, 16, 4>), grid, block, 0, s, a);
+    else if (a.k == 8)  hipLaunchKernelGGL((k_aggregate<true, 8, 8>), grid, block, 0, s, a);
+    else if (wide)      hipLaunchKernelGGL((k_aggregate<false, 16, 4>), grid, block, 0, s, a);
+    else                hipLaunchKernelGGL((k_aggregate<false, 8, 8>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 
