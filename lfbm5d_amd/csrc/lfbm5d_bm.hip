@@ -363,7 +363,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
              * ranges are simply rounded to whole groups. */
             const int band_rows = H - 2 * b;
             constexpr int G = DEP * T;
-            int tS0 = ((last_lane + G - 1) / G) * G;
+            int tS0 = ((last_lane + 1 + G - 1) / G) * G;       /* step last_lane (that lane's start) is still an edge step */
             int tS1 = min(nrows - 1, band_rows - K - DEP * T);   /* chunks [t0, t0+T) with t0+T <= tS1 are steady */
             tS1 = tS1 > tS0 ? tS0 + ((tS1 - tS0) / G) * G : tS0;
             int t0 = 0;

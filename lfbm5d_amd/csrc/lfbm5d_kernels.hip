@@ -1501,21 +1501,15 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
  *            per round: the loads of a round are issued together, the adds stay in list order.
  * Workgroups are renumbered so that the tiles one XCD works on at a time are neighbours: the
  * filtered patches they share are then fetched into that XCD's L2 once. */
-#ifndef LFBM5D_AGG_PF
-#define LFBM5D_AGG_PF 4
-#endif
-#ifndef LFBM5D_AGG_U
-#define LFBM5D_AGG_U 8
-#endif
-#ifndef LFBM5D_AGG_FLUSH
-#define LFBM5D_AGG_FLUSH 64
-#endif
-constexpr int kAggPF = LFBM5D_AGG_PF, kAggU = LFBM5D_AGG_U, kAggFlush = LFBM5D_AGG_FLUSH, kAggCap = kAggFlush + kAggPF * 64;
+constexpr int kAggFlush = 64;   /* hits that make a consume phase worth starting */
 /* WINDOWED: Kaiser window (k = 8, 12); any other size has an all-ones window (bm3d.cpp:1144-1146).
  * TW x TH: tile shape (64 pixels).  A filtered patch row is k floats, so wide flat tiles read longer
- * contiguous runs of it: 16x4 for k >= 12 (64-byte rows), 8x8 for k = 8 (a whole patch is two cache lines). */
-template <bool WINDOWED, int TW, int TH>
+ * contiguous runs of it: 16x4 for k >= 12 (64-byte rows), 8x8 for k = 8 (a whole patch is two cache lines).
+ * kAggPF chunks per scan round and kAggU hits per load round trade latency hiding against registers and LDS
+ * (occupancy): the k = 8 pass has few hits per candidate and wants occupancy, the k = 16 pass deeper rounds. */
+template <bool WINDOWED, int TW, int TH, int kAggPF, int kAggU>
 __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
+    constexpr int kAggCap = kAggFlush + kAggPF * 64;
     __shared__ uint4 hit_a[kAggCap];       /* (py << 16) | px, offset of the patch in filt, weights of channels 0 and 1 */
     __shared__ float hit_w2[kAggCap];      /* weight of channel 2 */
     __shared__ float kai[WINDOWED ? kMaxK * kMaxK : 1];
@@ -1742,10 +1736,10 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
     const unsigned tw = wide ? 16 : 8, th = wide ? 4 : 8;
     const unsigned tiles = ((a.Wb + tw - 1) / tw) * ((a.Hb + th - 1) / th) * a.A;
     const dim3 grid(((tiles + 7) / 8) * 8), block(64);
-    if (a.k == 12)      hipLaunchKernelGGL((k_aggregate<true, 16, 4>), grid, block, 0, s, a);
-    else if (a.k == 8)  hipLaunchKernelGGL((k_aggregate<true, 8, 8>), grid, block, 0, s, a);
-    else if (wide)      hipLaunchKernelGGL((k_aggregate<false, 16, 4>), grid, block, 0, s, a);
-    else                hipLaunchKernelGGL((k_aggregate<false, 8, 8>), grid, block, 0, s, a);
+    if (a.k == 12)      hipLaunchKernelGGL((k_aggregate<true, 16, 4, 3, 12>), grid, block, 0, s, a);
+    else if (a.k == 8)  hipLaunchKernelGGL((k_aggregate<true, 8, 8, 2, 6>), grid, block, 0, s, a);
+    else if (wide)      hipLaunchKernelGGL((k_aggregate<false, 16, 4, 3, 12>), grid, block, 0, s, a);
+    else                hipLaunchKernelGGL((k_aggregate<false, 8, 8, 2, 6>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -542,7 +542,9 @@ unsigned pow2_floor(unsigned n) { unsigned r = 1; while (r * 2 <= n) r *= 2; ret
 /* Block matching                                                                               */
 /* ------------------------------------------------------------------------------------------ */
 /* Integral-image recurrence of core:3342-3389 / :3527-3573 for one displacement.
- * diff: W*H scratch whose entries outside [b, dim-b) must be (and stay) zero;
+ * diff: W*H + k*W + k scratch whose entries outside [b, dim-b) must be (and stay) zero.  The k rows of slack
+ *       matter when k - 1 > b: the recurrence then reads rows past the image for table rows no caller uses
+ *       (the reference reads past its W*H vector there, core:3384); here those reads see zeros;
  * sum : W*H table, entries outside the written region keep whatever the caller put there.
  * Written region: rows/cols [b, dim - b - trim).                                            */
 void integral_table(const float* img1, const float* img2, int dk, unsigned W, unsigned H,
@@ -600,7 +602,7 @@ int bm_self(const float* img, unsigned W, unsigned H, unsigned k, unsigned N, un
     try { tables.assign(nT * WH, 2 * threshold); } catch (...) { return 1; }
     #pragma omp parallel num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
     {
-        std::vector<float> diff(WH, 0.0f);
+        std::vector<float> diff(WH + (size_t)k * W + k, 0.0f);
         #pragma omp for schedule(dynamic, 1)
         for (int ddk = 0; ddk < (int)nT; ddk++) {
             const unsigned di = ddk / Ns, dj = ddk % Ns;
@@ -650,7 +652,7 @@ int bm_stereo(const float* img1, const float* img2, unsigned W, unsigned H, unsi
     const unsigned Ns = 2 * nDisp + 1;
     const float threshold = tauMatch * k * k;
     const size_t WH = (size_t)W * H;
-    std::vector<float> diff(WH, 0.0f), sum(WH, 0.0f), bestd(WH, 0.0f);
+    std::vector<float> diff(WH + (size_t)k * W + k, 0.0f), sum(WH, 0.0f), bestd(WH, 0.0f);
     std::vector<unsigned> bestorder(WH, 0xffffffffu);
     const unsigned lo = nDisp, hi_r = H - nDisp - k + 1, hi_c = W - nDisp - k + 1;
     for (unsigned di = 0; di < Ns; di++)

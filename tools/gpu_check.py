@@ -85,6 +85,10 @@ def check_pass(ctx, name, lf, sigma, step, pk, crop=None, basic_from=None):
     s_g = shape[7].reshape(Hb, Wb)[yy, yy]
     print(f"[{name}] refs {len(refs)} self cnt match {same_cnt:.6f} idx match {same_idx:.6f} "
           f"stereo best match {(b_o == b_g).mean():.6f} shape match {(s_o == s_g).mean():.6f}")
+    if not (b_o == b_g).all():
+        bad = np.argwhere(b_o != b_g)
+        print(f"[{name}] stereo mismatches {len(bad)}: rows {bad[:, 0].min() + nDisp}..{bad[:, 0].max() + nDisp} "
+              f"cols {bad[:, 1].min() + nDisp}..{bad[:, 1].max() + nDisp} (window {Wb}x{Hb}); first {bad[:6].tolist()}")
     dn = np.abs(num_g - num_o).max() / max(1e-9, np.abs(num_o).max())
     dd = np.abs(den_g - den_o).max() / max(1e-9, np.abs(den_o).max())
     cov = ((den_o > 0) == (den_g > 0)).mean()
@@ -140,6 +144,8 @@ if __name__ == "__main__":
         check_pass(ctx, "small-wien-dct", lf, 25.0, 2, (8, 6, 2, 8, 3, "dct", "sadct", "haar"), crop=64)
         check_pass(ctx, "small-ht-n1", lf, 50.0, 1, (1, 6, 2, 16, 3, "bior", "sadct", "haar"), crop=96)
         check_pass(ctx, "small-ht-hw", lf, 25.0, 1, (4, 6, 2, 8, 3, "dct", "dct", "hw"), crop=64)
+    if "k16n8" in which:
+        check_pass(ctx, "ht-k16-n8", lf, 25.0, 1, (8, 8, 3, 16, 4, "id", "sadct", "haar"), crop=96)
     if "readme" in which:
         check_pass(ctx, "readme-ht", lf, 25.0, 1, (8, 18, 6, 16, 4, "id", "sadct", "haar"))
         check_pass(ctx, "readme-wien", lf, 25.0, 2, (16, 18, 6, 8, 4, "dct", "sadct", "haar"))
