@@ -47,6 +47,8 @@ struct PassEvents { hipEvent_t e[5]; bool comm; };
 
 } /* namespace */
 
+constexpr size_t kEstLead = 64;   /* floats of slack in front of the estimate planes */
+
 struct lfbm5d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -294,9 +296,12 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     unsigned slots[kMaxA]; unsigned n_slots = 0;
     for (unsigned st = 0; st < A; st++) if (st != pst && ((mask_bits >> st) & 1)) slots[n_slots++] = st;
     const unsigned Nst = N > 1 ? N : 1;
-    HIPCK(c, c->est.reserve((A * plane + 256) * sizeof(float)));   /* slack: strip loads may overrun a row end by <= nHW */
+    /* slack on both sides: the scan's 16-byte row loads start one column left of the band (one float before
+     * the first plane for the left-most displacement) and overrun the last row by less than a ring row */
+    HIPCK(c, c->est.reserve((kEstLead + A * plane + 256) * sizeof(float)));
+    float* const est = c->est.as<float>() + kEstLead;
     if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
-    HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * plane * sizeof(float)));
+    HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * stereo_table_stride(Wb, Hb, k, P->nDisp) * sizeof(float)));
     HIPCK(c, c->self_idx.reserve((size_t)R * Nst * sizeof(unsigned)));
     HIPCK(c, c->self_cnt.reserve((size_t)R * sizeof(unsigned)));
     HIPCK(c, c->best.reserve(A * plane * sizeof(unsigned)));
@@ -324,7 +329,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     for (unsigned st = 0; st < A; st++) {
         if (!((mask_bits >> st) & 1)) continue;
         const size_t o = (size_t)st * C * plane;
-        HIPCK(c, launch_estimate(s, d_num + o, d_den + o, sub + o, c->est.as<float>() + st * plane, plane));
+        HIPCK(c, launch_estimate(s, d_num + o, d_den + o, sub + o, est + st * plane, plane));
     }
     /* multi-GPU: ranks > 0 accumulate their shard into zeroed buffers; the all-reduce restores
      * base + all contributions on every rank */
@@ -337,7 +342,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* block matching (core:209-236): all distance tables in one launch, then the two selections */
     ScanArgs sa;
     std::memset(&sa, 0, sizeof(sa));
-    sa.est = c->est.as<float>(); sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
+    sa.est = est; sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
     sa.nSim = P->nSim; sa.nDisp = P->nDisp; sa.nHW = nHW;
     sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p;
     sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = c->rslot.as<int>(); sa.refmap = centre ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)std::min<size_t>((size_t)R * NsS * NsS * sizeof(float), 0x7fffffffu);

@@ -62,8 +62,9 @@ __device__ __forceinline__ int grid_index(int v, int n, int last, int nHW, int p
  * column to the next strip through `lcol`.
  */
 #ifndef LFBM5D_SCAN_DEPTH
-#define LFBM5D_SCAN_DEPTH(T) ((T) == 4 ? 4 : 3)
+#define LFBM5D_SCAN_DEPTH(T) ((T) == 4 ? 7 : 4)
 #endif
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int K, int MODE>   /* MODE 0: self search on the regular grid, 1: self search on an irregular list, 2: disparity */
 __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, float* lds) {
     /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows.  Sized so that five waves fit a CU
@@ -76,6 +77,18 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     /* rows RR .. RR+T-2 mirror rows 0 .. T-2, so T consecutive ring rows can be read without wrapping */
     float* lcol = lds + (RR + T - 1) * CW;   /* [nrows] column left of the current strip (strip 0: first column) */
     const int lane = threadIdx.x;
+    /* A chunk's T new D rows (T x CW entries, row-major) are fetched with as few memory instructions as
+     * possible -- vmcnt is an in-order counter of at most 63 loads AND stores, so the fewer operations a
+     * chunk issues, the further ahead of the (slow) table stores the loads can run: NA 16-byte loads of
+     * four consecutive entries per lane (CW is a multiple of 4, a quad never straddles rows) and one
+     * 4-byte load for the REM <= 64 entries left. */
+    constexpr int E = T * CW, NA = E / 256, REM = E - 256 * NA;
+    static_assert(CW % 4 == 0 && REM >= 0 && REM <= 64 && RR % T == 0 && (K + T) % T == 0, "chunk geometry");
+    int qrow[NA], qcol[NA];
+#pragma unroll
+    for (int q = 0; q < NA; q++) { qrow[q] = (256 * q + 4 * lane) / CW; qcol[q] = (256 * q + 4 * lane) % CW; }
+    const int xrow = (256 * NA + lane) / CW, xcol = (256 * NA + lane) % CW;
+    const bool hasB = lane < REM;
     const int half = stereo ? (int)a.nDisp : (int)a.nSim;
     const int trim = stereo ? (int)a.k - 1 : 0;
     const int W = a.W, H = a.H, b = stereo ? (int)a.nDisp : (int)a.nHW;
@@ -98,7 +111,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         D.dk = di * W + dj - half;
     }
     D.W = W; D.H = H; D.b = b;
-    float* table = stereo ? a.tables + (size_t)bid * WH : nullptr;
+    const size_t tstride = stereo ? stereo_table_stride(a.W, a.H, a.k, a.nDisp) : 0;
+    float* table = stereo ? a.tables + (size_t)bid * tstride : nullptr;   /* [strip][row][64] */
     const int djs = dj - half;
     const int nSim = half;
     const int ord_fwd = dj * Ns + di;
@@ -115,7 +129,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     const int lastR = H - (int)a.k - gN, lastC = W - (int)a.k - gN;
 
     auto emit = [&](int y, int x, float S) {
-        if (stereo) { table[y * W + x] = S; return; }
+        if (stereo) { table[((size_t)((x - b) / 64) * H + y) * 64 + (x - b) % 64] = S; return; }
         if (irregular) { /* irregular reference list (subset path, core:3631-3788): slots come from a position map */
             const int r = a.refmap[y * W + x];
             if (r >= 0) a.scores[(size_t)r * ncand + ord_fwd] = S;
@@ -219,13 +233,40 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
 #pragma unroll
             for (int s = 0; s < T; s++) store_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
         }
-        /* the next (DEP-1)*T rows wait in registers: row loads run DEP-1 chunks ahead of the ring writes, far
-         * enough that a chunk never waits on the memory latency (vmcnt also counts the table stores) */
-        float B1[DEP][T], B2[DEP][T], E1[DEP][T], E2[DEP][T];
+        /* per-lane pieces of the chunk loads: byte offset inside the chunk's first row, in-band column masks */
+        int vA[NA], mA[NA];
 #pragma unroll
-        for (int j = 0; j < DEP - 1; j++)
+        for (int q = 0; q < NA; q++) {
+            vA[q] = (qrow[q] * W + cb - 1 + qcol[q]) * 4;
+            mA[q] = 0;
 #pragma unroll
-            for (int s = 0; s < T; s++) load_row(K + T + j * T + s, B1[j][s], B2[j][s], E1[j][s], E2[j][s]);
+            for (int j = 0; j < 4; j++) { const int xx = cb - 1 + qcol[q] + j; mA[q] |= (xx >= b && xx < W - b) ? 1 << j : 0; }
+        }
+        const int vB = (xrow * W + cb - 1 + xcol) * 4;
+        const bool mB = hasB && cb - 1 + xcol >= b && cb - 1 + xcol < W - b;
+        /* chunk loads.  steady: one scalar row offset; edge: every lane clamps its own row into the image
+         * (rows past the band are zeroed when they are written to the ring) */
+        auto load_chunk = [&](auto edge_tag, int R0, v4f* a1, v4f* a2, float& b1, float& b2) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+#pragma unroll
+            for (int q = 0; q < NA; q++) {
+                const int vo = EDGE ? (min(b + R0 + qrow[q], H - 1) * W + cb - 1 + qcol[q]) * 4 : vA[q];
+                const int so = EDGE ? 0 : (b + R0) * W * 4;
+                a1[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs1, vo, so, 0));
+                a2[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs2, vo, so, 0));
+            }
+            if (REM > 0) {
+                const int vo = hasB ? (EDGE ? (min(b + R0 + xrow, H - 1) * W + cb - 1 + xcol) * 4 : vB) : -1;   /* -1: reads 0 */
+                const int so = EDGE ? 0 : (b + R0) * W * 4;
+                b1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vo, so, 0));
+                b2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, so, 0));
+            }
+        };
+        /* the next (DEP-1)*T rows wait in registers: row loads run DEP-1 chunks ahead of the ring writes */
+        v4f A1[DEP][NA], A2[DEP][NA];
+        float Bq1[DEP], Bq2[DEP];
+#pragma unroll
+        for (int j = 0; j < DEP - 1; j++) load_chunk(std::true_type{}, K + T + j * T, A1[j], A2[j], Bq1[j], Bq2[j]);
         int filled = K + T;   /* rows [0, filled) are in the ring; rows [filled, filled + (DEP-1)T) wait in registers */
         __syncthreads();
 
@@ -265,26 +306,16 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         const int lane_eff = col_ok ? lane : 0x40000000;   /* lanes past the last column are never active */
         /* table stores: lane-constant offset (>= 0) + scalar row offset; the resource starts 64 rows above the
          * table so that the scalar part stays non-negative during the ramp-up */
-        const __amdgpu_buffer_rsrc_t rsTb = __builtin_amdgcn_make_buffer_rsrc((void*)(table - 64 * W), 0, (int)((WH + 64 * (size_t)W) * 4), kRsrcFlags);
-        const int voT = col_ok ? (x + (last_lane - lane) * W) * 4 : -1;
-        const int offE = lane < K ? 64 + lane : lane;   /* extra-column slot; lanes >= K rewrite their own main slot */
-        const int soff_max = (H - b - 1) * W * 4;
+        const __amdgpu_buffer_rsrc_t rsTb = __builtin_amdgcn_make_buffer_rsrc((void*)(table - 64 * 64), 0, (int)((tstride + 64 * 64) * 4), kRsrcFlags);
+        const int voT = col_ok ? (lane + (last_lane - lane) * 64) * 4 : -1;
+        const int soT = (strip * H + b + 1 - last_lane + 64) * 256;      /* + 256 t: row b+1+t-last_lane of this strip */
         int rA = (K - lane + 64 * RR) % RR, rB = (64 * RR - lane) % RR;   /* ring rows of (t + K - lane) and (t - lane) */
-        int wrow = filled % RR;
-        int soff = (b + filled + (DEP - 1) * T) * W * 4;
+        int wrow = filled % RR;   /* a multiple of T, like RR: the T rows of a chunk never wrap inside the ring */
         auto chunk = [&](auto edge_tag, int t0,
-                         float* ld1, float* ld2, float* le1, float* le2,                                 /* receive rows filled+(DEP-1)T .. */
-                         const float* st1, const float* st2, const float* se1, const float* se2) {     /* rows filled .. go to the ring */
+                         v4f* la1, v4f* la2, float& lb1, float& lb2,                   /* receive rows filled+(DEP-1)T .. */
+                         const v4f* sa1, const v4f* sa2, float sb1, float sb2) {       /* rows filled .. go to the ring */
             constexpr bool EDGE = decltype(edge_tag)::value;
-#pragma unroll
-            for (int s = 0; s < T; s++) {
-                const int so = EDGE ? min(soff, soff_max) : soff;    /* uniform */
-                ld1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vm, so, 0));
-                ld2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vm, so, 0));
-                le1[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ve, so, 0));
-                le2[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, ve, so, 0));
-                soff += W * 4;
-            }
+            load_chunk(edge_tag, filled + (DEP - 1) * T, la1, la2, lb1, lb2);
             const float* pa = ring + rA * CW + lane;
             const float* pb = ring + rB * CW + lane;
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
@@ -319,7 +350,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 const bool act = EDGE ? (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2) : col_ok;
                 if (stereo) {
                     const int vo = EDGE ? (act ? voT : -1) : voT;    /* -1: out of range, store dropped */
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsTb, vo, (b + 1 + t - last_lane + 64) * W * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsTb, vo, soT + t * 256, 0);
                 } else {
                     int v1, v2;
                     if (irregular) {   /* irregular list: whole-slot lookups (out-of-range offsets read 0, masked by act) */
@@ -335,25 +366,37 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                         v1 = (act && cx >= 0 && r1 >= 0) ? (int)(((unsigned)(r1 * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
                         v2 = (act && cx2 >= 0 && r2 >= 0 && di > 0) ? (int)(((unsigned)(r2 * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
                     }
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
+                    /* a store no lane takes part in is skipped (on the regular grid three steps in four) */
+                    if (__builtin_amdgcn_ballot_w64(v1 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
+                    if (__builtin_amdgcn_ballot_w64(v2 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
                 }
                 /* hand-off column for the next strip (uniform address and value) */
                 const int il = 1 + t - last_lane;
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
                 lcol[EDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : il] = hv;
             }
-#pragma unroll
-            for (int s = 0; s < T; s++) {
+            {   /* squared differences of rows filled .. filled+T-1 into the ring (and its mirror rows) */
                 float* rr = ring + wrow * CW;       /* uniform */
-                const bool rin = !EDGE || b + filled + s < H - b;   /* uniform; rows past the band are zeros */
-                const float dm = st2[s] - st1[s], de = se2[s] - se1[s];
-                const float vmain = (rin && inm) ? dm * dm : 0.0f, vext = (rin && ine) ? de * de : 0.0f;
-                const float vsec = lane < K ? vext : vmain;
-                rr[lane] = vmain;
-                rr[offE] = vsec;
-                if (wrow < T - 1) { rr[RR * CW + lane] = vmain; rr[RR * CW + offE] = vsec; }   /* mirror row (uniform, rare) */
-                wrow = wrow + 1 == RR ? 0 : wrow + 1;
+#pragma unroll
+                for (int q = 0; q < NA; q++) {
+                    const v4f d = sa2[q] - sa1[q];
+                    v4f v = d * d;
+                    const bool rin = !EDGE || b + filled + qrow[q] < H - b;   /* rows past the band are zeros */
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = (rin && ((mA[q] >> j) & 1)) ? v[j] : 0.0f;
+                    *reinterpret_cast<v4f*>(rr + qrow[q] * CW + qcol[q]) = v;
+                    if (wrow == 0 && qrow[q] < T - 1) *reinterpret_cast<v4f*>(rr + (RR + qrow[q]) * CW + qcol[q]) = v;   /* mirror rows */
+                }
+                if (REM > 0) {
+                    const float d = sb2 - sb1;
+                    const bool rin = !EDGE || b + filled + xrow < H - b;
+                    const float v = (rin && mB) ? d * d : 0.0f;
+                    if (hasB) {
+                        rr[xrow * CW + xcol] = v;
+                        if (wrow == 0 && xrow < T - 1) rr[(RR + xrow) * CW + xcol] = v;
+                    }
+                }
+                wrow = wrow + T == RR ? 0 : wrow + T;
             }
             filled += T;
         };
@@ -372,15 +415,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 for (; t0 < te; t0 += G) {
 #pragma unroll
                     for (int j = 0; j < DEP; j++)
-                        chunk(std::true_type{}, t0 + j * T, B1[(j + DEP - 1) % DEP], B2[(j + DEP - 1) % DEP], E1[(j + DEP - 1) % DEP], E2[(j + DEP - 1) % DEP],
-                              B1[j], B2[j], E1[j], E2[j]);
+                        chunk(std::true_type{}, t0 + j * T, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
+                              A1[j], A2[j], Bq1[j], Bq2[j]);
                 }
                 if (ph == 0)
                     for (; t0 < tS1; t0 += G) {
 #pragma unroll
                         for (int j = 0; j < DEP; j++)
-                            chunk(std::false_type{}, t0 + j * T, B1[(j + DEP - 1) % DEP], B2[(j + DEP - 1) % DEP], E1[(j + DEP - 1) % DEP], E2[(j + DEP - 1) % DEP],
-                                  B1[j], B2[j], E1[j], E2[j]);
+                            chunk(std::false_type{}, t0 + j * T, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
+                                  A1[j], A2[j], Bq1[j], Bq2[j]);
                     }
             }
         }
@@ -471,7 +514,7 @@ __global__ void k_self_trivial(const unsigned* __restrict__ refs, unsigned n_ref
 
 /* argmin over the (2 nDisp+1)^2 displacement tables (core:3581-3608); ties keep scan order
  * (dj outer, di inner), the order the reference pushes candidates in.  grid.y = table slot. */
-struct ArgminArgs { const float* tables; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp; float thr; unsigned* best; unsigned char* shape; };
+struct ArgminArgs { const float* tables; size_t tstride; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp; float thr; unsigned* best; unsigned char* shape; };
 __global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
     const int W = a.W, H = a.H, nDisp = a.nDisp;
     const int span_c = W - 2 * nDisp - a.k + 1, span_r = H - 2 * nDisp - a.k + 1;
@@ -482,12 +525,12 @@ __global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
     const int Ns = 2 * nDisp + 1, ncand = Ns * Ns;
     const size_t WH = (size_t)W * H;
     const int pos = y * W + x;
-    const float* t = a.tables + (size_t)slot * ncand * WH + pos;
+    const float* t = a.tables + (size_t)slot * ncand * a.tstride + ((size_t)((x - nDisp) / 64) * H + y) * 64 + (x - nDisp) % 64;
     float bv = t[0]; int bo = 0, bd = 0;
     for (int d0 = 0; d0 < ncand; d0 += 8) {   /* eight independent table reads in flight */
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = t[(size_t)min(d0 + u, ncand - 1) * WH];
+        for (int u = 0; u < 8; u++) v[u] = t[(size_t)min(d0 + u, ncand - 1) * a.tstride];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int ddk = d0 + u;
@@ -551,7 +594,7 @@ hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsign
                                 unsigned* best, unsigned char* shape) {
     const unsigned n = (W - 2 * nDisp - k + 1) * (H - 2 * nDisp - k + 1);
     ArgminArgs a;
-    a.tables = tables; a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.thr = thr; a.best = best; a.shape = shape;
+    a.tables = tables; a.tstride = stereo_table_stride(W, H, k, nDisp); a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.thr = thr; a.best = best; a.shape = shape;
     for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
     hipLaunchKernelGGL(k_stereo_argmin, dim3((n + 255) / 256, n_slots), dim3(256), 0, s, a);
     return hipGetLastError();

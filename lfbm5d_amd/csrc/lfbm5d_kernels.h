@@ -87,6 +87,13 @@ struct AggArgs {
     unsigned irregular;         /* reference list is not the regular grid (subset path): scan every reference */
 };
 
+/* Disparity score tables are laid out strip-major -- [strip of 64 columns][row][64] -- so that the
+ * scan kernel, which walks one strip top to bottom, writes one contiguous stream per table. */
+__host__ __device__ inline size_t stereo_table_stride(unsigned W, unsigned H, unsigned k, unsigned nDisp) {
+    const unsigned ncols = W - 2 * nDisp - (k - 1);
+    return (size_t)((ncols + 63) / 64) * 64 * H;
+}
+
 struct ScanArgs {
     const float* est;           /* [A][Wb*Hb] channel-0 estimates (+ slack) */
     unsigned W, H, k;
@@ -101,7 +108,7 @@ struct ScanArgs {
     float* scores;              /* [R][Ns*Ns], pre-filled with 2*threshold */
     unsigned scores_bytes;
     /* stereo */
-    float* tables;              /* [n_slots][Ns*Ns][W*H] */
+    float* tables;              /* [n_slots][Ns*Ns][stereo_table_stride]: strip-major [strip][row][64 columns] */
     unsigned st_of_slot[kMaxA];
 };
 
