@@ -75,7 +75,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     constexpr bool irregular = MODE == 1;
     float* ring = lds;              /* [RR][CW] D rows of the current strip; ring col 0 <-> x = cb-1 */
     /* rows RR .. RR+T-2 mirror rows 0 .. T-2, so T consecutive ring rows can be read without wrapping */
-    float* lcol = lds + (RR + T - 1) * CW;   /* [nrows] column left of the current strip (strip 0: first column) */
+    float* lcol = lds + (RR + T - 1) * CW;   /* [nrows + T + 1] column left of the current strip (strip 0: first column) */
     const int lane = threadIdx.x;
     /* A chunk's T new D rows (T x CW entries, row-major) are fetched with as few memory instructions as
      * possible -- vmcnt is an in-order counter of at most 63 loads AND stores, so the fewer operations a
@@ -123,7 +123,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)D.i1, 0, (int)(WH * 4 + 1024), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(D.i2 + D.dk), 0, (int)(WH * 4 + 1024), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (int)a.scores_bytes, kRsrcFlags);
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)a.rslot, 0, (int)((H + 64) * 4), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void*)a.refmap, 0, irregular ? (int)(WH * 4) : 0, kRsrcFlags);
     const int gR = a.n_ref_rows, gC = a.n_ref_cols, gP = a.p, gN = a.nHW;
     const int lastR = H - (int)a.k - gN, lastC = W - (int)a.k - gN;
@@ -184,6 +183,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     __syncthreads();
 
     for (int i = nrows + lane; i < nrows + T + 1; i += 64) lcol[i] = 0.0f;
+    /* regular grid: row -> reference-grid row slot (-1: none) as 16-bit entries in LDS (a global lookup per
+     * step would make every step wait on vmcnt, i.e. on all the loads and stores in flight); like the global
+     * table it has 64 entries of -1 padding behind row H-1 for the rows y + di of the mirrored candidate */
+    short* rs16 = reinterpret_cast<short*>(lcol + nrows + T + 1);
+    /* disparity tables: 32 rows x 64 columns in which the skewed results of the last steps are straightened
+     * out before they are stored (see the chunk's store stage); 16-byte aligned */
+    float* usk = lds + (((RR + T - 1) * CW + nrows + T + 1 + (H + 64 + 1) / 2 + 3) & ~3);
+    if (MODE == 0)
+        for (int i = lane; i < H + 64; i += 64) rs16[i] = (short)a.rslot[i];
     __syncthreads();
 
     float row0_left = corner; /* S[b][cb-1] */
@@ -248,6 +256,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
          * (rows past the band are zeroed when they are written to the ring) */
         auto load_chunk = [&](auto edge_tag, int R0, v4f* a1, v4f* a2, float& b1, float& b2) {
             constexpr bool EDGE = decltype(edge_tag)::value;
+#ifdef LFBM5D_EXP
+            if (!EDGE && (LFBM5D_EXP & 4)) {
+                for (int q = 0; q < NA; q++) { a1[q] = v4f{1.f, 2.f, 3.f, (float)R0}; a2[q] = v4f{2.f, 1.f, 5.f, 4.f}; }
+                b1 = 1.f; b2 = (float)R0;
+                return;
+            }
+#endif
 #pragma unroll
             for (int q = 0; q < NA; q++) {
                 const int vo = EDGE ? (min(b + R0 + qrow[q], H - 1) * W + cb - 1 + qcol[q]) * 4 : vA[q];
@@ -307,17 +322,22 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         /* table stores: lane-constant offset (>= 0) + scalar row offset; the resource starts 64 rows above the
          * table so that the scalar part stays non-negative during the ramp-up */
         const __amdgpu_buffer_rsrc_t rsTb = __builtin_amdgcn_make_buffer_rsrc((void*)(table - 64 * 64), 0, (int)((tstride + 64 * 64) * 4), kRsrcFlags);
-        const int voT = col_ok ? (lane + (last_lane - lane) * 64) * 4 : -1;
-        const int soT = (strip * H + b + 1 - last_lane + 64) * 256;      /* + 256 t: row b+1+t-last_lane of this strip */
-        int rA = (K - lane + 64 * RR) % RR, rB = (64 * RR - lane) % RR;   /* ring rows of (t + K - lane) and (t - lane) */
+        /* lane (g, j) of the store stage: row t0 - 16g - 14 + j/4 (+ 4h) of the strip, columns 16g + 4(j%4) .. +3; a piece
+         * that starts past the last column is dropped (columns past it inside a piece are never read back) */
+        const int ucl = -16 * (lane >> 4) - 14 + ((lane & 15) >> 2);
+        const int ucol = 16 * (lane >> 4) + 4 * (lane & 3);
+        const int uvo = ucol <= last_lane ? ((ucl + 64) * 64 + ucol) * 4 : -1;
+        int uo = ((((1 - lane) & 31) << 6) | lane) * 4;     /* byte offset in usk of (row 1+t-lane, column lane), t = 0 */
+        /* running LDS offsets (floats) of ring rows (t + K - lane) and (t - lane), column lane */
+        int oA = ((K - lane + 64 * RR) % RR) * CW + lane, oB = ((64 * RR - lane) % RR) * CW + lane;
         int wrow = filled % RR;   /* a multiple of T, like RR: the T rows of a chunk never wrap inside the ring */
         auto chunk = [&](auto edge_tag, int t0,
                          v4f* la1, v4f* la2, float& lb1, float& lb2,                   /* receive rows filled+(DEP-1)T .. */
                          const v4f* sa1, const v4f* sa2, float sb1, float sb2) {       /* rows filled .. go to the ring */
             constexpr bool EDGE = decltype(edge_tag)::value;
             load_chunk(edge_tag, filled + (DEP - 1) * T, la1, la2, lb1, lb2);
-            const float* pa = ring + rA * CW + lane;
-            const float* pb = ring + rB * CW + lane;
+            const float* pa = ring + oA;
+            const float* pb = ring + oB;
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
 #pragma unroll
             for (int s = 0; s < T; s++) {
@@ -325,8 +345,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
                 lc[s] = lcol[EDGE ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
             }
-            rA += T; rA = rA >= RR ? rA - RR : rA;
-            rB += T; rB = rB >= RR ? rB - RR : rB;
+            oA += T * CW; oA = oA >= RR * CW ? oA - RR * CW : oA;
+            oB += T * CW; oB = oB >= RR * CW ? oB - RR * CW : oB;
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 if (EDGE) curS = (lane_eff == t0 + s) ? S0 : curS;      /* becomes active: start from its row-0 value */
@@ -349,8 +369,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 const int t = t0 + s;
                 const bool act = EDGE ? (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2) : col_ok;
                 if (stereo) {
-                    const int vo = EDGE ? (act ? voT : -1) : voT;    /* -1: out of range, store dropped */
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsTb, vo, soT + t * 256, 0);
+                    /* lane l holds row 1+t-l: park it in the straightening buffer (row mod 32, column l) */
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(usk) + uo) = Sout[s];
+                    uo = (uo + 256) & 0x1fff;
                 } else {
                     int v1, v2;
                     if (irregular) {   /* irregular list: whole-slot lookups (out-of-range offsets read 0, masked by act) */
@@ -360,9 +381,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                         v1 = (act && r1 >= 0) ? (int)(((unsigned)r1 * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
                         v2 = (act && r2 >= 0) ? (int)(((unsigned)r2 * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
                     } else {
-                        const int vy = (b + 1 + t - lane) * 4;   /* negative for lanes not yet started: reads 0, masked by act */
-                        const int r1 = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, 0, 0);
-                        const int r2 = __builtin_amdgcn_raw_buffer_load_b32(rsR, vy, di * 4, 0);   /* table has 64 slots of -1 padding */
+                        /* rows of lanes that have not started / have finished are clamped into the table (masked by act) */
+                        const short* rp = rs16 + min(max(b + 1 + t0 - lane, 0), H - T);
+                        const int r1 = rp[s], r2 = rp[s + di];
                         v1 = (act && cx >= 0 && r1 >= 0) ? (int)(((unsigned)(r1 * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
                         v2 = (act && cx2 >= 0 && r2 >= 0 && di > 0) ? (int)(((unsigned)(r2 * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
                     }
@@ -374,6 +395,19 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 const int il = 1 + t - last_lane;
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
                 lcol[EDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : il] = hv;
+            }
+            if (stereo) {
+                /* every 16-lane group has just completed 64-byte segments of four more rows (its last lane wrote
+                 * rows up to t0+T-1-(16g+15)+1): each lane stores one 16-byte piece of four of them.  One store
+                 * instruction per four steps, 16 cache lines touched instead of 4 x 64. */
+                typedef int v4i __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int h = 0; h < T / 4; h++) {
+                    const int urow = t0 + 4 * h + ucl;          /* table row, see ucl */
+                    const bool rv = (unsigned)(urow - 1) <= (unsigned)(nrows - 2);
+                    const v4f val = *reinterpret_cast<const v4f*>(usk + ((urow & 31) << 6) + ucol);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, val), rsTb, rv ? uvo : -1, (strip * H + b + t0 + 4 * h) * 256, 0);
+                }
             }
             {   /* squared differences of rows filled .. filled+T-1 into the ring (and its mirror rows) */
                 float* rr = ring + wrow * CW;       /* uniform */
@@ -411,7 +445,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             tS1 = tS1 > tS0 ? tS0 + ((tS1 - tS0) / G) * G : tS0;
             int t0 = 0;
             for (int ph = 0; ph < 2; ph++) {
-                const int te = ph == 0 ? min(tS0, nsteps) : nsteps;
+                const int te = ph == 0 ? min(tS0, nsteps) : nsteps + (stereo ? 16 : 0);   /* + the chunks that flush the store stage */
                 for (; t0 < te; t0 += G) {
 #pragma unroll
                     for (int j = 0; j < DEP; j++)
@@ -562,13 +596,16 @@ hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
     const unsigned rows_self = a.n_self ? a.H - 2 * a.nHW : 0, rows_st = a.n_stereo ? a.H - 2 * a.nDisp - (a.k - 1) : 0;
     const unsigned nrows = rows_self > rows_st ? rows_self : rows_st;
     const unsigned T = a.k >= 12 ? 4 : 8;
-    const size_t lds = (size_t)((64 + a.k + 2 * T + T - 1) * (64 + a.k) + nrows + T + 1) * sizeof(float);
+    const size_t lds = (size_t)((64 + a.k + 2 * T + T - 1) * (64 + a.k) + nrows + T + 1) * sizeof(float)
+                     + (size_t)(a.H + 64 + 8) * sizeof(short)        /* row-slot table of the regular grid (+ alignment) */
+                     + (a.n_stereo ? 32 * 64 * sizeof(float) : 0);    /* straightening buffer of the disparity tables */
     const unsigned n = a.n_self + a.n_stereo;
     if (!n) return hipSuccess;
+    static const size_t extra_lds = getenv("LFBM5D_SCAN_EXTRA_LDS") ? (size_t)atoi(getenv("LFBM5D_SCAN_EXTRA_LDS")) : 0;   /* occupancy experiments */
     switch (a.k) {
-        case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(n), dim3(64), lds, s, a); break;
-        case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(n), dim3(64), lds, s, a); break;
-        case 16: hipLaunchKernelGGL(k_bm_scan<16>, dim3(n), dim3(64), lds, s, a); break;
+        case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(n), dim3(64), lds + extra_lds, s, a); break;
+        case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(n), dim3(64), lds + extra_lds, s, a); break;
+        case 16: hipLaunchKernelGGL(k_bm_scan<16>, dim3(n), dim3(64), lds + extra_lds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
