@@ -4,9 +4,11 @@
 Metric (BASELINE.json): SAI-megapixels/s of the full HT + Wiener denoise, sigma = 25, on the
 17x17x512x512 synthetic light field with the README "Stanford" parameters.
 One "step" = run_bm5d_1st_step + run_bm5d_2nd_step over the whole light field, inputs already
-resident in HBM.  N GPUs = one process per GPU (torchrun), reference-patch rows of every pass
-sharded over the ranks, window num/den summed with an RCCL all-reduce: fixed total work ->
-"scaling": "strong".
+resident in HBM.  N GPUs = one process per GPU (torchrun), every rank holds the light field, the
+step's sequence of angular windows is cut into one contiguous block per rank and the per-rank
+num/den summed with one RCCL all-reduce per step (`--sharding rows`: the exact single-GPU window
+order with row-sharded core passes instead): fixed total work -> "scaling": "strong".  The PSNR of
+the run is part of the JSON line.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -92,12 +94,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="lf17x17x512x512_sigma25", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharding", default="windows", choices=["windows", "rows"],
+                    help="multi-GPU step scheme: blocks of angular windows per rank (default) or row-sharded passes")
     args = ap.parse_args()
 
     import torch
     import lfbm5d_amd as L
     from lfbm5d_amd import core, synth
 
+    if args.sharding == "rows":
+        os.environ["LFBM5D_STEP_SHARDING"] = "rows"
+    else:
+        os.environ.pop("LFBM5D_STEP_SHARDING", None)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -190,7 +198,10 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "light_field": f"{ah}x{aw}x{H}x{W}x3", "sigma": sigma,
                        "params_ht": list(map(str, wl["p1"])), "params_wiener": list(map(str, wl["p2"])),
-                       "asw": 1, "color_space": "opp", "parallelism": f"ref-row shards x{world} + RCCL all-reduce"},
+                       "asw": 1, "color_space": "opp", "parallelism": ("single GPU" if world == 1 else
+                                       f"{world} x blocks of angular windows + 1 RCCL all-reduce of num/den per step"
+                                       if args.sharding == "windows" else
+                                       f"{world} x reference-patch rows of every pass + RCCL all-reduce per pass")},
             "roofline": {"bound": "hbm", "kernel": "k_group+k_aggregate (transform + shrink + aggregate)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

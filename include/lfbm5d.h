@@ -87,10 +87,19 @@ void lfbm5d_get_stats(const lfbm5d_ctx* ctx, lfbm5d_stats* out);
 /* The HIP stream (hipStream_t) the context launches on, for callers that time with events. */
 void* lfbm5d_stream(lfbm5d_ctx* ctx);
 
-/* ---- multi-GPU: one process per GPU; reference patches of a pass are sharded by rows over the
- * ranks and the window's aggregation buffers are summed with an RCCL all-reduce over xGMI.
+/* ---- multi-GPU: one process per GPU, every rank holds the whole light field.
+ * Whole steps (lfbm5d_step*): the sequence of angular windows of the reference's schedule
+ * (bm5d.cpp:165-407; a pure function of the SAI mask, see lfbm5d_plan_windows) is cut into one
+ * contiguous block per rank and the per-rank aggregation buffers (num, den of the whole light field)
+ * are summed with ONE RCCL all-reduce per step over xGMI; every rank ends with the full result.
+ * A rank's block matching sees the running estimate of its own earlier windows only, which moves the
+ * final PSNR by about -0.01 / -0.03 / -0.07 dB on 2 / 4 / 8 ranks (the reference's own parallel mode,
+ * spatial tiles, costs 0.5 dB).  Environment LFBM5D_STEP_SHARDING=rows keeps the single-GPU order
+ * exactly instead: every core pass row-sharded as below (two all-reduces per pass, little speed-up).
+ * Single core passes (lfbm5d_pass_device): the reference patches are sharded by rows over the ranks and
+ * the window's num/den all-reduced.
  * Replaces the reference's only parallelism, the OpenMP tile loop + undivide_LF merge
- * (bm5d.cpp:411-708, utilities_LF.cpp:438-515). ---- */
+ * (bm5d.cpp:411-708, utilities_LF.cpp:438-515), without its tile-border quality loss. ---- */
 #define LFBM5D_UNIQUE_ID_BYTES 128
 int lfbm5d_comm_unique_id(void* id_out /* LFBM5D_UNIQUE_ID_BYTES */);
 int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);
@@ -98,6 +107,14 @@ int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);
 int lfbm5d_set_shard(lfbm5d_ctx* ctx, int rank, int world);
 /* Row range [begin,end) of n_rows reference-patch rows owned by `rank` of `world`. */
 void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, unsigned* end);
+/* The window schedule of a step as the processed SAI (index in `ang_major` order) of each window, in
+ * order: the centre SAI first, then always the last SAI not covered yet (bm5d.cpp:187-213 -- all
+ * candidates tie on the zero-weight count because a window always finishes all of its SAIs).  Host
+ * only, needs no GPU.  Returns the number of windows (-1 on bad arguments); writes min(n, cap) entries. */
+int lfbm5d_plan_windows(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask,
+                        unsigned* out_sai, unsigned cap);
+/* The windows the last lfbm5d_step* call on this context actually ran (same encoding). */
+int lfbm5d_last_windows(const lfbm5d_ctx* ctx, unsigned* out_sai, unsigned cap);
 
 /* ---- outer seam, device-resident: LF buffers already in HBM ----
  * lfbm5d_step1_device == run_bm5d_1st_step (bm5d.h:11-35, nb_threads == 1 semantics):

@@ -84,6 +84,8 @@ def lib():
     L.lfbm5d_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.lfbm5d_shard_rows.argtypes = [C.c_uint, C.c_int, C.c_int, up, up]
     L.lfbm5d_shard_rows.restype = None
+    L.lfbm5d_plan_windows.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, up, C.c_uint]
+    L.lfbm5d_last_windows.argtypes = [vp, up, C.c_uint]
     tail = [C.c_uint] * 7
     L.lfbm5d_step1_device.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
     L.lfbm5d_step2_device.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
@@ -99,6 +101,18 @@ def lib():
     L.lfbm5d_device_count.restype = C.c_int
     _lib = L
     return L
+
+
+def plan_windows(awidth, aheight, an=1, ang_major=None, mask=None):
+    """Window schedule of a step (processed SAI of every window, in order); host only."""
+    ang_major = ROWMAJOR if ang_major is None else ang_major
+    m = np.ones(awidth * aheight, np.uint32) if mask is None else _u32(mask)
+    out = np.zeros(awidth * aheight, np.uint32)
+    n = lib().lfbm5d_plan_windows(awidth, aheight, an, ang_major, m.ctypes.data_as(C.POINTER(C.c_uint)),
+                                  out.ctypes.data_as(C.POINTER(C.c_uint)), out.size)
+    if n < 0:
+        raise LfBm5dError("lfbm5d_plan_windows: bad arguments")
+    return out[:n].copy()
 
 
 def shard_rows(n_rows, rank, world):
@@ -210,6 +224,13 @@ class Context:
             self._h, step, C.byref(P), aw, ah, Wb, Hb, Cc, _dev_ptr(noisy),
             _dev_ptr(basic) if basic is not None else None, _dev_ptr(num), _dev_ptr(den),
             m.ctypes.data_as(C.POINTER(C.c_uint)), pr.ctypes.data_as(C.POINTER(C.c_uint)), cst, pst))
+
+    def last_windows(self):
+        """Processed SAI of every window the last step call ran, in order."""
+        n = self._L.lfbm5d_last_windows(self._h, None, 0)
+        out = np.zeros(max(n, 1), np.uint32)
+        self._L.lfbm5d_last_windows(self._h, out.ctypes.data_as(C.POINTER(C.c_uint)), out.size)
+        return out[:max(n, 0)].copy()
 
     def last_bm(self, N, A, plane):
         """Block-matching tables of the last pass, as numpy arrays."""

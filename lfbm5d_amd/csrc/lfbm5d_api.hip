@@ -55,9 +55,15 @@ struct lfbm5d_ctx {
     std::string err;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
+    /* sharding actually applied inside a core pass: rows of reference patches over pass_world ranks (direct
+     * lfbm5d_pass_device calls use rank/world; whole steps on several GPUs shard by WINDOWS instead and run
+     * every pass unsharded) */
+    int pass_rank = 0, pass_world = 1;
+    bool pass_reduce = false;
+    std::vector<unsigned> last_windows;   /* processed SAI of every window of the last step, in order */
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
-    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small;
+    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
@@ -333,7 +339,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     }
     /* multi-GPU: ranks > 0 accumulate their shard into zeroed buffers; the all-reduce restores
      * base + all contributions on every rank */
-    if (c->world > 1 && c->rank > 0) {
+    if (c->pass_world > 1 && c->pass_rank > 0) {
         HIPCK(c, hipMemsetAsync(d_num, 0, A * C * plane * sizeof(float), s));
         HIPCK(c, hipMemsetAsync(d_den, 0, A * C * plane * sizeof(float), s));
     }
@@ -365,11 +371,11 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     unsigned ref_begin, n_groups;
     if (centre) {
         unsigned rb = 0, re = c->n_ref_rows;
-        lfbm5d_shard_rows(c->n_ref_rows, c->rank, c->world, &rb, &re);
+        lfbm5d_shard_rows(c->n_ref_rows, c->pass_rank, c->pass_world, &rb, &re);
         ref_begin = rb * c->n_ref_cols; n_groups = (re - rb) * c->n_ref_cols;
     } else {
         unsigned rb = 0, re = (unsigned)row_start.size() - 1;
-        lfbm5d_shard_rows((unsigned)row_start.size() - 1, c->rank, c->world, &rb, &re);
+        lfbm5d_shard_rows((unsigned)row_start.size() - 1, c->pass_rank, c->pass_world, &rb, &re);
         ref_begin = row_start[rb]; n_groups = row_start[re] - row_start[rb];
     }
 
@@ -400,7 +406,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     if (n_groups) HIPCK(c, launch_aggregate(s, aa));
     HIPCK(c, hipEventRecord(pe.e[3], s));
 
-    if (c->comm) { /* sum the window's aggregation buffers over the ranks (xGMI) */
+    if (c->comm && c->pass_reduce) { /* sum the window's aggregation buffers over the ranks (xGMI) */
         const size_t cnt = (size_t)A * C * plane;
         if (ncclAllReduce(d_num, d_num, cnt, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(num) failed");
         if (ncclAllReduce(d_den, d_den, cnt, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(den) failed");
@@ -441,6 +447,39 @@ int fold_counters(lfbm5d_ctx* c, const lfbm5d_params* P, unsigned A, unsigned C,
 }
 
 /* bm5d.cpp:165-407 (step 1) / :861-1106 (step 2) on device-resident buffers */
+/* The sequence of windows run_step processes, as the processed SAI of each (see the comment in run_step):
+ * first the centre SAI if it is not empty, then always the last unprocessed SAI; every SAI of a
+ * window is processed when the window is done (bm5d.cpp:165-402). */
+void plan_windows(const unsigned* h_mask, unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major,
+                  std::vector<unsigned>& plan) {
+    const unsigned asize = awidth * aheight, asw = 2 * an + 1;
+    const unsigned cs = aheight / 2, ct = awidth / 2;
+    const unsigned cst = ang_major == LFBM5D_ROWMAJOR ? cs * awidth + ct : cs + ct * aheight;
+    std::vector<unsigned> proc(asize);
+    for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
+    unsigned remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
+    const unsigned total = remaining;
+    plan.clear();
+    while (remaining) {
+        unsigned pst = 0;
+        if (remaining == total && h_mask[cst]) pst = cst;
+        else for (unsigned st = 0; st < asize; st++) if (!proc[st]) pst = st;
+        const unsigned ps = ang_major == LFBM5D_ROWMAJOR ? pst / awidth : pst % aheight;
+        const unsigned pt = ang_major == LFBM5D_ROWMAJOR ? pst % awidth : pst / aheight;
+        int cs_w, mins, maxs, ct_w, mint, maxt;
+        search_window((int)ps, aheight, an, cs_w, mins, maxs);
+        search_window((int)pt, awidth, an, ct_w, mint, maxt);
+        for (unsigned si = 0; si < asw; si++)
+            for (unsigned ti = 0; ti < asw; ti++) {
+                const unsigned S = si + mins, T = ti + mint;
+                const unsigned st = ang_major == LFBM5D_ROWMAJOR ? S * awidth + T : S + T * aheight;
+                if (h_mask[st]) proc[st] = 1;
+            }
+        plan.push_back(pst);
+        remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
+    }
+}
+
 int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
              float* d_basic, float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight,
              unsigned an, unsigned W, unsigned H, unsigned C) {
@@ -488,29 +527,10 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
 
     std::vector<unsigned> proc(asize);
     for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
-    unsigned remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
-    const unsigned total = remaining;
-    unsigned ps = 0, pt = 0, pst = 0;
-    while (remaining) {
-        if (remaining == total && h_mask[cst]) { ps = cs; pt = ct; }
-        else { /* bm5d.cpp:187-213: SAI with most exact-zero weights, last index wins ties.  Counts
-                * only change for the SAIs of the window just processed: recount those. */
-            if (!dirty.empty()) {
-                HIPCK(c, hipMemsetAsync(d_small, 0, asize * sizeof(unsigned), s));
-                for (unsigned st : dirty) HIPCK(c, launch_count_zeros(s, g_den + st * img, img, 1, d_small + st));
-                HIPCK(c, hipMemcpyAsync(h_tmp.data(), d_small, asize * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-                HIPCK(c, hipStreamSynchronize(s));
-                for (unsigned st : dirty) h_cnt[st] = h_tmp[st];
-                dirty.clear();
-            }
-            long best_cnt = -1;
-            for (unsigned st = 0; st < asize; st++) {
-                if (proc[st]) continue;
-                if ((long)h_cnt[st] >= best_cnt) { pst = st; best_cnt = (long)h_cnt[st]; }
-            }
-            if (ang_major == LFBM5D_ROWMAJOR) { ps = pst / awidth; pt = pst - ps * awidth; }
-            else { pt = pst / aheight; ps = pst - pt * aheight; }
-        }
+    c->last_windows.clear();
+
+    /* one angular window around SAI (ps, pt): bm5d.cpp:215-402 */
+    auto do_window = [&](unsigned ps, unsigned pt) -> int {
         int cs_w, mins, maxs, ct_w, mint, maxt;
         search_window((int)ps, aheight, an, cs_w, mins, maxs);
         search_window((int)pt, awidth, an, ct_w, mint, maxt);
@@ -582,8 +602,106 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             HIPCK(c, launch_unsymetrize(s, g_den + st * img, w_den + i * imgb, W, H, C, nHW));
             dirty.push_back(st);
         }
-        remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
+        c->last_windows.push_back(ang_major == LFBM5D_ROWMAJOR ? ps * awidth + pt : ps + pt * aheight);
         c->stats.windows += 1;
+        return 0;
+    };
+
+    /* Window schedule.  The reference picks the unprocessed SAI with the most exact-zero weights, last
+     * index winning ties (bm5d.cpp:187-213).  A window always ends with all of its SAIs processed
+     * (bm5d.cpp:283-402), so an unprocessed SAI has never been aggregated into: all candidates tie and
+     * the sequence of windows is a pure function of the mask -- plan_windows().  One GPU follows the
+     * reference's data-driven selection literally; several GPUs take the planned sequence, split it into
+     * one contiguous block of windows per rank, and add the per-rank num/den with one all-reduce per step.
+     * Windows interact through those sums and through the running estimate block matching uses for SAIs
+     * that earlier windows already processed; a rank only sees its own earlier windows there, which costs
+     * about 0.01 / 0.03 / 0.07 dB of final PSNR on 2 / 4 / 8 ranks (the reference's own parallel
+     * mode, spatial tiles, costs 0.5 dB).  LFBM5D_STEP_SHARDING=rows selects the exact alternative. */
+    const char* emu_s = std::getenv("LFBM5D_EMULATE_WORLD");
+    const int emu = emu_s ? std::atoi(emu_s) : 0;                    /* test hook: play all ranks on this GPU */
+    const char* shard_s = std::getenv("LFBM5D_STEP_SHARDING");
+    /* "rows": keep the reference's window-after-window order on several GPUs too and shard every core pass by
+     * reference-patch rows (bit-for-bit the single-GPU schedule, two all-reduces per pass, little speed-up) */
+    const bool by_rows = c->world > 1 && shard_s && std::strcmp(shard_s, "rows") == 0;
+    const bool planned = (c->world > 1 && !by_rows) || emu > 1 || std::getenv("LFBM5D_PLAN_WINDOWS") != nullptr;
+    struct PassShard {   /* restores the unsharded default whatever way the function returns */
+        lfbm5d_ctx* c;
+        PassShard(lfbm5d_ctx* cc, bool on) : c(cc) { if (on) { c->pass_rank = c->rank; c->pass_world = c->world; c->pass_reduce = c->comm != nullptr; } }
+        ~PassShard() { c->pass_rank = 0; c->pass_world = 1; c->pass_reduce = false; }
+    } pass_shard(c, by_rows);
+    if (by_rows && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+    if (!planned) {
+        unsigned remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
+        const unsigned total = remaining;
+        unsigned ps = 0, pt = 0, pst = 0;
+        while (remaining) {
+            if (remaining == total && h_mask[cst]) { ps = cs; pt = ct; }
+            else { /* counts only change for the SAIs of the window just processed: recount those */
+                if (!dirty.empty()) {
+                    HIPCK(c, hipMemsetAsync(d_small, 0, asize * sizeof(unsigned), s));
+                    for (unsigned st : dirty) HIPCK(c, launch_count_zeros(s, g_den + st * img, img, 1, d_small + st));
+                    HIPCK(c, hipMemcpyAsync(h_tmp.data(), d_small, asize * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                    HIPCK(c, hipStreamSynchronize(s));
+                    for (unsigned st : dirty) h_cnt[st] = h_tmp[st];
+                    dirty.clear();
+                }
+                long best_cnt = -1;
+                for (unsigned st = 0; st < asize; st++) {
+                    if (proc[st]) continue;
+                    if ((long)h_cnt[st] >= best_cnt) { pst = st; best_cnt = (long)h_cnt[st]; }
+                }
+                if (ang_major == LFBM5D_ROWMAJOR) { ps = pst / awidth; pt = pst - ps * awidth; }
+                else { pt = pst / aheight; ps = pst - pt * aheight; }
+            }
+            if (do_window(ps, pt)) return 1;
+            remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
+        }
+    } else {
+        std::vector<unsigned> plan;
+        plan_windows(h_mask, awidth, aheight, an, ang_major, plan);
+        const int nranks = emu > 1 ? emu : c->world;
+        float* t_num = nullptr; float* t_den = nullptr;
+        if (emu > 1) {
+            HIPCK(c, c->t_num.reserve(asize * img * sizeof(float)));
+            HIPCK(c, c->t_den.reserve(asize * img * sizeof(float)));
+            t_num = c->t_num.as<float>(); t_den = c->t_den.as<float>();
+            HIPCK(c, hipMemsetAsync(t_num, 0, asize * img * sizeof(float), s));
+            HIPCK(c, hipMemsetAsync(t_den, 0, asize * img * sizeof(float), s));
+        }
+        for (int r = (emu > 1 ? 0 : c->rank); r < (emu > 1 ? emu : c->rank + 1); r++) {
+            /* contiguous blocks of the sequence: consecutive windows overlap, so most of a window's already
+             * processed SAIs (whose running estimate the matching uses) were processed by the same rank */
+            const size_t w_begin = plan.size() * (size_t)r / (size_t)nranks, w_end = plan.size() * (size_t)(r + 1) / (size_t)nranks;
+            for (size_t wi = w_begin; wi < w_end; wi++) {
+                const unsigned pst = plan[wi];
+                const unsigned ps = ang_major == LFBM5D_ROWMAJOR ? pst / awidth : pst % aheight;
+                const unsigned pt = ang_major == LFBM5D_ROWMAJOR ? pst % awidth : pst / aheight;
+                if (do_window(ps, pt)) return 1;
+            }
+            if (emu > 1) { /* what the all-reduce does, rank by rank */
+                HIPCK(c, launch_add(s, t_num, g_num, asize * img));
+                HIPCK(c, launch_add(s, t_den, g_den, asize * img));
+                HIPCK(c, hipMemsetAsync(g_num, 0, asize * img * sizeof(float), s));
+                HIPCK(c, hipMemsetAsync(g_den, 0, asize * img * sizeof(float), s));
+            }
+        }
+        if (emu > 1) {
+            HIPCK(c, hipMemcpyAsync(g_num, t_num, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+            HIPCK(c, hipMemcpyAsync(g_den, t_den, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+        } else if (c->comm) {
+            hipEvent_t e0, e1;
+            HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+            HIPCK(c, hipEventRecord(e0, s));
+            if (ncclAllReduce(g_num, g_num, asize * img, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(num) failed");
+            if (ncclAllReduce(g_den, g_den, asize * img, ncclFloat, ncclSum, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(den) failed");
+            HIPCK(c, hipEventRecord(e1, s));
+            HIPCK(c, hipStreamSynchronize(s));
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->stats.ms_comm += ms;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        } else if (c->world > 1) {
+            return fail(c, "whole steps on several ranks need lfbm5d_comm_init (lfbm5d_set_shard only shards core passes)");
+        }
     }
     /* final estimate (bm5d.cpp:405) and inverse colour transforms (bm5d.cpp:711-714 / :1414-1418) */
     const float* sub = step == 1 ? d_noisy : d_basic;
@@ -642,7 +760,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -683,6 +801,22 @@ int lfbm5d_comm_init(lfbm5d_ctx* c, const void* idb, int rank, int world) {
     return 0;
 }
 
+int lfbm5d_plan_windows(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask,
+                        unsigned* out_sai, unsigned cap) {
+    if (!mask || !awidth || !aheight || 2 * an + 1 > awidth || 2 * an + 1 > aheight) return -1;
+    if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return -1;
+    std::vector<unsigned> plan;
+    plan_windows(mask, awidth, aheight, an, ang_major, plan);
+    for (size_t i = 0; i < plan.size() && i < cap && out_sai; i++) out_sai[i] = plan[i];
+    return (int)plan.size();
+}
+
+int lfbm5d_last_windows(const lfbm5d_ctx* c, unsigned* out_sai, unsigned cap) {
+    if (!c) return -1;
+    for (size_t i = 0; i < c->last_windows.size() && i < cap && out_sai; i++) out_sai[i] = c->last_windows[i];
+    return (int)c->last_windows.size();
+}
+
 int lfbm5d_set_shard(lfbm5d_ctx* c, int rank, int world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return 1;
     c->rank = rank; c->world = world;
@@ -695,7 +829,10 @@ int lfbm5d_pass_device(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned
                        unsigned cst, unsigned pst) {
     if (!c || !P) return 1;
     (void)hipSetDevice(c->device);
-    if (pass_impl(c, step, P, aw, ah, Wb, Hb, C, d_noisy, d_basic, d_num, d_den, h_mask, h_procSAI, cst, pst)) return 1;
+    c->pass_rank = c->rank; c->pass_world = c->world; c->pass_reduce = c->comm != nullptr;
+    const int rc = pass_impl(c, step, P, aw, ah, Wb, Hb, C, d_noisy, d_basic, d_num, d_den, h_mask, h_procSAI, cst, pst);
+    c->pass_rank = 0; c->pass_world = 1; c->pass_reduce = false;
+    if (rc) return 1;
     HIPCK(c, hipStreamSynchronize(c->stream));
     drain_events(c);
     return fold_counters(c, P, aw * ah, C, step);

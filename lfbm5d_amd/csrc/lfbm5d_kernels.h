@@ -122,6 +122,7 @@ hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, co
                            float* est, size_t n);
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n);
 hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n);
+hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   /* dst += src */
 /* counts[i] += number of exact zeros in seg i; segments are `seg` floats long, n_seg of them */
 hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsigned n_seg,
                               unsigned* counts);

@@ -83,6 +83,10 @@ __global__ void k_fill_f32(float* p, float v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+__global__ void k_add(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
 __global__ void k_fill_i32(int* p, int v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1665,6 +1669,10 @@ hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, co
 }
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n) {
     hipLaunchKernelGGL(k_fill_f32, grid1d(n), dim3(256), 0, s, p, v, n);
+    return hipGetLastError();
+}
+hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n) {
+    if (n) hipLaunchKernelGGL(k_add, grid1d(n), dim3(256), 0, s, dst, src, n);
     return hipGetLastError();
 }
 hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n) {

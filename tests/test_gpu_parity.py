@@ -288,6 +288,48 @@ def test_window_schedule_5x5_and_colmajor(ctx):
         assert abs(pg - po) < 0.06 and pg > O.psnr_lf(noisy, clean) + 8
 
 
+def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
+    """Multi-GPU step scheme with all ranks played in turn on this GPU (LFBM5D_EMULATE_WORLD): the planned
+    window sequence is the data-driven one, one planned rank is bit-identical to the default path, and
+    2 / 4 ranks stay within the documented PSNR distance of the single-GPU result."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core, synth
+    ah, aw, Hh_, Ww = 5, 7, 64, 64
+    lf = synth.make_lf(ah, aw, Hh_, Ww)
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    P1 = core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "sadct", "haar")
+    P2 = core.make_params(25.0, 2.7, 8, 6, 2, 8, 4, "dct", "sadct", "haar")
+
+    def run():
+        d_noisy = torch.from_numpy(noisy).cuda()
+        d_basic = torch.zeros_like(d_noisy)
+        d_den = torch.zeros_like(d_noisy)
+        ctx.step1(P1, d_noisy, mask, d_basic, L.ROWMAJOR, aw, ah, 1, Ww, Hh_, 3)
+        w = ctx.last_windows()
+        ctx.step2(P2, d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, 1, Ww, Hh_, 3)
+        return d_basic.cpu().numpy(), d_den.cpu().numpy(), w
+
+    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_PLAN_WINDOWS", "LFBM5D_STEP_SHARDING"):
+        monkeypatch.delenv(k, raising=False)
+    b0, d0, w0 = run()
+    plan = core.plan_windows(aw, ah, 1, L.ROWMAJOR)
+    assert np.array_equal(plan, w0) and w0[0] == (ah // 2) * aw + aw // 2
+    monkeypatch.setenv("LFBM5D_PLAN_WINDOWS", "1")
+    b1, d1, w1 = run()
+    assert np.array_equal(w1, w0) and np.array_equal(b1, b0) and np.array_equal(d1, d0)
+    monkeypatch.delenv("LFBM5D_PLAN_WINDOWS")
+    p0 = O.psnr_lf(d0, clean)
+    for n in (2, 4):
+        monkeypatch.setenv("LFBM5D_EMULATE_WORLD", str(n))
+        b, d, w = run()
+        assert sorted(w.tolist()) == sorted(w0.tolist())          # every window exactly once
+        # tiny SAIs: a few tenths of a dB either way (block matching of a rank's first windows runs on noisy
+        # instead of already denoised neighbours); 0.01-0.07 dB on the 17x17x512x512 workload, see DESIGN.md
+        assert abs(O.psnr_lf(d, clean) - p0) < 0.5 and O.psnr_lf(d, clean) > O.psnr_lf(noisy, clean) + 8
+    monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
+
+
 def test_unsupported_configurations_fail_loudly(ctx):
     import lfbm5d_amd as L
     from lfbm5d_amd import core
