@@ -212,7 +212,7 @@ def main():
             "passes_per_step": s.passes / args.steps, "windows_per_step": s.windows / args.steps,
             "psnr": {"noisy": psnr_lf(noisy0), "basic": psnr_lf(basic), "denoised": psnr_lf(den)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             try:
                 c = (ah // 2) * aw + aw // 2
                 idx = [c + ds * aw + dt for ds in (-1, 0, 1) for dt in (-1, 0, 1)]
