@@ -332,11 +332,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
 
     /* current estimate for matching, channel 0 (core:167-170) */
     const float* sub = step == 1 ? d_noisy : d_basic;
-    for (unsigned st = 0; st < A; st++) {
-        if (!((mask_bits >> st) & 1)) continue;
-        const size_t o = (size_t)st * C * plane;
-        HIPCK(c, launch_estimate(s, d_num + o, d_den + o, sub + o, est + st * plane, plane));
-    }
+    HIPCK(c, launch_estimate_multi(s, d_num, d_den, sub, est, plane, C, A, mask_bits));
     /* multi-GPU: ranks > 0 accumulate their shard into zeroed buffers; the all-reduce restores
      * base + all contributions on every rank */
     if (c->pass_world > 1 && c->pass_rank > 0) {
@@ -542,15 +538,18 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
                 if (ang_major == LFBM5D_ROWMAJOR) st_idx[si * asw + ti] = S * awidth + T;
                 else st_idx[si + ti * asw] = S + T * aheight;
             }
+        SaiList sl;
+        sl.n = Aw;
+        unsigned win_bits = 0;
         for (unsigned i = 0; i < Aw; i++) {
-            const unsigned st = st_idx[i];
-            mask_w[i] = h_mask[st];
-            if (!h_mask[st]) continue;
-            HIPCK(c, launch_symetrize(s, d_noisy + st * img, w_noisy + i * imgb, W, H, C, nHW));
-            if (step == 2) HIPCK(c, launch_symetrize(s, d_basic + st * img, w_basic + i * imgb, W, H, C, nHW));
-            HIPCK(c, launch_symetrize(s, g_num + st * img, w_num + i * imgb, W, H, C, nHW));
-            HIPCK(c, launch_symetrize(s, g_den + st * img, w_den + i * imgb, W, H, C, nHW));
+            mask_w[i] = h_mask[st_idx[i]];
+            sl.st[i] = mask_w[i] ? st_idx[i] : 0xffffffffu;
+            if (mask_w[i]) win_bits |= 1u << i;
         }
+        HIPCK(c, launch_symetrize_multi(s, d_noisy, img, w_noisy, imgb, sl, W, H, C, nHW));
+        if (step == 2) HIPCK(c, launch_symetrize_multi(s, d_basic, img, w_basic, imgb, sl, W, H, C, nHW));
+        HIPCK(c, launch_symetrize_multi(s, g_num, img, w_num, imgb, sl, W, H, C, nHW));
+        HIPCK(c, launch_symetrize_multi(s, g_den, img, w_den, imgb, sl, W, H, C, nHW));
         for (unsigned i = 0; i < Aw; i++) proc_w[i] = !mask_w[i];
         unsigned rem_w = (unsigned)std::count(proc_w.begin(), proc_w.end(), 0u);
         const unsigned tot_w = rem_w;
@@ -581,12 +580,8 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             proc[st] += 1;
             /* LF_denoised_percent (utilities_LF.cpp:967-995): counts (i,j,c) triples, divides without C */
             HIPCK(c, hipMemsetAsync(d_small, 0, sizeof(unsigned), s));
-            unsigned n_mask = 0;
-            for (unsigned i = 0; i < Aw; i++) {
-                if (!mask_w[i]) continue;
-                n_mask++;
-                HIPCK(c, launch_count_denoised(s, w_den + i * imgb, W, H, C, nHW, P->k, d_small));
-            }
+            const unsigned n_mask = (unsigned)__builtin_popcount(win_bits);
+            HIPCK(c, launch_count_denoised(s, w_den, imgb, Aw, win_bits, W, H, C, nHW, P->k, d_small));
             HIPCK(c, hipMemcpyAsync(h_one.data(), d_small, sizeof(unsigned), hipMemcpyDeviceToHost, s));
             HIPCK(c, hipStreamSynchronize(s));
             const float pct = (float)h_one[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
@@ -595,13 +590,9 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
                     if (proc_w[i] == 0) { proc_w[i] += 1; proc[st_idx[i]] += 1; }
             rem_w = (unsigned)std::count(proc_w.begin(), proc_w.end(), 0u);
         }
-        for (unsigned i = 0; i < Aw; i++) {
-            const unsigned st = st_idx[i];
-            if (!h_mask[st]) continue;
-            HIPCK(c, launch_unsymetrize(s, g_num + st * img, w_num + i * imgb, W, H, C, nHW));
-            HIPCK(c, launch_unsymetrize(s, g_den + st * img, w_den + i * imgb, W, H, C, nHW));
-            dirty.push_back(st);
-        }
+        HIPCK(c, launch_unsymetrize_multi(s, g_num, img, w_num, imgb, sl, W, H, C, nHW));
+        HIPCK(c, launch_unsymetrize_multi(s, g_den, img, w_den, imgb, sl, W, H, C, nHW));
+        for (unsigned i = 0; i < Aw; i++) if (mask_w[i]) dirty.push_back(st_idx[i]);
         c->last_windows.push_back(ang_major == LFBM5D_ROWMAJOR ? ps * awidth + pt : ps + pt * aheight);
         c->stats.windows += 1;
         return 0;
@@ -610,8 +601,8 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     /* Window schedule.  The reference picks the unprocessed SAI with the most exact-zero weights, last
      * index winning ties (bm5d.cpp:187-213).  A window always ends with all of its SAIs processed
      * (bm5d.cpp:283-402), so an unprocessed SAI has never been aggregated into: all candidates tie and
-     * the sequence of windows is a pure function of the mask -- plan_windows().  One GPU follows the
-     * reference's data-driven selection literally; several GPUs take the planned sequence, split it into
+     * the sequence of windows is a pure function of the mask -- plan_windows() (tests check it against the
+     * data-driven selection, which stays available).  Several GPUs split the planned sequence into
      * one contiguous block of windows per rank, and add the per-rank num/den with one all-reduce per step.
      * Windows interact through those sums and through the running estimate block matching uses for SAIs
      * that earlier windows already processed; a rank only sees its own earlier windows there, which costs
@@ -623,7 +614,9 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     /* "rows": keep the reference's window-after-window order on several GPUs too and shard every core pass by
      * reference-patch rows (bit-for-bit the single-GPU schedule, two all-reduces per pass, little speed-up) */
     const bool by_rows = c->world > 1 && shard_s && std::strcmp(shard_s, "rows") == 0;
-    const bool planned = (c->world > 1 && !by_rows) || emu > 1 || std::getenv("LFBM5D_PLAN_WINDOWS") != nullptr;
+    /* LFBM5D_DATA_DRIVEN_SCHEDULE: select every window from the zero-weight counts like the reference does (one
+     * device round trip per window); the default takes the same sequence from plan_windows() */
+    const bool planned = (c->world > 1 && !by_rows) || emu > 1 || std::getenv("LFBM5D_DATA_DRIVEN_SCHEDULE") == nullptr;
     struct PassShard {   /* restores the unsharded default whatever way the function returns */
         lfbm5d_ctx* c;
         PassShard(lfbm5d_ctx* cc, bool on) : c(cc) { if (on) { c->pass_rank = c->rank; c->pass_world = c->world; c->pass_reduce = c->comm != nullptr; } }

@@ -120,6 +120,14 @@ hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsig
 /* est = den ? num/den : sub on `n` elements */
 hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub,
                            float* est, size_t n);
+/* all SAIs of an angular window in one launch: slot i of the window <-> SAI L.st[i] of the light field */
+struct SaiList { unsigned st[16]; unsigned n; };
+hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,
+                                  const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
+hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride, const float* src, size_t src_stride,
+                                    const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
+hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
+                                 size_t plane, unsigned C, unsigned A, unsigned mask_bits);
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n);
 hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n);
 hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   /* dst += src */
@@ -127,8 +135,8 @@ hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   
 hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsigned n_seg,
                               unsigned* counts);
 /* LF_denoised_percent numerator on a padded window image (utilities_LF.cpp:985-992) */
-hipError_t launch_count_denoised(hipStream_t s, const float* den, unsigned W, unsigned H, unsigned C,
-                                 unsigned N, unsigned k, unsigned* count);
+hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned mask_bits,
+                                 unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count);
 hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, int* refmap);
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a);
 hipError_t launch_self_select(hipStream_t s, const float* scores, const unsigned* refs, unsigned n_refs,

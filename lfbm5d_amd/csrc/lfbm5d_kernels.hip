@@ -70,6 +70,32 @@ __global__ void k_unsymetrize(float* __restrict__ dst, const float* __restrict__
     dst[i] = src[(size_t)c * w * h + (size_t)(r / W + N) * w + r % W + N];
 }
 
+/* the same for all SAIs of an angular window in one launch: blockIdx.y = window slot, L.st[slot] = SAI
+ * index in the light-field buffer (0xffffffff: empty slot) */
+__global__ void k_symetrize_multi(const float* __restrict__ src, size_t src_stride, float* __restrict__ dst, size_t dst_stride,
+                                  SaiList L, int W, int H, int C, int N) {
+    const unsigned st = L.st[blockIdx.y];
+    if (st == 0xffffffffu) return;
+    const int w = W + 2 * N, h = H + 2 * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)w * h * C) return;
+    const int c = (int)(i / ((size_t)w * h));
+    const int r = (int)(i % ((size_t)w * h));
+    const int y = mirror(r / w - N, H), x = mirror(r % w - N, W);
+    dst[blockIdx.y * dst_stride + i] = src[st * src_stride + (size_t)c * W * H + (size_t)y * W + x];
+}
+__global__ void k_unsymetrize_multi(float* __restrict__ dst, size_t dst_stride, const float* __restrict__ src, size_t src_stride,
+                                    SaiList L, int W, int H, int C, int N) {
+    const unsigned st = L.st[blockIdx.y];
+    if (st == 0xffffffffu) return;
+    const int w = W + 2 * N, h = H + 2 * N;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)W * H * C) return;
+    const int c = (int)(i / ((size_t)W * H));
+    const int r = (int)(i % ((size_t)W * H));
+    dst[st * dst_stride + i] = src[blockIdx.y * src_stride + (size_t)c * w * h + (size_t)(r / W + N) * w + r % W + N];
+}
+
 /* compute_LF_estimate utilities_LF.cpp:944-950 (IEEE division) */
 __global__ void k_estimate(const float* __restrict__ num, const float* __restrict__ den,
                            const float* __restrict__ sub, float* __restrict__ est, size_t n) {
@@ -77,6 +103,18 @@ __global__ void k_estimate(const float* __restrict__ num, const float* __restric
     if (i >= n) return;
     const float d = den[i];
     est[i] = d ? __fdiv_rn(num[i], d) : sub[i];
+}
+
+/* matching estimate (channel 0) of every non-empty SAI of a window: blockIdx.y = SAI */
+__global__ void k_estimate_multi(const float* __restrict__ num, const float* __restrict__ den, const float* __restrict__ sub,
+                                 float* __restrict__ est, size_t plane, unsigned C, unsigned mask_bits) {
+    const unsigned st = blockIdx.y;
+    if (!((mask_bits >> st) & 1)) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= plane) return;
+    const size_t o = (size_t)st * C * plane + i;
+    const float d = den[o];
+    est[st * plane + i] = d ? __fdiv_rn(num[o], d) : sub[o];
 }
 
 __global__ void k_fill_f32(float* p, float v, size_t n) {
@@ -111,9 +149,11 @@ __global__ void k_count_zeros(const float* __restrict__ den, size_t seg, unsigne
     if (threadIdx.x == 0 && t) atomicAdd(&counts[blockIdx.y], t);
 }
 
-__global__ void k_count_denoised(const float* __restrict__ den, int W, int H, int C, int N, int k,
+__global__ void k_count_denoised(const float* __restrict__ den, size_t sai_stride, unsigned mask_bits, int W, int H, int C, int N, int k,
                                  unsigned* __restrict__ count) {
     __shared__ unsigned red[4];
+    if (!((mask_bits >> blockIdx.y) & 1)) return;      /* blockIdx.y = window slot */
+    den += blockIdx.y * sai_stride;
     const int w = W + 2 * N, h = H + 2 * N;
     const int sw = W - k + 1, sh = H - k + 1;
     const size_t total = (size_t)sw * sh * C;
@@ -1663,6 +1703,23 @@ hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsig
     hipLaunchKernelGGL(k_unsymetrize, grid1d((size_t)W * H * C), dim3(256), 0, s, dst, src, (int)W, (int)H, (int)C, (int)N);
     return hipGetLastError();
 }
+hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,
+                                  const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N) {
+    hipLaunchKernelGGL(k_symetrize_multi, dim3(grid1d((size_t)(W + 2 * N) * (H + 2 * N) * C).x, L.n), dim3(256), 0, s,
+                       src, src_stride, dst, dst_stride, L, (int)W, (int)H, (int)C, (int)N);
+    return hipGetLastError();
+}
+hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride, const float* src, size_t src_stride,
+                                    const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N) {
+    hipLaunchKernelGGL(k_unsymetrize_multi, dim3(grid1d((size_t)W * H * C).x, L.n), dim3(256), 0, s,
+                       dst, dst_stride, src, src_stride, L, (int)W, (int)H, (int)C, (int)N);
+    return hipGetLastError();
+}
+hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
+                                 size_t plane, unsigned C, unsigned A, unsigned mask_bits) {
+    hipLaunchKernelGGL(k_estimate_multi, dim3(grid1d(plane).x, A), dim3(256), 0, s, num, den, sub, est, plane, C, mask_bits);
+    return hipGetLastError();
+}
 hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t n) {
     hipLaunchKernelGGL(k_estimate, grid1d(n), dim3(256), 0, s, num, den, sub, est, n);
     return hipGetLastError();
@@ -1685,8 +1742,9 @@ hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsig
     hipLaunchKernelGGL(k_count_zeros, dim3(gx, n_seg), dim3(256), 0, s, den, seg, counts);
     return hipGetLastError();
 }
-hipError_t launch_count_denoised(hipStream_t s, const float* den, unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count) {
-    hipLaunchKernelGGL(k_count_denoised, dim3(128), dim3(256), 0, s, den, (int)W, (int)H, (int)C, (int)N, (int)k, count);
+hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned mask_bits,
+                                 unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count) {
+    hipLaunchKernelGGL(k_count_denoised, dim3(128, n_slots), dim3(256), 0, s, den, sai_stride, mask_bits, (int)W, (int)H, (int)C, (int)N, (int)k, count);
     return hipGetLastError();
 }
 

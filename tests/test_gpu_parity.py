@@ -290,7 +290,7 @@ def test_window_schedule_5x5_and_colmajor(ctx):
 
 def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
     """Multi-GPU step scheme with all ranks played in turn on this GPU (LFBM5D_EMULATE_WORLD): the planned
-    window sequence is the data-driven one, one planned rank is bit-identical to the default path, and
+    window sequence is the data-driven one (bit-identical results), and
     2 / 4 ranks stay within the documented PSNR distance of the single-GPU result."""
     import lfbm5d_amd as L
     from lfbm5d_amd import core, synth
@@ -310,15 +310,15 @@ def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
         ctx.step2(P2, d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, 1, Ww, Hh_, 3)
         return d_basic.cpu().numpy(), d_den.cpu().numpy(), w
 
-    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_PLAN_WINDOWS", "LFBM5D_STEP_SHARDING"):
+    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_STEP_SHARDING"):
         monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LFBM5D_DATA_DRIVEN_SCHEDULE", "1")     # the reference's selection from zero-weight counts
     b0, d0, w0 = run()
+    monkeypatch.delenv("LFBM5D_DATA_DRIVEN_SCHEDULE")
     plan = core.plan_windows(aw, ah, 1, L.ROWMAJOR)
     assert np.array_equal(plan, w0) and w0[0] == (ah // 2) * aw + aw // 2
-    monkeypatch.setenv("LFBM5D_PLAN_WINDOWS", "1")
-    b1, d1, w1 = run()
+    b1, d1, w1 = run()                                            # default: the planned sequence
     assert np.array_equal(w1, w0) and np.array_equal(b1, b0) and np.array_equal(d1, d0)
-    monkeypatch.delenv("LFBM5D_PLAN_WINDOWS")
     p0 = O.psnr_lf(d0, clean)
     for n in (2, 4):
         monkeypatch.setenv("LFBM5D_EMULATE_WORLD", str(n))

@@ -35,16 +35,16 @@ def main():
     noisy0 = clean + sigma * torch.randn(clean.shape, generator=g, device="cuda")
     psnr = lambda x: float((20 * torch.log10(255.0 / torch.sqrt(((x - clean) ** 2).mean(dim=1)))).mean())
     ctx = L.Context(0)
-    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_PLAN_WINDOWS"):
+    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_DATA_DRIVEN_SCHEDULE"):
         os.environ.pop(k, None)
+    os.environ["LFBM5D_DATA_DRIVEN_SCHEDULE"] = "1"
     b0, d0, w0 = run(ctx, noisy0, ah, aw, H, W, sigma)
-    print(f"sequential: windows {len(w0)} psnr basic {psnr(b0):.4f} denoised {psnr(d0):.4f}")
+    os.environ.pop("LFBM5D_DATA_DRIVEN_SCHEDULE")
+    print(f"sequential, data-driven schedule: windows {len(w0)} psnr basic {psnr(b0):.4f} denoised {psnr(d0):.4f}")
     plan = core.plan_windows(aw, ah, 1, L.ROWMAJOR)
     print("planned sequence == data-driven sequence:", bool(np.array_equal(plan, w0)))
-    os.environ["LFBM5D_PLAN_WINDOWS"] = "1"
     b1, d1, w1 = run(ctx, noisy0, ah, aw, H, W, sigma)
-    print("planned, one rank: bit-identical", bool(torch.equal(b0, b1) and torch.equal(d0, d1)))
-    os.environ.pop("LFBM5D_PLAN_WINDOWS")
+    print("planned (default), one rank: bit-identical", bool(torch.equal(b0, b1) and torch.equal(d0, d1)))
     for n in (2, 4, 8):
         os.environ["LFBM5D_EMULATE_WORLD"] = str(n)
         b, d, w = run(ctx, noisy0, ah, aw, H, W, sigma)
