@@ -319,8 +319,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->gshape.reserve((size_t)R * kShapeInfoBytes));
     HIPCK(c, c->tb.reserve(sizeof(GroupTables)));
     if (!c->counters.p) {
-        HIPCK(c, c->counters.reserve(4 * sizeof(unsigned long long)));
-        HIPCK(c, hipMemsetAsync(c->counters.p, 0, 4 * sizeof(unsigned long long), s));
+        HIPCK(c, c->counters.reserve(16 * sizeof(unsigned long long)));
+        HIPCK(c, hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), s));
     }
     GroupTables tb;
     build_tables(tb, k, aw, ah);
@@ -437,6 +437,16 @@ int fold_counters(lfbm5d_ctx* c, const lfbm5d_params* P, unsigned A, unsigned C,
     HIPCK(c, hipMemsetAsync(c->counters.p, 0, sizeof(h), c->stream));
     c->stats.stack_patches += h[0];
     c->stats.sadct_groups += h[1];
+#ifdef LFBM5D_PHASE_TIMING   /* kernel-internal phase clocks of development builds (tools/build_variant.sh) */
+    {
+        unsigned long long ph[12];
+        (void)hipMemcpy(ph, c->counters.as<unsigned long long>() + 4, sizeof(ph), hipMemcpyDeviceToHost);
+        (void)hipMemset(c->counters.as<unsigned long long>() + 4, 0, sizeof(ph));
+        std::fprintf(stderr, "[phases step %d]", step);
+        for (int i = 0; i < 12; i++) std::fprintf(stderr, " %.3g", (double)ph[i]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     /* gather 4 B * S + aggregation 16 B per stacked pixel */
     c->stats.algorithmic_bytes += (double)h[0] * A * P->k * P->k * C * (4.0 * (step == 2 ? 2 : 1) + 16.0);
     return 0;

@@ -228,7 +228,8 @@ __device__ __forceinline__ void dct9_inv(float* x, TbPtr tb) {
             x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));   /* two values per lane: v_pk_{add,mul,fma}_f32 */
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));   /* two values per lane: v_pk_{add,mul,fma}_f32 */
 /* dct9_fwd / dct9_inv on a pair of fibres */
 __device__ __forceinline__ void dct9_fwd2(v2f* x, TbPtr tb) {
     v2f t[9];
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
  * Where only the filtered stack remains (inverse transforms) two fibres / two patches are paired
  * instead.  The arithmetic per element is the same sequence as in k_group_dct8<2>.
  * Phases (256 threads, barriers between them):
- *   1  thread = patch: 16-byte loads of the 8 rows from both images, 16 packed 8-point DCTs, 64 LDS writes
+ *   1  cooperative 16-byte gather of both images through LDS, then thread = patch: 16 packed 8-point DCTs, 64 LDS writes
  *   2  thread = (n, pq) fibre over the 9 SAIs: packed 3x3 DCT (shape-adaptive variant on the scalar path)
  *   3  thread = (st, pq) fibre over the nSx patches: packed Haar, Wiener shrinkage, inverse Haar
  *   4  thread = two (n, pq) fibres of the filtered stack: packed inverse 3x3 DCT
@@ -1339,46 +1340,82 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
 
     ShRef sh = group_shape(a, g);
 
-    /* 1: gather + forward 2-D DCT of both images, one thread per patch */
-    for (int patch = tid; patch < NP; patch += kDct8wThreads) {
-        const int st = patch % A;
-        const unsigned p = a.gpos[(size_t)g * N * A + patch];
-        const bool ok = p != 0xffffffffu;
-        const size_t off = ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
-        const float* in0 = a.noisy + off;
-        const float* in1 = a.basic + off;
-#ifdef LFBM5D_EXP
-        if (LFBM5D_EXP & 16) { in0 = a.noisy + ((size_t)st * a.C + c) * plane + (tid & 63) * 8; in1 = a.basic + ((size_t)st * a.C + c) * plane + (tid & 63) * 8; }
+#ifdef LFBM5D_PHASE_TIMING
+    long long tc[6]; int tci = 0;
+#define PHASE_MARK() do { if (tid == 0) tc[tci] = (long long)__builtin_readcyclecounter(); tci++; } while (0)
+    PHASE_MARK();
+#else
+#define PHASE_MARK() do {} while (0)
 #endif
-        v2f x[8][8];
+    /* 1a: cooperative gather.  The unit is one 16-byte half of a patch row: 16 adjacent lanes fetch the 8 rows of
+     * one patch (two lanes per 32-byte row, one cache-line request), instead of every lane walking its own
+     * patch.  The pieces are parked in LDS, [image][patch][16 pieces], piece index XOR-ed with the patch
+     * index so that phase 1b reads them without bank conflicts; the area is reused by the stack afterwards. */
+    {
+        __shared__ unsigned pos[kMaxN * kMaxA];
+        for (int i = tid; i < NP; i += kDct8wThreads) pos[i] = a.gpos[(size_t)g * N * A + i];
+        __syncthreads();
+        constexpr int kItems = (kMaxN * kMaxA * 16 + kDct8wThreads - 1) / kDct8wThreads;   /* 9 */
+        f4u v0[kItems], v1[kItems];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const f4u l0 = *reinterpret_cast<const f4u*>(in0 + (size_t)i * a.Wb), l1 = *reinterpret_cast<const f4u*>(in0 + (size_t)i * a.Wb + 4);
-            const f4u r0 = *reinterpret_cast<const f4u*>(in1 + (size_t)i * a.Wb), r1 = *reinterpret_cast<const f4u*>(in1 + (size_t)i * a.Wb + 4);
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                x[i][j] = ok ? v2f{l0.v[j], r0.v[j]} : v2f{0.0f, 0.0f};
-                x[i][4 + j] = ok ? v2f{l1.v[j], r1.v[j]} : v2f{0.0f, 0.0f};
+        for (int j = 0; j < kItems; j++) {
+            const int it = tid + j * kDct8wThreads, patch = it >> 4, piece = it & 15;
+            if (patch < NP) {
+                const unsigned p = pos[patch];
+                const size_t off = ((size_t)(patch % A) * a.C + c) * plane + (p != 0xffffffffu ? p : 0u)
+                                   + (size_t)(piece >> 1) * a.Wb + 4 * (piece & 1);
+                v0[j] = *reinterpret_cast<const f4u*>(a.noisy + off);
+                v1[j] = *reinterpret_cast<const f4u*>(a.basic + off);
             }
         }
+        v4f* stage = reinterpret_cast<v4f*>(lds);
 #pragma unroll
-        for (int i = 0; i < 8; i++) dct8_fwd_t(x[i]);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            v2f col[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) col[i] = x[i][j];
-            dct8_fwd_t(col);
-#pragma unroll
-            for (int i = 0; i < 8; i++) x[i][j] = col[i];
+        for (int j = 0; j < kItems; j++) {
+            const int it = tid + j * kDct8wThreads, patch = it >> 4, piece = it & 15;
+            if (patch < NP) {
+                const bool ok = pos[patch] != 0xffffffffu;     /* empty SAI / never-filled table column: zeros */
+                const int slot = patch * 16 + (piece ^ (patch & 15));
+                stage[slot] = ok ? v4f{v0[j].v[0], v0[j].v[1], v0[j].v[2], v0[j].v[3]} : v4f{0.f, 0.f, 0.f, 0.f};
+                stage[NP * 16 + slot] = ok ? v4f{v1[j].v[0], v1[j].v[1], v1[j].v[2], v1[j].v[3]} : v4f{0.f, 0.f, 0.f, 0.f};
+            }
         }
-        v2f* dst = stack + patch;
+        __syncthreads();
+    }
+    /* 1b: forward 2-D DCT of both images, one thread per patch */
+    {
+        const int patch = tid;       /* NP <= 144 < 256 threads */
+        v2f x[8][8];
+        if (patch < NP) {
+            const v4f* stage = reinterpret_cast<const v4f*>(lds);
 #pragma unroll
-        for (int i = 0; i < 8; i++)
+            for (int piece = 0; piece < 16; piece++) {
+                const v4f l = stage[patch * 16 + (piece ^ (patch & 15))], r = stage[NP * 16 + patch * 16 + (piece ^ (patch & 15))];
 #pragma unroll
-            for (int j = 0; j < 8; j++) dst[(i * 8 + j) * NPp] = x[i][j];
+                for (int j = 0; j < 4; j++) x[piece >> 1][4 * (piece & 1) + j] = v2f{l[j], r[j]};
+            }
+        }
+        __syncthreads();             /* every patch is in registers: the area becomes the stack */
+        if (patch < NP) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) dct8_fwd_t(x[i]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                v2f col[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) col[i] = x[i][j];
+                dct8_fwd_t(col);
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i][j] = col[i];
+            }
+            v2f* dst = stack + patch;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) dst[(i * 8 + j) * NPp] = x[i][j];
+        }
     }
     __syncthreads();
+    PHASE_MARK();
 
     /* 2: 4-D forward, one (n, pq) fibre of 9 float2 per thread */
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
@@ -1412,6 +1449,7 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         __syncthreads();
     }
 
+    PHASE_MARK();
     /* 3: 5th dimension + Wiener shrinkage, one (st, pq) fibre of nSx float2 per thread; result -> .y */
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     {
@@ -1456,6 +1494,7 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         }
     }
 
+    PHASE_MARK();
     /* 4: 4-D inverse of the filtered stack (.y), two (n, pq) fibres per thread: pq and pq + 32 */
 #ifdef LFBM5D_EXP
     if (!(LFBM5D_EXP & 32))
@@ -1486,6 +1525,7 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     }
     __syncthreads();
 
+    PHASE_MARK();
     /* 5: inverse 2-D DCT + store, two patches per thread (patch, patch + NPh): filt[g][n][st][c][64] */
     const int NPh = (NP + 1) / 2;
 #ifdef LFBM5D_EXP
@@ -1527,6 +1567,13 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
             }
         }
     }
+#ifdef LFBM5D_PHASE_TIMING
+    PHASE_MARK();
+    if (tid == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&a.counters[4 + i], (unsigned long long)(tc[i + 1] - tc[i]));
+        atomicAdd(&a.counters[9], 1ull);
+    }
+#endif
 }
 
 /* ================================ aggregation kernel ====================================== */
