@@ -206,41 +206,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         const int cx = stereo ? -1 : grid_index(x, gC, lastC, gN, gP);
         const int cx2 = (stereo || di == 0) ? -1 : grid_index(x + djs, gC, lastC, gN, gP);
 
-        /* D-row loads of the strip: ring column 0 <-> x = cb-1; columns are clamped into the row
-         * (loads stay inside the plane, est has slack) and out-of-band entries zeroed afterwards */
-        const int xm0 = cb - 1 + lane;
-        const int xm = min(max(xm0, b), W - 1), xe = min(cb + 63 + lane, W - 1);
-        const bool inm = xm0 >= b && xm0 < W - b;
-        const bool ine = lane < K && cb + 63 + lane < W - b;
-        const int vm = xm * 4, ve = xe * 4;                 /* per-lane byte offsets inside a row */
-        auto load_row = [&](int R, float& m1, float& m2, float& e1, float& e2) {
-            const int yy = min(b + R, H - b - 1);        /* uniform; rows past the band are zeroed in store_row */
-            const int so = yy * W * 4;
-            m1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, vm, so, 0));
-            m2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vm, so, 0));
-            e1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs1, ve, so, 0));
-            e2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, ve, so, 0));
-        };
-        auto store_row = [&](int R, float m1, float m2, float e1, float e2) {
-            const int rw = R % RR;               /* uniform */
-            float* rr = ring + rw * CW;
-            const bool rin = b + R < H - b;      /* uniform */
-            const float dm = m2 - m1, de = e2 - e1;
-            const float vmain = (rin && inm) ? dm * dm : 0.0f, vext = (rin && ine) ? de * de : 0.0f;
-            rr[lane] = vmain;
-            if (lane < K) rr[64 + lane] = vext;
-            if (rw < T - 1) {                    /* mirror row (uniform, rare) */
-                rr[RR * CW + lane] = vmain;
-                if (lane < K) rr[RR * CW + 64 + lane] = vext;
-            }
-        };
-        for (int R0 = 0; R0 < K + T; R0 += T) {
-            float m1[T], m2[T], e1[T], e2[T];
-#pragma unroll
-            for (int s = 0; s < T; s++) load_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
-#pragma unroll
-            for (int s = 0; s < T; s++) store_row(R0 + s, m1[s], m2[s], e1[s], e2[s]);
-        }
+        /* D rows of the strip: ring column 0 <-> x = cb-1 */
         /* per-lane pieces of the chunk loads: byte offset inside the chunk's first row, in-band column masks */
         int vA[NA], mA[NA];
 #pragma unroll
@@ -277,11 +243,46 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 b2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs2, vo, so, 0));
             }
         };
-        /* the next (DEP-1)*T rows wait in registers: row loads run DEP-1 chunks ahead of the ring writes */
+        /* squared differences of T rows (first row R0, a multiple of T) into ring rows wr .. wr+T-1 (wr a multiple
+         * of T like RR: no wrap inside a chunk) and into the mirror rows behind the ring when wr == 0 */
+        auto write_chunk = [&](auto edge_tag, int R0, int wr, const v4f* sa1, const v4f* sa2, float sb1, float sb2) {
+            constexpr bool EDGE = decltype(edge_tag)::value;
+            float* rr = ring + wr * CW;       /* uniform */
+#pragma unroll
+            for (int q = 0; q < NA; q++) {
+                const v4f d = sa2[q] - sa1[q];
+                v4f v = d * d;
+                const bool rin = !EDGE || b + R0 + qrow[q] < H - b;   /* rows past the band are zeros */
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = (rin && ((mA[q] >> j) & 1)) ? v[j] : 0.0f;
+                *reinterpret_cast<v4f*>(rr + qrow[q] * CW + qcol[q]) = v;
+                if (wr == 0 && qrow[q] < T - 1) *reinterpret_cast<v4f*>(rr + (RR + qrow[q]) * CW + qcol[q]) = v;   /* mirror rows */
+            }
+            if (REM > 0) {
+                const float d = sb2 - sb1;
+                const bool rin = !EDGE || b + R0 + xrow < H - b;
+                const float v = (rin && mB) ? d * d : 0.0f;
+                if (hasB) {
+                    rr[xrow * CW + xcol] = v;
+                    if (wr == 0 && xrow < T - 1) rr[(RR + xrow) * CW + xcol] = v;
+                }
+            }
+        };
+        /* rows 0 .. K+T-1 go straight to the ring, the next (DEP-1)*T rows wait in registers (row loads run
+         * DEP-1 chunks ahead of the ring writes); all of these loads are in flight together */
+        constexpr int NPRE = (K + T) / T;
         v4f A1[DEP][NA], A2[DEP][NA];
         float Bq1[DEP], Bq2[DEP];
+        {
+            v4f P1[NPRE][NA], P2[NPRE][NA];
+            float Pb1[NPRE], Pb2[NPRE];
 #pragma unroll
-        for (int j = 0; j < DEP - 1; j++) load_chunk(std::true_type{}, K + T + j * T, A1[j], A2[j], Bq1[j], Bq2[j]);
+            for (int j = 0; j < NPRE; j++) load_chunk(std::true_type{}, j * T, P1[j], P2[j], Pb1[j], Pb2[j]);
+#pragma unroll
+            for (int j = 0; j < DEP - 1; j++) load_chunk(std::true_type{}, K + T + j * T, A1[j], A2[j], Bq1[j], Bq2[j]);
+#pragma unroll
+            for (int j = 0; j < NPRE; j++) write_chunk(std::true_type{}, j * T, j * T, P1[j], P2[j], Pb1[j], Pb2[j]);
+        }
         int filled = K + T;   /* rows [0, filled) are in the ring; rows [filled, filled + (DEP-1)T) wait in registers */
         __syncthreads();
 
@@ -341,8 +342,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
 #pragma unroll
             for (int s = 0; s < T; s++) {
-                d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
-                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
+#ifdef LFBM5D_EXP
+                if (!EDGE && (LFBM5D_EXP & 8)) { d1[s] = (float)oA; d2[s] = (float)oB; d3[s] = 1.f; d4[s] = 2.f; } else
+#endif
+                { d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
+                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW]; }
                 lc[s] = lcol[EDGE ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
             }
             oA += T * CW; oA = oA >= RR * CW ? oA - RR * CW : oA;
@@ -353,6 +357,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 /* left neighbour's value of the previous step; lane 0 takes the hand-off column */
                 const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lc[s]), __float_as_int(curS),
                                                                               0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+#ifdef LFBM5D_EXP
+                if (!EDGE && (LFBM5D_EXP & 16)) { const float Sx = lc[s] + d1[s] + d2[s] + d3[s] + d4[s]; Sout[s] = Sx; curS = Sx; continue; }
+#endif
                 float S = left + curS;             /* core:3379-3386, same association */
                 S = S - left_prev;
                 S = S + d1[s];
@@ -392,6 +399,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                     if (__builtin_amdgcn_ballot_w64(v2 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
                 }
                 /* hand-off column for the next strip (uniform address and value) */
+#ifdef LFBM5D_EXP
+                if (!EDGE && (LFBM5D_EXP & 128)) continue;
+#endif
                 const int il = 1 + t - last_lane;
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
                 lcol[EDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : il] = hv;
@@ -409,29 +419,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, val), rsTb, rv ? uvo : -1, (strip * H + b + t0 + 4 * h) * 256, 0);
                 }
             }
-            {   /* squared differences of rows filled .. filled+T-1 into the ring (and its mirror rows) */
-                float* rr = ring + wrow * CW;       /* uniform */
-#pragma unroll
-                for (int q = 0; q < NA; q++) {
-                    const v4f d = sa2[q] - sa1[q];
-                    v4f v = d * d;
-                    const bool rin = !EDGE || b + filled + qrow[q] < H - b;   /* rows past the band are zeros */
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] = (rin && ((mA[q] >> j) & 1)) ? v[j] : 0.0f;
-                    *reinterpret_cast<v4f*>(rr + qrow[q] * CW + qcol[q]) = v;
-                    if (wrow == 0 && qrow[q] < T - 1) *reinterpret_cast<v4f*>(rr + (RR + qrow[q]) * CW + qcol[q]) = v;   /* mirror rows */
-                }
-                if (REM > 0) {
-                    const float d = sb2 - sb1;
-                    const bool rin = !EDGE || b + filled + xrow < H - b;
-                    const float v = (rin && mB) ? d * d : 0.0f;
-                    if (hasB) {
-                        rr[xrow * CW + xcol] = v;
-                        if (wrow == 0 && xrow < T - 1) rr[(RR + xrow) * CW + xcol] = v;
-                    }
-                }
-                wrow = wrow + T == RR ? 0 : wrow + T;
-            }
+            write_chunk(edge_tag, filled, wrow, sa1, sa2, sb1, sb2);
+            wrow = wrow + T == RR ? 0 : wrow + T;
             filled += T;
         };
         {
