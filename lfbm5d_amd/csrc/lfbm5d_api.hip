@@ -344,6 +344,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* block matching (core:209-236): all distance tables in one launch, then the two selections */
     ScanArgs sa;
     std::memset(&sa, 0, sizeof(sa));
+    sa.dbg = c->counters.as<unsigned long long>() + 4;
     sa.est = est; sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
     sa.nSim = P->nSim; sa.nDisp = P->nDisp; sa.nHW = nHW;
     sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p;

@@ -154,6 +154,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         }
     };
 
+#ifdef LFBM5D_PHASE_TIMING
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    long long tlast = (long long)__builtin_readcyclecounter();
+#define SCAN_MARK(i) do { const long long tn = (long long)__builtin_readcyclecounter(); tk[i] += tn - tlast; tlast = tn; } while (0)
+#else
+#define SCAN_MARK(i) do {} while (0)
+#endif
     /* ---- corner (core:3344-3352) and first column (core:3367-3372) -> lcol ---- */
     for (int e = lane; e < K * K; e += 64) ring[e] = D(b + e / K, b + e % K);
     __syncthreads();
@@ -194,6 +201,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         for (int i = lane; i < H + 64; i += 64) rs16[i] = (short)a.rslot[i];
     __syncthreads();
 
+    SCAN_MARK(0);
     float row0_left = corner; /* S[b][cb-1] */
     const int nstrips = (ncols + 63) / 64;
     for (int strip = 0; strip < nstrips; strip++) {
@@ -283,6 +291,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
 #pragma unroll
             for (int j = 0; j < NPRE; j++) write_chunk(std::true_type{}, j * T, j * T, P1[j], P2[j], Pb1[j], Pb2[j]);
         }
+        SCAN_MARK(1);
         int filled = K + T;   /* rows [0, filled) are in the ring; rows [filled, filled + (DEP-1)T) wait in registers */
         __syncthreads();
 
@@ -305,6 +314,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             if (col_ok) emit(b, x, S0);
         }
 
+        SCAN_MARK(2);
         /* remaining rows: T steps per chunk -- loads, then the register-only chain, then stores.
          * Lane l works on table row i = 1 + t - l at step t, i.e. it is active for t in [l, nrows-2+l].
          * Two flavours of the same chunk:
@@ -435,12 +445,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             int t0 = 0;
             for (int ph = 0; ph < 2; ph++) {
                 const int te = ph == 0 ? min(tS0, nsteps) : nsteps + (stereo ? 16 : 0);   /* + the chunks that flush the store stage */
+                SCAN_MARK(ph == 0 ? 2 : 4);
                 for (; t0 < te; t0 += G) {
 #pragma unroll
                     for (int j = 0; j < DEP; j++)
                         chunk(std::true_type{}, t0 + j * T, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
                               A1[j], A2[j], Bq1[j], Bq2[j]);
                 }
+                SCAN_MARK(3);
                 if (ph == 0)
                     for (; t0 < tS1; t0 += G) {
 #pragma unroll
@@ -450,9 +462,17 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                     }
             }
         }
+        SCAN_MARK(3);
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
         __syncthreads();
     }
+#ifdef LFBM5D_PHASE_TIMING
+    if (lane == 0 && a.dbg) {
+        const int base = stereo ? 0 : 6;
+        for (int i = 0; i < 5; i++) atomicAdd(&a.dbg[base + i], (unsigned long long)tk[i]);
+        atomicAdd(&a.dbg[base + 5], 1ull);
+    }
+#endif
 }
 
 template <int K>

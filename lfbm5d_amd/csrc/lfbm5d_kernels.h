@@ -112,6 +112,7 @@ struct ScanArgs {
     float* scores;              /* [R][Ns*Ns], pre-filled with 2*threshold */
     unsigned scores_bytes;
     /* stereo */
+    unsigned long long* dbg;    /* development builds (LFBM5D_PHASE_TIMING): phase clocks; else unused */
     float* tables;              /* [n_slots][Ns*Ns][stereo_table_stride]: strip-major [strip][row][64 columns] */
     unsigned st_of_slot[kMaxA];
 };

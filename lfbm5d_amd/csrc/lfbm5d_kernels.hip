@@ -230,7 +230,9 @@ __device__ __forceinline__ void dct9_inv(float* x, TbPtr tb) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));   /* two values per lane: v_pk_{add,mul,fma}_f32 */
-/* dct9_fwd / dct9_inv on a pair of fibres */
+/* dct9_fwd / dct9_inv on a pair of fibres: the same operation sequence as the scalar versions (folding the
+ * constant factors into the stage matrices saves a third of the multiplies but moves results by an ulp, enough
+ * to flip the odd hard-threshold decision against the reference) */
 __device__ __forceinline__ void dct9_fwd2(v2f* x, TbPtr tb) {
     v2f t[9];
 #pragma unroll
@@ -258,6 +260,36 @@ __device__ __forceinline__ void dct9_inv2(v2f* x, TbPtr tb) {
 #pragma unroll
         for (int j = 0; j < 3; j++)
             x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
+}
+/* Haar over the NS patches of a group held as pairs P[h] = {patch h, patch h + NS/2} (lib_transforms.cpp:403-471
+ * / :290-321, same butterflies and scaling, evaluated two at a time).  Forward leaves the coefficients in
+ * C[0..NS/2) (a permutation of the reference order -- the shrinkage treats all coefficients alike); the inverse
+ * takes that layout back to P. */
+template <int NS> __device__ __forceinline__ void haar_fwd_pairs(v2f* P) {
+    const float s = 0.70710678118654752f;
+    if (NS == 8) {
+        const v2f S01 = (P[0] + P[1]) * s, D01 = (P[0] - P[1]) * s, S23 = (P[2] + P[3]) * s, D23 = (P[2] - P[3]) * s;
+        const v2f SS = (S01 + S23) * s, DD = (S01 - S23) * s;
+        P[0] = v2f{(SS.x + SS.y) * s, (SS.x - SS.y) * s}; P[1] = DD; P[2] = D01; P[3] = D23;
+    } else if (NS == 4) {
+        const v2f S = (P[0] + P[1]) * s, D = (P[0] - P[1]) * s;
+        P[0] = v2f{(S.x + S.y) * s, (S.x - S.y) * s}; P[1] = D;
+    } else if (NS == 2) {
+        P[0] = v2f{(P[0].x + P[0].y) * s, (P[0].x - P[0].y) * s};
+    }
+}
+template <int NS> __device__ __forceinline__ void haar_inv_pairs(v2f* P) {
+    const float s = 0.70710678118654752f;
+    if (NS == 8) {
+        const v2f X = v2f{(P[0].x + P[0].y) * s, (P[0].x - P[0].y) * s};
+        const v2f U = (X + P[1]) * s, V = (X - P[1]) * s, D01 = P[2], D23 = P[3];
+        P[0] = (U + D01) * s; P[1] = (U - D01) * s; P[2] = (V + D23) * s; P[3] = (V - D23) * s;
+    } else if (NS == 4) {
+        const v2f X = v2f{(P[0].x + P[0].y) * s, (P[0].x - P[0].y) * s}, D = P[1];
+        P[0] = (X + D) * s; P[1] = (X - D) * s;
+    } else if (NS == 2) {
+        P[0] = v2f{(P[0].x + P[0].y) * s, (P[0].x - P[0].y) * s};
+    }
 }
 /* 1-D REDFT10 / REDFT01 of runtime length n <= 3 (SADCT rows / columns) */
 __device__ void r10_small(const float* x, float* y, int n, TbPtr tb) {
@@ -848,8 +880,9 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)((size_t)a.A * a.C * plane * 4), kRsrcFlags);
     float* const out = a.filt + (size_t)g * a.N * A * a.C * k2;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((size_t)a.N * A * a.C * k2 * 4), kRsrcFlags);
+    /* the pixel's NS * 9 values as pairs of patches: V[h][st] = {patch h, patch h + NS/2} (NS = 1: .y unused) */
     constexpr int NH = NS > 1 ? NS / 2 : 1;
-    float v[NS][9];
+    v2f V[NH][9];
     const int voff = (int)(((unsigned)(pq / k) * a.Wb + pq % k) * 4u);
     unsigned okbits[NS];
 #pragma unroll
@@ -861,102 +894,94 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
             const bool ok = p != 0xffffffffu;
             okbits[n] |= ok ? 1u << st : 0u;
             const unsigned so = (((unsigned)st * a.C + c) * plane + (ok ? p : 0u)) * 4u;
-#ifdef LFBM5D_EXP
-            if (LFBM5D_EXP & 512) { v[n][st] = (float)(pq + so); continue; }
-#endif
-            v[n][st] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
+            const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
+            if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
         }
+    }
+    if (NS == 1) {
+#pragma unroll
+        for (int st = 0; st < 9; st++) V[0][st].y = 0.0f;
     }
 #pragma unroll
     for (int n = 0; n < NS; n++)
         if (okbits[n] != 0x1ffu) {   /* uniform, rare: patches of empty SAIs / never-filled table column read as zeros */
 #pragma unroll
-            for (int st = 0; st < 9; st++) v[n][st] = ((okbits[n] >> st) & 1) ? v[n][st] : 0.0f;
+            for (int st = 0; st < 9; st++) {
+                if (n < NH) V[n][st].x = ((okbits[n] >> st) & 1) ? V[n][st].x : 0.0f;
+                else V[n - NH][st].y = ((okbits[n] >> st) & 1) ? V[n - NH][st].y : 0.0f;
+            }
         }
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
-    if (do_dct4) {
-        if (NS == 1) dct9_fwd(v[0], tb);
-        else {
+    auto sadct_pairs = [&](bool fwd) {   /* rare: shape-adaptive transform on the scalar path, staged through t9 */
 #pragma unroll
-            for (int h = 0; h < NH; h++) {
-                v2f x[9];
+        for (int h = 0; h < NH; h++)
 #pragma unroll
-                for (int st = 0; st < 9; st++) x[st] = v2f{v[2 * h][st], v[(2 * h + 1) % NS][st]};
-                dct9_fwd2(x, tb);
+            for (int half = 0; half < (NS > 1 ? 2 : 1); half++) {
+                float t9[9];
 #pragma unroll
-                for (int st = 0; st < 9; st++) { v[2 * h][st] = x[st].x; v[(2 * h + 1) % NS][st] = x[st].y; }
+                for (int i = 0; i < 9; i++) t9[i] = half ? V[h][i].y : V[h][i].x;
+                if (fwd) sadct9_fwd(t9, sh, tb); else sadct9_inv(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { if (half) V[h][i].y = t9[i]; else V[h][i].x = t9[i]; }
             }
-        }
-    } else if (do_sa4) { /* rare: staged through a small scratch vector so v[][] stays in registers */
+    };
+    if (do_dct4) {
 #pragma unroll
-        for (int n = 0; n < NS; n++) {
-            float t9[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) t9[i] = v[n][i];
-            sadct9_fwd(t9, sh, tb);
-#pragma unroll
-            for (int i = 0; i < 9; i++) v[n][i] = t9[i];
-        }
-    }
+        for (int h = 0; h < NH; h++) dct9_fwd2(V[h], tb);
+    } else if (do_sa4) sadct_pairs(true);
     const float sig = a.sigma[c];
     const float T = a.lambda * sig * 1.41421356237309505f;
 #pragma unroll
     for (int st = 0; st < 9; st++) {
-        float o[NS], e[1] = {0.0f};
-#pragma unroll
-        for (int n = 0; n < NS; n++) o[n] = v[n][st];
         const bool in_shape = !use_sadct || sh.mask_dct[st];
         if (HAAR) {
-            if (NS > 1) haar_fwd<NS>(o);
+            v2f P[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) P[h] = V[h][st];
+            haar_fwd_pairs<NS>(P);
             if (in_shape) {
 #pragma unroll
-                for (int n = 0; n < NS; n++) { const bool keep = fabsf(o[n]) > T; wacc += keep ? 1.0f : 0.0f; o[n] = keep ? o[n] : 0.0f; }
+                for (int h = 0; h < NH; h++) {
+                    const bool kx = fabsf(P[h].x) > T, ky = (NS > 1) && fabsf(P[h].y) > T;
+                    wacc += (kx ? 1.0f : 0.0f) + (ky ? 1.0f : 0.0f);
+                    P[h].x = kx ? P[h].x : 0.0f;
+                    P[h].y = ky ? P[h].y : 0.0f;
+                }
             }
-            if (NS > 1) haar_inv<NS>(o);
-        } else shrink_fibre<NS, 1>(o, e, a.tau5, T, sig * sig, in_shape, wacc, tb);
+            haar_inv_pairs<NS>(P);
 #pragma unroll
-        for (int n = 0; n < NS; n++) v[n][st] = o[n];
+            for (int h = 0; h < NH; h++) V[h][st] = P[h];
+        } else {
+            float o[NS], e[1] = {0.0f};
+#pragma unroll
+            for (int n = 0; n < NS; n++) o[n] = n < NH ? V[n][st].x : V[n - NH][st].y;
+            shrink_fibre<NS, 1>(o, e, a.tau5, T, sig * sig, in_shape, wacc, tb);
+#pragma unroll
+            for (int n = 0; n < NS; n++) { if (n < NH) V[n][st].x = o[n]; else V[n - NH][st].y = o[n]; }
+        }
     }
     if (a.useSD) {
 #pragma unroll
-        for (int n = 0; n < NS; n++)
+        for (int h = 0; h < NH; h++)
 #pragma unroll
-            for (int st = 0; st < 9; st++) { s1 += v[n][st]; s2 += v[n][st] * v[n][st]; }
+            for (int st = 0; st < 9; st++) {
+                s1 += V[h][st].x; s2 += V[h][st].x * V[h][st].x;
+                if (NS > 1) { s1 += V[h][st].y; s2 += V[h][st].y * V[h][st].y; }
+            }
     }
     if (do_dct4) {
-        if (NS == 1) dct9_inv(v[0], tb);
-        else {
 #pragma unroll
-            for (int h = 0; h < NH; h++) {
-                v2f x[9];
-#pragma unroll
-                for (int st = 0; st < 9; st++) x[st] = v2f{v[2 * h][st], v[(2 * h + 1) % NS][st]};
-                dct9_inv2(x, tb);
-#pragma unroll
-                for (int st = 0; st < 9; st++) { v[2 * h][st] = x[st].x; v[(2 * h + 1) % NS][st] = x[st].y; }
-            }
-        }
-    } else if (do_sa4) {
-#pragma unroll
-        for (int n = 0; n < NS; n++) {
-            float t9[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) t9[i] = v[n][i];
-            sadct9_inv(t9, sh, tb);
-#pragma unroll
-            for (int i = 0; i < 9; i++) v[n][i] = t9[i];
-        }
-    }
+        for (int h = 0; h < NH; h++) dct9_inv2(V[h], tb);
+    } else if (do_sa4) sadct_pairs(false);
     const int vout = pq * 4;
 #pragma unroll
     for (int n = 0; n < NS; n++)
 #pragma unroll
-        for (int st = 0; st < 9; st++)
-#ifdef LFBM5D_EXP
-            if ((LFBM5D_EXP & 256) && v[n][st] != 1234.5f) continue; else
-#endif
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[n][st]), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
+        for (int st = 0; st < 9; st++) {
+            const float r = n < NH ? V[n][st].x : V[n - NH][st].y;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
+        }
 }
 
 template <bool HAAR>

@@ -1,16 +1,22 @@
+# SQ counters of the hot kernels on one 3x3x512x512 window pass per step (tools/pass_time.py); run on the GPU box:
+#   gpurun -- 'bash tools/pmc_scan.sh'
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmcs
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --output-format csv -d gpurun_out/pmcs -- python3 tools/gpu_check.py readme > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVES --output-format csv -d gpurun_out/pmcs/a -- python3 tools/pass_time.py 1 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmcs/b -- python3 tools/pass_time.py 1 > /dev/null 2>&1
 python3 - <<PY
 import csv,glob,collections
-f=glob.glob("gpurun_out/pmcs/*/*counter_collection.csv")[0]
 acc=collections.defaultdict(lambda: collections.defaultdict(float))
-for r in csv.DictReader(open(f)):
-    n=r["Kernel_Name"]
-    key=None
-    for k in ("k_bm_scan<16>","k_bm_scan<8>","k_group_dct8","k_group_id","k_aggregate","k_stereo_argmin"):
-        if k in n: key=k
-    if key: acc[key][r["Counter_Name"]]+=float(r["Counter_Value"])
+cnt=collections.defaultdict(set)
+for f in glob.glob("gpurun_out/pmcs/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        n=r["Kernel_Name"]
+        key=None
+        for k in ("k_bm_scan<16>","k_bm_scan<8>","k_group_dct8w","k_group_id","k_aggregate<false","k_aggregate<true","k_stereo_argmin","k_self_select"):
+            if k in n: key=k
+        if key:
+            acc[key][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[key].add(r["Dispatch_Id"])
 for k,v in acc.items():
-    print(k, {a:int(b) for a,b in v.items()})
+    n=max(1,len(cnt[k])//2)
+    print(k, "launches", n, {a:"%.3g"%(b/n) for a,b in sorted(v.items())})
 PY
