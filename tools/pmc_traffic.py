@@ -19,8 +19,8 @@ def per_kernel(d, counter):
             if r.get("Counter_Name") != counter:
                 continue
             name = r["Kernel_Name"]
-            key = "group" if "k_group" in name else "aggregate" if "k_aggregate" in name else "scan" if "k_bm_scan" in name else \
-                  "argmin" if "argmin" in name else None
+            key = "group" if ("k_group" in name and "k_group_pos" not in name and "k_group_shape" not in name) else \
+                  "aggregate" if "k_aggregate" in name else "scan" if "k_bm_scan" in name else "argmin" if "argmin" in name else None
             if key is None:
                 continue
             e = out.setdefault(key, [0.0, set()])
