@@ -21,7 +21,8 @@ C5_WIEN = (8, 18, 3, 8, 3, "dct", "sadct", "haar")
 def source_lf(crop=None):
     lf = np.load(os.path.join(GOLDEN, "sourceLF_3x3_256_u8.npy"))
     if crop:
-        lf = lf[:, :, :crop, :crop]
+        ch, cw = (crop, crop) if np.isscalar(crop) else crop     # (rows, columns) for non-square SAIs
+        lf = lf[:, :, :ch, :cw]
     return np.ascontiguousarray(lf)
 
 

@@ -48,7 +48,8 @@ def window(sigma, pk, crop, grey=False):
         lf = lf[:, :1]
     clean, noisy = Hh.noisy_lf(lf, sigma)
     Cc = lf.shape[1]
-    win, Wb, Hb = Hh.padded_window(noisy, crop, crop, Cc, pk[1] + pk[2])
+    ch, cw = (crop, crop) if np.isscalar(crop) else crop
+    win, Wb, Hb = Hh.padded_window(noisy, cw, ch, Cc, pk[1] + pk[2])
     return win, Wb, Hb, Cc
 
 
@@ -70,6 +71,10 @@ PASS_CASES = [
     ("ht-dct-sadct-dct5", 1, 25.0, (4, 6, 2, 8, 3, "dct", "sadct", "dct"), 64, 0),
     ("ht-id-dct-dct5", 1, 25.0, (8, 6, 2, 8, 4, "id", "dct", "dct"), 64, 0),
     ("wien-dct-sadct-dct5", 2, 25.0, (8, 6, 2, 8, 3, "dct", "sadct", "dct"), 64, 0),
+    # non-square SAIs, step 3, wider than one 64-column strip with a ragged last strip (config-5 style: 625x434)
+    ("ht-wide-n1-p3", 1, 50.0, (1, 9, 3, 16, 3, "bior", "sadct", "haar"), (72, 150), 0),
+    ("ht-tall-id-p3", 1, 25.0, (8, 8, 3, 16, 3, "id", "sadct", "haar"), (150, 72), 0),
+    ("wien-wide-n8-p3", 2, 25.0, (8, 9, 3, 8, 3, "dct", "sadct", "haar"), (72, 150), 0),
 ]
 
 
@@ -98,12 +103,12 @@ def test_core_pass_matches_oracle(ctx, case):
     assert np.array_equal(o_cnt, cnt)
     for r in range(len(refs)):
         assert np.array_equal(o_idx[r, :o_cnt[r]], idx[r, :cnt[r]]), (name, r)
-    reg = slice(nDisp, Hb - k - nDisp + 1)
+    regr, regc = slice(nDisp, Hb - k - nDisp + 1), slice(nDisp, Wb - k - nDisp + 1)
     for st_i in (0, 5, 7):
         ob, osh = np.zeros(Wb * Hb, np.uint32), np.zeros(Wb * Hb, np.uint8)
         O.lib().orc_bm_stereo(np.ascontiguousarray(est[4]), np.ascontiguousarray(est[st_i]), Wb, Hb, k, nDisp, tau, ob, osh)
-        assert np.array_equal(ob.reshape(Hb, Wb)[reg, reg], best[st_i].reshape(Hb, Wb)[reg, reg])
-        assert np.array_equal(osh.reshape(Hb, Wb)[reg, reg], shape[st_i].reshape(Hb, Wb)[reg, reg])
+        assert np.array_equal(ob.reshape(Hb, Wb)[regr, regc], best[st_i].reshape(Hb, Wb)[regr, regc])
+        assert np.array_equal(osh.reshape(Hb, Wb)[regr, regc], shape[st_i].reshape(Hb, Wb)[regr, regc])
     # aggregation buffers
     assert np.array_equal(den_o != 0, den_g != 0)
     np.testing.assert_allclose(den_g, den_o, rtol=2e-5, atol=1e-7)
