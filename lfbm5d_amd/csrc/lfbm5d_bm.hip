@@ -502,21 +502,39 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
     const unsigned ref = blockIdx.x;
     if (ref >= n_refs) return;
     const int Ns = 2 * nSim + 1, ncand = Ns * Ns;
+    /* e / Ns by multiplication: exact for e < 2^20 / Ns, i.e. for every candidate index (Ns <= 127) */
+    const unsigned div_m = ((1u << 20) + (unsigned)Ns - 1) / (unsigned)Ns;
     const float* sc = scores + (size_t)ref * ncand;
     const int k_r = (int)refs[ref];
+    /* keys of the candidates that pass the threshold, compacted in scan order (ballot prefix): the selection
+     * rounds below then only walk those */
     int cnt = 0;
-    for (int e = lane; e < ncand; e += 64) {
-        const int djp = e / Ns - nSim, r = e % Ns;
-        const bool fwd = r <= nSim;
-        const int dip = fwd ? r : r - 2 * nSim - 1;
-        const float score = sc[e];
-        /* backward half: tested with the mirrored table at k_r, scored at the candidate (core:3415-3419) */
-        const float test = fwd ? score : sc[(-djp + nSim) * Ns + (-dip)];
-        const bool pass = test < thr;
-        keys[e] = pass ? (((unsigned long long)f2ord(score) << 32) | (unsigned)e) : ~0ull;
-        cnt += pass ? 1 : 0;
+    constexpr int kB = 8;    /* 64-candidate chunks whose score loads are in flight together */
+    for (int e0 = 0; e0 < ncand; e0 += 64 * kB) {
+        float score[kB], test[kB];
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+            const int e = e0 + u * 64 + lane;
+            score[u] = 0.0f; test[u] = 0.0f;
+            if (e < ncand) {
+                const int q = (int)(((unsigned)e * div_m) >> 20);
+                const int djp = q - nSim, r = e - q * Ns;
+                const bool fwd = r <= nSim;
+                const int dip = fwd ? r : r - 2 * nSim - 1;
+                score[u] = sc[e];
+                /* backward half: tested with the mirrored table at k_r, scored at the candidate (core:3415-3419) */
+                test[u] = fwd ? score[u] : sc[(-djp + nSim) * Ns + (-dip)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+            const int e = e0 + u * 64 + lane;
+            const bool pass = e < ncand && test[u] < thr;
+            const unsigned long long bal = __ballot(pass);
+            if (pass) keys[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long)f2ord(score[u]) << 32) | (unsigned)e;
+            cnt += __popcll(bal);
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     __syncthreads();
     unsigned nSx;
     if (N > cnt) { nSx = 1; while (nSx * 2 <= (unsigned)cnt) nSx *= 2; } else nSx = N;
@@ -529,7 +547,7 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
     bool first = true;
     for (unsigned n = 0; n < nSx; n++) { /* n-th smallest (distance, scan order) key */
         unsigned long long best = ~0ull;
-        for (int e = lane; e < ncand; e += 64) {
+        for (int e = lane; e < cnt; e += 64) {
             const unsigned long long kk = keys[e];
             if ((first || kk > last) && kk < best) best = kk;
         }
