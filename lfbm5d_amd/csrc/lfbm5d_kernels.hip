@@ -985,7 +985,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
 }
 
 template <bool HAAR>
-__global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
+__device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
     __shared__ float red[3][4];
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x;
@@ -1028,6 +1028,11 @@ __global__ __launch_bounds__(256) void k_group_id(GroupArgs a) {
         }
     }
 }
+
+/* Haar configuration (README): capped at 168 VGPRs so that three waves fit a SIMD (a dozen spilled values buy 20 %);
+ * the Hadamard / DCT fibre transforms need more registers and keep two */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar(GroupArgs a) { group_id_kernel<true>(a); }
+__global__ __launch_bounds__(256) void k_group_id_any(GroupArgs a) { group_id_kernel<false>(a); }
 
 /* ------------------------------------------------------------------------------------------
  * 8x8 2-D DCT variant (the README Wiener configuration: k = 8, tau_2D = dct).  The 2-D transform
@@ -1831,8 +1836,8 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
     if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
-        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id<true>, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
-        else             hipLaunchKernelGGL(k_group_id<false>, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        else             hipLaunchKernelGGL(k_group_id_any, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
         return hipGetLastError();
     }
     if (a.tau2 == 5 && a.k == 8 && a.A == 9) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
