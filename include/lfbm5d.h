@@ -103,6 +103,9 @@ void* lfbm5d_stream(lfbm5d_ctx* ctx);
 #define LFBM5D_UNIQUE_ID_BYTES 128
 int lfbm5d_comm_unique_id(void* id_out /* LFBM5D_UNIQUE_ID_BYTES */);
 int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);
+/* Diagnostics: all-reduce n floats on the context's stream through the context's communicator (or a
+ * one-rank communicator created for the call) and verify the sums.  Returns 0 when RCCL works here. */
+int lfbm5d_comm_selftest(lfbm5d_ctx* ctx, unsigned n);
 /* Shard without a communicator (tests): this rank only processes its rows; no reduction. */
 int lfbm5d_set_shard(lfbm5d_ctx* ctx, int rank, int world);
 /* Row range [begin,end) of n_rows reference-patch rows owned by `rank` of `world`. */

@@ -82,6 +82,7 @@ def lib():
     L.lfbm5d_comm_unique_id.argtypes = [vp]
     L.lfbm5d_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.lfbm5d_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.lfbm5d_comm_selftest.argtypes = [vp, C.c_uint]
     L.lfbm5d_shard_rows.argtypes = [C.c_uint, C.c_int, C.c_int, up, up]
     L.lfbm5d_shard_rows.restype = None
     L.lfbm5d_plan_windows.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, up, C.c_uint]
@@ -176,6 +177,10 @@ class Context:
     def comm_init(self, unique_id, rank, world):
         buf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._ck(self._L.lfbm5d_comm_init(self._h, buf, rank, world))
+
+    def comm_selftest(self, n=1 << 20):
+        """All-reduce n floats through RCCL on the context's stream and check the sums."""
+        self._ck(self._L.lfbm5d_comm_selftest(self._h, n))
 
     def set_shard(self, rank, world):
         self._ck(self._L.lfbm5d_set_shard(self._h, rank, world))

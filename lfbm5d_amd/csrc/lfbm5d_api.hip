@@ -824,6 +824,35 @@ int lfbm5d_last_windows(const lfbm5d_ctx* c, unsigned* out_sai, unsigned cap) {
     return (int)c->last_windows.size();
 }
 
+int lfbm5d_comm_selftest(lfbm5d_ctx* c, unsigned n) {
+    if (!c || !n) return 1;
+    (void)hipSetDevice(c->device);
+    ncclComm_t comm = c->comm;
+    bool own = false;
+    if (!comm) {   /* no communicator yet: a one-rank one exercises the same RCCL code path */
+        ncclUniqueId id;
+        if (ncclGetUniqueId(&id) != ncclSuccess) return fail(c, "ncclGetUniqueId failed");
+        if (ncclCommInitRank(&comm, 1, id, 0) != ncclSuccess) return fail(c, "ncclCommInitRank failed");
+        own = true;
+    }
+    const int world = own ? 1 : c->world;
+    float* d = nullptr;
+    std::vector<float> h(n);
+    for (unsigned i = 0; i < n; i++) h[i] = (float)(i % 251) + 0.5f;
+    int rc = 0;
+    if (hipMalloc(&d, n * sizeof(float)) != hipSuccess) rc = fail(c, "hipMalloc failed");
+    if (!rc && hipMemcpyAsync(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, "copy failed");
+    if (!rc && ncclAllReduce(d, d, n, ncclFloat, ncclSum, comm, c->stream) != ncclSuccess) rc = fail(c, "ncclAllReduce failed");
+    std::vector<float> r(n);
+    if (!rc && hipMemcpyAsync(r.data(), d, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(c, "copy failed");
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "stream failed");
+    for (unsigned i = 0; i < n && !rc; i++)
+        if (r[i] != h[i] * (float)world) rc = fail(c, "all-reduce returned a wrong sum");
+    if (d) (void)hipFree(d);
+    if (own) ncclCommDestroy(comm);
+    return rc;
+}
+
 int lfbm5d_set_shard(lfbm5d_ctx* c, int rank, int world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return 1;
     c->rank = rank; c->world = world;

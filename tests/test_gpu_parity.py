@@ -335,6 +335,12 @@ def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
     monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
 
 
+def test_rccl_all_reduce_on_the_library_stream(ctx):
+    """The collective of the multi-GPU schemes, on a one-rank communicator: RCCL loads, takes the library's
+    non-blocking stream and returns the right sums (the only part of N > 1 a one-GPU box can run for real)."""
+    ctx.comm_selftest(1 << 22)
+
+
 def test_unsupported_configurations_fail_loudly(ctx):
     import lfbm5d_amd as L
     from lfbm5d_amd import core
