@@ -63,7 +63,7 @@ struct lfbm5d_ctx {
     std::vector<unsigned> last_windows;   /* processed SAI of every window of the last step, in order */
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
-    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den;
+    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den, d_mask;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
@@ -513,11 +513,13 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
 
     if (C == 3 && P->color_space != LFBM5D_RGB) {
         if (P->color_space > LFBM5D_RGB) return fail(c, "bad color space");
-        for (unsigned st = 0; st < asize; st++) {
-            if (!h_mask[st]) continue;
-            HIPCK(c, launch_color(s, d_noisy + st * img, P->color_space, W * H, 1));
-            if (step == 2) HIPCK(c, launch_color(s, d_basic + st * img, P->color_space, W * H, 1));
-        }
+    }
+    HIPCK(c, c->d_mask.reserve(asize * sizeof(unsigned)));
+    unsigned* d_mask = c->d_mask.as<unsigned>();
+    HIPCK(c, hipMemcpyAsync(d_mask, h_mask, asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
+    if (C == 3 && P->color_space != LFBM5D_RGB) {
+        HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P->color_space, W * H, 1));
+        if (step == 2) HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P->color_space, W * H, 1));
     }
     HIPCK(c, c->g_num.reserve(asize * img * sizeof(float)));
     HIPCK(c, c->g_den.reserve(asize * img * sizeof(float)));
@@ -712,17 +714,12 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     }
     /* final estimate (bm5d.cpp:405) and inverse colour transforms (bm5d.cpp:711-714 / :1414-1418) */
     const float* sub = step == 1 ? d_noisy : d_basic;
-    for (unsigned st = 0; st < asize; st++) {
-        if (!h_mask[st]) continue;
-        HIPCK(c, launch_estimate(s, g_num + st * img, g_den + st * img, sub + st * img, d_out + st * img, img));
+    HIPCK(c, launch_estimate_lf(s, g_num, g_den, sub, d_out, img, asize, d_mask));
+    if (C == 3 && P->color_space != LFBM5D_RGB) {
+        HIPCK(c, launch_color_lf(s, d_out, img, asize, d_mask, P->color_space, W * H, 0));
+        if (step == 2) HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P->color_space, W * H, 0));
+        HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P->color_space, W * H, 0));
     }
-    if (C == 3 && P->color_space != LFBM5D_RGB)
-        for (unsigned st = 0; st < asize; st++) {
-            if (!h_mask[st]) continue;
-            HIPCK(c, launch_color(s, d_out + st * img, P->color_space, W * H, 0));
-            if (step == 2) HIPCK(c, launch_color(s, d_basic + st * img, P->color_space, W * H, 0));
-            HIPCK(c, launch_color(s, d_noisy + st * img, P->color_space, W * H, 0));
-        }
     HIPCK(c, hipStreamSynchronize(s));
     drain_events(c);
     return fold_counters(c, P, Aw, C, step);
@@ -767,7 +764,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

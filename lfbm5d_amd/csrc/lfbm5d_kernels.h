@@ -118,6 +118,11 @@ struct ScanArgs {
 };
 
 hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward);
+/* whole light field [SAI][3][n_px] / [SAI][seg] in one launch; d_mask: device copy of the SAI mask (0 = skip) */
+hipError_t launch_color_lf(hipStream_t s, float* lf, size_t sai_stride, unsigned n_sai, const unsigned* d_mask, unsigned cs,
+                           unsigned n_px, int forward);
+hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t seg,
+                              unsigned n_sai, const unsigned* d_mask);
 hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigned W, unsigned H,
                             unsigned C, unsigned N);
 hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsigned W, unsigned H,

@@ -26,9 +26,11 @@ typedef const __attribute__((address_space(4))) float* TbFloats;
 
 /* ============================== elementwise helpers ======================================= */
 
-__global__ void k_color(float* __restrict__ img, unsigned cs, unsigned n, int fwd) {
+/* blockIdx.y = SAI of a light field laid out [SAI][3][n]; SAIs whose mask entry is 0 are left alone */
+__global__ void k_color(float* __restrict__ img, size_t sai_stride, const unsigned* __restrict__ mask, unsigned cs, unsigned n, int fwd) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (mask && !mask[blockIdx.y])) return;
+    img += blockIdx.y * sai_stride;
     /* utilities.cpp:482-599, same expressions; contraction off to keep their rounding */
     float x, y, z;
     {
@@ -115,6 +117,17 @@ __global__ void k_estimate_multi(const float* __restrict__ num, const float* __r
     const size_t o = (size_t)st * C * plane + i;
     const float d = den[o];
     est[st * plane + i] = d ? __fdiv_rn(num[o], d) : sub[o];
+}
+
+/* final estimate of a whole light field [SAI][seg]: SAIs whose mask entry is 0 are left alone */
+__global__ void k_estimate_lf(const float* __restrict__ num, const float* __restrict__ den, const float* __restrict__ sub,
+                              float* __restrict__ est, size_t seg, const unsigned* __restrict__ mask) {
+    if (mask && !mask[blockIdx.y]) return;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= seg) return;
+    const size_t o = blockIdx.y * seg + i;
+    const float d = den[o];
+    est[o] = d ? __fdiv_rn(num[o], d) : sub[o];
 }
 
 __global__ void k_fill_f32(float* p, float v, size_t n) {
@@ -1769,7 +1782,17 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
 static inline dim3 grid1d(size_t n, unsigned b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 
 hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward) {
-    hipLaunchKernelGGL(k_color, grid1d(n_px), dim3(256), 0, s, img, cs, n_px, forward);
+    hipLaunchKernelGGL(k_color, grid1d(n_px), dim3(256), 0, s, img, (size_t)0, (const unsigned*)nullptr, cs, n_px, forward);
+    return hipGetLastError();
+}
+hipError_t launch_color_lf(hipStream_t s, float* lf, size_t sai_stride, unsigned n_sai, const unsigned* d_mask, unsigned cs,
+                           unsigned n_px, int forward) {
+    hipLaunchKernelGGL(k_color, dim3(grid1d(n_px).x, n_sai), dim3(256), 0, s, lf, sai_stride, d_mask, cs, n_px, forward);
+    return hipGetLastError();
+}
+hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t seg,
+                              unsigned n_sai, const unsigned* d_mask) {
+    hipLaunchKernelGGL(k_estimate_lf, dim3(grid1d(seg).x, n_sai), dim3(256), 0, s, num, den, sub, est, seg, d_mask);
     return hipGetLastError();
 }
 hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigned W, unsigned H, unsigned C, unsigned N) {
