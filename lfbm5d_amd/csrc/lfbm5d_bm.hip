@@ -230,13 +230,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
          * (rows past the band are zeroed when they are written to the ring) */
         auto load_chunk = [&](auto edge_tag, int R0, v4f* a1, v4f* a2, float& b1, float& b2) {
             constexpr bool EDGE = decltype(edge_tag)::value;
-#ifdef LFBM5D_EXP
-            if (!EDGE && (LFBM5D_EXP & 4)) {
-                for (int q = 0; q < NA; q++) { a1[q] = v4f{1.f, 2.f, 3.f, (float)R0}; a2[q] = v4f{2.f, 1.f, 5.f, 4.f}; }
-                b1 = 1.f; b2 = (float)R0;
-                return;
-            }
-#endif
 #pragma unroll
             for (int q = 0; q < NA; q++) {
                 const int vo = EDGE ? (min(b + R0 + qrow[q], H - 1) * W + cb - 1 + qcol[q]) * 4 : vA[q];
@@ -352,11 +345,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
 #pragma unroll
             for (int s = 0; s < T; s++) {
-#ifdef LFBM5D_EXP
-                if (!EDGE && (LFBM5D_EXP & 8)) { d1[s] = (float)oA; d2[s] = (float)oB; d3[s] = 1.f; d4[s] = 2.f; } else
-#endif
-                { d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
-                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW]; }
+                d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
+                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
                 lc[s] = lcol[EDGE ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
             }
             oA += T * CW; oA = oA >= RR * CW ? oA - RR * CW : oA;
@@ -367,9 +357,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 /* left neighbour's value of the previous step; lane 0 takes the hand-off column */
                 const float left = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lc[s]), __float_as_int(curS),
                                                                               0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-#ifdef LFBM5D_EXP
-                if (!EDGE && (LFBM5D_EXP & 16)) { const float Sx = lc[s] + d1[s] + d2[s] + d3[s] + d4[s]; Sout[s] = Sx; curS = Sx; continue; }
-#endif
                 float S = left + curS;             /* core:3379-3386, same association */
                 S = S - left_prev;
                 S = S + d1[s];
@@ -409,9 +396,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                     if (__builtin_amdgcn_ballot_w64(v2 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v2, 0, 0);
                 }
                 /* hand-off column for the next strip (uniform address and value) */
-#ifdef LFBM5D_EXP
-                if (!EDGE && (LFBM5D_EXP & 128)) continue;
-#endif
                 const int il = 1 + t - last_lane;
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
                 lcol[EDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : il] = hv;
@@ -628,11 +612,10 @@ hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
                      + (a.n_stereo ? 32 * 64 * sizeof(float) : 0);    /* straightening buffer of the disparity tables */
     const unsigned n = a.n_self + a.n_stereo;
     if (!n) return hipSuccess;
-    static const size_t extra_lds = getenv("LFBM5D_SCAN_EXTRA_LDS") ? (size_t)atoi(getenv("LFBM5D_SCAN_EXTRA_LDS")) : 0;   /* occupancy experiments */
     switch (a.k) {
-        case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(n), dim3(64), lds + extra_lds, s, a); break;
-        case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(n), dim3(64), lds + extra_lds, s, a); break;
-        case 16: hipLaunchKernelGGL(k_bm_scan<16>, dim3(n), dim3(64), lds + extra_lds, s, a); break;
+        case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(n), dim3(64), lds, s, a); break;
+        case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(n), dim3(64), lds, s, a); break;
+        case 16: hipLaunchKernelGGL(k_bm_scan<16>, dim3(n), dim3(64), lds, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

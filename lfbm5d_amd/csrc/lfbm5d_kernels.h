@@ -91,11 +91,7 @@ struct AggArgs {
  * scan kernel, which walks one strip top to bottom, writes one contiguous stream per table. */
 __host__ __device__ inline size_t stereo_table_stride(unsigned W, unsigned H, unsigned k, unsigned nDisp) {
     const unsigned ncols = W - 2 * nDisp - (k - 1);
-#ifdef LFBM5D_TABLE_PAD
-    return (size_t)((ncols + 63) / 64) * 64 * H + LFBM5D_TABLE_PAD;
-#else
     return (size_t)((ncols + 63) / 64) * 64 * H;
-#endif
 }
 
 struct ScanArgs {

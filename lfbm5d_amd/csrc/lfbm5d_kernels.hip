@@ -1125,9 +1125,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
         const unsigned p = pos[patch];
         const bool ok = p != 0xffffffffu;
         const float* img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (ok ? p : 0u);
-#ifdef LFBM5D_EXP
-        if (LFBM5D_EXP & 16) img = (s ? a.basic : a.noisy) + ((size_t)st * a.C + c) * plane + (tid & 63) * 8;
-#endif
         float x[8][8];
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -1155,9 +1152,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     /* 4-D forward: one (n, pq) fibre of 9 values per thread */
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
-#ifdef LFBM5D_EXP
-    if (!(LFBM5D_EXP & 32))
-#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < S * nSx * K2; f += kDct8Threads) {
             const int s = f / (nSx * K2), r = f % (nSx * K2), n = r / K2, pq = r % K2;
@@ -1178,9 +1172,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
         const float sig = a.sigma[c];
         const float T = a.lambda * sig * 1.41421356237309505f;
         const float sig2 = sig * sig;
-#ifdef LFBM5D_EXP
-        if (!(LFBM5D_EXP & 64))
-#endif
         for (int f = tid; f < A * K2; f += kDct8Threads) {
             const int st = f / K2, pq = f % K2;
             const bool in_shape = !use_sadct || sh.mask_dct[st];
@@ -1218,9 +1209,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     float* F = STEP == 2 ? S1 : S0;
 
     /* 4-D inverse */
-#ifdef LFBM5D_EXP
-    if (!(LFBM5D_EXP & 32))
-#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * K2; f += kDct8Threads) {
             const int n = f / K2, pq = f % K2;
@@ -1236,9 +1224,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     __syncthreads();
 
     /* inverse 2-D DCT + store, one thread per patch: filt[g][n][st][c][64] */
-#ifdef LFBM5D_EXP
-    if (!(LFBM5D_EXP & 128))
-#endif
     for (int patch = tid; patch < NP; patch += kDct8Threads) {
         float x[8][8];
         const float* src = F + patch;
@@ -1464,9 +1449,6 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
-#ifdef LFBM5D_EXP
-    if (!(LFBM5D_EXP & 32))
-#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * K2; f += kDct8wThreads) {
             const int n = f / K2, pq = f % K2;
@@ -1499,9 +1481,6 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         const float sig = a.sigma[c];
         const float sig2 = sig * sig;
         const bool useSD = a.useSD != 0;
-#ifdef LFBM5D_EXP
-        if (!(LFBM5D_EXP & 64))
-#endif
         for (int f = tid; f < A * K2; f += kDct8wThreads) {
             const int st = f / K2, pq = f % K2;
             const bool in_shape = !use_sadct || sh.mask_dct[st];
@@ -1539,9 +1518,6 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
 
     PHASE_MARK();
     /* 4: 4-D inverse of the filtered stack (.y), two (n, pq) fibres per thread: pq and pq + 32 */
-#ifdef LFBM5D_EXP
-    if (!(LFBM5D_EXP & 32))
-#endif
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * (K2 / 2); f += kDct8wThreads) {
             const int n = f / (K2 / 2), pq = f % (K2 / 2);
@@ -1571,9 +1547,6 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     PHASE_MARK();
     /* 5: inverse 2-D DCT + store, two patches per thread (patch, patch + NPh): filt[g][n][st][c][64] */
     const int NPh = (NP + 1) / 2;
-#ifdef LFBM5D_EXP
-    if (!(LFBM5D_EXP & 128))
-#endif
     for (int pa = tid; pa < NPh; pa += kDct8wThreads) {
         const int pb = pa + NPh;
         const bool has_b = pb < NP;
