@@ -213,6 +213,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         /* column slots of this lane: constant over the strip */
         const int cx = stereo ? -1 : grid_index(x, gC, lastC, gN, gP);
         const int cx2 = (stereo || di == 0) ? -1 : grid_index(x + djs, gC, lastC, gN, gP);
+        /* byte offset of (grid column of this lane, this table's candidate) inside a grid row of `scores`; negative:
+         * this lane never stores.  A slot's offset is then row_slot * row_bytes + base (one multiply-add per step) */
+        const int base_fwd = (col_ok && cx >= 0) ? (cx * ncand + ord_fwd) * 4 : -1;
+        const int base_bwd = (col_ok && cx2 >= 0 && di > 0) ? (cx2 * ncand + ord_bwd) * 4 : -1;
+        const int row_bytes = gC * ncand * 4;
 
         /* D rows of the strip: ring column 0 <-> x = cb-1 */
         /* per-lane pieces of the chunk loads: byte offset inside the chunk's first row, in-band column masks */
@@ -387,9 +392,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                     } else {
                         /* rows of lanes that have not started / have finished are clamped into the table (masked by act) */
                         const short* rp = rs16 + min(max(b + 1 + t0 - lane, 0), H - T);
-                        const int r1 = rp[s], r2 = rp[s + di];
-                        v1 = (act && cx >= 0 && r1 >= 0) ? (int)(((unsigned)(r1 * gC + cx) * (unsigned)ncand + (unsigned)ord_fwd) * 4u) : -1;
-                        v2 = (act && cx2 >= 0 && r2 >= 0 && di > 0) ? (int)(((unsigned)(r2 * gC + cx2) * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
+                        const int r1 = rp[s], r2 = rp[s + di];                  /* -1: not a grid row */
+                        const bool ok1 = (r1 | base_fwd) >= 0, ok2 = (r2 | base_bwd) >= 0;
+                        v1 = (ok1 && (!EDGE || act)) ? r1 * row_bytes + base_fwd : -1;
+                        v2 = (ok2 && (!EDGE || act)) ? r2 * row_bytes + base_bwd : -1;
                     }
                     /* a store no lane takes part in is skipped (on the regular grid three steps in four) */
                     if (__builtin_amdgcn_ballot_w64(v1 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, v1, 0, 0);
