@@ -12,8 +12,9 @@
  * from the lane's own previous value and a one-lane shift -- instead of re-deriving distances by
  * direct SSD.  No FMA contraction in this file: it would change the rounding.
  *
- * Bound: latency of the dependent add chain (about 8 dependent VALU ops per step, ~(cols+64)*rows/64
- * steps per table); every table is an independent wave, so a pass keeps ~2000 waves in flight.
+ * Bound: one wave per SIMD (LDS), about 45 instructions per step (~(cols+64)*rows/64 steps per table) of which
+ * 58 % of the wave's cycles are issue and a third waits; plus the HBM write of the disparity tables.  Every
+ * table is an independent wave: a pass keeps ~2000 of them in two rounds of four per CU.
  */
 #include "lfbm5d_kernels.h"
 
@@ -67,8 +68,9 @@ __device__ __forceinline__ int grid_index(int v, int n, int last, int nHW, int p
 typedef float v4f __attribute__((ext_vector_type(4)));
 template <int K, int MODE>   /* MODE 0: self search on the regular grid, 1: self search on an irregular list, 2: disparity */
 __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, float* lds) {
-    /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows.  Sized so that five waves fit a CU
-     * at 560-wide windows (32 KiB each): the launch then takes two rounds of resident waves, not three */
+    /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows (+ T-1 mirror rows).  With the hand-off column,
+     * the row-slot table and the straightening buffer a wave takes just under 40 KiB at 560-wide windows: four
+     * waves per CU, one per SIMD */
     constexpr int T = K >= 12 ? 4 : 8, RR = 64 + K + 2 * T, CW = 64 + K;
     constexpr int DEP = LFBM5D_SCAN_DEPTH(T);   /* row-load pipeline depth in chunks */
     constexpr bool stereo = MODE == 2;

@@ -2,17 +2,23 @@
  * lfbm5d_kernels.hip -- HIP kernels of the LFBM5D core for gfx950 (MI355X), except block matching
  * (lfbm5d_bm.hip).
  *
- *   k_group      one workgroup per (5-D group, channel): gathers the nSx * A patches of the group
- *                into an LDS-resident stack, 2-D transform (id / DCT / bior1.5), 4-D angular
- *                transform (DCT or shape-adaptive DCT), 5th-dimension Haar/Hadamard + hard
- *                threshold or Wiener shrinkage, inverses, and writes the filtered patches plus the
- *                group weight.  Restates core:277-481 / :1054-1282.  LDS-bound (about 8 passes
- *                over a 72 KiB stack), no MFMA: the largest transform is 16 points.
- *   k_aggregate  per 16x16 output tile and SAI: gathers every filtered patch that overlaps the
+ *   k_group_pos / k_group_shape   geometry pre-pass of a core pass: where every patch of every 5-D group
+ *                is gathered from and aggregated at, SADCT bookkeeping per group (core:286-323, :503).
+ *   k_group_id_haar / _any        hard-thresholding step with tau_2D = id: one thread per pixel holds the
+ *                pixel of all nSx * A patches in registers (packed fp32), no LDS stack.
+ *   k_group_dct8w                  Wiener step with 8x8 patches and a 2-D DCT: noisy and pilot stacks as the
+ *                two halves of float2 values, LDS stack [coefficient][patch], packed fp32.
+ *   k_group_dct8, k_group          the other configurations: one workgroup per (group, channel), the
+ *                nSx * A * k^2 stack(s) in LDS, 2-D transform (id / DCT / bior1.5), 4-D angular
+ *                transform (DCT or shape-adaptive DCT), 5th-dimension Haar / Hadamard / DCT + hard
+ *                threshold or Wiener shrinkage, inverses, filtered patches and group weight out.
+ *                Restate core:277-481 / :1054-1282.  No MFMA: the largest transform is 16 points.
+ *   k_aggregate  per tile of 64 output pixels and SAI: gathers every filtered patch that overlaps the
  *                tile, in the reference's own order (reference patches in raster order, then match
  *                index), so num/den are reproducible run to run and need no float atomics.
  *                Restates core:484-528.
- *   small elementwise / reduction kernels for the window schedule of bm5d.cpp:165-407.
+ *   small elementwise / reduction kernels for the window schedule of bm5d.cpp:165-407, batched over the
+ *                SAIs of a window / of the light field.
  */
 #include "lfbm5d_kernels.h"
 
@@ -1595,7 +1601,7 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
 /* ================================ aggregation kernel ====================================== */
 
 
-/* Gather form of core:484-528.  One wavefront = one 8x8 pixel tile of one SAI (thread = pixel).
+/* Gather form of core:484-528.  One wavefront = one tile of 64 pixels of one SAI (thread = pixel).
  * Candidates are the patch instances (reference patch in raster order, then match index n) of the
  * reference patches whose search range can reach the tile; every pixel adds its contributions in
  * that order -- the reference's order for that pixel -- starting from the value already in num/den.
