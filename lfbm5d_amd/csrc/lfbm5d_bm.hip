@@ -171,12 +171,36 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     __syncthreads();
     if (lane == 0) lcol[0] = corner;
     {
+        /* First column (core:3367-3372): S[i][b] = S[i-1][b] + sum_q (D[i-1+K][b+q] - D[i-1][b+q]), the K terms added
+         * one after the other.  A lane owns a row: its K differences come from four 16-byte loads per image row (the
+         * columns b .. b+K-1 are always inside the band; rows past it are zeros), the loads of the next 64 rows are in
+         * flight while the serial chain of the current 64 runs. */
+        constexpr int K4 = K / 4;
+        auto load_e = [&](int i, v4f* lo1, v4f* lo2, v4f* hi1, v4f* hi2) {   /* row i-1 and row i-1+K of both images */
+            const int r0 = min(b + i - 1, H - 1), r1 = min(b + i - 1 + K, H - 1);
+#pragma unroll
+            for (int j = 0; j < K4; j++) {
+                lo1[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs1, (r0 * W + b + 4 * j) * 4, 0, 0));
+                lo2[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs2, (r0 * W + b + 4 * j) * 4, 0, 0));
+                hi1[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs1, (r1 * W + b + 4 * j) * 4, 0, 0));
+                hi2[j] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rs2, (r1 * W + b + 4 * j) * 4, 0, 0));
+            }
+        };
+        v4f lo1[K4], lo2[K4], hi1[K4], hi2[K4], nlo1[K4], nlo2[K4], nhi1[K4], nhi2[K4];
+        load_e(1 + lane, lo1, lo2, hi1, hi2);
         float carry = corner;
         for (int i0 = 1; i0 < nrows; i0 += 64) {
             const int i = i0 + lane;
+            if (i0 + 64 < nrows) load_e(i + 64, nlo1, nlo2, nhi1, nhi2);
             float e[K];
+            const bool lo_in = b + i - 1 < H - b, hi_in = b + i - 1 + K < H - b;   /* rows outside [b, H-b) read as zero */
 #pragma unroll
-            for (int q = 0; q < K; q++) e[q] = i < nrows ? D(b + i - 1 + K, b + q) - D(b + i - 1, b + q) : 0.0f;
+            for (int j = 0; j < K4; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float dl = lo2[j][q] - lo1[j][q], dh = hi2[j][q] - hi1[j][q];
+                    e[4 * j + q] = i < nrows ? (hi_in ? dh * dh : 0.0f) - (lo_in ? dl * dl : 0.0f) : 0.0f;
+                }
             const int m = min(64, nrows - i0);
             float mine = 0.0f;
             for (int l = 0; l < m; l++) {
@@ -187,6 +211,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 if (lane == l) mine = carry;
             }
             if (i < nrows) lcol[i] = mine;
+#pragma unroll
+            for (int j = 0; j < K4; j++) { lo1[j] = nlo1[j]; lo2[j] = nlo2[j]; hi1[j] = nhi1[j]; hi2[j] = nhi2[j]; }
         }
     }
     __syncthreads();
