@@ -371,8 +371,12 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         auto chunk = [&](auto edge_tag, int t0,
                          v4f* la1, v4f* la2, float& lb1, float& lb2,                   /* receive rows filled+(DEP-1)T .. */
                          const v4f* sa1, const v4f* sa2, float sb1, float sb2) {       /* rows filled .. go to the ring */
-            constexpr bool EDGE = decltype(edge_tag)::value;
-            load_chunk(edge_tag, filled + (DEP - 1) * T, la1, la2, lb1, lb2);
+            /* flavour 0: steady; 1: ramp-up (lanes start one after the other, every row and index still in range);
+             * 2: general edge (ramp-down, rows past the band, short tables) */
+            constexpr int FL = decltype(edge_tag)::value;
+            constexpr bool EDGE = FL != 0;          /* lane predicates */
+            constexpr bool REDGE = FL == 2;         /* row / index range handling */
+            load_chunk(std::integral_constant<bool, REDGE>{}, filled + (DEP - 1) * T, la1, la2, lb1, lb2);
             const float* pa = ring + oA;
             const float* pb = ring + oB;
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
@@ -380,7 +384,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             for (int s = 0; s < T; s++) {
                 d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
                 d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
-                lc[s] = lcol[EDGE ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
+                lc[s] = lcol[REDGE ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
             }
             oA += T * CW; oA = oA >= RR * CW ? oA - RR * CW : oA;
             oB += T * CW; oB = oB >= RR * CW ? oB - RR * CW : oB;
@@ -432,7 +436,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 /* hand-off column for the next strip (uniform address and value) */
                 const int il = 1 + t - last_lane;
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
-                lcol[EDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : il] = hv;
+                lcol[REDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : FL == 1 ? max(il, 0) : il] = hv;   /* ramp-up: rows < 1 land in slot 0... */
             }
             if (stereo) {
                 /* every 16-lane group has just completed 64-byte segments of four more rows (its last lane wrote
@@ -447,7 +451,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, val), rsTb, rv ? uvo : -1, (strip * H + b + t0 + 4 * h) * 256, 0);
                 }
             }
-            write_chunk(edge_tag, filled, wrow, sa1, sa2, sb1, sb2);
+            write_chunk(std::integral_constant<bool, REDGE>{}, filled, wrow, sa1, sa2, sb1, sb2);
             wrow = wrow + T == RR ? 0 : wrow + T;
             filled += T;
         };
@@ -460,25 +464,22 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             int tS0 = ((last_lane + 1 + G - 1) / G) * G;       /* step last_lane (that lane's start) is still an edge step */
             int tS1 = min(nrows - 1, band_rows - K - DEP * T);   /* chunks [t0, t0+T) with t0+T <= tS1 are steady */
             tS1 = tS1 > tS0 ? tS0 + ((tS1 - tS0) / G) * G : tS0;
+            /* ramp-up chunks may use the light flavour when every row they load, write and hand off is in range */
+            const bool light_up = tS0 + K + (DEP + 1) * T <= band_rows && tS0 + T < nrows;
             int t0 = 0;
-            for (int ph = 0; ph < 2; ph++) {
-                const int te = ph == 0 ? min(tS0, nsteps) : nsteps + (stereo ? 16 : 0);   /* + the chunks that flush the store stage */
-                SCAN_MARK(ph == 0 ? 2 : 4);
-                for (; t0 < te; t0 += G) {
+            auto group = [&](auto tag, int tg) {
 #pragma unroll
-                    for (int j = 0; j < DEP; j++)
-                        chunk(std::true_type{}, t0 + j * T, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
-                              A1[j], A2[j], Bq1[j], Bq2[j]);
-                }
-                SCAN_MARK(3);
-                if (ph == 0)
-                    for (; t0 < tS1; t0 += G) {
-#pragma unroll
-                        for (int j = 0; j < DEP; j++)
-                            chunk(std::false_type{}, t0 + j * T, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
-                                  A1[j], A2[j], Bq1[j], Bq2[j]);
-                    }
-            }
+                for (int j = 0; j < DEP; j++)
+                    chunk(tag, tg + j * T, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
+                          A1[j], A2[j], Bq1[j], Bq2[j]);
+            };
+            SCAN_MARK(2);
+            if (light_up) for (; t0 < min(tS0, nsteps); t0 += G) group(std::integral_constant<int, 1>{}, t0);
+            else          for (; t0 < min(tS0, nsteps); t0 += G) group(std::integral_constant<int, 2>{}, t0);
+            SCAN_MARK(3);
+            for (; t0 < tS1; t0 += G) group(std::integral_constant<int, 0>{}, t0);
+            SCAN_MARK(4);
+            for (; t0 < nsteps + (stereo ? 16 : 0); t0 += G) group(std::integral_constant<int, 2>{}, t0);   /* + the chunks that flush the store stage */
         }
         SCAN_MARK(3);
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
