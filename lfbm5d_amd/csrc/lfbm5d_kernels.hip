@@ -1317,6 +1317,15 @@ template <int NS> __device__ __forceinline__ void haar_fwd2(v2f* v) {
     }
 }
 
+/* a / b for the Wiener coefficient e^2 / (e^2 + sigma^2) (0 <= a < b, both normal or a = 0): reciprocal estimate and
+ * one correction step instead of the IEEE division sequence -- within one ulp of the quotient, which is well inside
+ * the float tolerance of this stage (the division was a tenth of the kernel's instructions) */
+__device__ __forceinline__ float wiener_div(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+
 /* phase 3 of k_group_dct8w on one (st, pq) fibre of nSx = NS float2 entries (x: noisy, y: pilot) */
 template <int NS, bool HAAR>
 __device__ __forceinline__ void wiener_fibre2(v2f* stack, int base, int stride, unsigned tau5, float sig2, bool in_shape,
@@ -1333,7 +1342,7 @@ __device__ __forceinline__ void wiener_fibre2(v2f* stack, int base, int stride, 
 #pragma unroll
             for (int n = 0; n < NS; n++) {
                 float value = e[n] * e[n];
-                value = __fdiv_rn(value, value + sig2);
+                value = wiener_div(value, value + sig2);
                 e[n] = o[n] * value;
                 wacc += value;
             }
