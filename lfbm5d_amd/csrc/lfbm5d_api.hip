@@ -397,7 +397,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
 
     AggArgs aa;
     std::memset(&aa, 0, sizeof(aa));
-    aa.num = d_num; aa.den = d_den; aa.filt = ga.filt; aa.wgt = ga.wgt; aa.aggpos = ga.aggpos; aa.n_refs_total = R; aa.refs = ga.refs;
+    aa.num = d_num; aa.den = d_den; aa.filt = ga.filt; aa.filt_bytes = (unsigned long long)R * Nst * A * C * k2 * sizeof(float); aa.wgt = ga.wgt; aa.aggpos = ga.aggpos; aa.n_refs_total = R; aa.refs = ga.refs;
     aa.self_idx = ga.self_idx; aa.self_cnt = ga.self_cnt; aa.best = ga.best; aa.shape = ga.shape; aa.tb = ga.tb;
     aa.ref_begin = ref_begin; aa.n_groups = n_groups; aa.n_ref_rows = c->n_ref_rows; aa.n_ref_cols = c->n_ref_cols;
     aa.Wb = Wb; aa.Hb = Hb; aa.C = C; aa.A = A; aa.k = k; aa.N = Nst; aa.pst = pst; aa.p = P->p;

@@ -71,6 +71,7 @@ struct AggArgs {
     float* num;
     float* den;
     const float* filt;
+    unsigned long long filt_bytes;   /* size of filt: below 4 GiB the gathers go through a buffer resource */
     const float* wgt;
     const unsigned* aggpos;     /* [A][R][N] */
     unsigned n_refs_total;

@@ -1628,10 +1628,11 @@ constexpr int kAggFlush = 64;   /* hits that make a consume phase worth starting
  * TW x TH: tile shape (64 pixels).  A filtered patch row is k floats, so wide flat tiles read longer
  * contiguous runs of it: 16x4 for k >= 12 (64-byte rows), 8x8 for k = 8 (a whole patch is two cache lines).
  * kAggPF chunks per scan round and kAggU hits per load round trade latency hiding against registers and LDS
- * (occupancy): the k = 8 pass has few hits per candidate and wants occupancy, the k = 16 pass deeper rounds. */
-template <bool WINDOWED, int TW, int TH, int kAggPF, int kAggU>
+ * (occupancy): the k = 8 pass has few hits per candidate and wants occupancy, the k = 16 pass deeper rounds.
+ * BIG: filt is 4 GiB or more (windows far beyond 560 x 560): 64-bit gather addresses instead of a buffer resource. */
+template <bool WINDOWED, int TW, int TH, int kAggPF, int kAggU, bool BIG>
 __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
-    constexpr int kAggCap = kAggFlush + kAggPF * 64;
+    constexpr int kAggCap = kAggFlush + kAggPF * 64 + kAggU;   /* + padding of the last round */
     __shared__ uint4 hit_a[kAggCap];       /* (py << 16) | px, offset of the patch in filt, weights of channels 0 and 1 */
     __shared__ float hit_w2[kAggCap];      /* weight of channel 2 */
     __shared__ float kai[WINDOWED ? kMaxK * kMaxK : 1];
@@ -1680,27 +1681,39 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     const unsigned div_m = ((1u << 20) + (unsigned)max(ncols_span, 1) - 1) / (unsigned)max(ncols_span, 1);
     const unsigned g_end = a.ref_begin + a.n_groups;
     const unsigned* apos = a.aggpos + (size_t)st * a.n_refs_total * N;
-    const unsigned cstride = (unsigned)k2 * 4u;       /* channel stride inside a filtered patch, bytes */
+    /* channel stride inside a filtered patch, bytes; greyscale: all three loads read channel 0 (its weights are 0) */
+    const unsigned cstride = C > 1 ? (unsigned)k2 * 4u : 0u;
+    const __amdgpu_buffer_rsrc_t rs_filt = __builtin_amdgcn_make_buffer_rsrc((void*)a.filt, 0, BIG ? 0 : (int)(unsigned)a.filt_bytes, 0x00020000u);
     unsigned nh = 0;   /* hits in the list (uniform) */
 
     auto consume = [&]() {
-        for (unsigned h0 = 0; h0 < nh; h0 += kAggU) {
+        /* pad the list to whole rounds with entries no pixel is covered by (position 0xffff, 0xffff; first patch; weight 0) */
+        const unsigned nh_pad = (nh + kAggU - 1) / kAggU * kAggU;
+        if (nh + lane < nh_pad) { hit_a[nh + lane] = make_uint4(0xffffffffu, 0u, 0u, 0u); hit_w2[nh + lane] = 0.0f; }
+        __builtin_amdgcn_wave_barrier();
+        for (unsigned h0 = 0; h0 < nh_pad; h0 += kAggU) {
             float val[kAggU][3], kw[kAggU][3];
 #pragma unroll
             for (int u = 0; u < kAggU; u++) {
-                const unsigned h = min(h0 + u, nh - 1);          /* rounds are padded with the last hit at zero weight */
-                const uint4 ha = hit_a[h];
-                const float w2 = hit_w2[h];
+                const uint4 ha = hit_a[h0 + u];
+                const float w2 = hit_w2[h0 + u];
                 const int dy = y - (int)(ha.x >> 16), dx = x - (int)(ha.x & 0xffffu);
-                const bool on = (unsigned)dy < (unsigned)k && (unsigned)dx < (unsigned)k && h0 + u < nh;
+                const bool on = (unsigned)dy < (unsigned)k && (unsigned)dx < (unsigned)k;
                 /* pixels the patch does not cover read the nearest pixel it does cover -- a pixel of this tile,
                  * so no extra cache line is touched ... */
                 const unsigned o = (unsigned)(min(max(dy, 0), k - 1) * k + min(max(dx, 0), k - 1));
                 const float kz = WINDOWED ? kai[o] : 1.0f;
-                const char* fp = reinterpret_cast<const char*>(a.filt) + ((size_t)ha.y + o) * 4;
-                val[u][0] = *reinterpret_cast<const float*>(fp);
-                val[u][1] = C > 1 ? *reinterpret_cast<const float*>(fp + cstride) : 0.0f;
-                val[u][2] = C > 2 ? *reinterpret_cast<const float*>(fp + 2 * cstride) : 0.0f;
+                if (BIG) {
+                    const char* fp = reinterpret_cast<const char*>(a.filt) + ((size_t)ha.y + o) * 4;
+                    val[u][0] = *reinterpret_cast<const float*>(fp);
+                    val[u][1] = *reinterpret_cast<const float*>(fp + cstride);
+                    val[u][2] = *reinterpret_cast<const float*>(fp + 2 * cstride);
+                } else {
+                    const int vo = (int)((ha.y + o) * 4u);
+                    val[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_filt, vo, 0, 0));
+                    val[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_filt, vo, (int)cstride, 0));
+                    val[u][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_filt, vo, (int)(2 * cstride), 0));
+                }
                 kw[u][0] = on ? kz * __uint_as_float(ha.z) : 0.0f;   /* ... and add it with weight zero */
                 kw[u][1] = on ? kz * __uint_as_float(ha.w) : 0.0f;
                 kw[u][2] = on ? kz * w2 : 0.0f;
@@ -1890,10 +1903,15 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
     const unsigned tw = wide ? 16 : 8, th = wide ? 4 : 8;
     const unsigned tiles = ((a.Wb + tw - 1) / tw) * ((a.Hb + th - 1) / th) * a.A;
     const dim3 grid(((tiles + 7) / 8) * 8), block(64);
-    if (a.k == 12)      hipLaunchKernelGGL((k_aggregate<true, 16, 4, 3, 12>), grid, block, 0, s, a);
-    else if (a.k == 8)  hipLaunchKernelGGL((k_aggregate<true, 8, 8, 2, 6>), grid, block, 0, s, a);
-    else if (wide)      hipLaunchKernelGGL((k_aggregate<false, 16, 4, 3, 12>), grid, block, 0, s, a);
-    else                hipLaunchKernelGGL((k_aggregate<false, 8, 8, 2, 6>), grid, block, 0, s, a);
+    const bool big = a.filt_bytes > 0xfffff000ull || getenv("LFBM5D_AGG_64BIT") != nullptr;   /* env: exercise the 64-bit path in tests */
+#define LFBM5D_AGG(W_, TW_, TH_, PF_, U_) \
+    do { if (big) hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, true>), grid, block, 0, s, a); \
+         else     hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, false>), grid, block, 0, s, a); } while (0)
+    if (a.k == 12)      LFBM5D_AGG(true, 16, 4, 3, 12);
+    else if (a.k == 8)  LFBM5D_AGG(true, 8, 8, 2, 6);
+    else if (wide)      LFBM5D_AGG(false, 16, 4, 3, 12);
+    else                LFBM5D_AGG(false, 8, 8, 2, 6);
+#undef LFBM5D_AGG
     return hipGetLastError();
 }
 

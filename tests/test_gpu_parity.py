@@ -335,6 +335,19 @@ def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
     monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
 
 
+def test_aggregation_64bit_gather_path_is_identical(ctx, monkeypatch):
+    """filt of 4 GiB and more switches the aggregation gathers from a buffer resource to 64-bit addresses; the
+    environment override runs that path on a small window: same bits."""
+    pk = (8, 6, 2, 8, 3, "dct", "sadct", "haar")
+    win, Wb, Hb, Cc = window(25.0, pk, 64)
+    basic = np.ascontiguousarray(0.5 * win + 0.5 * np.roll(win, 1, axis=1))
+    monkeypatch.delenv("LFBM5D_AGG_64BIT", raising=False)
+    n0, d0 = gpu_pass(ctx, 2, 25.0, pk, win, basic, Wb, Hb, Cc)
+    monkeypatch.setenv("LFBM5D_AGG_64BIT", "1")
+    n1, d1 = gpu_pass(ctx, 2, 25.0, pk, win, basic, Wb, Hb, Cc)
+    assert np.array_equal(n0, n1) and np.array_equal(d0, d1) and np.abs(d0).max() > 0
+
+
 def test_rccl_all_reduce_on_the_library_stream(ctx):
     """The collective of the multi-GPU schemes, on a one-rank communicator: RCCL loads, takes the library's
     non-blocking stream and returns the right sums (the only part of N > 1 a one-GPU box can run for real)."""
