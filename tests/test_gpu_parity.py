@@ -80,6 +80,10 @@ PASS_CASES = [
 
 @pytest.mark.parametrize("case", PASS_CASES, ids=[c[0] for c in PASS_CASES])
 def test_core_pass_matches_oracle(ctx, case):
+    _check_pass(ctx, case, strict=True)
+
+
+def _check_pass(ctx, case, strict):
     name, step, sigma, pk, crop, useSD = case
     win, Wb, Hb, Cc = window(sigma, pk, crop)
     basic = None
@@ -111,10 +115,18 @@ def test_core_pass_matches_oracle(ctx, case):
         assert np.array_equal(osh.reshape(Hb, Wb)[regr, regc], shape[st_i].reshape(Hb, Wb)[regr, regc])
     # aggregation buffers
     assert np.array_equal(den_o != 0, den_g != 0)
-    np.testing.assert_allclose(den_g, den_o, rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(num_g, num_o, rtol=2e-5, atol=2e-2 * max(1.0, float(np.abs(den_o).max())))
     eo, eg = Hh.estimate(num_o, den_o, win), Hh.estimate(num_g, den_g, win)
-    assert np.abs(eo - eg).max() < 2e-3
+    if strict:
+        np.testing.assert_allclose(den_g, den_o, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(num_g, num_o, rtol=2e-5, atol=2e-2 * max(1.0, float(np.abs(den_o).max())))
+        assert np.abs(eo - eg).max() < 2e-3
+    else:
+        # arbitrary configurations: the transforms accumulate in float here and in double in the oracle, so a hard
+        # threshold decision can flip for a coefficient within ~1e-6 of the threshold (one weight count changes by
+        # one) -- a few groups in a thousand with a 16x16 DCT; everything else stays at float round-off
+        bad = ~np.isclose(den_g, den_o, rtol=1e-4, atol=1e-7)
+        assert bad.mean() < (0.03 if step == 1 else 1e-4), bad.mean()
+        assert np.abs(eo - eg).mean() < 2e-4 and np.quantile(np.abs(eo - eg), 0.999) < 5e-2
 
 
 def test_pass_accumulates_into_existing_buffers_and_skips_processed_sais(ctx):
@@ -333,6 +345,35 @@ def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
         # instead of already denoised neighbours); 0.01-0.07 dB on the 17x17x512x512 workload, see DESIGN.md
         assert abs(O.psnr_lf(d, clean) - p0) < 0.5 and O.psnr_lf(d, clean) > O.psnr_lf(noisy, clean) + 8
     monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
+
+
+def _random_cases():
+    rng = np.random.default_rng(20261002)
+    cases = []
+    while len(cases) < 12:
+        step = int(rng.integers(1, 3))
+        k = int(rng.choice([8, 12, 16]))
+        N = int(rng.choice([1, 2, 4, 8, 16] if step == 2 else [1, 2, 4, 8]))
+        nSim, nDisp, p = int(rng.integers(3, 9)), int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        tau2 = str(rng.choice(["id", "dct", "bior"] if k != 12 else ["id", "dct"]))
+        tau4 = str(rng.choice(["id", "dct", "sadct"]))
+        tau5 = str(rng.choice(["haar", "hw", "dct"]))
+        ch, cw = int(rng.integers(k + 2 * (nSim + nDisp) + 6, 110)), int(rng.integers(k + 2 * (nSim + nDisp) + 6, 140))
+        sigma = float(rng.choice([10.0, 25.0, 50.0]))
+        if step * N * 9 * k * k * 4 > 150 * 1024:      # stack(s) beyond the LDS: refused loudly, see the unsupported test
+            continue
+        # useSD stays 0 here: the reference's sd_weighting_5d (core:3140-3173) subtracts two float sums of k^2 N
+        # terms that nearly cancel, so its value depends on the summation order to ~1e-3; the two dedicated
+        # useSD cases above pin well-conditioned inputs
+        cases.append((f"rnd{len(cases)}-s{step}-k{k}-N{N}-{tau2}-{tau4}-{tau5}-p{p}-{ch}x{cw}", step, sigma,
+                      (N, nSim, nDisp, k, p, tau2, tau4, tau5), (ch, cw), 0))
+    return cases
+
+
+@pytest.mark.parametrize("case", _random_cases(), ids=[c[0] for c in _random_cases()])
+def test_random_configurations_match_oracle(ctx, case):
+    """Seeded sweep over patch sizes, search ranges, steps, transforms and odd window shapes."""
+    _check_pass(ctx, case, strict=False)
 
 
 def test_aggregation_64bit_gather_path_is_identical(ctx, monkeypatch):
