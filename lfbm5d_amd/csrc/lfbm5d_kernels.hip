@@ -513,6 +513,149 @@ __device__ __forceinline__ void filter5(float* S0, float* S1, int base, int stri
 
 __device__ __forceinline__ int per_ext(int j, int L, int N) { int m = (j - L) % N; return m < 0 ? m + N : m; }
 
+/* ------------------------------------------------------------------------------------------
+ * bior1.5 2-D transform of K x K patches (K = 8, 16; lib_transforms.cpp:46-120 forward, :135-204 inverse), fast
+ * path: K threads per patch, thread = one row in the row passes and one column in the column passes, the row /
+ * column held in registers, all periodic-extension indices resolved at compile time.  A patch is copied from
+ * the stack into a work area laid out [patch][K][K+1] (the odd row stride makes both access directions free of
+ * LDS bank conflicts), transformed there through all levels and copied back.  The K threads of a patch sit in
+ * one wavefront, whose DS operations execute in order: no workgroup barrier inside.  Same taps in the same
+ * order as the generic path -- identical results.
+ * ------------------------------------------------------------------------------------------ */
+constexpr int bior_ext(int j, int N) { return (((j - 4) % N) + N) % N; }   /* per_ext(j, 4, N) */
+
+template <int K, int N1>
+__device__ __forceinline__ void bior_fwd_level(float* Tp, int r, TbPtr tb) {
+#pragma clang fp contract(off)   /* the reference's (and the oracle's) separate multiply and add: bit-identical coefficients */
+    if constexpr (N1 > 1) {
+        constexpr int N2 = N1 / 2, RS = K + 1;
+        if (r < N1) {   /* rows: first N2 outputs low-pass, next N2 high-pass */
+            float v[N1], o[N1];
+#pragma unroll
+            for (int c = 0; c < N1; c++) v[c] = Tp[r * RS + c];
+#pragma unroll
+            for (int j = 0; j < N1; j++) {
+                const int jj = j < N2 ? j : j - N2;
+                float acc = 0.0f;
+                if (j < N2) {
+#pragma unroll
+                    for (int t = 0; t < 10; t++) acc += v[bior_ext(t + 2 * jj, N1)] * tb->lpd[t];
+                } else {   /* the high-pass analysis filter has two taps (lib_transforms.cpp:215-277); the eight products with
+                            * its zero taps only ever add a zero */
+                    acc = v[bior_ext(4 + 2 * jj, N1)] * tb->hpd[4];
+                    acc += v[bior_ext(5 + 2 * jj, N1)] * tb->hpd[5];
+                }
+                o[j] = acc;
+            }
+#pragma unroll
+            for (int c = 0; c < N1; c++) Tp[r * RS + c] = o[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (r < N1) {   /* columns (thread = column r) */
+            float v[N1], o[N1];
+#pragma unroll
+            for (int i = 0; i < N1; i++) v[i] = Tp[i * RS + r];
+#pragma unroll
+            for (int i = 0; i < N1; i++) {
+                const int ii = i < N2 ? i : i - N2;
+                float acc = 0.0f;
+                if (i < N2) {
+#pragma unroll
+                    for (int t = 0; t < 10; t++) acc += v[bior_ext(t + 2 * ii, N1)] * tb->lpd[t];
+                } else {
+                    acc = v[bior_ext(4 + 2 * ii, N1)] * tb->hpd[4];
+                    acc += v[bior_ext(5 + 2 * ii, N1)] * tb->hpd[5];
+                }
+                o[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < N1; i++) Tp[i * RS + r] = o[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        bior_fwd_level<K, N1 / 2>(Tp, r, tb);
+    }
+}
+template <int K, int N1>
+__device__ __forceinline__ void bior_inv_level(float* Tp, int r, TbPtr tb) {
+#pragma clang fp contract(off)
+    if constexpr (N1 <= K) {
+        constexpr int N2 = N1 / 2, RS = K + 1;
+        if (r < N1) {   /* columns: out[2m] from the high-pass taps, out[2m+1] from the low-pass taps */
+            float v[N1], o[N1];
+#pragma unroll
+            for (int i = 0; i < N1; i++) v[i] = Tp[i * RS + r];
+#pragma unroll
+            for (int i = 0; i < N1; i++) {
+                const int m = i / 2;
+                float acc = 0.0f;
+                if (i & 1) {   /* the low-pass synthesis filter has two taps */
+                    acc = tb->lpr[4] * v[(4 * N2 + m) % N1];
+                    acc += tb->lpr[5] * v[(5 * N2 + m) % N1];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 10; t++) acc += tb->hpr[t] * v[(t * N2 + m) % N1];
+                }
+                o[i] = acc;
+            }
+#pragma unroll
+            for (int i = 0; i < N1; i++) Tp[i * RS + r] = o[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (r < N1) {   /* rows */
+            float v[N1], o[N1];
+#pragma unroll
+            for (int c = 0; c < N1; c++) v[c] = Tp[r * RS + c];
+#pragma unroll
+            for (int j = 0; j < N1; j++) {
+                const int m = j / 2;
+                float acc = 0.0f;
+                if (j & 1) {
+                    acc = tb->lpr[4] * v[(4 * N2 + m) % N1];
+                    acc += tb->lpr[5] * v[(5 * N2 + m) % N1];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 10; t++) acc += tb->hpr[t] * v[(t * N2 + m) % N1];
+                }
+                o[j] = acc;
+            }
+#pragma unroll
+            for (int c = 0; c < N1; c++) Tp[r * RS + c] = o[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+        bior_inv_level<K, N1 * 2>(Tp, r, tb);
+    }
+}
+/* work area: (kThreads / K) patches of K x (K+1) floats */
+template <int K> constexpr int bior_tmp_floats() { return (kThreads / K) * K * (K + 1); }
+template <int K, bool FWD>
+__device__ void bior2d_fast(float* S, float* tmp, int np, TbPtr tb) {
+    constexpr int PPI = kThreads / K, RS = K + 1;
+    const int tid = threadIdx.x, slot = tid / K, r = tid % K;
+    float* Tp = tmp + slot * K * RS;
+    for (int p0 = 0; p0 < np; p0 += PPI) {
+        const int patch = p0 + slot;
+        if (patch < np) {     /* uniform for the K threads of a patch */
+            float* X = S + (size_t)patch * K * K + r * K;
+            float x[K];
+#pragma unroll
+            for (int c4 = 0; c4 < K; c4 += 4) {
+                const v4f q = *reinterpret_cast<const v4f*>(X + c4);
+                x[c4] = q[0]; x[c4 + 1] = q[1]; x[c4 + 2] = q[2]; x[c4 + 3] = q[3];
+            }
+#pragma unroll
+            for (int c = 0; c < K; c++) Tp[r * RS + c] = x[c];
+            __builtin_amdgcn_wave_barrier();
+            if (FWD) bior_fwd_level<K, K>(Tp, r, tb); else bior_inv_level<K, 2>(Tp, r, tb);
+#pragma unroll
+            for (int c = 0; c < K; c++) x[c] = Tp[r * RS + c];
+#pragma unroll
+            for (int c4 = 0; c4 < K; c4 += 4) *reinterpret_cast<v4f*>(X + c4) = v4f{x[c4], x[c4 + 1], x[c4 + 2], x[c4 + 3]};
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+}
+
 /* 2-D forward transform of `np` patches stored back to back at S (k*k floats each).  All threads
  * of the workgroup call this. */
 
@@ -588,6 +731,8 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr 
         if (k == 12) return fwd2d_dct<12>(S, tmp, np, tb);
         return fwd2d_dct<16>(S, tmp, np, tb);
     }
+    if (tau2 == 7 && k == 16) return bior2d_fast<16, true>(S, tmp, np, tb);
+    if (tau2 == 7 && k == 8) return bior2d_fast<8, true>(S, tmp, np, tb);
     const int k2 = k * k, tid = threadIdx.x;
     const bool wave_local = k2 == 64;
     const int ppi = kThreads / k2 > 0 ? kThreads / k2 : 1; /* patches per iteration */
@@ -632,6 +777,8 @@ __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr 
         if (k == 12) return inv2d_dct<12>(S, tmp, np, tb);
         return inv2d_dct<16>(S, tmp, np, tb);
     }
+    if (tau2 == 7 && k == 16) return bior2d_fast<16, false>(S, tmp, np, tb);
+    if (tau2 == 7 && k == 8) return bior2d_fast<8, false>(S, tmp, np, tb);
     const int k2 = k * k, tid = threadIdx.x;
     const bool wave_local = k2 == 64;
     const int ppi = kThreads / k2 > 0 ? kThreads / k2 : 1;
@@ -889,9 +1036,9 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
  * through buffer resources with the per-patch part of the address in a scalar register (the patch
  * positions are uniform), so none of the 2 * NS * 9 memory operations needs address VGPRs; the
  * 3x3 angular DCTs run on pairs of patches (n, n + 1) with packed fp32 arithmetic. */
-template <int NS, bool HAAR>
+template <int NS, bool HAAR, bool LDSW = false>   /* LDSW: values come from / go back to an LDS work area [patch][k][k+1] (2-D transformed patches) */
 __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
-                                              ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2) {
+                                              ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2, float* work = nullptr) {
     const int k = a.k, k2 = k * k, A = 9;
     const unsigned plane = a.Wb * a.Hb;
     const TbPtr tb = (TbPtr)a.tb;
@@ -903,7 +1050,18 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
     constexpr int NH = NS > 1 ? NS / 2 : 1;
     v2f V[NH][9];
     const int voff = (int)(((unsigned)(pq / k) * a.Wb + pq % k) * 4u);
+    const int woff = (pq / k) * (k + 1) + pq % k;      /* this pixel inside a work-area patch */
     unsigned okbits[NS];
+    if (LDSW) {
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+#pragma unroll
+            for (int st = 0; st < 9; st++) {
+                const float x = work[(n * A + st) * k * (k + 1) + woff];
+                if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
+                okbits[n] = 0x1ffu;
+            }
+    } else
 #pragma unroll
     for (int n = 0; n < NS; n++) {
         okbits[n] = 0;
@@ -999,7 +1157,8 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
 #pragma unroll
         for (int st = 0; st < 9; st++) {
             const float r = n < NH ? V[n][st].x : V[n - NH][st].y;
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
+            if (LDSW) work[(n * A + st) * k * (k + 1) + woff] = r;
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
         }
 }
 
@@ -1052,6 +1211,104 @@ __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
  * the Hadamard / DCT fibre transforms need more registers and keep two */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar(GroupArgs a) { group_id_kernel<true>(a); }
 __global__ __launch_bounds__(256) void k_group_id_any(GroupArgs a) { group_id_kernel<false>(a); }
+
+/* ------------------------------------------------------------------------------------------
+ * Hard-thresholding step with tau_2D = bior1.5 and 16x16 patches (BASELINE configurations 4 and 5): the
+ * register-resident kernel above with a 2-D stage in front and behind it.  All nSx * A patches of the group
+ * are gathered into an LDS work area [patch][16][17], transformed in place by the fast bior1.5 path
+ * (bior_fwd_level / bior_inv_level, 16 threads per patch), handed to the per-pixel threads for the angular and
+ * 5th-dimension stages (group_id_body on the work area), transformed back and stored.
+ * ------------------------------------------------------------------------------------------ */
+template <bool HAAR>
+__device__ __forceinline__ void group_bior16_kernel(const GroupArgs& a) {
+    extern __shared__ float lds[];
+    __shared__ float red[3][4];
+    constexpr int K = 16, RS = K + 1, PSZ = K * RS, A = 9;
+    const int tid = threadIdx.x;
+    const unsigned g = a.ref_begin + blockIdx.x;
+    const int c = blockIdx.y;
+    const int N = a.N;
+    const int nSx = (int)a.self_cnt[g], NP = nSx * A;
+    typedef const __attribute__((address_space(4))) unsigned* cuptr;
+    const cuptr pos = (cuptr)(a.gpos + (size_t)g * N * A);
+    ShRef sh = group_shape(a, g);
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    const TbPtr tb = (TbPtr)a.tb;
+    float* work = lds;
+    /* gather: thread = pixel, scalar patch offsets like the tau_2D = id kernel */
+    {
+        const unsigned plane = a.Wb * a.Hb;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)((size_t)a.A * a.C * plane * 4), 0x00020000u);
+        const int voff = (int)(((unsigned)(tid / K) * a.Wb + tid % K) * 4u);
+        const int woff = (tid / K) * RS + tid % K;
+        for (int p0 = 0; p0 < NP; p0 += 24) {          /* 24 loads in flight */
+            float x[24];
+#pragma unroll
+            for (int u = 0; u < 24; u++) {
+                const int patch = p0 + u;
+                x[u] = 0.0f;
+                if (patch < NP) {
+                    const unsigned p = pos[patch];
+                    const bool ok = p != 0xffffffffu;
+                    const unsigned so = (((unsigned)(patch % A) * a.C + c) * plane + (ok ? p : 0u)) * 4u;
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
+                    x[u] = ok ? v : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 24; u++) if (p0 + u < NP) work[(p0 + u) * PSZ + woff] = x[u];
+        }
+    }
+    __syncthreads();
+    {   /* forward 2-D transform in place, 16 threads per patch */
+        const int slot = tid / K, r = tid % K;
+        for (int p0 = 0; p0 < NP; p0 += kThreads / K)
+            if (p0 + slot < NP) bior_fwd_level<K, K>(work + (p0 + slot) * PSZ, r, tb);
+    }
+    __syncthreads();
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    switch (nSx) {
+        case 1:  group_id_body<1, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
+        case 2:  group_id_body<2, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
+        case 4:  group_id_body<4, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
+        default: group_id_body<8, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
+    }
+    __syncthreads();
+    {   /* inverse 2-D transform in place */
+        const int slot = tid / K, r = tid % K;
+        for (int p0 = 0; p0 < NP; p0 += kThreads / K)
+            if (p0 + slot < NP) bior_inv_level<K, 2>(work + (p0 + slot) * PSZ, r, tb);
+    }
+    __syncthreads();
+    {   /* store the filtered patches: filt[g][n][st][c][256] */
+        float* const out = a.filt + (size_t)g * N * A * a.C * K * K;
+        const int woff = (tid / K) * RS + tid % K;
+        for (int patch = 0; patch < NP; patch++) out[((size_t)patch * a.C + c) * K * K + tid] = work[patch * PSZ + woff];
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < 4; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(nSx * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)nSx);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
+    }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_bior16_haar(GroupArgs a) { group_bior16_kernel<true>(a); }
+__global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_bior16_kernel<false>(a); }
 
 /* ------------------------------------------------------------------------------------------
  * 8x8 2-D DCT variant (the README Wiener configuration: k = 8, tau_2D = dct).  The 2-D transform
@@ -1851,7 +2108,9 @@ hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_str
 
 size_t group_lds_bytes(const GroupArgs& a) {
     const size_t stack = (size_t)a.N * a.A * a.k * a.k;
-    return ((a.step == 2 ? 2 : 1) * stack + 256) * sizeof(float);
+    /* + the 2-D stage's work area: one patch per wave-quarter for the generic path, [patch][k][k+1] for bior1.5 */
+    const size_t tmp = (a.tau2 == 7 && (a.k == 8 || a.k == 16)) ? (size_t)(kThreads / a.k) * a.k * (a.k + 1) : 256;
+    return ((a.step == 2 ? 2 : 1) * stack + tmp) * sizeof(float);
 }
 hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* geometry pre-pass: patch positions, aggregation positions, angular shapes */
@@ -1862,6 +2121,18 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
         if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
         else             hipLaunchKernelGGL(k_group_id_any, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.tau2 == 7 && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 on 16x16 patches, HT step */
+        const size_t lb = (size_t)a.N * 9 * 16 * 17 * sizeof(float);
+        static bool attrb = false;
+        if (!attrb) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_bior16_haar), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_bior16_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            attrb = true;
+        }
+        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_bior16_haar, dim3(a.n_groups, a.C), dim3(256), lb, s, a);
+        else             hipLaunchKernelGGL(k_group_bior16_any, dim3(a.n_groups, a.C), dim3(256), lb, s, a);
         return hipGetLastError();
     }
     if (a.tau2 == 5 && a.k == 8 && a.A == 9) {   /* 8x8 DCT: one thread per patch for the 2-D stage */

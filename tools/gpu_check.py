@@ -146,6 +146,8 @@ if __name__ == "__main__":
         check_pass(ctx, "small-ht-hw", lf, 25.0, 1, (4, 6, 2, 8, 3, "dct", "dct", "hw"), crop=64)
     if "k16n8" in which:
         check_pass(ctx, "ht-k16-n8", lf, 25.0, 1, (8, 8, 3, 16, 4, "id", "sadct", "haar"), crop=96)
+    if "c4" in which:
+        check_pass(ctx, "c4-ht-bior", lf, 10.0, 1, (8, 18, 6, 16, 4, "bior", "sadct", "haar"))
     if "readme" in which:
         check_pass(ctx, "readme-ht", lf, 25.0, 1, (8, 18, 6, 16, 4, "id", "sadct", "haar"))
         check_pass(ctx, "readme-wien", lf, 25.0, 2, (16, 18, 6, 8, 4, "dct", "sadct", "haar"))
