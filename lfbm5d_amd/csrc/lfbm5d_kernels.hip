@@ -1212,15 +1212,107 @@ __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar(GroupArgs a) { group_id_kernel<true>(a); }
 __global__ __launch_bounds__(256) void k_group_id_any(GroupArgs a) { group_id_kernel<false>(a); }
 
+__device__ __forceinline__ void dct8_fwd(float* x) {
+    const float a0 = 0.35355339059327376f;   /* 1/sqrt(8) */
+    const float h = 0.5f;
+    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
+                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
+    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
+    const float d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
+    const float p0 = s0 + s3, p1 = s1 + s2, m0 = s0 - s3, m1 = s1 - s2;
+    x[0] = a0 * (p0 + p1);
+    x[4] = (h * c4) * (p0 - p1);
+    x[2] = h * (c2 * m0 + c6 * m1);
+    x[6] = h * (c6 * m0 - c2 * m1);
+    x[1] = h * (c1 * d0 + c3 * d1 + c5 * d2 + c7 * d3);
+    x[3] = h * (c3 * d0 - c7 * d1 - c1 * d2 - c5 * d3);
+    x[5] = h * (c5 * d0 - c1 * d1 + c7 * d2 + c3 * d3);
+    x[7] = h * (c7 * d0 - c5 * d1 + c3 * d2 - c1 * d3);
+}
+__device__ __forceinline__ void dct8_inv(float* X) {
+    const float a0 = 0.35355339059327376f;
+    const float h = 0.5f;
+    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
+                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
+    const float e0 = a0 * X[0] + (h * c4) * X[4], e1 = a0 * X[0] - (h * c4) * X[4];
+    const float f0 = h * (c2 * X[2] + c6 * X[6]), f1 = h * (c6 * X[2] - c2 * X[6]);
+    const float E0 = e0 + f0, E1 = e1 + f1, E2 = e1 - f1, E3 = e0 - f0;
+    const float O0 = h * (c1 * X[1] + c3 * X[3] + c5 * X[5] + c7 * X[7]);
+    const float O1 = h * (c3 * X[1] - c7 * X[3] - c1 * X[5] - c5 * X[7]);
+    const float O2 = h * (c5 * X[1] - c1 * X[3] + c7 * X[5] + c3 * X[7]);
+    const float O3 = h * (c7 * X[1] - c5 * X[3] + c3 * X[5] - c1 * X[7]);
+    X[0] = E0 + O0; X[7] = E0 - O0;
+    X[1] = E1 + O1; X[6] = E1 - O1;
+    X[2] = E2 + O2; X[5] = E2 - O2;
+    X[3] = E3 + O3; X[4] = E3 - O3;
+}
+
+/* orthonormal 16-point DCT-II / its inverse in registers: even outputs = the 8-point transform of the folded sums
+ * (scaled by 1/sqrt2), odd outputs = an 8x8 product of the folded differences with cos((2n+1)(2k+1) pi/32) */
+constexpr float kCos32[16] = {1.0f, 0.99518472667219689f, 0.98078528040323044f, 0.95694033573220887f, 0.92387953251128674f,
+                              0.88192126434835503f, 0.83146961230254524f, 0.77301045336273696f, 0.70710678118654752f,
+                              0.63439328416364549f, 0.55557023301960222f, 0.47139673682599764f, 0.38268343236508977f,
+                              0.29028467725446236f, 0.19509032201612827f, 0.09801714032956060f};
+constexpr float cos32(int m) {   /* cos(m pi / 32), m odd */
+    m &= 63;
+    return m < 16 ? kCos32[m] : m < 32 ? -kCos32[32 - m] : m < 48 ? -kCos32[m - 32] : kCos32[64 - m];
+}
+__device__ __forceinline__ void dct16_fwd(float* x) {
+    const float r2 = 0.70710678118654752f, h = 0.35355339059327376f;   /* sqrt(2/16) */
+    float e[8], o[8];
+#pragma unroll
+    for (int n = 0; n < 8; n++) { e[n] = (x[n] + x[15 - n]) * r2; o[n] = (x[n] - x[15 - n]) * h; }
+    dct8_fwd(e);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 8; n++) acc += o[n] * cos32((2 * n + 1) * (2 * u + 1));
+        x[2 * u] = e[u]; x[2 * u + 1] = acc;
+    }
+}
+__device__ __forceinline__ void dct16_inv(float* X) {
+    const float r2 = 0.70710678118654752f, h = 0.35355339059327376f;
+    float e[8], o[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { e[u] = X[2 * u] * r2; o[u] = X[2 * u + 1] * h; }
+    dct8_inv(e);
+#pragma unroll
+    for (int n = 0; n < 8; n++) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += o[u] * cos32((2 * n + 1) * (2 * u + 1));
+        X[n] = e[n] + acc; X[15 - n] = e[n] - acc;
+    }
+}
+/* 2-D DCT of one 16x16 patch of the work area [16][17] by 16 threads (thread r: row r, then column r) */
+template <bool FWD>
+__device__ __forceinline__ void dct16_2d(float* Tp, int r) {
+    constexpr int RS = 17;
+    float x[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) x[c] = Tp[r * RS + c];
+    if (FWD) dct16_fwd(x); else dct16_inv(x);
+#pragma unroll
+    for (int c = 0; c < 16; c++) Tp[r * RS + c] = x[c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = Tp[i * RS + r];
+    if (FWD) dct16_fwd(x); else dct16_inv(x);
+#pragma unroll
+    for (int i = 0; i < 16; i++) Tp[i * RS + r] = x[i];
+    __builtin_amdgcn_wave_barrier();
+}
+
 /* ------------------------------------------------------------------------------------------
- * Hard-thresholding step with tau_2D = bior1.5 and 16x16 patches (BASELINE configurations 4 and 5): the
- * register-resident kernel above with a 2-D stage in front and behind it.  All nSx * A patches of the group
- * are gathered into an LDS work area [patch][16][17], transformed in place by the fast bior1.5 path
- * (bior_fwd_level / bior_inv_level, 16 threads per patch), handed to the per-pixel threads for the angular and
+ * Hard-thresholding step with tau_2D = bior1.5 or dct and 16x16 patches (BASELINE configurations 2, 4 and 5):
+ * the register-resident kernel above with a 2-D stage in front and behind it.  All nSx * A patches of the group
+ * are gathered into an LDS work area [patch][16][17], transformed in place, 16 threads per patch (bior1.5:
+ * bior_fwd_level / bior_inv_level; DCT: dct16_2d), handed to the per-pixel threads for the angular and
  * 5th-dimension stages (group_id_body on the work area), transformed back and stored.
  * ------------------------------------------------------------------------------------------ */
-template <bool HAAR>
-__device__ __forceinline__ void group_bior16_kernel(const GroupArgs& a) {
+template <bool HAAR, bool BIOR>
+__device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     extern __shared__ float lds[];
     __shared__ float red[3][4];
     constexpr int K = 16, RS = K + 1, PSZ = K * RS, A = 9;
@@ -1263,7 +1355,9 @@ __device__ __forceinline__ void group_bior16_kernel(const GroupArgs& a) {
     {   /* forward 2-D transform in place, 16 threads per patch */
         const int slot = tid / K, r = tid % K;
         for (int p0 = 0; p0 < NP; p0 += kThreads / K)
-            if (p0 + slot < NP) bior_fwd_level<K, K>(work + (p0 + slot) * PSZ, r, tb);
+            if (p0 + slot < NP) {
+                if (BIOR) bior_fwd_level<K, K>(work + (p0 + slot) * PSZ, r, tb); else dct16_2d<true>(work + (p0 + slot) * PSZ, r);
+            }
     }
     __syncthreads();
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -1277,7 +1371,9 @@ __device__ __forceinline__ void group_bior16_kernel(const GroupArgs& a) {
     {   /* inverse 2-D transform in place */
         const int slot = tid / K, r = tid % K;
         for (int p0 = 0; p0 < NP; p0 += kThreads / K)
-            if (p0 + slot < NP) bior_inv_level<K, 2>(work + (p0 + slot) * PSZ, r, tb);
+            if (p0 + slot < NP) {
+                if (BIOR) bior_inv_level<K, 2>(work + (p0 + slot) * PSZ, r, tb); else dct16_2d<false>(work + (p0 + slot) * PSZ, r);
+            }
     }
     __syncthreads();
     {   /* store the filtered patches: filt[g][n][st][c][256] */
@@ -1307,8 +1403,10 @@ __device__ __forceinline__ void group_bior16_kernel(const GroupArgs& a) {
         }
     }
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_bior16_haar(GroupArgs a) { group_bior16_kernel<true>(a); }
-__global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_bior16_kernel<false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true>(a); }
+__global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_t16_kernel<false, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false>(a); }
+__global__ __launch_bounds__(256) void k_group_dct16_any(GroupArgs a) { group_t16_kernel<false, false>(a); }
 
 /* ------------------------------------------------------------------------------------------
  * 8x8 2-D DCT variant (the README Wiener configuration: k = 8, tau_2D = dct).  The 2-D transform
@@ -1322,41 +1420,6 @@ __global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_b
  * its 64 coefficients and storing the 64 pixels of the filtered patch as four-float vectors.
  * ------------------------------------------------------------------------------------------ */
 constexpr int kDct8Threads = 320;
-
-__device__ __forceinline__ void dct8_fwd(float* x) {
-    const float a0 = 0.35355339059327376f;   /* 1/sqrt(8) */
-    const float h = 0.5f;
-    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
-                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
-    const float s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
-    const float d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
-    const float p0 = s0 + s3, p1 = s1 + s2, m0 = s0 - s3, m1 = s1 - s2;
-    x[0] = a0 * (p0 + p1);
-    x[4] = (h * c4) * (p0 - p1);
-    x[2] = h * (c2 * m0 + c6 * m1);
-    x[6] = h * (c6 * m0 - c2 * m1);
-    x[1] = h * (c1 * d0 + c3 * d1 + c5 * d2 + c7 * d3);
-    x[3] = h * (c3 * d0 - c7 * d1 - c1 * d2 - c5 * d3);
-    x[5] = h * (c5 * d0 - c1 * d1 + c7 * d2 + c3 * d3);
-    x[7] = h * (c7 * d0 - c5 * d1 + c3 * d2 - c1 * d3);
-}
-__device__ __forceinline__ void dct8_inv(float* X) {
-    const float a0 = 0.35355339059327376f;
-    const float h = 0.5f;
-    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
-                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
-    const float e0 = a0 * X[0] + (h * c4) * X[4], e1 = a0 * X[0] - (h * c4) * X[4];
-    const float f0 = h * (c2 * X[2] + c6 * X[6]), f1 = h * (c6 * X[2] - c2 * X[6]);
-    const float E0 = e0 + f0, E1 = e1 + f1, E2 = e1 - f1, E3 = e0 - f0;
-    const float O0 = h * (c1 * X[1] + c3 * X[3] + c5 * X[5] + c7 * X[7]);
-    const float O1 = h * (c3 * X[1] - c7 * X[3] - c1 * X[5] - c5 * X[7]);
-    const float O2 = h * (c5 * X[1] - c1 * X[3] + c7 * X[5] + c3 * X[7]);
-    const float O3 = h * (c7 * X[1] - c5 * X[3] + c3 * X[5] - c1 * X[7]);
-    X[0] = E0 + O0; X[7] = E0 - O0;
-    X[1] = E1 + O1; X[6] = E1 - O1;
-    X[2] = E2 + O2; X[5] = E2 - O2;
-    X[3] = E3 + O3; X[4] = E3 - O3;
-}
 
 template <int STEP>
 __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
@@ -1621,7 +1684,65 @@ __device__ __forceinline__ void wiener_fibre2(v2f* stack, int base, int stride, 
 
 constexpr int kDct8wThreads = 256;
 
-template <bool HAAR>
+/* bior1.5 on an 8x8 patch held by ONE thread (rows x[i][0..8)), all three levels in registers; T = float or a packed pair.
+ * Same taps, order and unfused arithmetic as bior_fwd_level / bior_inv_level (lib_transforms.cpp:46-204). */
+template <int N1, class T> __device__ __forceinline__ void bior_fwd_vec(T* v, TbPtr tb) {
+#pragma clang fp contract(off)
+    constexpr int N2 = N1 / 2;
+    T o[N1];
+#pragma unroll
+    for (int j = 0; j < N2; j++) {
+        T acc = v[bior_ext(2 * j, N1)] * tb->lpd[0];
+#pragma unroll
+        for (int t = 1; t < 10; t++) acc += v[bior_ext(t + 2 * j, N1)] * tb->lpd[t];
+        o[j] = acc;
+        T hi = v[bior_ext(4 + 2 * j, N1)] * tb->hpd[4];
+        hi += v[bior_ext(5 + 2 * j, N1)] * tb->hpd[5];
+        o[N2 + j] = hi;
+    }
+#pragma unroll
+    for (int j = 0; j < N1; j++) v[j] = o[j];
+}
+template <int N1, class T> __device__ __forceinline__ void bior_inv_vec(T* v, TbPtr tb) {
+#pragma clang fp contract(off)
+    constexpr int N2 = N1 / 2;
+    T o[N1];
+#pragma unroll
+    for (int m = 0; m < N2; m++) {
+        T acc = v[m % N1] * tb->hpr[0];
+#pragma unroll
+        for (int t = 1; t < 10; t++) acc += v[(t * N2 + m) % N1] * tb->hpr[t];
+        o[2 * m] = acc;
+        T lo = v[(4 * N2 + m) % N1] * tb->lpr[4];
+        lo += v[(5 * N2 + m) % N1] * tb->lpr[5];
+        o[2 * m + 1] = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < N1; j++) v[j] = o[j];
+}
+template <int N1, bool FWD, bool ROWS, class T> __device__ __forceinline__ void bior8_pass(T (*x)[8], TbPtr tb) {
+#pragma unroll
+    for (int a = 0; a < N1; a++) {
+        T v[N1];
+#pragma unroll
+        for (int b = 0; b < N1; b++) v[b] = ROWS ? x[a][b] : x[b][a];
+        if (FWD) bior_fwd_vec<N1>(v, tb); else bior_inv_vec<N1>(v, tb);
+#pragma unroll
+        for (int b = 0; b < N1; b++) { if (ROWS) x[a][b] = v[b]; else x[b][a] = v[b]; }
+    }
+}
+template <class T> __device__ __forceinline__ void bior8_fwd_2d(T (*x)[8], TbPtr tb) {
+    bior8_pass<8, true, true>(x, tb); bior8_pass<8, true, false>(x, tb);
+    bior8_pass<4, true, true>(x, tb); bior8_pass<4, true, false>(x, tb);
+    bior8_pass<2, true, true>(x, tb); bior8_pass<2, true, false>(x, tb);
+}
+template <class T> __device__ __forceinline__ void bior8_inv_2d(T (*x)[8], TbPtr tb) {
+    bior8_pass<2, false, false>(x, tb); bior8_pass<2, false, true>(x, tb);
+    bior8_pass<4, false, false>(x, tb); bior8_pass<4, false, true>(x, tb);
+    bior8_pass<8, false, false>(x, tb); bior8_pass<8, false, true>(x, tb);
+}
+
+template <bool HAAR, bool BIOR = false>   /* BIOR: tau_2D = bior1.5 instead of the DCT */
 __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     extern __shared__ float lds[];
     __shared__ float red[3][kDct8wThreads / 64];
@@ -1696,16 +1817,19 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         }
         __syncthreads();             /* every patch is in registers: the area becomes the stack */
         if (patch < NP) {
+            if (BIOR) bior8_fwd_2d(x, tb);
+            else {
 #pragma unroll
-            for (int i = 0; i < 8; i++) dct8_fwd_t(x[i]);
+                for (int i = 0; i < 8; i++) dct8_fwd_t(x[i]);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                v2f col[8];
+                for (int j = 0; j < 8; j++) {
+                    v2f col[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) col[i] = x[i][j];
-                dct8_fwd_t(col);
+                    for (int i = 0; i < 8; i++) col[i] = x[i][j];
+                    dct8_fwd_t(col);
 #pragma unroll
-                for (int i = 0; i < 8; i++) x[i][j] = col[i];
+                    for (int i = 0; i < 8; i++) x[i][j] = col[i];
+                }
             }
             v2f* dst = stack + patch;
 #pragma unroll
@@ -1829,17 +1953,20 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         for (int i = 0; i < 8; i++)
 #pragma unroll
             for (int j = 0; j < 8; j++) x[i][j] = v2f{sa[2 * (i * 8 + j) * NPp], sb[2 * (i * 8 + j) * NPp]};
+        if (BIOR) bior8_inv_2d(x, tb);
+        else {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            v2f col[8];
+            for (int j = 0; j < 8; j++) {
+                v2f col[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) col[i] = x[i][j];
-            dct8_inv_t(col);
+                for (int i = 0; i < 8; i++) col[i] = x[i][j];
+                dct8_inv_t(col);
 #pragma unroll
-            for (int i = 0; i < 8; i++) x[i][j] = col[i];
+                for (int i = 0; i < 8; i++) x[i][j] = col[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) dct8_inv_t(x[i]);
         }
-#pragma unroll
-        for (int i = 0; i < 8; i++) dct8_inv_t(x[i]);
         float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -2123,16 +2250,36 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         else             hipLaunchKernelGGL(k_group_id_any, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
         return hipGetLastError();
     }
-    if (a.tau2 == 7 && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 on 16x16 patches, HT step */
+    if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
         const size_t lb = (size_t)a.N * 9 * 16 * 17 * sizeof(float);
         static bool attrb = false;
         if (!attrb) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_bior16_haar), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_bior16_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct16_haar), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct16_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
             attrb = true;
         }
-        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_bior16_haar, dim3(a.n_groups, a.C), dim3(256), lb, s, a);
-        else             hipLaunchKernelGGL(k_group_bior16_any, dim3(a.n_groups, a.C), dim3(256), lb, s, a);
+        const dim3 grid(a.n_groups, a.C), block(256);
+        if (a.tau2 == 7) {
+            if (a.tau5 == 9) hipLaunchKernelGGL(k_group_bior16_haar, grid, block, lb, s, a);
+            else             hipLaunchKernelGGL(k_group_bior16_any, grid, block, lb, s, a);
+        } else {
+            if (a.tau5 == 9) hipLaunchKernelGGL(k_group_dct16_haar, grid, block, lb, s, a);
+            else             hipLaunchKernelGGL(k_group_dct16_any, grid, block, lb, s, a);
+        }
+        return hipGetLastError();
+    }
+    if (a.tau2 == 7 && a.k == 8 && a.A == 9 && a.step == 2) {   /* 8x8 bior1.5, Wiener step: the DCT kernel with the wavelet in its 2-D stage */
+        const size_t l8 = (size_t)2 * 64 * ((a.N * 9) | 1) * sizeof(float);
+        static bool attrwb = false;
+        if (!attrwb) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            attrwb = true;
+        }
+        if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
+        else             hipLaunchKernelGGL((k_group_dct8w<false, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
         return hipGetLastError();
     }
     if (a.tau2 == 5 && a.k == 8 && a.A == 9) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
@@ -2146,12 +2293,12 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* packed noisy/pilot pair */
             static bool attrw = false;
             if (!attrw) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
                 attrw = true;
             }
-            if (a.tau5 == 9) hipLaunchKernelGGL(k_group_dct8w<true>, dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
-            else             hipLaunchKernelGGL(k_group_dct8w<false>, dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
+            if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
+            else             hipLaunchKernelGGL((k_group_dct8w<false, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
             return hipGetLastError();
         }
         if (a.step == 2) hipLaunchKernelGGL(k_group_dct8<2>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);

@@ -63,6 +63,10 @@ PASS_CASES = [
     ("ht-k16-n8", 1, 25.0, (8, 8, 3, 16, 4, "id", "sadct", "haar"), 96, 0),
     ("ht-k16-bior-n1", 1, 50.0, (1, 6, 2, 16, 3, "bior", "sadct", "haar"), 96, 0),   # sigma >= 35: tauMatch 5000
     ("ht-k12", 1, 25.0, (4, 6, 2, 12, 4, "dct", "sadct", "haar"), 72, 0),
+    ("ht-k16-dct-n8", 1, 25.0, (8, 8, 3, 16, 4, "dct", "sadct", "haar"), 96, 0),     # BASELINE configuration 2's HT step
+    ("ht-k16-dct-hw", 1, 25.0, (4, 6, 2, 16, 3, "dct", "dct", "hw"), 96, 0),
+    ("ht-k16-bior-n8", 1, 10.0, (8, 8, 3, 16, 4, "bior", "sadct", "haar"), 96, 0),    # configuration 4's HT step
+    ("wien-bior-n8-hw", 2, 25.0, (8, 6, 2, 8, 3, "bior", "dct", "hw"), 64, 0),
     ("ht-usesd", 1, 25.0, (4, 6, 2, 8, 3, "id", "sadct", "haar"), 64, 1),
     ("wien-dct-sadct-haar", 2, 25.0, (8, 6, 2, 8, 3, "dct", "sadct", "haar"), 64, 0),
     ("wien-id-dct-hw", 2, 25.0, (8, 6, 2, 8, 3, "id", "dct", "hw"), 64, 0),

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel-class time of one centre-window core pass at the headline window size (3x3 SAIs of
 512x512, padded to 560x560), both steps, README parameters.  No oracle, GPU only: a quick
-A/B tool for kernel work.  usage: python tools/pass_time.py [reps] [H] [tau_2D of the HT step: id / bior / dct]"""
+A/B tool for kernel work.
+usage: python tools/pass_time.py [reps] [H] [tau_2D of the HT step: id / bior / dct] [tau_2D of the Wiener step]
+       [N of the HT step] [N of the Wiener step]"""
 import os
 import sys
 
@@ -23,7 +25,10 @@ def main():
     lf += sigma * rng.standard_normal(lf.shape).astype(np.float32)
     ctx = L.Context(0)
     ht2d = sys.argv[3] if len(sys.argv) > 3 else "id"
-    for step, pk in ((1, (8, 18, 6, 16, 4, ht2d, "sadct", "haar")), (2, (16, 18, 6, 8, 4, "dct", "sadct", "haar"))):
+    wi2d = sys.argv[4] if len(sys.argv) > 4 else "dct"
+    n1 = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+    n2 = int(sys.argv[6]) if len(sys.argv) > 6 else 16
+    for step, pk in ((1, (n1, 18, 6, 16, 4, ht2d, "sadct", "haar")), (2, (n2, 18, 6, 8, 4, wi2d, "sadct", "haar"))):
         P = core.make_params(sigma, 2.7, *pk)
         nHW = pk[1] + pk[2]
         pad = np.pad(lf, ((0, 0), (0, 0), (nHW, nHW), (nHW, nHW)), mode="symmetric")
