@@ -155,6 +155,34 @@ int lfbm5d_pass_device(lfbm5d_ctx* ctx, int step, const lfbm5d_params* P, unsign
                        const float* d_basic, float* d_num, float* d_den, const unsigned* h_mask,
                        const unsigned* h_procSAI, unsigned cst, unsigned pst);
 
+/* ---- per-SAI BM3D: the reference's comparison tool LFBM3Ddenoising, on the same kernels ----
+ * One step's parameters of run_bm3d (src/bm3d.h:11-34). */
+typedef struct {
+    float    sigma;        /* sigma                                   */
+    float    lambda3D;     /* lambdaHard3D (ignored by step 2)        */
+    unsigned N;            /* NHard / NWien: power of two, 2..32      */
+    unsigned nHW;          /* nHard / nWien: half search window       */
+    unsigned k;            /* kHard / kWien                           */
+    unsigned p;            /* pHard / pWien                           */
+    unsigned useSD;        /* useSD_h / useSD_w                       */
+    unsigned tau_2D;       /* LFBM5D_DCT | LFBM5D_BIOR                */
+    unsigned color_space;  /* LFBM5D_YUV | _YCBCR | _OPP | _RGB       */
+} lfbm5d_bm3d_params;
+/* == bm3d_1st_step (step = 1, src/bm3d.h:37-55) / bm3d_2nd_step (step = 2, src/bm3d.h:58-76) on a mirror-padded,
+ * colour-transformed image [C][Hb][Wb] in HBM; d_basic may be NULL for step 1.  d_out [C][Hb][Wb] receives
+ * numerator / denominator (pixels no patch reached keep the step's input image). */
+int lfbm5d_bm3d_step_device(lfbm5d_ctx* ctx, int step, const lfbm5d_bm3d_params* P, unsigned Wb, unsigned Hb,
+                            unsigned C, const float* d_noisy, const float* d_basic, float* d_out);
+/* == run_bm3d_LF (src/bm3d_LF.h:11-36; run_bm3d src/bm3d.h:11-34 with nb_threads == 1 for every SAI of the mask).
+ * Buffers [asize][C*H*W]; d_noisy is colour-transformed at entry and back at exit like the reference mutates
+ * LF_noisy (bm3d.cpp:115, :290); d_basic and d_denoised are outputs (RGB).  nHard must equal nWien. */
+int lfbm5d_bm3d_lf_device(lfbm5d_ctx* ctx, const lfbm5d_bm3d_params* hard, const lfbm5d_bm3d_params* wien,
+                          float* d_noisy, const unsigned* h_mask, float* d_basic, float* d_denoised,
+                          unsigned asize, unsigned W, unsigned H, unsigned C);
+int lfbm5d_bm3d_lf_host(lfbm5d_ctx* ctx, const lfbm5d_bm3d_params* hard, const lfbm5d_bm3d_params* wien,
+                        float* h_noisy, const unsigned* h_mask, float* h_basic, float* h_denoised,
+                        unsigned asize, unsigned W, unsigned H, unsigned C);
+
 /* ---- inspection of the last pass's block matching (parity tests) ----
  * n_refs reference patches in raster order; h_refs[n_refs] flat index i*Wb+j;
  * h_self_idx[n_refs*N], h_self_cnt[n_refs] (precompute_BM, core:3301);

@@ -6,11 +6,11 @@ Host-side mirror of the reference's operator interface for the hot path
 runs in liblfbm5d_hip.so (hand-written HIP for gfx950); there is no CPU fallback: importing works
 anywhere, creating a context without a GPU raises.
 """
-from .core import (Context, Params, Stats, run_bm5d_1st_step, run_bm5d_2nd_step, shard_rows,
+from .core import (Context, Params, Bm3dParams, Stats, run_bm5d_1st_step, run_bm5d_2nd_step, run_bm3d_LF, shard_rows,
                    YUV, YCBCR, OPP, RGB, ID, DCT, SADCT, BIOR, HADAMARD, HAAR, ROWMAJOR, COLMAJOR,
                    TAU, COLOR_SPACE, LfBm5dError, library_path, build_library)
 
-__all__ = ["Context", "Params", "Stats", "run_bm5d_1st_step", "run_bm5d_2nd_step", "shard_rows",
+__all__ = ["Context", "Params", "Bm3dParams", "Stats", "run_bm5d_1st_step", "run_bm5d_2nd_step", "run_bm3d_LF", "shard_rows",
            "YUV", "YCBCR", "OPP", "RGB", "ID", "DCT", "SADCT", "BIOR", "HADAMARD", "HAAR",
            "ROWMAJOR", "COLMAJOR", "TAU", "COLOR_SPACE", "LfBm5dError", "library_path",
            "build_library"]

@@ -31,6 +31,12 @@ class Params(C.Structure):
                 ("color_space", C.c_uint)]
 
 
+class Bm3dParams(C.Structure):
+    """lfbm5d_bm3d_params: one step's parameters of run_bm3d (src/bm3d.h:11-34)."""
+    _fields_ = [("sigma", C.c_float), ("lambda3D", C.c_float), ("N", C.c_uint), ("nHW", C.c_uint), ("k", C.c_uint),
+                ("p", C.c_uint), ("useSD", C.c_uint), ("tau_2D", C.c_uint), ("color_space", C.c_uint)]
+
+
 class Stats(C.Structure):
     _fields_ = [("windows", C.c_ulonglong), ("passes", C.c_ulonglong), ("groups", C.c_ulonglong),
                 ("stack_patches", C.c_ulonglong), ("sadct_groups", C.c_ulonglong),
@@ -95,6 +101,10 @@ def lib():
     L.lfbm5d_pass_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint, C.c_uint, C.c_uint,
                                      C.c_uint, C.c_uint, fp, fp, fp, fp, up, up, C.c_uint, C.c_uint]
     L.lfbm5d_last_bm.argtypes = [vp, up, vp, vp, vp, vp, vp]
+    bp = C.POINTER(Bm3dParams)
+    L.lfbm5d_bm3d_step_device.argtypes = [vp, C.c_int, bp, C.c_uint, C.c_uint, C.c_uint, fp, fp, fp]
+    L.lfbm5d_bm3d_lf_device.argtypes = [vp, bp, bp, fp, up, fp, fp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    L.lfbm5d_bm3d_lf_host.argtypes = [vp, bp, bp, fp, up, fp, fp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     L.lfbm5d_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.lfbm5d_free.argtypes = [vp]
     L.lfbm5d_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
@@ -127,6 +137,12 @@ def make_params(sigma, lam, N, nSim, nDisp, k, p, tau_2D, tau_4D, tau_5D, useSD=
     cs = COLOR_SPACE[color_space] if isinstance(color_space, str) else int(color_space)
     return Params(float(sigma), float(lam), int(N), int(nSim), int(nDisp), int(k), int(p),
                   int(bool(useSD)), t(tau_2D), t(tau_4D), t(tau_5D), cs)
+
+
+def make_bm3d_params(sigma, lam, N, nHW, k, p, tau_2D, useSD=0, color_space=OPP):
+    cs = COLOR_SPACE[color_space] if isinstance(color_space, str) else int(color_space)
+    return Bm3dParams(float(sigma), float(lam), int(N), int(nHW), int(k), int(p), int(bool(useSD)),
+                      TAU[tau_2D] if isinstance(tau_2D, str) else int(tau_2D), cs)
 
 
 def _u32(a):
@@ -230,6 +246,24 @@ class Context:
             _dev_ptr(basic) if basic is not None else None, _dev_ptr(num), _dev_ptr(den),
             m.ctypes.data_as(C.POINTER(C.c_uint)), pr.ctypes.data_as(C.POINTER(C.c_uint)), cst, pst))
 
+    # ---- per-SAI BM3D (LFBM3Ddenoising) ----
+    def bm3d_step(self, step, P, Wb, Hb, Cc, noisy, basic, out):
+        """bm3d_1st_step / bm3d_2nd_step on a mirror-padded image held in CUDA tensors; out = num / den."""
+        self._ck(self._L.lfbm5d_bm3d_step_device(self._h, step, C.byref(P), Wb, Hb, Cc, _dev_ptr(noisy),
+                                                 _dev_ptr(basic) if basic is not None else None, _dev_ptr(out)))
+
+    def bm3d_lf(self, hard, wien, noisy, mask, basic, denoised, W, H, Cc):
+        """run_bm3d_LF on device tensors (torch CUDA) or host arrays (numpy float32), [asize][C*H*W]."""
+        m = _u32(mask)
+        mp = m.ctypes.data_as(C.POINTER(C.c_uint))
+        if isinstance(noisy, np.ndarray):
+            self._ck(self._L.lfbm5d_bm3d_lf_host(self._h, C.byref(hard), C.byref(wien), noisy.ctypes.data_as(C.c_void_p), mp,
+                                                 basic.ctypes.data_as(C.c_void_p), denoised.ctypes.data_as(C.c_void_p),
+                                                 m.size, W, H, Cc))
+        else:
+            self._ck(self._L.lfbm5d_bm3d_lf_device(self._h, C.byref(hard), C.byref(wien), _dev_ptr(noisy), mp, _dev_ptr(basic),
+                                                   _dev_ptr(denoised), m.size, W, H, Cc))
+
     def last_windows(self):
         """Processed SAI of every window the last step call ran, in order."""
         n = self._L.lfbm5d_last_windows(self._h, None, 0)
@@ -281,4 +315,15 @@ def run_bm5d_2nd_step(sigma, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, ang_m
     P = make_params(sigma, 0.0, NWien, nSim, nDisp, kWien, pWien, tau_2D, tau_4D, tau_5D, useSD, color_space)
     (ctx or _ctx()).step2(P, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, ang_major, awidth, aheight, anWien,
                           width, height, chnls)
+    return 0
+
+
+def run_bm3d_LF(sigma, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, width, height, chnls, nHard, nWien, kHard, kWien,
+                NHard, NWien, pHard, pWien, useSD_h, useSD_w, tau_2D_hard, tau_2D_wien, lambdaHard3D, color_space,
+                nb_threads=1, sub_img_name="SAI", ctx=None):
+    """Same argument list as the reference's run_bm3d_LF (src/bm3d_LF.h:11-36): BM3D on every SAI of the mask.
+    nb_threads is accepted and ignored (untiled, nb_threads == 1 semantics)."""
+    hard = make_bm3d_params(sigma, lambdaHard3D, NHard, nHard, kHard, pHard, tau_2D_hard, useSD_h, color_space)
+    wien = make_bm3d_params(sigma, lambdaHard3D, NWien, nWien, kWien, pWien, tau_2D_wien, useSD_w, color_space)
+    (ctx or _ctx()).bm3d_lf(hard, wien, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, width, height, chnls)
     return 0

@@ -196,7 +196,17 @@ void build_tables(GroupTables& t, unsigned k, unsigned aw, unsigned ah) {
 
 bool is_pow2(unsigned n) { return n && !(n & (n - 1)); }
 
-int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsigned ah, unsigned C) {
+int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsigned ah, unsigned C, bool bm3d = false) {
+    if (bm3d) {   /* per-SAI BM3D flavour: one image, search band = search window, Hadamard along the stack */
+        if (aw != 1 || ah != 1) return fail(c, "BM3D works on single images");
+        if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
+        if (P->k != 8 && P->k != 12 && P->k != 16) return fail(c, "unsupported: patch size k must be 8, 12 or 16");
+        if (P->tau_2D != LFBM5D_DCT && P->tau_2D != LFBM5D_BIOR) return fail(c, "BM3D: tau_2D must be dct or bior");
+        if (P->tau_2D == LFBM5D_BIOR && !is_pow2(P->k)) return fail(c, "bior1.5 needs a power-of-two patch size");
+        if (!is_pow2(P->N) || P->N < 2 || P->N > (unsigned)kMaxN3) return fail(c, "unsupported: BM3D N must be a power of two in 2..32");
+        if (P->nSim < 1 || P->nSim > 48 || P->p < 1) return fail(c, "bad search window / step");
+        return 0;
+    }
     if (aw != 3 || ah != 3) return fail(c, "unsupported: angular search window must be 3x3 (aswSize 1)");
     if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
     if (P->k != 8 && P->k != 12 && P->k != 16) return fail(c, "unsupported: patch size k must be 8, 12 or 16");
@@ -218,8 +228,9 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
 /* ------------------------------------------------------------------------------------------ */
 int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsigned ah, unsigned Wb,
               unsigned Hb, unsigned C, const float* d_noisy, const float* d_basic, float* d_num,
-              float* d_den, const unsigned* h_mask, const unsigned* h_proc, unsigned cst, unsigned pst) {
-    if (validate(c, step, P, aw, ah, C)) return 1;
+              float* d_den, const unsigned* h_mask, const unsigned* h_proc, unsigned cst, unsigned pst,
+              bool bm3d = false) {
+    if (validate(c, step, P, aw, ah, C, bm3d)) return 1;
     if (step == 2 && !d_basic) return fail(c, "step 2 needs the basic estimate");
     const unsigned A = aw * ah, k = P->k, k2 = k * k, N = P->N, nHW = P->nSim + P->nDisp;
     const size_t plane = (size_t)Wb * Hb;
@@ -229,10 +240,12 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
 
     float sig[3] = {0, 0, 0};
     if (sigma_table(P->sigma, C, P->color_space, sig)) return fail(c, "bad color space");
-    const float tauMatch = (C == 1 ? 3.f : 1.f) * (sig[0] < 35.0f ? (step == 1 ? 3000 : 2000) : 5000); /* core:146/:915 */
+    const float tauMatch = bm3d ? (step == 1 ? (C == 1 ? 3.f : 1.f) * (sig[0] < 35.0f ? 2500 : 5000)        /* bm3d.cpp:339 */
+                                             : (sig[0] < 35.0f ? 400.f : 3500.f))                           /* bm3d.cpp:531 */
+                                : (C == 1 ? 3.f : 1.f) * (sig[0] < 35.0f ? (step == 1 ? 3000 : 2000) : 5000); /* core:146/:915 */
     const float thr = tauMatch * k * k;                                                                  /* core:3315 */
     float lambda = P->lambda;
-    if (step == 1 && P->tau_2D == LFBM5D_ID && P->tau_4D == LFBM5D_DCT) lambda /= (float)kSqrt2;          /* core:206-207 */
+    if (!bm3d && step == 1 && P->tau_2D == LFBM5D_ID && P->tau_4D == LFBM5D_DCT) lambda /= (float)kSqrt2; /* core:206-207 */
     unsigned mask_bits = 0, proc_bits = 0;
     for (unsigned st = 0; st < A; st++) { if (h_mask[st]) mask_bits |= 1u << st; if (h_proc[st]) proc_bits |= 1u << st; }
     if (!((mask_bits >> pst) & 1)) return fail(c, "processed SAI is empty");
@@ -391,6 +404,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.tau2 = P->tau_2D; ga.tau4 = P->tau_4D; ga.tau5 = P->tau_5D; ga.useSD = P->useSD;
     ga.step = step; ga.lambda = lambda; ga.fill_quirk = centre ? 1u : 0u;
     for (int i = 0; i < 3; i++) ga.sigma[i] = sig[i];
+    ga.bm3d = bm3d ? 1u : 0u;
     if (group_lds_bytes(ga) > 160 * 1024 - 4096) return fail(c, "unsupported: N*k*k stack does not fit the 160 KiB LDS");
     if (n_groups) HIPCK(c, launch_group(s, ga));
     HIPCK(c, hipEventRecord(pe.e[2], s));
@@ -403,6 +417,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     aa.Wb = Wb; aa.Hb = Hb; aa.C = C; aa.A = A; aa.k = k; aa.N = Nst; aa.pst = pst; aa.p = P->p;
     aa.nHW = nHW; aa.nSim = P->nSim; aa.nDisp = P->nDisp;
     aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D; aa.irregular = centre ? 0u : 1u;
+    aa.wchan0 = (bm3d && P->useSD) ? 1u : 0u;
     if (n_groups) HIPCK(c, launch_aggregate(s, aa));
     HIPCK(c, hipEventRecord(pe.e[3], s));
 
@@ -916,6 +931,107 @@ int lfbm5d_step2_host(lfbm5d_ctx* c, const lfbm5d_params* P, float* h_noisy, con
     HIPCK(c, hipMemcpy(c->h2d_basic.p, h_basic, bytes, hipMemcpyHostToDevice));
     HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
     if (run_step(c, 2, P, c->h2d_noisy.as<float>(), h_mask, c->h2d_basic.as<float>(), c->h2d_out.as<float>(), ang_major, awidth, aheight, an, W, H, C)) return 1;
+    HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h_basic, c->h2d_basic.p, bytes, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h_denoised, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* ---- per-SAI BM3D (LFBM3Ddenoising) ---- */
+namespace {
+/* bm3d_1st_step / bm3d_2nd_step (bm3d.cpp:315-690) on a mirror-padded image already in HBM: the core pass with a
+ * one-image "window" (A = 1, no disparity search, no angular transform, Hadamard along the stack), then
+ * d_out = numerator / denominator over the whole padded image (pixels no patch reached keep the input). */
+int bm3d_step(lfbm5d_ctx* c, int step, const lfbm5d_bm3d_params* B, unsigned Wb, unsigned Hb, unsigned C,
+              const float* d_noisy, const float* d_basic, float* d_out) {
+    lfbm5d_params P;
+    std::memset(&P, 0, sizeof(P));
+    P.sigma = B->sigma; P.lambda = B->lambda3D; P.N = B->N; P.nSim = B->nHW; P.nDisp = 0; P.k = B->k; P.p = B->p;
+    P.useSD = B->useSD; P.tau_2D = B->tau_2D; P.tau_4D = LFBM5D_ID; P.tau_5D = LFBM5D_HADAMARD; P.color_space = B->color_space;
+    const size_t n = (size_t)C * Wb * Hb;
+    HIPCK(c, c->w_num.reserve(n * sizeof(float)));
+    HIPCK(c, c->w_den.reserve(n * sizeof(float)));
+    HIPCK(c, hipMemsetAsync(c->w_num.p, 0, n * sizeof(float), c->stream));
+    HIPCK(c, hipMemsetAsync(c->w_den.p, 0, n * sizeof(float), c->stream));
+    const unsigned one = 1, zero = 0;
+    c->pass_rank = 0; c->pass_world = 1; c->pass_reduce = false;
+    if (pass_impl(c, step, &P, 1, 1, Wb, Hb, C, d_noisy, d_basic, c->w_num.as<float>(), c->w_den.as<float>(), &one, &zero, 0, 0, true))
+        return 1;
+    HIPCK(c, launch_estimate(c->stream, c->w_num.as<float>(), c->w_den.as<float>(), step == 1 ? d_noisy : d_basic, d_out, n));
+    return 0;
+}
+int bm3d_fold(lfbm5d_ctx* c, const lfbm5d_bm3d_params* B, unsigned C, int step) {
+    lfbm5d_params P; std::memset(&P, 0, sizeof(P)); P.k = B->k;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    return fold_counters(c, &P, 1, C, step);
+}
+/* run_bm3d_LF (bm3d_LF.cpp:75-125) -> run_bm3d (bm3d.cpp:86-300, nb_threads == 1) on device-resident buffers */
+int run_bm3d_lf(lfbm5d_ctx* c, const lfbm5d_bm3d_params* Hd, const lfbm5d_bm3d_params* Wn, float* d_noisy, const unsigned* h_mask,
+                float* d_basic, float* d_denoised, unsigned asize, unsigned W, unsigned H, unsigned C) {
+    if (Hd->nHW != Wn->nHW)   /* the reference pads both steps by nHard but crops the second by nWien (bm3d.cpp:126-189) */
+        return fail(c, "unsupported: BM3D needs nHard == nWien (the reference's crop is only right then)");
+    if (Hd->color_space != Wn->color_space || Hd->sigma != Wn->sigma) return fail(c, "BM3D: both steps share sigma and colour space");
+    hipStream_t s = c->stream;
+    const unsigned nP = Hd->nHW, Wb = W + 2 * nP, Hb = H + 2 * nP;
+    const size_t img = (size_t)C * W * H, imgb = (size_t)C * Wb * Hb;
+    HIPCK(c, c->w_noisy.reserve(imgb * sizeof(float)));
+    HIPCK(c, c->w_basic.reserve(imgb * sizeof(float)));
+    HIPCK(c, c->t_num.reserve(imgb * sizeof(float)));
+    float* const wn = c->w_noisy.as<float>(); float* const wb = c->w_basic.as<float>(); float* const wo = c->t_num.as<float>();
+    for (unsigned st = 0; st < asize; st++) {
+        if (!h_mask[st]) continue;
+        float* noisy = d_noisy + st * img; float* basic = d_basic + st * img; float* deno = d_denoised + st * img;
+        if (C == 3) HIPCK(c, launch_color(s, noisy, Hd->color_space, W * H, 1));
+        HIPCK(c, launch_symetrize(s, noisy, wn, W, H, C, nP));
+        if (bm3d_step(c, 1, Hd, Wb, Hb, C, wn, nullptr, wo)) return 1;
+        HIPCK(c, launch_unsymetrize(s, basic, wo, W, H, C, nP));
+        HIPCK(c, launch_symetrize(s, basic, wb, W, H, C, nP));
+        if (bm3d_step(c, 2, Wn, Wb, Hb, C, wn, wb, wo)) return 1;
+        HIPCK(c, launch_unsymetrize(s, deno, wo, W, H, C, nP));
+        if (C == 3) {
+            HIPCK(c, launch_color(s, deno, Hd->color_space, W * H, 0));
+            HIPCK(c, launch_color(s, noisy, Hd->color_space, W * H, 0));
+            HIPCK(c, launch_color(s, basic, Hd->color_space, W * H, 0));
+        }
+        if (c->pending.size() >= 64) {   /* bound the event pool on large light fields */
+            if (bm3d_fold(c, Hd, C, 1)) return 1;
+        }
+    }
+    return bm3d_fold(c, Wn, C, 2);
+}
+} /* namespace */
+
+int lfbm5d_bm3d_step_device(lfbm5d_ctx* c, int step, const lfbm5d_bm3d_params* P, unsigned Wb, unsigned Hb, unsigned C,
+                            const float* d_noisy, const float* d_basic, float* d_out) {
+    if (!c || !P || (step != 1 && step != 2)) return 1;
+    (void)hipSetDevice(c->device);
+    if (step == 2 && !d_basic) return fail(c, "step 2 needs the basic estimate");
+    if (bm3d_step(c, step, P, Wb, Hb, C, d_noisy, d_basic, d_out)) return 1;
+    return bm3d_fold(c, P, C, step);
+}
+
+int lfbm5d_bm3d_lf_device(lfbm5d_ctx* c, const lfbm5d_bm3d_params* hard, const lfbm5d_bm3d_params* wien, float* d_noisy,
+                          const unsigned* h_mask, float* d_basic, float* d_denoised, unsigned asize, unsigned W, unsigned H,
+                          unsigned C) {
+    if (!c || !hard || !wien || !h_mask) return 1;
+    (void)hipSetDevice(c->device);
+    return run_bm3d_lf(c, hard, wien, d_noisy, h_mask, d_basic, d_denoised, asize, W, H, C);
+}
+
+int lfbm5d_bm3d_lf_host(lfbm5d_ctx* c, const lfbm5d_bm3d_params* hard, const lfbm5d_bm3d_params* wien, float* h_noisy,
+                        const unsigned* h_mask, float* h_basic, float* h_denoised, unsigned asize, unsigned W, unsigned H,
+                        unsigned C) {
+    if (!c || !hard || !wien || !h_mask) return 1;
+    (void)hipSetDevice(c->device);
+    const size_t bytes = (size_t)asize * C * W * H * sizeof(float);
+    HIPCK(c, c->h2d_noisy.reserve(bytes));
+    HIPCK(c, c->h2d_basic.reserve(bytes));
+    HIPCK(c, c->h2d_out.reserve(bytes));
+    HIPCK(c, hipMemcpy(c->h2d_noisy.p, h_noisy, bytes, hipMemcpyHostToDevice));
+    HIPCK(c, hipMemsetAsync(c->h2d_basic.p, 0, bytes, c->stream));
+    HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
+    if (run_bm3d_lf(c, hard, wien, c->h2d_noisy.as<float>(), h_mask, c->h2d_basic.as<float>(), c->h2d_out.as<float>(), asize, W, H, C)) return 1;
     HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
     HIPCK(c, hipMemcpy(h_basic, c->h2d_basic.p, bytes, hipMemcpyDeviceToHost));
     HIPCK(c, hipMemcpy(h_denoised, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));

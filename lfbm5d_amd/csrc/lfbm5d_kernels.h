@@ -12,7 +12,8 @@ namespace lfbm5d {
 
 constexpr int kMaxK = 16;       /* patch side supported by the group kernel */
 constexpr int kMaxA = 9;        /* SAIs per angular window (an = 1) */
-constexpr int kMaxN = 16;      /* max similar patches (power of two) */
+constexpr int kMaxN = 16;      /* max similar patches (power of two) of the light-field core and its dedicated kernels */
+constexpr int kMaxN3 = 32;     /* ... of the per-SAI BM3D flavour (generic group kernel only) */
 
 /* Normalisation tables and filter taps, computed on the host exactly as the reference's
  * preProcess / preProcess_4d / preProcess_4d_sadct / bior15_coef do (bm3d.cpp:1101-1169,
@@ -65,6 +66,7 @@ struct GroupArgs {
     int step;
     float lambda;
     float sigma[3];
+    unsigned bm3d;              /* per-SAI BM3D arithmetic (bm3d.cpp:914-1027, :1345-1373): threshold without sqrt2, SD weight over nSx*k^2 */
 };
 
 struct AggArgs {
@@ -86,6 +88,7 @@ struct AggArgs {
     unsigned Wb, Hb, C, A, k, N, pst, p, nHW, nSim, nDisp;
     unsigned mask_bits, proc_bits, tau4;
     unsigned irregular;         /* reference list is not the regular grid (subset path): scan every reference */
+    unsigned wchan0;            /* every channel uses channel 0's group weight (sd_weighting of bm3d.cpp:1345-1373) */
 };
 
 /* Disparity score tables are laid out strip-major -- [strip of 64 columns][row][64] -- so that the

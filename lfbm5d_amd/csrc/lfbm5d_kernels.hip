@@ -883,7 +883,7 @@ __device__ __forceinline__ ShRef group_shape(const GroupArgs& a, unsigned g) {
 template <int STEP>
 __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     extern __shared__ float lds[];
-    __shared__ unsigned pos[kMaxN * kMaxA];
+    __shared__ unsigned pos[kMaxN * kMaxA];   /* >= kMaxN3 * 1 */
     __shared__ float red[3][kThreads / 64];
 
     const int tid = threadIdx.x;
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     {
         const float sig = a.sigma[c];
-        const float T = a.lambda * sig * 1.41421356237309505f; /* core:2431 */
+        const float T = a.bm3d ? a.lambda * sig : a.lambda * sig * 1.41421356237309505f; /* core:2431; bm3d.cpp:941 */
         const float sig2 = sig * sig;
         for (int f = tid; f < A * k2; f += kThreads) {
             const int st = f / k2, pq = f % k2;
@@ -973,7 +973,8 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
                 case 2:  filter5<2, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
                 case 4:  filter5<4, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
                 case 8:  filter5<8, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
-                default: filter5<16, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                case 16: filter5<16, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                default: filter5<32, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;   /* BM3D flavour only */
             }
         }
     }
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
         for (int i = 0; i < kThreads / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
         float wx;
         if (a.useSD) {
-            const float Nn = (float)(nSx * A);
+            const float Nn = a.bm3d ? (float)(nSx * k2) : (float)(nSx * A);
             const float res = (q - m * m / Nn) / (Nn - 1.0f);
             wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
         } else {
@@ -2140,7 +2141,7 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
             const int py = (int)(p[u] >> 16), px = (int)(p[u] & 0xffffu);
             hit[u] = p[u] != 0xffffffffu && py < ty0 + TH && py + k > ty0 && px < tx0 + TW && px + k > tx0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) w[u][c] = (hit[u] && c < C) ? a.wgt[(size_t)g[u] * C + c] : 0.0f;
+            for (int c = 0; c < 3; c++) w[u][c] = (hit[u] && c < C) ? a.wgt[(size_t)g[u] * C + (a.wchan0 ? 0 : c)] : 0.0f;
         }
         /* ordered append of the hits of these chunks */
 #pragma unroll
@@ -2244,7 +2245,7 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N * a.A), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_group_shape, grid1d(a.n_groups), dim3(256), 0, s, a);
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
-    if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) {
+    if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
         if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
         else             hipLaunchKernelGGL(k_group_id_any, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);

@@ -1154,6 +1154,181 @@ int run_step(int step, const orc_params* P, float* LF_noisy, const unsigned* mas
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Per-SAI BM3D (LFBM3Ddenoising): bm3d.cpp:86-690, bm3d_LF.cpp:75-125, nb_threads == 1          */
+/* ------------------------------------------------------------------------------------------ */
+/* One step on a mirror-padded image [C][Hb][Wb] (bm3d_1st_step bm3d.cpp:315-505, bm3d_2nd_step :507-690):
+ * out = numerator / denominator over the whole padded image.  tau_2D in {DCT, BIOR}; the third
+ * dimension is always the Hadamard transform (ht_filtering_hadamard :914-966,
+ * wiener_filtering_hadamard :980-1027).  Groups of one row of reference patches are independent. */
+int bm3d_step(int step, float sigma, float lambda3D, const float* noisy, const float* basic, float* out,
+              unsigned Wb, unsigned Hb, unsigned C, unsigned nHW, unsigned k, unsigned N, unsigned p,
+              unsigned useSD, unsigned color_space, unsigned tau_2D, orc_stats* stats) {
+    if (C > 3 || (step == 2 && !basic) || (tau_2D != ORC_DCT && tau_2D != ORC_BIOR)) return 1;
+    float sig[4];
+    if (sigma_table(sigma, C, color_space, sig)) return 1;
+    const float tauMatch = step == 1 ? (C == 1 ? 3.f : 1.f) * (sig[0] < 35.0f ? 2500 : 5000)   /* bm3d.cpp:339 */
+                                     : (sig[0] < 35.0f ? 400 : 3500);                         /* bm3d.cpp:531 */
+    const unsigned k2 = k * k;
+    const size_t plane = (size_t)Wb * Hb;
+    std::vector<unsigned> rows, cols;
+    ind_init(rows, Hb - k + 1, nHW, p);
+    ind_init(cols, Wb - k + 1, nHW, p);
+    std::vector<float> kaiser;
+    kaiser_window(k, kaiser);
+    Norms2D n2; n2.k = k; dct2d_norms(k, n2.cn, n2.cni);
+    /* block matching on channel 0 of the noisy image (step 1) / the basic estimate (step 2): bm3d.cpp:1187-1343
+     * is the routine core:3301-3461 was derived from (same tables, same scan order, same duplicate rule) --
+     * except that N == 1 has no short cut here: the single match is stored twice like any nSx_r == 1 */
+    std::vector<unsigned> refs;
+    for (unsigned i : rows) for (unsigned j : cols) refs.push_back(i * Wb + j);
+    const unsigned Nst = N > 2 ? N : 2;
+    std::vector<unsigned> self_idx(refs.size() * Nst), self_cnt(refs.size());
+    {
+        /* bm_self stores N entries per reference; run it with N >= 2 slots so that the duplicate fits */
+        const double t0 = now_s();
+        if (N >= 2) { if (bm_self(step == 1 ? noisy : basic, Wb, Hb, k, N, nHW, nHW, tauMatch, refs.data(), (unsigned)refs.size(), self_idx.data(), self_cnt.data())) return 1; }
+        else {
+            std::vector<unsigned> i2(refs.size() * 2), c2(refs.size());
+            if (bm_self(step == 1 ? noisy : basic, Wb, Hb, k, 2, nHW, nHW, tauMatch, refs.data(), (unsigned)refs.size(), i2.data(), c2.data())) return 1;
+            for (size_t r = 0; r < refs.size(); r++) { self_idx[2 * r] = i2[2 * r]; self_idx[2 * r + 1] = i2[2 * r]; self_cnt[r] = 2; }
+        }
+        if (stats) stats->bm_seconds += now_s() - t0;
+    }
+    std::vector<float> num(C * plane, 0.0f), den(C * plane, 0.0f);
+    struct G3 { unsigned nSx; std::vector<float> patches; float w[4]; };
+    for (size_t ri = 0; ri < rows.size(); ri++) {
+        std::vector<G3> outs(cols.size());
+        #pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
+        for (int jj = 0; jj < (int)cols.size(); jj++) {
+            const size_t slot = ri * cols.size() + jj;
+            const unsigned nSx = self_cnt[slot];
+            G3& go = outs[jj];
+            go.nSx = nSx;
+            const int S = step == 2 ? 2 : 1;
+            /* group_3D[s][c][pq][n] (bm3d.cpp:393-401 / :594-606); patches at column Wb - k read the tables'
+             * zero initialisation (bm3d.cpp:737, :857) */
+            std::vector<float> X((size_t)S * C * k2 * nSx, 0.0f), tmp(k2);
+            for (int s2 = 0; s2 < S; s2++) {
+                const float* src = (step == 2 && s2 == 1) ? basic : noisy;   /* s2 = 0: img, 1: est */
+                for (unsigned c = 0; c < C; c++)
+                    for (unsigned n = 0; n < nSx; n++) {
+                        const unsigned pos = self_idx[slot * Nst + n];
+                        if (pos % Wb >= Wb - k) continue;
+                        if (tau_2D == ORC_DCT) dct2d_fwd(src + c * plane + pos, Wb, tmp.data(), k, n2);
+                        else bior_fwd(src + c * plane + pos, Wb, tmp.data(), k);
+                        for (unsigned pq = 0; pq < k2; pq++) X[(((size_t)s2 * C + c) * k2 + pq) * nSx + n] = tmp[pq];
+                    }
+            }
+            float weight[4] = {0, 0, 0, 0};
+            const float coef = 1.0f / (float)nSx;
+            float* img = X.data();
+            float* est = X.data() + (size_t)C * k2 * nSx;
+            float* F;
+            if (step == 1) {   /* bm3d.cpp:914-966 */
+                const float coef_norm = std::sqrt((float)nSx);
+                for (unsigned v = 0; v < k2 * C; v++) hadamard(img + v * nSx, nSx);
+                for (unsigned c = 0; c < C; c++) {
+                    const float T = lambda3D * sig[c] * coef_norm;
+                    float* g = img + (size_t)c * nSx * k2;
+                    for (unsigned i = 0; i < k2 * nSx; i++) { if (std::fabs(g[i]) > T) weight[c]++; else g[i] = 0.0f; }
+                }
+                for (unsigned v = 0; v < k2 * C; v++) hadamard(img + v * nSx, nSx);
+                for (size_t i = 0; i < (size_t)C * k2 * nSx; i++) img[i] *= coef;
+                F = img;
+            } else {           /* bm3d.cpp:980-1027 */
+                for (unsigned v = 0; v < k2 * C; v++) { hadamard(img + v * nSx, nSx); hadamard(est + v * nSx, nSx); }
+                for (unsigned c = 0; c < C; c++) {
+                    const size_t dc = (size_t)c * nSx * k2;
+                    for (unsigned i = 0; i < k2 * nSx; i++) {
+                        float value = est[dc + i] * est[dc + i] * coef;
+                        value /= (value + sig[c] * sig[c]);
+                        est[dc + i] = img[dc + i] * value * coef;
+                        weight[c] += value;
+                    }
+                }
+                for (unsigned v = 0; v < k2 * C; v++) hadamard(est + v * nSx, nSx);
+                F = est;
+            }
+            if (!useSD)
+                for (unsigned c = 0; c < C; c++)
+                    go.w[c] = weight[c] > 0.0f ? 1.0f / (float)(sig[c] * sig[c] * weight[c]) : 1.0f;
+            else {             /* sd_weighting bm3d.cpp:1345-1373: reads the first nSx*k2 entries -- channel 0 -- for every channel */
+                const unsigned Nn = nSx * k2;
+                for (unsigned c = 0; c < C; c++) {
+                    float mean = 0.0f, sd = 0.0f;
+                    for (unsigned i = 0; i < Nn; i++) { mean += F[i]; sd += F[i] * F[i]; }
+                    const float res = (sd - mean * mean / (float)Nn) / (float)(Nn - 1);
+                    go.w[c] = res > 0.0f ? 1.0f / std::sqrt(res) : 0.0f;
+                }
+            }
+            /* inverse 2-D of every filtered patch (bm3d.cpp:428-432 / :639-643) */
+            go.patches.assign((size_t)C * nSx * k2, 0.0f);
+            for (unsigned c = 0; c < C; c++)
+                for (unsigned n = 0; n < nSx; n++) {
+                    float* pp = &go.patches[((size_t)c * nSx + n) * k2];
+                    for (unsigned pq = 0; pq < k2; pq++) pp[pq] = F[((size_t)c * k2 + pq) * nSx + n];
+                    if (tau_2D == ORC_DCT) dct2d_inv(pp, k, n2); else bior_inv(pp, k);
+                }
+        }
+        /* aggregation in the reference's order (bm3d.cpp:434-463 / :645-674) */
+        for (size_t jj = 0; jj < cols.size(); jj++) {
+            const size_t slot = ri * cols.size() + jj;
+            const G3& go = outs[jj];
+            for (unsigned c = 0; c < C; c++)
+                for (unsigned n = 0; n < go.nSx; n++) {
+                    const size_t base = self_idx[slot * Nst + n] + c * plane;
+                    const float* pp = &go.patches[((size_t)c * go.nSx + n) * k2];
+                    for (unsigned a = 0; a < k; a++)
+                        for (unsigned b = 0; b < k; b++) {
+                            num[base + a * Wb + b] += kaiser[a * k + b] * go.w[c] * pp[a * k + b];
+                            den[base + a * Wb + b] += kaiser[a * k + b] * go.w[c];
+                        }
+                }
+            if (stats) { stats->groups += 1; stats->stack_patches += go.nSx; }
+        }
+    }
+    for (size_t i = 0; i < C * plane; i++) out[i] = num[i] / den[i];   /* bm3d.cpp:467-468 / :678-679 */
+    if (stats) stats->passes += 1;
+    return 0;
+}
+
+/* run_bm3d (bm3d.cpp:86-300, nb_threads == 1 branch) for every SAI of the mask (bm3d_LF.cpp:111-121) */
+int run_bm3d_lf(float sigma, float* LF_noisy, const unsigned* mask, float* LF_basic, float* LF_denoised,
+                unsigned asize, unsigned W, unsigned H, unsigned C, unsigned nHard, unsigned nWien,
+                unsigned kHard, unsigned kWien, unsigned NHard, unsigned NWien, unsigned pHard, unsigned pWien,
+                unsigned useSD_h, unsigned useSD_w, unsigned tau_2D_hard, unsigned tau_2D_wien, float lambda3D,
+                unsigned color_space, orc_stats* stats) {
+    const double t0 = now_s();
+    const size_t img = (size_t)C * W * H;
+    const unsigned wb = W + 2 * nHard, hb = H + 2 * nHard;   /* both steps pad by nHard (bm3d.cpp:126-127, :158) */
+    std::vector<float> sym_noisy, sym_basic((size_t)C * wb * hb), sym_out((size_t)C * wb * hb);
+    for (unsigned st = 0; st < asize; st++) {
+        if (!mask[st]) continue;
+        float* noisy = LF_noisy + st * img; float* basic = LF_basic + st * img; float* deno = LF_denoised + st * img;
+        if (color_transform(noisy, color_space, W, H, C, true)) return 1;
+        sym_noisy.assign((size_t)C * wb * hb, 0.0f);
+        symetrize(noisy, sym_noisy.data(), W, H, C, nHard);
+        if (bm3d_step(1, sigma, lambda3D, sym_noisy.data(), nullptr, sym_out.data(), wb, hb, C, nHard, kHard, NHard, pHard,
+                      useSD_h, color_space, tau_2D_hard, stats)) return 1;
+        unsymetrize(basic, sym_out.data(), W, H, C, nHard);      /* crop bm3d.cpp:148-156 */
+        symetrize(basic, sym_basic.data(), W, H, C, nHard);
+        if (bm3d_step(2, sigma, lambda3D, sym_noisy.data(), sym_basic.data(), sym_out.data(), wb, hb, C, nWien, kWien, NWien,
+                      pWien, useSD_w, color_space, tau_2D_wien, stats)) return 1;
+        /* the crop of the second step uses nWien as the offset into the nHard-padded image (bm3d.cpp:181-189):
+         * only right when the two are equal, which every documented parameter set satisfies */
+        for (unsigned c = 0; c < C; c++)
+            for (unsigned i = 0; i < H; i++)
+                for (unsigned j = 0; j < W; j++)
+                    deno[((size_t)c * H + i) * W + j] = sym_out[(size_t)c * wb * hb + (size_t)(nWien + i) * wb + nWien + j];
+        if (color_transform(deno, color_space, W, H, C, false)) return 1;
+        if (color_transform(noisy, color_space, W, H, C, false)) return 1;
+        if (color_transform(basic, color_space, W, H, C, false)) return 1;
+    }
+    if (stats) stats->total_seconds += now_s() - t0;
+    return 0;
+}
+
 /* MT19937 (mt19937ar.c) */
 struct MT {
     unsigned long mt[624]; int mti = 625;
@@ -1203,6 +1378,19 @@ MT g_mt;
 /* ============================================================================================ */
 extern "C" {
 
+int orc_bm3d_step(int step, float sigma, float lambda3D, const float* noisy, const float* basic, float* out,
+                  unsigned Wb, unsigned Hb, unsigned C, unsigned nHW, unsigned k, unsigned N, unsigned p,
+                  unsigned useSD, unsigned color_space, unsigned tau_2D, orc_stats* stats) {
+    return bm3d_step(step, sigma, lambda3D, noisy, basic, out, Wb, Hb, C, nHW, k, N, p, useSD, color_space, tau_2D, stats);
+}
+int orc_run_bm3d_lf(float sigma, float* LF_noisy, const unsigned* mask, float* LF_basic, float* LF_denoised,
+                    unsigned asize, unsigned W, unsigned H, unsigned C, unsigned nHard, unsigned nWien,
+                    unsigned kHard, unsigned kWien, unsigned NHard, unsigned NWien, unsigned pHard, unsigned pWien,
+                    unsigned useSD_h, unsigned useSD_w, unsigned tau_2D_hard, unsigned tau_2D_wien, float lambda3D,
+                    unsigned color_space, orc_stats* stats) {
+    return run_bm3d_lf(sigma, LF_noisy, mask, LF_basic, LF_denoised, asize, W, H, C, nHard, nWien, kHard, kWien, NHard, NWien,
+                       pHard, pWien, useSD_h, useSD_w, tau_2D_hard, tau_2D_wien, lambda3D, color_space, stats);
+}
 void orc_haar_forward(float* v, unsigned n) { haar_fwd(v, n); }
 void orc_haar_inverse(float* v, unsigned n) { haar_inv(v, n); }
 void orc_hadamard(float* v, unsigned n) { hadamard(v, n); }

@@ -12,7 +12,10 @@
  *                                 normalisation tables :3191-3276, block matching :3301-3945
  *   src/bm5d.cpp                  run_bm5d_1st_step :88-747, run_bm5d_2nd_step :782-1452
  *                                 (nb_threads == 1 branch only)
- *   src/bm3d.cpp                  preProcess :1101-1169, dct_2d_inverse :1039-1071
+ *   src/bm3d.cpp                  preProcess :1101-1169, dct_2d_inverse :1039-1071; the per-SAI BM3D of
+ *                                 LFBM3Ddenoising: run_bm3d :86-300, bm3d_1st_step :315-505,
+ *                                 bm3d_2nd_step :507-690, Hadamard filters :914-1027, precompute_BM :1187-1343,
+ *                                 sd_weighting :1345-1373; src/bm3d_LF.cpp run_bm3d_LF :75-125
  *   src/lib_transforms.cpp        bior1.5 :46-277, Hadamard :290-321, Haar :403-471
  *   src/utilities.cpp             add_noise :154-185, symetrize :215-298, colour :482-599,
  *                                 estimate_sigma :633-684, ind_initialize :697-736, psnr :412-435
@@ -127,6 +130,19 @@ int orc_run_step2(const orc_params* P, float* LF_noisy, const unsigned* mask, fl
                   float* LF_denoised, unsigned ang_major, unsigned awidth, unsigned aheight,
                   unsigned an, unsigned W, unsigned H, unsigned C, int max_windows,
                   orc_stats* stats);
+
+/* ---- per-SAI BM3D (LFBM3Ddenoising: bm3d.cpp:86-690, bm3d_LF.cpp:75-125; nb_threads == 1 semantics) ----
+ * orc_bm3d_step: one step on a mirror-padded image [C][Hb][Wb]; out = numerator / denominator over the whole
+ * padded image.  orc_run_bm3d_lf: run_bm3d on every SAI of the mask; LF buffers [asize][C*W*H], LF_noisy
+ * mutated like the reference (colour forward, then inverse). */
+int orc_bm3d_step(int step, float sigma, float lambda3D, const float* noisy, const float* basic, float* out,
+                  unsigned Wb, unsigned Hb, unsigned C, unsigned nHW, unsigned k, unsigned N, unsigned p,
+                  unsigned useSD, unsigned color_space, unsigned tau_2D, orc_stats* stats);
+int orc_run_bm3d_lf(float sigma, float* LF_noisy, const unsigned* mask, float* LF_basic, float* LF_denoised,
+                    unsigned asize, unsigned W, unsigned H, unsigned C, unsigned nHard, unsigned nWien,
+                    unsigned kHard, unsigned kWien, unsigned NHard, unsigned NWien, unsigned pHard, unsigned pWien,
+                    unsigned useSD_h, unsigned useSD_w, unsigned tau_2D_hard, unsigned tau_2D_wien, float lambda3D,
+                    unsigned color_space, orc_stats* stats);
 
 /* ---- host helpers on the path ---- */
 void orc_mt_seed(unsigned long s);

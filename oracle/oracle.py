@@ -84,6 +84,8 @@ def lib():
     L.orc_run_step2.argtypes = [C.POINTER(Params), _f32p, _u32p, _f32p, _f32p, C.c_uint, C.c_uint,
                                 C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int,
                                 C.POINTER(Stats)]
+    L.orc_bm3d_step.argtypes = [C.c_int, C.c_float, C.c_float, _f32p, C.c_void_p, _f32p] + [C.c_uint] * 10 + [C.POINTER(Stats)]
+    L.orc_run_bm3d_lf.argtypes = [C.c_float, _f32p, _u32p, _f32p, _f32p] + [C.c_uint] * 16 + [C.c_float, C.c_uint, C.POINTER(Stats)]
     L.orc_mt_seed.argtypes = [C.c_ulong]
     L.orc_mt_int32.restype = C.c_ulong
     L.orc_mt_res53.restype = C.c_double
@@ -181,4 +183,38 @@ def run_step2(P, noisy, basic, mask, ang_major, aw, ah, an, W, H, Cc, max_window
                          max_windows, C.byref(st))
     if rc:
         raise RuntimeError("orc_run_step2 failed")
+    return noisy, basic, den, st
+
+
+def bm3d_step(step, sigma, lam, noisy_sym, basic_sym, Wb, Hb, Cc, nHW, k, N, p, tau2, useSD=0, cs="opp"):
+    """One BM3D step (bm3d.cpp:315-690) on a mirror-padded image [C][Hb][Wb]; returns numerator / denominator."""
+    L = lib()
+    noisy_sym = np.ascontiguousarray(noisy_sym, np.float32)
+    out = np.zeros_like(noisy_sym)
+    st = Stats()
+    b = None
+    if basic_sym is not None:
+        basic_sym = np.ascontiguousarray(basic_sym, np.float32)
+        b = basic_sym.ctypes.data_as(C.c_void_p)
+    rc = L.orc_bm3d_step(step, sigma, lam, noisy_sym.reshape(-1), b, out.reshape(-1), Wb, Hb, Cc, nHW, k, N, p, useSD,
+                         CS[cs] if isinstance(cs, str) else cs, TAU[tau2] if isinstance(tau2, str) else tau2, C.byref(st))
+    if rc:
+        raise RuntimeError("orc_bm3d_step failed")
+    return out, st
+
+
+def run_bm3d_lf(sigma, lam, noisy, mask, W, H, Cc, hard, wien, cs="opp"):
+    """run_bm3d_LF (bm3d_LF.cpp:75-125).  hard / wien = (N, n, k, p, tau_2D, useSD).  Returns the mutated noisy LF,
+    the basic and the denoised light fields and the stats."""
+    L = lib()
+    noisy = np.ascontiguousarray(noisy, np.float32).copy()
+    basic = np.zeros_like(noisy)
+    den = np.zeros_like(noisy)
+    st = Stats()
+    t = lambda v: TAU[v] if isinstance(v, str) else v
+    rc = L.orc_run_bm3d_lf(sigma, noisy.reshape(-1), np.ascontiguousarray(mask, np.uint32), basic.reshape(-1), den.reshape(-1),
+                           noisy.shape[0], W, H, Cc, hard[1], wien[1], hard[2], wien[2], hard[0], wien[0], hard[3], wien[3],
+                           hard[5], wien[5], t(hard[4]), t(wien[4]), lam, CS[cs] if isinstance(cs, str) else cs, C.byref(st))
+    if rc:
+        raise RuntimeError("orc_run_bm3d_lf failed")
     return noisy, basic, den, st

@@ -442,3 +442,87 @@ def test_full_size_properties_9x9x512(ctx):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert psnr(noisy0) + 8 < psnr(outs[0][0]) < psnr(outs[0][1])
     assert torch.isfinite(outs[0][1]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# per-SAI BM3D (LFBM3Ddenoising): the same kernels with a one-image window
+# ------------------------------------------------------------------------------------------------
+BM3D_CASES = [
+    # name, sigma, grey, crop, hard (N, n, k, p, tau_2D, useSD), wien
+    ("readme", 25.0, False, 80, (16, 16, 8, 3, "bior", 0), (32, 16, 8, 3, "dct", 0)),       # README.md:51
+    ("sigma40-dct-bior", 40.0, False, 64, (8, 8, 8, 4, "dct", 0), (16, 8, 8, 4, "bior", 0)),   # tauMatch 5000 / 3500
+    ("grey-k12", 25.0, True, 72, (16, 10, 12, 4, "dct", 0), (16, 10, 12, 4, "dct", 0)),
+    ("k16-bior", 10.0, False, 96, (4, 6, 16, 5, "bior", 0), (8, 6, 16, 5, "bior", 0)),
+]
+
+
+@pytest.mark.parametrize("case", BM3D_CASES, ids=[c[0] for c in BM3D_CASES])
+def test_bm3d_steps_match_oracle(ctx, case):
+    """bm3d_1st_step / bm3d_2nd_step through lfbm5d_bm3d_step_device against the oracle's restatement
+    (bm3d.cpp:315-690) on the same padded image; step 2 runs on the ORACLE's basic estimate."""
+    from lfbm5d_amd import core
+    _, sigma, grey, crop, hard, wien = case
+    lf = Hh.source_lf(crop=crop)[:1]
+    if grey:
+        lf = lf[:, :1]
+    Cc = lf.shape[1]
+    clean, noisy = Hh.noisy_lf(lf, sigma)
+    nP = hard[1]
+    win, Wb, Hb = Hh.padded_window(noisy, crop, crop, Cc, nP)
+    inner = np.zeros((Cc, Hb, Wb), bool)
+    inner[:, nP:-nP, nP:-nP] = True
+    inner = inner.reshape(-1)
+    b_o, st1 = O.bm3d_step(1, sigma, 2.7, win[0], None, Wb, Hb, Cc, hard[1], hard[2], hard[0], hard[3], hard[4], hard[5])
+    d_win = torch.from_numpy(win[0]).cuda()
+    d_out = torch.zeros_like(d_win)
+    ctx.reset_stats()
+    ctx.bm3d_step(1, core.make_bm3d_params(sigma, 2.7, hard[0], hard[1], hard[2], hard[3], hard[4], hard[5]), Wb, Hb, Cc, d_win, None, d_out)
+    s = ctx.stats()
+    assert (s.groups, s.stack_patches) == (st1.groups, st1.stack_patches)      # identical matching
+    b_g = d_out.cpu().numpy()
+    assert np.isfinite(b_o[inner]).all()
+    assert np.abs(b_g - b_o)[inner].max() < 2e-3
+    # second step on identical inputs: crop + re-pad the oracle's basic estimate like run_bm3d does (bm3d.cpp:148-158)
+    basic = np.zeros((1, Cc * crop * crop), np.float32)
+    O.lib().orc_unsymetrize(basic[0], b_o, crop, crop, Cc, nP)
+    bwin, _, _ = Hh.padded_window(basic, crop, crop, Cc, nP, color=False)
+    d_o, st2 = O.bm3d_step(2, sigma, 2.7, win[0], bwin[0], Wb, Hb, Cc, wien[1], wien[2], wien[0], wien[3], wien[4], wien[5])
+    d_b = torch.from_numpy(bwin[0]).cuda()
+    ctx.reset_stats()
+    ctx.bm3d_step(2, core.make_bm3d_params(sigma, 2.7, wien[0], wien[1], wien[2], wien[3], wien[4], wien[5]), Wb, Hb, Cc, d_win, d_b, d_out)
+    s = ctx.stats()
+    assert (s.groups, s.stack_patches) == (st2.groups, st2.stack_patches)
+    assert np.abs(d_out.cpu().numpy() - d_o)[inner].max() < 2e-3
+
+
+def test_run_bm3d_lf_matches_oracle(ctx):
+    """run_bm3d_LF (bm3d_LF.cpp:75-125) on a 2-SAI light field with one empty SAI in between, host buffers through the
+    reference-named wrapper: outputs and the in-place drift of LF_noisy like the oracle."""
+    import lfbm5d_amd as L
+    crop, sigma = 64, 25.0
+    clean, noisy = Hh.noisy_lf(Hh.source_lf(crop=crop)[:3], sigma)
+    mask = np.array([1, 0, 1], np.uint32)
+    hard, wien = (16, 8, 8, 3, "bior", 0), (32, 8, 8, 3, "dct", 0)
+    n_o, b_o, d_o, _ = O.run_bm3d_lf(sigma, 2.7, noisy, mask, crop, crop, 3, hard, wien)
+    n_g = noisy.copy(); b_g = np.zeros_like(noisy); d_g = np.zeros_like(noisy)
+    rc = L.run_bm3d_LF(sigma, n_g, mask, b_g, d_g, crop, crop, 3, hard[1], wien[1], hard[2], wien[2], hard[0], wien[0],
+                       hard[3], wien[3], False, False, L.BIOR, L.DCT, 2.7, L.OPP, ctx=ctx)
+    assert rc == 0
+    assert np.abs(n_g - n_o).max() < 1e-4 and np.abs(n_g[1] - noisy[1]).max() == 0     # empty SAI untouched
+    assert np.abs(b_g - b_o).max() < 2e-3
+    assert np.abs(d_g - d_o).max() < 5e-3
+    for a, b in ((b_g, b_o), (d_g, d_o)):
+        assert abs(O.psnr_lf(a[[0, 2]], clean[[0, 2]]) - O.psnr_lf(b[[0, 2]], clean[[0, 2]])) < 1e-3
+
+
+def test_bm3d_rejects_what_is_not_built(ctx):
+    from lfbm5d_amd import core
+    t = torch.zeros(3 * 64 * 64, device="cuda")
+    with pytest.raises(core.LfBm5dError, match="power of two"):
+        ctx.bm3d_step(1, core.make_bm3d_params(25, 2.7, 1, 8, 8, 3, "bior"), 64, 64, 3, t, None, t.clone())
+    with pytest.raises(core.LfBm5dError, match="dct or bior"):
+        ctx.bm3d_step(1, core.make_bm3d_params(25, 2.7, 8, 8, 8, 3, "id"), 64, 64, 3, t, None, t.clone())
+    z = np.zeros((1, 3 * 32 * 32), np.float32)
+    with pytest.raises(core.LfBm5dError, match="nHard == nWien"):
+        ctx.bm3d_lf(core.make_bm3d_params(25, 2.7, 8, 8, 8, 3, "bior"), core.make_bm3d_params(25, 2.7, 8, 6, 8, 3, "dct"),
+                    z.copy(), np.ones(1, np.uint32), z.copy(), z.copy(), 32, 32, 3)
