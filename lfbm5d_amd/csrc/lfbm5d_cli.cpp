@@ -15,6 +15,13 @@
  *   LFBM5D_DEVICE=<i> HIP device index.
  * nbThreads is parsed and ignored: the GPU path has the reference's untiled (nb_threads == 1)
  * semantics.
+ *
+ * Compiled with -DLFBM3D_CLI the same file is `LFBM3Ddenoising` (src/main_bm3d_LF.cpp:56-272, arguments of
+ * get_params_BM3D, utilities_LF.cpp:1342-1468 / README.md:85), BM3D on every SAI independently:
+ *
+ *   LFBM3Ddenoising LFSourceDir|none SAIName sep awidth aheight sIdxStart tIdxStart aswSizeHard aswSizeWien row|col
+ *       sigma lambda LFNoisyDir LFBasicDir LFDenoisedDir LFDiffDir NHard nHard kHard pHard dct|bior useSDHard
+ *       NWien nWien kWien pWien dct|bior useSDWien rgb|yuv|ycbcr|opp nbThreads resultsFile
  */
 #include <sys/time.h>
 #include <unistd.h>
@@ -33,6 +40,7 @@
 #include "../../include/lfbm5d.h"
 #include "png_min.h"
 #include "run_bm5d.h"
+#include "run_bm3d_lf.h"
 
 using namespace std;
 
@@ -152,7 +160,23 @@ void diff_LF(const vector<vector<float> >& A, const vector<vector<float> >& B, c
     }
 }
 
-int tau(const char* s, int which) {
+/* add_noise_LF, utilities_LF.cpp:244-263 + add_noise, utilities.cpp:154-185 */
+void add_noise_LF(const vector<vector<float> >& LF, const vector<unsigned>& mask, vector<vector<float> >& LF_noisy, float sigma) {
+    const char* seed = getenv("LFBM5D_SEED");
+    Mt fixed(seed ? strtoul(seed, nullptr, 10) : 0);
+    for (size_t st = 0; st < LF.size(); st++) {
+        if (!mask[st]) continue;
+        timeval tp; gettimeofday(&tp, nullptr);
+        Mt per(tp.tv_sec * 1000 + tp.tv_usec / 1000 + (unsigned long)getpid());
+        Mt& g = seed ? fixed : per;
+        for (size_t q = 0; q < LF[st].size(); q++) {
+            const double x = g.res53(), y = g.res53();
+            LF_noisy[st][q] = LF[st][q] + (float)((double)sigma * sqrt(-2.0 * log(x)) * cos(2.0 * M_PI * y));
+        }
+    }
+}
+
+[[maybe_unused]] int tau(const char* s, int which) {
     if (!strcmp(s, "id")) return LFBM5D_ID;
     if (!strcmp(s, "dct")) return LFBM5D_DCT;
     if (which == 2 && !strcmp(s, "bior")) return LFBM5D_BIOR;
@@ -162,7 +186,7 @@ int tau(const char* s, int which) {
     return -1;
 }
 
-void usage(const char* a0) {
+[[maybe_unused]] void usage(const char* a0) {
     cout << "usage: " << a0 << " LFSourceDir|none SAIName sep awidth aheight sIdxStart tIdxStart aswSizeHard aswSizeWien row|col "
             "sigma lambda LFNoisyDir LFBasicDir LFDenoisedDir LFDiffDir NHard nSimHard nDispHard kHard pHard id|dct|bior id|dct|sadct "
             "hw|haar|dct useSDHard NWien nSimWien nDispWien kWien pWien id|dct|bior id|dct|sadct hw|haar|dct useSDWien "
@@ -171,6 +195,101 @@ void usage(const char* a0) {
 
 } // namespace
 
+#ifdef LFBM3D_CLI
+int main(int argc, char** argv) {
+    cout << "*********************************************************************************************************************" << endl;
+    cout << "********************************************              START               ***************************************" << endl;
+    cout << "*********************************************************************************************************************" << endl;
+    if (argc < 32) {
+        cout << "usage: " << argv[0] << " LFSourceDir|none SAIName sep awidth aheight sIdxStart tIdxStart aswSizeHard aswSizeWien row|col "
+                "sigma lambda LFNoisyDir LFBasicDir LFDenoisedDir LFDiffDir NHard nHard kHard pHard dct|bior useSDHard "
+                "NWien nWien kWien pWien dct|bior useSDWien rgb|yuv|ycbcr|opp nbThreads resultsFile" << endl;
+        cout << "Problem while reading parameters from command line !" << endl;
+        return EXIT_FAILURE;
+    }
+    int a = 1;
+    const char* src = argv[a++]; const char* name = argv[a++]; const char* sep_in = argv[a++];
+    const bool gt = strcmp(src, "none") != 0;
+    const char* sep = strcmp(sep_in, "none") ? sep_in : "";
+    if (!strcmp(name, "none")) name = "";
+    const unsigned aw = atoi(argv[a++]), ah = atoi(argv[a++]), s0 = atoi(argv[a++]), t0 = atoi(argv[a++]);
+    a += 2;   /* aswSizeHard, aswSizeWien: parsed by the reference, unused by BM3D */
+    const char* maj = argv[a++];
+    const unsigned ang_major = !strcmp(maj, "row") ? LFBM5D_ROWMAJOR : !strcmp(maj, "col") ? LFBM5D_COLMAJOR : 0;
+    const float sigma = (float)atof(argv[a++]), lambda = (float)atof(argv[a++]);
+    const char* d_noisy = argv[a++]; const char* d_basic = argv[a++]; const char* d_den = argv[a++]; const char* d_diff = argv[a++];
+    unsigned N[2], n[2], k[2], p[2], sd[2]; int t2[2];
+    for (int i = 0; i < 2; i++) {
+        N[i] = atoi(argv[a++]); n[i] = atoi(argv[a++]); k[i] = atoi(argv[a++]); p[i] = atoi(argv[a++]);
+        const char* t = argv[a++];
+        t2[i] = !strcmp(t, "dct") ? LFBM5D_DCT : !strcmp(t, "bior") ? LFBM5D_BIOR : -1;
+        sd[i] = atoi(argv[a++]);
+        if (t2[i] < 0) { cout << (i ? "tau_2d_wien" : "tau_2d_hard") << " is not known. Choice is :" << endl << " -dct" << endl << " -bior" << endl; return EXIT_FAILURE; }
+    }
+    const char* csn = argv[a++];
+    const int cs = !strcmp(csn, "rgb") ? LFBM5D_RGB : !strcmp(csn, "yuv") ? LFBM5D_YUV : !strcmp(csn, "ycbcr") ? LFBM5D_YCBCR : !strcmp(csn, "opp") ? LFBM5D_OPP : -1;
+    const unsigned nb_threads = atoi(argv[a++]);
+    const char* results = argv[a++];
+    if (!ang_major || cs < 0) { cout << "Problem while reading parameters from command line !" << endl; return EXIT_FAILURE; }
+
+    vector<vector<float> > LF, LF_noisy, LF_basic, LF_den, LF_diff;
+    vector<unsigned> mask;
+    unsigned W = 0, H = 0, C = 0;
+    const unsigned awh = aw * ah;
+    if (gt) {
+        double t = now_s();
+        if (load_LF(src, name, sep, LF, mask, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+        cout << "Loading LF elapsed time = " << now_s() - t << "s." << endl;
+        LF_noisy.assign(awh, vector<float>((size_t)W * H * C, 0.0f));
+        cout << endl << "Add noise [sigma = " << sigma << "] ... " << flush;
+        t = now_s();
+        add_noise_LF(LF, mask, LF_noisy, sigma);
+        cout << "done in " << now_s() - t << "s." << endl << endl << "Save noisy light field..." << endl;
+        if (save_LF(d_noisy, name, sep, LF_noisy, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    } else {
+        if (load_LF(d_noisy, name, sep, LF_noisy, mask, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    }
+    LF_basic.assign(awh, vector<float>((size_t)W * H * C, 0.0f));
+    LF_den = LF_basic; LF_diff = LF_basic;
+    vector<float> ps, rm; float ap_n = 0, sp = 0, ar = 0, sr = 0, ap_b = 0;
+    if (gt) {
+        psnr_LF(LF, LF_noisy, mask, ps, ap_n, sp, rm, ar, sr);
+        cout << endl << "Average PSNR:" << endl << "- Noisy light field: " << ap_n << endl;
+        write_psnr(results, "noisy", mask, ang_major, aw, ah, ps, ap_n, sp, rm, ar, sr);
+    }
+    cout << endl << " ---> Running LFBM3D filter <--- " << endl << endl;
+    const double tb = now_s();
+    char sub[] = "SAI";
+    if (run_bm3d_LF(sigma, LF_noisy, mask, LF_basic, LF_den, W, H, C, n[0], n[1], k[0], k[1], N[0], N[1], p[0], p[1], sd[0] != 0, sd[1] != 0,
+                    t2[0], t2[1], lambda, cs, nb_threads, sub) != EXIT_SUCCESS) return EXIT_FAILURE;
+    const double secs = now_s() - tb;
+    if (gt) {
+        psnr_LF(LF, LF_basic, mask, ps, ap_b, sp, rm, ar, sr);
+        write_psnr(results, "basic", mask, ang_major, aw, ah, ps, ap_b, sp, rm, ar, sr);
+    }
+    cout << endl << "Save basic light field..." << endl;
+    if (save_LF(d_basic, name, sep, LF_basic, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (gt) {
+        float ap_d;
+        psnr_LF(LF, LF_den, mask, ps, ap_d, sp, rm, ar, sr);
+        cout << endl << "Average PSNR:" << endl << "- Noisy light field: " << ap_n << endl << "- Basic light field: " << ap_b << endl
+             << "- Denoised light field: " << ap_d << endl << endl;
+        write_psnr(results, "denoised", mask, ang_major, aw, ah, ps, ap_d, sp, rm, ar, sr);
+        diff_LF(LF, LF_den, mask, LF_diff, sigma);
+    }
+    cout << endl << "Save denoised light field..." << endl;
+    if (save_LF(d_den, name, sep, LF_den, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    if (gt) {
+        cout << endl << "Save diff light field..." << endl;
+        if (save_LF(d_diff, name, sep, LF_diff, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
+    }
+    cout << "Total LFBM3D computing time = " << secs << "s." << endl << endl;
+    cout << "*********************************************************************************************************************" << endl;
+    cout << "********************************************         THIS IS THE END          ***************************************" << endl;
+    cout << "*********************************************************************************************************************" << endl;
+    return EXIT_SUCCESS;
+}
+#else
 int main(int argc, char** argv) {
     cout << "*********************************************************************************************************************" << endl;
     cout << "********************************************              START               ***************************************" << endl;
@@ -214,22 +333,10 @@ int main(int argc, char** argv) {
         double t = now_s();
         if (load_LF(src, name, sep, LF, mask, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
         cout << "Loading LF elapsed time = " << now_s() - t << "s." << endl;
-        /* add_noise_LF, utilities_LF.cpp:244-263 + add_noise, utilities.cpp:154-185 */
         LF_noisy.assign(awh, vector<float>((size_t)W * H * C, 0.0f));
         cout << endl << "Add noise [sigma = " << sigma << "] ... " << flush;
         t = now_s();
-        const char* seed = getenv("LFBM5D_SEED");
-        Mt fixed(seed ? strtoul(seed, nullptr, 10) : 0);
-        for (unsigned st = 0; st < awh; st++) {
-            if (!mask[st]) continue;
-            timeval tp; gettimeofday(&tp, nullptr);
-            Mt per(tp.tv_sec * 1000 + tp.tv_usec / 1000 + (unsigned long)getpid());
-            Mt& g = seed ? fixed : per;
-            for (size_t q = 0; q < LF[st].size(); q++) {
-                const double x = g.res53(), y = g.res53();
-                LF_noisy[st][q] = LF[st][q] + (float)((double)sigma * sqrt(-2.0 * log(x)) * cos(2.0 * M_PI * y));
-            }
-        }
+        add_noise_LF(LF, mask, LF_noisy, sigma);
         cout << "done in " << now_s() - t << "s." << endl << endl << "Save noisy light field..." << endl;
         if (save_LF(d_noisy, name, sep, LF_noisy, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
     } else {
@@ -285,3 +392,4 @@ int main(int argc, char** argv) {
     cout << "*********************************************************************************************************************" << endl;
     return EXIT_SUCCESS;
 }
+#endif

@@ -526,7 +526,7 @@ constexpr int bior_ext(int j, int N) { return (((j - 4) % N) + N) % N; }   /* pe
 
 template <int K, int N1>
 __device__ __forceinline__ void bior_fwd_level(float* Tp, int r, TbPtr tb) {
-#pragma clang fp contract(off)   /* the reference's (and the oracle's) separate multiply and add: bit-identical coefficients */
+#pragma clang fp contract(off)   /* the reference's separate multiply and add: bit-identical coefficients */
     if constexpr (N1 > 1) {
         constexpr int N2 = N1 / 2, RS = K + 1;
         if (r < N1) {   /* rows: first N2 outputs low-pass, next N2 high-pass */

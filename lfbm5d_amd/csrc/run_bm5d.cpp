@@ -110,3 +110,40 @@ int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_no
     unflatten(LF_denoised, LF_SAI_mask, img, den);
     return EXIT_SUCCESS;
 }
+
+/* run_bm3d_LF (src/bm3d_LF.h:11-36, bm3d_LF.cpp:75-125): BM3D on every SAI of the mask */
+#include "run_bm3d_lf.h"
+int run_bm3d_LF(const float sigma, std::vector<std::vector<float> >& LF_noisy, std::vector<unsigned>& LF_SAI_mask,
+                std::vector<std::vector<float> >& LF_basic, std::vector<std::vector<float> >& LF_denoised,
+                const unsigned width, const unsigned height, const unsigned chnls, const unsigned nHard, const unsigned nWien,
+                const unsigned kHard, const unsigned kWien, const unsigned NHard, const unsigned NWien, const unsigned pHard,
+                const unsigned pWien, const bool useSD_h, const bool useSD_w, const unsigned tau_2D_hard,
+                const unsigned tau_2D_wien, const float lambdaHard3D, const unsigned color_space, unsigned /*nb_threads*/,
+                char* sub_img_name) {
+    const size_t asize = LF_noisy.size();
+    if (LF_SAI_mask.size() != asize) {
+        std::cout << "run_bm3d_LF: light field and mask must hold the same number of SAIs" << std::endl;
+        return EXIT_FAILURE;
+    }
+    lfbm5d_ctx* ctx = context();
+    if (!ctx) return EXIT_FAILURE;
+    if (LF_basic.size() != asize) LF_basic.resize(asize);       /* bm3d_LF.cpp:99-102 */
+    if (LF_denoised.size() != asize) LF_denoised.resize(asize);
+    const size_t img = (size_t)width * height * chnls;
+    std::vector<float> noisy, basic(asize * img, 0.0f), den(asize * img, 0.0f);
+    flatten(LF_noisy, LF_SAI_mask, img, noisy);
+    lfbm5d_bm3d_params Hd, Wn;
+    Hd.sigma = sigma; Hd.lambda3D = lambdaHard3D; Hd.N = NHard; Hd.nHW = nHard; Hd.k = kHard; Hd.p = pHard;
+    Hd.useSD = useSD_h ? 1u : 0u; Hd.tau_2D = tau_2D_hard; Hd.color_space = color_space;
+    Wn = Hd; Wn.N = NWien; Wn.nHW = nWien; Wn.k = kWien; Wn.p = pWien; Wn.useSD = useSD_w ? 1u : 0u; Wn.tau_2D = tau_2D_wien;
+    std::cout << " - > Running BM3D filter on every " << (sub_img_name ? sub_img_name : "SAI") << " (GPU)" << std::endl;
+    if (lfbm5d_bm3d_lf_host(ctx, &Hd, &Wn, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), (unsigned)asize, width,
+                            height, chnls) != 0) {
+        std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
+        return EXIT_FAILURE;
+    }
+    unflatten(LF_noisy, LF_SAI_mask, img, noisy);
+    unflatten(LF_basic, LF_SAI_mask, img, basic);
+    unflatten(LF_denoised, LF_SAI_mask, img, den);
+    return EXIT_SUCCESS;
+}

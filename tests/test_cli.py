@@ -59,3 +59,41 @@ def test_readme_command_matches_oracle(tmp_path):
     im = np.asarray(Image.open(f"{tmp}/denoised/SAI_02_02.png")).astype(np.float32).transpose(2, 0, 1)
     mse = ((im - lf[4].astype(np.float32)) ** 2).mean()
     assert 20 * np.log10(255 / np.sqrt(mse)) > 36.0
+
+
+CLI3 = os.path.join(ROOT, "lfbm5d_amd", "LFBM3Ddenoising")
+
+
+def test_bm3d_usage_on_missing_arguments():
+    r = subprocess.run([CLI3, "a", "b"], capture_output=True, text=True)
+    assert r.returncode != 0 and "usage:" in r.stdout
+
+
+@pytest.mark.gpu
+def test_bm3d_readme_command_matches_oracle(tmp_path):
+    """README.md:51 test command (LFBM3Ddenoising, BM3D on every SAI) with LFBM5D_SEED=1 against the oracle's
+    restatement of run_bm3d_LF on the same noise; four SAIs of the light field to bound the oracle's time."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    tmp = str(tmp_path)
+    src, lf = write_source_lf(tmp)
+    for d in ("noisy", "basic", "denoised", "diff"):
+        os.makedirs(os.path.join(tmp, d))
+    res = os.path.join(tmp, "measures3d.txt")
+    args = [CLI3, src, "SAI", "_", "2", "2", "1", "1", "1", "1", "row", "25", "2.7", f"{tmp}/noisy", f"{tmp}/basic",
+            f"{tmp}/denoised", f"{tmp}/diff", "16", "16", "8", "3", "bior", "0", "32", "16", "8", "3", "dct", "0", "opp", "8", res]
+    out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, LFBM5D_SEED="1"))
+    assert out.returncode == 0, out.stdout[-2000:]
+    txt = open(res).read()
+    vals = {k: float(txt.split(f"-> Average PSNR {k} = ")[1].split()[0]) for k in ("noisy", "basic", "denoised")}
+    sel = [0, 1, 3, 4]                                      # SAI_01_01, _01_02, _02_01, _02_02 in the 3x3 golden array
+    clean = np.ascontiguousarray(lf[sel].astype(np.float32)).reshape(4, -1)
+    noisy = O.add_noise_lf(clean, 25.0, seed=1)
+    _, b_o, d_o, _ = O.run_bm3d_lf(25.0, 2.7, noisy, np.ones(4, np.uint32), 256, 256, 3, (16, 16, 8, 3, "bior", 0), (32, 16, 8, 3, "dct", 0))
+    assert abs(vals["noisy"] - O.psnr_lf(noisy, clean)) < 1e-3
+    assert abs(vals["basic"] - O.psnr_lf(b_o, clean)) < 0.01 and abs(vals["denoised"] - O.psnr_lf(d_o, clean)) < 0.01
+    assert vals["denoised"] > vals["basic"] > vals["noisy"] + 10
+    from PIL import Image
+    im = np.asarray(Image.open(f"{tmp}/denoised/SAI_02_02.png")).astype(np.float32).transpose(2, 0, 1)
+    assert np.abs(im - np.clip(np.round(d_o[3].reshape(3, 256, 256)), 0, 255)).max() <= 1
