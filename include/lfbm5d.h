@@ -173,7 +173,7 @@ typedef struct {
  * numerator / denominator (pixels no patch reached keep the step's input image). */
 int lfbm5d_bm3d_step_device(lfbm5d_ctx* ctx, int step, const lfbm5d_bm3d_params* P, unsigned Wb, unsigned Hb,
                             unsigned C, const float* d_noisy, const float* d_basic, float* d_out);
-/* == run_bm3d_LF (src/bm3d_LF.h:11-36; run_bm3d src/bm3d.h:11-34 with nb_threads == 1 for every SAI of the mask).
+/* == run_bm3d_LF (src/bm3d_LF.h:10-35; run_bm3d src/bm3d.h:11-34 with nb_threads == 1 for every SAI of the mask).
  * Buffers [asize][C*H*W]; d_noisy is colour-transformed at entry and back at exit like the reference mutates
  * LF_noisy (bm3d.cpp:115, :290); d_basic and d_denoised are outputs (RGB).  nHard must equal nWien. */
 int lfbm5d_bm3d_lf_device(lfbm5d_ctx* ctx, const lfbm5d_bm3d_params* hard, const lfbm5d_bm3d_params* wien,

@@ -321,7 +321,7 @@ def run_bm5d_2nd_step(sigma, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, ang_m
 def run_bm3d_LF(sigma, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, width, height, chnls, nHard, nWien, kHard, kWien,
                 NHard, NWien, pHard, pWien, useSD_h, useSD_w, tau_2D_hard, tau_2D_wien, lambdaHard3D, color_space,
                 nb_threads=1, sub_img_name="SAI", ctx=None):
-    """Same argument list as the reference's run_bm3d_LF (src/bm3d_LF.h:11-36): BM3D on every SAI of the mask.
+    """Same argument list as the reference's run_bm3d_LF (src/bm3d_LF.h:10-35): BM3D on every SAI of the mask.
     nb_threads is accepted and ignored (untiled, nb_threads == 1 semantics)."""
     hard = make_bm3d_params(sigma, lambdaHard3D, NHard, nHard, kHard, pHard, tau_2D_hard, useSD_h, color_space)
     wien = make_bm3d_params(sigma, lambdaHard3D, NWien, nWien, kWien, pWien, tau_2D_wien, useSD_w, color_space)

@@ -1,5 +1,5 @@
 /*
- * run_bm3d_lf.h -- drop-in declaration with the reference's exact signature (V-Sense/LFBM5D src/bm3d_LF.h:11-36):
+ * run_bm3d_lf.h -- drop-in declaration with the reference's exact signature (V-Sense/LFBM5D src/bm3d_LF.h:10-35):
  * BM3D on every SAI of the light field independently, on the GPU through the C-ABI of include/lfbm5d.h.
  */
 #ifndef LFBM5D_RUN_BM3D_LF_H

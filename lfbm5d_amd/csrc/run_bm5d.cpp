@@ -111,7 +111,7 @@ int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_no
     return EXIT_SUCCESS;
 }
 
-/* run_bm3d_LF (src/bm3d_LF.h:11-36, bm3d_LF.cpp:75-125): BM3D on every SAI of the mask */
+/* run_bm3d_LF (src/bm3d_LF.h:10-35, bm3d_LF.cpp:75-125): BM3D on every SAI of the mask */
 #include "run_bm3d_lf.h"
 int run_bm3d_LF(const float sigma, std::vector<std::vector<float> >& LF_noisy, std::vector<unsigned>& LF_SAI_mask,
                 std::vector<std::vector<float> >& LF_basic, std::vector<std::vector<float> >& LF_denoised,
