@@ -772,6 +772,7 @@ int lfbm5d_create(lfbm5d_ctx** out, int device) {
     c->device = device;
     std::memset(&c->stats, 0, sizeof(c->stats));
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return 1; }
+    if ((e = prepare_group_kernels()) != hipSuccess) { g_create_error = std::string("kernel LDS limits: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return 1; }
     if ((e = hipHostMalloc((void**)&c->h_small, 64 * sizeof(unsigned))) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return 1; }
     *out = c;
     return 0;

@@ -157,6 +157,7 @@ hipError_t launch_self_trivial(hipStream_t s, const unsigned* refs, unsigned n_r
 hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,
                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
                                 unsigned* best, unsigned char* shape);
+hipError_t prepare_group_kernels();   /* once per device: LDS limits of the group kernels */
 hipError_t launch_group(hipStream_t s, const GroupArgs& a);
 size_t group_lds_bytes(const GroupArgs& a);
 hipError_t launch_aggregate(hipStream_t s, const AggArgs& a);

@@ -2234,6 +2234,24 @@ hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_str
     return hipGetLastError();
 }
 
+/* Kernels whose LDS stack can exceed the 64 KiB a launch gets by default: raise the limit once per device
+ * (called from lfbm5d_create after hipSetDevice; the attribute belongs to the device's code object). */
+hipError_t prepare_group_kernels() {
+    const int lim = 160 * 1024 - 4096;
+    const void* fns[] = {
+        reinterpret_cast<const void*>(&k_group<1>), reinterpret_cast<const void*>(&k_group<2>),
+        reinterpret_cast<const void*>(&k_group_dct8<1>), reinterpret_cast<const void*>(&k_group_dct8<2>),
+        reinterpret_cast<const void*>(&k_group_dct8w<true, false>), reinterpret_cast<const void*>(&k_group_dct8w<false, false>),
+        reinterpret_cast<const void*>(&k_group_dct8w<true, true>), reinterpret_cast<const void*>(&k_group_dct8w<false, true>),
+        reinterpret_cast<const void*>(&k_group_bior16_haar), reinterpret_cast<const void*>(&k_group_bior16_any),
+        reinterpret_cast<const void*>(&k_group_dct16_haar), reinterpret_cast<const void*>(&k_group_dct16_any)};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 size_t group_lds_bytes(const GroupArgs& a) {
     const size_t stack = (size_t)a.N * a.A * a.k * a.k;
     /* + the 2-D stage's work area: one patch per wave-quarter for the generic path, [patch][k][k+1] for bior1.5 */
@@ -2253,14 +2271,6 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     }
     if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
         const size_t lb = (size_t)a.N * 9 * 16 * 17 * sizeof(float);
-        static bool attrb = false;
-        if (!attrb) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_bior16_haar), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_bior16_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct16_haar), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct16_any), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            attrb = true;
-        }
         const dim3 grid(a.n_groups, a.C), block(256);
         if (a.tau2 == 7) {
             if (a.tau5 == 9) hipLaunchKernelGGL(k_group_bior16_haar, grid, block, lb, s, a);
@@ -2273,31 +2283,13 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     }
     if (a.tau2 == 7 && a.k == 8 && a.A == 9 && a.step == 2) {   /* 8x8 bior1.5, Wiener step: the DCT kernel with the wavelet in its 2-D stage */
         const size_t l8 = (size_t)2 * 64 * ((a.N * 9) | 1) * sizeof(float);
-        static bool attrwb = false;
-        if (!attrwb) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            attrwb = true;
-        }
         if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
         else             hipLaunchKernelGGL((k_group_dct8w<false, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
         return hipGetLastError();
     }
     if (a.tau2 == 5 && a.k == 8 && a.A == 9) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
         const size_t l8 = (size_t)(a.step == 2 ? 2 : 1) * 64 * ((a.N * 9) | 1) * sizeof(float);
-        static bool attr8 = false;
-        if (!attr8) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            attr8 = true;
-        }
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* packed noisy/pilot pair */
-            static bool attrw = false;
-            if (!attrw) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group_dct8w<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-                attrw = true;
-            }
             if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
             else             hipLaunchKernelGGL((k_group_dct8w<false, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
             return hipGetLastError();
@@ -2307,12 +2299,6 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         return hipGetLastError();
     }
     const size_t lds = group_lds_bytes(a);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_group<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_set = true;
-    }
     if (a.step == 2) hipLaunchKernelGGL(k_group<2>, dim3(a.n_groups, a.C), dim3(kThreads), lds, s, a);
     else             hipLaunchKernelGGL(k_group<1>, dim3(a.n_groups, a.C), dim3(kThreads), lds, s, a);
     return hipGetLastError();
