@@ -45,6 +45,16 @@ WORKLOADS = {
     "lf3x3x256x256_sigma25": dict(ah=3, aw=3, H=256, W=256, sigma=25.0,
                                   p1=(8, 18, 6, 16, 4, "id", "sadct", "haar"),
                                   p2=(16, 18, 6, 8, 4, "dct", "sadct", "haar")),
+    # the other BASELINE.json configurations (parity-test cases; selectable here to time them)
+    "lf3x3x256x256_sigma25_dct": dict(ah=3, aw=3, H=256, W=256, sigma=25.0,            # configs[1]: dct/sadct/haar in both steps
+                                      p1=(8, 18, 6, 16, 4, "dct", "sadct", "haar"),
+                                      p2=(16, 18, 6, 8, 4, "dct", "sadct", "haar")),
+    "lf17x17x512x512_sigma10_bior": dict(ah=17, aw=17, H=512, W=512, sigma=10.0,       # configs[3]: bior/sadct/haar
+                                         p1=(8, 18, 6, 16, 4, "bior", "sadct", "haar"),
+                                         p2=(16, 18, 6, 8, 4, "dct", "sadct", "haar")),
+    "lf15x15x625x434_sigma50_n1": dict(ah=15, aw=15, H=434, W=625, sigma=50.0,         # configs[4]: EPFL-style, NHard = 1
+                                       p1=(1, 18, 3, 16, 3, "bior", "sadct", "haar"),
+                                       p2=(8, 18, 3, 8, 3, "dct", "sadct", "haar")),
 }
 
 

@@ -249,6 +249,7 @@ __device__ __forceinline__ void dct9_inv(float* x, TbPtr tb) {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));   /* two values per lane: v_pk_{add,mul,fma}_f32 */
+struct __attribute__((packed, aligned(4))) f4u { float v[4]; };   /* 16-byte load at 4-byte alignment */
 /* dct9_fwd / dct9_inv on a pair of fibres: the same operation sequence as the scalar versions (folding the
  * constant factors into the stage matrices saves a third of the multiplies but moves results by an ulp, enough
  * to flip the odd hard-threshold decision against the reference) */
@@ -624,6 +625,68 @@ __device__ __forceinline__ void bior_inv_level(float* Tp, int r, TbPtr tb) {
         __builtin_amdgcn_wave_barrier();
         bior_inv_level<K, N1 * 2>(Tp, r, tb);
     }
+}
+/* The same levels for the 16x16 kernel below, two rows (then two columns) per thread as packed pairs: a level of
+ * side N1 takes N1/2 threads per patch, rows r and r + N1/2 travel as one v2f (one ds_read2 / ds_write2 per
+ * element: the partner sits N1/2 rows, or N1/2 floats, away), every tap is one packed multiply or add.  Same
+ * taps, order and unfused arithmetic as bior_fwd_level / bior_inv_level -> identical coefficients. */
+template <int N1, bool FWD>
+__device__ __forceinline__ void bior_taps2(const v2f* v, v2f* o, TbPtr tb) {
+#pragma clang fp contract(off)
+    constexpr int N2 = N1 / 2;
+    if (FWD) {
+#pragma unroll
+        for (int j = 0; j < N2; j++) {
+            v2f acc = v[bior_ext(2 * j, N1)] * tb->lpd[0];
+#pragma unroll
+            for (int t = 1; t < 10; t++) acc += v[bior_ext(t + 2 * j, N1)] * tb->lpd[t];
+            o[j] = acc;
+            v2f hi = v[bior_ext(4 + 2 * j, N1)] * tb->hpd[4];
+            hi += v[bior_ext(5 + 2 * j, N1)] * tb->hpd[5];
+            o[N2 + j] = hi;
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < N2; m++) {
+            v2f acc = v[m % N1] * tb->hpr[0];
+#pragma unroll
+            for (int t = 1; t < 10; t++) acc += v[(t * N2 + m) % N1] * tb->hpr[t];
+            o[2 * m] = acc;
+            v2f lo = v[(4 * N2 + m) % N1] * tb->lpr[4];
+            lo += v[(5 * N2 + m) % N1] * tb->lpr[5];
+            o[2 * m + 1] = lo;
+        }
+    }
+}
+template <int N1, bool FWD, bool ROWS>
+__device__ __forceinline__ void bior16_pass2(float* Tp, int r, TbPtr tb) {
+    constexpr int N2 = N1 / 2, RS = 17;
+    v2f v[N1], o[N1];
+#pragma unroll
+    for (int c = 0; c < N1; c++)
+        v[c] = ROWS ? v2f{Tp[r * RS + c], Tp[(r + N2) * RS + c]} : v2f{Tp[c * RS + r], Tp[c * RS + r + N2]};
+    bior_taps2<N1, FWD>(v, o, tb);
+#pragma unroll
+    for (int c = 0; c < N1; c++) {
+        if (ROWS) { Tp[r * RS + c] = o[c].x; Tp[(r + N2) * RS + c] = o[c].y; }
+        else      { Tp[c * RS + r] = o[c].x; Tp[c * RS + r + N2] = o[c].y; }
+    }
+}
+/* one level of all NP patches of the work area [patch][16][17]; all 256 threads call it */
+template <int N1, bool FWD>
+__device__ __forceinline__ void bior16_level_all(float* work, int NP, int tid, TbPtr tb) {
+    constexpr int TPP = N1 / 2, PPI = kThreads / TPP, PSZ = 16 * 17;   /* threads per patch (one wavefront holds them all) */
+    const int slot = tid / TPP, r = tid % TPP;
+    for (int p0 = 0; p0 < NP; p0 += PPI) {
+        const int patch = p0 + slot;
+        if (patch < NP) {
+            float* Tp = work + patch * PSZ;
+            bior16_pass2<N1, FWD, FWD>(Tp, r, tb);         /* forward: rows first; inverse: columns first */
+            __builtin_amdgcn_wave_barrier();
+            bior16_pass2<N1, FWD, !FWD>(Tp, r, tb);
+        }
+    }
+    __syncthreads();   /* the next level deals the patches to other threads */
 }
 /* work area: (kThreads / K) patches of K x (K+1) floats */
 template <int K> constexpr int bior_tmp_floats() { return (kThreads / K) * K * (K + 1); }
@@ -1286,31 +1349,14 @@ __device__ __forceinline__ void dct16_inv(float* X) {
         X[n] = e[n] + acc; X[15 - n] = e[n] - acc;
     }
 }
-/* 2-D DCT of one 16x16 patch of the work area [16][17] by 16 threads (thread r: row r, then column r) */
-template <bool FWD>
-__device__ __forceinline__ void dct16_2d(float* Tp, int r) {
-    constexpr int RS = 17;
-    float x[16];
-#pragma unroll
-    for (int c = 0; c < 16; c++) x[c] = Tp[r * RS + c];
-    if (FWD) dct16_fwd(x); else dct16_inv(x);
-#pragma unroll
-    for (int c = 0; c < 16; c++) Tp[r * RS + c] = x[c];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = Tp[i * RS + r];
-    if (FWD) dct16_fwd(x); else dct16_inv(x);
-#pragma unroll
-    for (int i = 0; i < 16; i++) Tp[i * RS + r] = x[i];
-    __builtin_amdgcn_wave_barrier();
-}
-
 /* ------------------------------------------------------------------------------------------
  * Hard-thresholding step with tau_2D = bior1.5 or dct and 16x16 patches (BASELINE configurations 2, 4 and 5):
  * the register-resident kernel above with a 2-D stage in front and behind it.  All nSx * A patches of the group
- * are gathered into an LDS work area [patch][16][17], transformed in place, 16 threads per patch (bior1.5:
- * bior_fwd_level / bior_inv_level; DCT: dct16_2d), handed to the per-pixel threads for the angular and
- * 5th-dimension stages (group_id_body on the work area), transformed back and stored.
+ * go through an LDS work area [patch][16][17]: the first pass of the forward transform reads whole patch rows from
+ * the window images, the per-pixel threads run the angular and 5th-dimension stages on the work area
+ * (group_id_body), the last pass of the inverse transform stores the filtered rows.  bior1.5: two rows / columns
+ * per thread as packed pairs (bior_taps2), levels 8, 4, 2 with the patches re-dealt to fewer threads each; DCT: 16
+ * threads per patch (dct16_fwd / dct16_inv).
  * ------------------------------------------------------------------------------------------ */
 template <bool HAAR, bool BIOR>
 __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
@@ -1328,39 +1374,80 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
     const TbPtr tb = (TbPtr)a.tb;
     float* work = lds;
-    /* gather: thread = pixel, scalar patch offsets like the tau_2D = id kernel */
-    {
-        const unsigned plane = a.Wb * a.Hb;
-        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)((size_t)a.A * a.C * plane * 4), 0x00020000u);
-        const int voff = (int)(((unsigned)(tid / K) * a.Wb + tid % K) * 4u);
-        const int woff = (tid / K) * RS + tid % K;
-        for (int p0 = 0; p0 < NP; p0 += 24) {          /* 24 loads in flight */
-            float x[24];
+#ifdef LFBM5D_PHASE_TIMING
+    long long tq[6]; int tqi = 0;
+#define T16_MARK() do { if (tid == 0) tq[tqi] = (long long)__builtin_readcyclecounter(); tqi++; } while (0)
+    T16_MARK();
+#else
+#define T16_MARK() do {} while (0)
+#endif
+    /* forward 2-D transform; its first pass (the rows of the 16x16 level) takes the patches straight from the window
+     * images: a thread loads whole 64-byte patch rows (four 16-byte loads at 4-byte alignment), transforms them and
+     * parks the result in the work area -- no separate gather, and 8 (bior) / 4 (DCT) loads per thread and round where
+     * a thread-per-pixel gather issues one 4-byte load per patch */
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    auto patch_src = [&](int patch, bool& ok) -> const float* {
+        const unsigned p = a.gpos[(size_t)g * N * A + patch];
+        ok = p != 0xffffffffu;            /* empty SAI / never-filled table column: zeros */
+        return a.noisy + ((size_t)(patch % A) * a.C + c) * plane + (ok ? p : 0u);
+    };
+    if (BIOR) {
+        constexpr int TPP = 8, PPI = kThreads / TPP;   /* rows r and r + 8 per thread */
+        const int slot = tid / TPP, r = tid % TPP;
+        for (int p0 = 0; p0 < NP; p0 += PPI) {
+            const int patch = p0 + slot;
+            if (patch < NP) {
+                bool ok;
+                const float* src = patch_src(patch, ok);
+                v2f v[K], o[K];
 #pragma unroll
-            for (int u = 0; u < 24; u++) {
-                const int patch = p0 + u;
-                x[u] = 0.0f;
-                if (patch < NP) {
-                    const unsigned p = pos[patch];
-                    const bool ok = p != 0xffffffffu;
-                    const unsigned so = (((unsigned)(patch % A) * a.C + c) * plane + (ok ? p : 0u)) * 4u;
-                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
-                    x[u] = ok ? v : 0.0f;
+                for (int q = 0; q < 4; q++) {
+                    const f4u lo = *reinterpret_cast<const f4u*>(src + (size_t)r * a.Wb + 4 * q);
+                    const f4u hi = *reinterpret_cast<const f4u*>(src + (size_t)(r + 8) * a.Wb + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[4 * q + e] = ok ? v2f{lo.v[e], hi.v[e]} : v2f{0.0f, 0.0f};
                 }
-            }
+                bior_taps2<K, true>(v, o, tb);
+                float* Tp = work + patch * PSZ;
 #pragma unroll
-            for (int u = 0; u < 24; u++) if (p0 + u < NP) work[(p0 + u) * PSZ + woff] = x[u];
-        }
-    }
-    __syncthreads();
-    {   /* forward 2-D transform in place, 16 threads per patch */
-        const int slot = tid / K, r = tid % K;
-        for (int p0 = 0; p0 < NP; p0 += kThreads / K)
-            if (p0 + slot < NP) {
-                if (BIOR) bior_fwd_level<K, K>(work + (p0 + slot) * PSZ, r, tb); else dct16_2d<true>(work + (p0 + slot) * PSZ, r);
+                for (int cc = 0; cc < K; cc++) { Tp[r * RS + cc] = o[cc].x; Tp[(r + 8) * RS + cc] = o[cc].y; }
+                __builtin_amdgcn_wave_barrier();
+                bior16_pass2<K, true, false>(Tp, r, tb);
             }
+        }
+        __syncthreads();
+        bior16_level_all<8, true>(work, NP, tid, tb);
+        bior16_level_all<4, true>(work, NP, tid, tb);
+        bior16_level_all<2, true>(work, NP, tid, tb);
+    } else {
+        const int slot = tid / K, r = tid % K;         /* DCT: 16 threads per patch, thread = row, then column */
+        for (int p0 = 0; p0 < NP; p0 += kThreads / K) {
+            const int patch = p0 + slot;
+            if (patch < NP) {
+                bool ok;
+                const float* src = patch_src(patch, ok);
+                float x[K];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f4u t4 = *reinterpret_cast<const f4u*>(src + (size_t)r * a.Wb + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) x[4 * q + e] = ok ? t4.v[e] : 0.0f;
+                }
+                dct16_fwd(x);
+                float* Tp = work + patch * PSZ;
+#pragma unroll
+                for (int cc = 0; cc < K; cc++) Tp[r * RS + cc] = x[cc];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < K; i++) x[i] = Tp[i * RS + r];
+                dct16_fwd(x);
+#pragma unroll
+                for (int i = 0; i < K; i++) Tp[i * RS + r] = x[i];
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    T16_MARK();
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     switch (nSx) {
         case 1:  group_id_body<1, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
@@ -1369,19 +1456,60 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
         default: group_id_body<8, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
     }
     __syncthreads();
-    {   /* inverse 2-D transform in place */
-        const int slot = tid / K, r = tid % K;
-        for (int p0 = 0; p0 < NP; p0 += kThreads / K)
-            if (p0 + slot < NP) {
-                if (BIOR) bior_inv_level<K, 2>(work + (p0 + slot) * PSZ, r, tb); else dct16_2d<false>(work + (p0 + slot) * PSZ, r);
+    T16_MARK();
+    /* inverse 2-D transform; its last pass (the rows of the 16x16 level) stores the filtered patches: filt[g][n][st][c][256] */
+    float* const out = a.filt + (size_t)g * N * A * a.C * K * K;
+    if (BIOR) {
+        bior16_level_all<2, false>(work, NP, tid, tb);
+        bior16_level_all<4, false>(work, NP, tid, tb);
+        bior16_level_all<8, false>(work, NP, tid, tb);
+        constexpr int TPP = 8, PPI = kThreads / TPP;
+        const int slot = tid / TPP, r = tid % TPP;
+        for (int p0 = 0; p0 < NP; p0 += PPI) {
+            const int patch = p0 + slot;
+            if (patch < NP) {
+                float* Tp = work + patch * PSZ;
+                bior16_pass2<K, false, false>(Tp, r, tb);
+                __builtin_amdgcn_wave_barrier();
+                v2f v[K], o[K];
+#pragma unroll
+                for (int cc = 0; cc < K; cc++) v[cc] = v2f{Tp[r * RS + cc], Tp[(r + 8) * RS + cc]};
+                bior_taps2<K, false>(v, o, tb);
+                float4* dst = reinterpret_cast<float4*>(out + ((size_t)patch * a.C + c) * K * K);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    dst[r * 4 + q] = make_float4(o[4 * q].x, o[4 * q + 1].x, o[4 * q + 2].x, o[4 * q + 3].x);
+                    dst[(r + 8) * 4 + q] = make_float4(o[4 * q].y, o[4 * q + 1].y, o[4 * q + 2].y, o[4 * q + 3].y);
+                }
             }
+        }
+    } else {
+        const int slot = tid / K, r = tid % K;
+        for (int p0 = 0; p0 < NP; p0 += kThreads / K) {
+            const int patch = p0 + slot;
+            if (patch < NP) {
+                float* Tp = work + patch * PSZ;
+                float x[K];
+#pragma unroll
+                for (int i = 0; i < K; i++) x[i] = Tp[i * RS + r];
+                dct16_inv(x);
+#pragma unroll
+                for (int i = 0; i < K; i++) Tp[i * RS + r] = x[i];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int cc = 0; cc < K; cc++) x[cc] = Tp[r * RS + cc];
+                dct16_inv(x);
+                float4* dst = reinterpret_cast<float4*>(out + ((size_t)patch * a.C + c) * K * K);
+#pragma unroll
+                for (int q = 0; q < 4; q++) dst[r * 4 + q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+            }
+        }
     }
-    __syncthreads();
-    {   /* store the filtered patches: filt[g][n][st][c][256] */
-        float* const out = a.filt + (size_t)g * N * A * a.C * K * K;
-        const int woff = (tid / K) * RS + tid % K;
-        for (int patch = 0; patch < NP; patch++) out[((size_t)patch * a.C + c) * K * K + tid] = work[patch * PSZ + woff];
-    }
+    T16_MARK();
+#ifdef LFBM5D_PHASE_TIMING
+    T16_MARK();
+    if (tid == 0) { for (int i = 0; i < 5; i++) atomicAdd(&a.counters[4 + i], (unsigned long long)(tq[i + 1] - tq[i])); atomicAdd(&a.counters[9], 1ull); }
+#endif
     for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
     __syncthreads();
@@ -1592,7 +1720,6 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
  *   4  thread = two (n, pq) fibres of the filtered stack: packed inverse 3x3 DCT
  *   5  thread = two patches: packed inverse 8x8 DCT, 16-byte stores of the filtered patches
  * ------------------------------------------------------------------------------------------ */
-struct __attribute__((packed, aligned(4))) f4u { float v[4]; };   /* 16-byte load at 4-byte alignment */
 
 template <class T> __device__ __forceinline__ void dct8_fwd_t(T* x) {
     const float a0 = 0.35355339059327376f, h = 0.5f;
