@@ -1358,16 +1358,26 @@ __device__ __forceinline__ void dct16_inv(float* X) {
  * per thread as packed pairs (bior_taps2), levels 8, 4, 2 with the patches re-dealt to fewer threads each; DCT: 16
  * threads per patch (dct16_fwd / dct16_inv).
  * ------------------------------------------------------------------------------------------ */
-template <bool HAAR, bool BIOR>
+/* MULTI (N = 1, BASELINE configuration 5): a group is nine patches, so a workgroup takes kT16Groups consecutive groups
+ * through the 2-D stages together (their patches are contiguous in gpos and filt) and runs the per-pixel stage once
+ * per group.  Measured at 560^2: 0.90 ms with one group per workgroup, 0.34 / 0.33 / 0.36 / 0.38 / 0.46 / 0.47 / 0.71 ms
+ * with 2 / 3 / 4 / 5 / 7 / 8 / 14 -- three groups fill one round of the 16x16 level (216 of 256 threads) and leave
+ * room for five workgroups per CU. */
+#ifndef LFBM5D_T16_GROUPS
+#define LFBM5D_T16_GROUPS 3
+#endif
+constexpr int kT16Groups = LFBM5D_T16_GROUPS;
+template <bool HAAR, bool BIOR, bool MULTI>
 __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     extern __shared__ float lds[];
-    __shared__ float red[3][4];
+    __shared__ float red[MULTI ? kT16Groups : 1][3][4];
     constexpr int K = 16, RS = K + 1, PSZ = K * RS, A = 9;
     const int tid = threadIdx.x;
-    const unsigned g = a.ref_begin + blockIdx.x;
+    const unsigned g = a.ref_begin + blockIdx.x * (MULTI ? kT16Groups : 1);     /* first group of the workgroup */
+    const int ngr = MULTI ? (int)min((unsigned)kT16Groups, a.ref_begin + a.n_groups - g) : 1;
     const int c = blockIdx.y;
     const int N = a.N;
-    const int nSx = (int)a.self_cnt[g], NP = nSx * A;
+    const int nSx = MULTI ? 1 : (int)a.self_cnt[g], NP = MULTI ? ngr * A : nSx * A;
     typedef const __attribute__((address_space(4))) unsigned* cuptr;
     const cuptr pos = (cuptr)(a.gpos + (size_t)g * N * A);
     ShRef sh = group_shape(a, g);
@@ -1448,12 +1458,25 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
         __syncthreads();
     }
     T16_MARK();
-    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    switch (nSx) {
-        case 1:  group_id_body<1, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
-        case 2:  group_id_body<2, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
-        case 4:  group_id_body<4, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
-        default: group_id_body<8, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2, work); break;
+    float wacc[MULTI ? kT16Groups : 1], s1[MULTI ? kT16Groups : 1], s2[MULTI ? kT16Groups : 1];
+    if (MULTI) {
+#pragma unroll
+        for (int gi = 0; gi < kT16Groups; gi++) {
+            wacc[gi] = 0.0f; s1[gi] = 0.0f; s2[gi] = 0.0f;
+            if (gi < ngr) {
+                ShRef shg = group_shape(a, g + gi);
+                group_id_body<1, HAAR, true>(a, g + gi, c, tid, pos + gi * A, shg, a.tau4 == 6 && shg.use_sadct, wacc[gi], s1[gi], s2[gi],
+                                             work + gi * A * PSZ);
+            }
+        }
+    } else {
+        wacc[0] = 0.0f; s1[0] = 0.0f; s2[0] = 0.0f;
+        switch (nSx) {
+            case 1:  group_id_body<1, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc[0], s1[0], s2[0], work); break;
+            case 2:  group_id_body<2, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc[0], s1[0], s2[0], work); break;
+            case 4:  group_id_body<4, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc[0], s1[0], s2[0], work); break;
+            default: group_id_body<8, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc[0], s1[0], s2[0], work); break;
+        }
     }
     __syncthreads();
     T16_MARK();
@@ -1510,12 +1533,16 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     T16_MARK();
     if (tid == 0) { for (int i = 0; i < 5; i++) atomicAdd(&a.counters[4 + i], (unsigned long long)(tq[i + 1] - tq[i])); atomicAdd(&a.counters[9], 1ull); }
 #endif
-    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+#pragma unroll
+    for (int gi = 0; gi < (MULTI ? kT16Groups : 1); gi++) {
+        for (int o = 32; o > 0; o >>= 1) { wacc[gi] += __shfl_xor(wacc[gi], o); s1[gi] += __shfl_xor(s1[gi], o); s2[gi] += __shfl_xor(s2[gi], o); }
+        if ((tid & 63) == 0) { red[gi][0][tid >> 6] = wacc[gi]; red[gi][1][tid >> 6] = s1[gi]; red[gi][2][tid >> 6] = s2[gi]; }
+    }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < ngr) {   /* group weights (core:412-421, sd_weighting_5d core:3140-3173) */
+        const int gi = tid;
         float w = 0.0f, m = 0.0f, q = 0.0f;
-        for (int i = 0; i < 4; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        for (int i = 0; i < 4; i++) { w += red[gi][0][i]; m += red[gi][1][i]; q += red[gi][2][i]; }
         float wx;
         if (a.useSD) {
             const float Nn = (float)(nSx * A);
@@ -1525,17 +1552,20 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
             const float sig = a.sigma[c];
             wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
         }
-        a.wgt[(size_t)g * a.C + c] = wx;
+        a.wgt[(size_t)(g + gi) * a.C + c] = wx;
         if (c == 0) {
             atomicAdd(&a.counters[0], (unsigned long long)nSx);
-            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+            if (a.tau4 == 6 && group_shape(a, g + gi).use_sadct) atomicAdd(&a.counters[1], 1ull);
         }
     }
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true>(a); }
-__global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_t16_kernel<false, true>(a); }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false>(a); }
-__global__ __launch_bounds__(256) void k_group_dct16_any(GroupArgs a) { group_t16_kernel<false, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true, false>(a); }
+__global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_t16_kernel<false, true, false>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false, false>(a); }
+__global__ __launch_bounds__(256) void k_group_dct16_any(GroupArgs a) { group_t16_kernel<false, false, false>(a); }
+/* N = 1: kT16Groups groups per workgroup (the 5th-dimension transform is the identity, HAAR or not) */
+__global__ __launch_bounds__(256) void k_group_bior16_n1(GroupArgs a) { group_t16_kernel<true, true, true>(a); }
+__global__ __launch_bounds__(256) void k_group_dct16_n1(GroupArgs a) { group_t16_kernel<true, false, true>(a); }
 
 /* ------------------------------------------------------------------------------------------
  * 8x8 2-D DCT variant (the README Wiener configuration: k = 8, tau_2D = dct).  The 2-D transform
@@ -2371,7 +2401,8 @@ hipError_t prepare_group_kernels() {
         reinterpret_cast<const void*>(&k_group_dct8w<true, false>), reinterpret_cast<const void*>(&k_group_dct8w<false, false>),
         reinterpret_cast<const void*>(&k_group_dct8w<true, true>), reinterpret_cast<const void*>(&k_group_dct8w<false, true>),
         reinterpret_cast<const void*>(&k_group_bior16_haar), reinterpret_cast<const void*>(&k_group_bior16_any),
-        reinterpret_cast<const void*>(&k_group_dct16_haar), reinterpret_cast<const void*>(&k_group_dct16_any)};
+        reinterpret_cast<const void*>(&k_group_dct16_haar), reinterpret_cast<const void*>(&k_group_dct16_any),
+        reinterpret_cast<const void*>(&k_group_bior16_n1), reinterpret_cast<const void*>(&k_group_dct16_n1)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e != hipSuccess) return e;
@@ -2399,6 +2430,13 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
         const size_t lb = (size_t)a.N * 9 * 16 * 17 * sizeof(float);
         const dim3 grid(a.n_groups, a.C), block(256);
+        if (a.N == 1 && a.tau5 != 5) {   /* nine patches per group: a few groups share a workgroup (Haar / Hadamard of one patch: identity) */
+            const dim3 grid8((a.n_groups + kT16Groups - 1) / kT16Groups, a.C);
+            const size_t l1 = (size_t)kT16Groups * 9 * 16 * 17 * sizeof(float);
+            if (a.tau2 == 7) hipLaunchKernelGGL(k_group_bior16_n1, grid8, block, l1, s, a);
+            else             hipLaunchKernelGGL(k_group_dct16_n1, grid8, block, l1, s, a);
+            return hipGetLastError();
+        }
         if (a.tau2 == 7) {
             if (a.tau5 == 9) hipLaunchKernelGGL(k_group_bior16_haar, grid, block, lb, s, a);
             else             hipLaunchKernelGGL(k_group_bior16_any, grid, block, lb, s, a);
