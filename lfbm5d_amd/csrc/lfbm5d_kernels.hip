@@ -1840,7 +1840,10 @@ __device__ __forceinline__ void wiener_fibre2(v2f* stack, int base, int stride, 
     }
 }
 
-constexpr int kDct8wThreads = 256;
+#ifndef LFBM5D_DCT8W_THREADS
+#define LFBM5D_DCT8W_THREADS 256
+#endif
+constexpr int kDct8wThreads = LFBM5D_DCT8W_THREADS;
 
 /* bior1.5 on an 8x8 patch held by ONE thread (rows x[i][0..8)), all three levels in registers; T = float or a packed pair.
  * Same taps, order and unfused arithmetic as bior_fwd_level / bior_inv_level (lib_transforms.cpp:46-204). */
