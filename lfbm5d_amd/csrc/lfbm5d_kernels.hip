@@ -22,6 +22,8 @@
  */
 #include "lfbm5d_kernels.h"
 
+#include <type_traits>
+
 namespace lfbm5d {
 
 namespace {
@@ -2152,6 +2154,155 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
 #endif
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Per-SAI BM3D flavour, 8x8 patches (LFBM3Ddenoising's parameters: bm3d.cpp:315-690 with kHard = kWien = 8).
+ * A group is nSx <= 32 patches of ONE image, so a whole group fits a WAVEFRONT: four groups per workgroup, no
+ * workgroup barrier anywhere.  Lane = patch for the 2-D stages (the 8x8 patch and its transform in registers, the
+ * noisy / pilot pair packed in the Wiener step), lane = coefficient for the Hadamard + shrinkage along the stack
+ * (ht_filtering_hadamard :914-966, wiener_filtering_hadamard :980-1027), through an LDS stack [coefficient][patch]
+ * of the wave's own.  The generic group kernel spends a 256-thread workgroup on such a group.
+ * ------------------------------------------------------------------------------------------ */
+constexpr int kBm3dWaves = 4;
+template <int STEP> struct Bm3dT { typedef float type; };
+template <> struct Bm3dT<2> { typedef v2f type; };
+__device__ __forceinline__ float bm3d_first(float x) { return x; }
+__device__ __forceinline__ float bm3d_first(v2f x) { return x.x; }
+
+template <int STEP, bool BIOR>
+__global__ __launch_bounds__(64 * kBm3dWaves) void k_group_bm3d8(GroupArgs a) {
+    extern __shared__ float lds[];
+    typedef typename Bm3dT<STEP>::type T;
+    constexpr int K2 = 64, ST = kMaxN3 + 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned gi = blockIdx.x * kBm3dWaves + wave;
+    if (gi >= a.n_groups) return;                      /* the whole wavefront leaves: nothing below synchronises waves */
+    const unsigned g = a.ref_begin + gi;
+    const int c = blockIdx.y;
+    const int N = a.N, nSx = (int)a.self_cnt[g];
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const TbPtr tb = (TbPtr)a.tb;
+    T* S = reinterpret_cast<T*>(lds) + (size_t)wave * K2 * ST;
+
+    /* A: lane = patch: load, forward 2-D transform, scatter to the stack */
+    if (lane < nSx) {
+        const unsigned p = a.gpos[(size_t)g * N + lane];
+        const bool ok = p != 0xffffffffu;              /* never-filled table column: zeros (bm3d.cpp:737, :857) */
+        const size_t off = (size_t)c * plane + (ok ? p : 0u);
+        T x[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const f4u q0 = *reinterpret_cast<const f4u*>(a.noisy + off + (size_t)i * a.Wb + 4 * h);
+                if (STEP == 2) {
+                    const f4u q1 = *reinterpret_cast<const f4u*>(a.basic + off + (size_t)i * a.Wb + 4 * h);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) reinterpret_cast<v2f&>(x[i][4 * h + e]) = ok ? v2f{q0.v[e], q1.v[e]} : v2f{0.0f, 0.0f};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) reinterpret_cast<float&>(x[i][4 * h + e]) = ok ? q0.v[e] : 0.0f;
+                }
+            }
+        if (BIOR) bior8_fwd_2d(x, tb);
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) dct8_fwd_t(x[i]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                T col[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) col[i] = x[i][j];
+                dct8_fwd_t(col);
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i][j] = col[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) S[(i * 8 + j) * ST + lane] = x[i][j];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    /* B: lane = coefficient: Hadamard along the stack, shrinkage, inverse; filtered value back in place (Wiener: into .y) */
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    {
+        const float sig = a.sigma[c];
+        const float Tthr = a.lambda * sig;             /* * sqrt(nSx) inside shrink_fibre (bm3d.cpp:941) */
+        T* F = S + lane * ST;
+        auto fibre = [&](auto ns_tag) {
+            constexpr int NS = decltype(ns_tag)::value;
+            float o[NS], e[NS];
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                if (STEP == 2) { const v2f t = reinterpret_cast<const v2f&>(F[n]); o[n] = t.x; e[n] = t.y; }
+                else { o[n] = reinterpret_cast<const float&>(F[n]); e[n] = 0.0f; }
+            }
+            shrink_fibre<NS, STEP>(o, e, 8u, Tthr, sig * sig, true, wacc, tb);
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                const float r = STEP == 1 ? o[n] : e[n];
+                s1 += r; s2 += r * r;
+                if (STEP == 2) reinterpret_cast<v2f&>(F[n]).y = r; else reinterpret_cast<float&>(F[n]) = r;
+            }
+        };
+        switch (nSx) {
+            case 2:  fibre(std::integral_constant<int, 2>{}); break;
+            case 4:  fibre(std::integral_constant<int, 4>{}); break;
+            case 8:  fibre(std::integral_constant<int, 8>{}); break;
+            case 16: fibre(std::integral_constant<int, 16>{}); break;
+            default: fibre(std::integral_constant<int, 32>{}); break;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) {
+        float wx;
+        if (a.useSD) {                                 /* sd_weighting, bm3d.cpp:1345-1373 */
+            const float Nn = (float)(nSx * K2);
+            const float res = (s2 - s1 * s1 / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = wacc > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * wacc) : 1.0f / wacc) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) atomicAdd(&a.counters[0], (unsigned long long)nSx);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    /* C: lane = patch: inverse 2-D transform of the filtered coefficients, 16-byte stores: filt[g][n][c][64] */
+    if (lane < nSx) {
+        float x[8][8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const T t = S[(i * 8 + j) * ST + lane];
+                if (STEP == 2) x[i][j] = reinterpret_cast<const v2f&>(t).y; else x[i][j] = bm3d_first(t);
+            }
+        if (BIOR) bior8_inv_2d(x, tb);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                float col[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) col[i] = x[i][j];
+                dct8_inv_t(col);
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i][j] = col[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) dct8_inv_t(x[i]);
+        }
+        float4* dst = reinterpret_cast<float4*>(a.filt + (((size_t)g * N + lane) * a.C + c) * K2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            dst[2 * i] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
+            dst[2 * i + 1] = make_float4(x[i][4], x[i][5], x[i][6], x[i][7]);
+        }
+    }
+}
+
 /* ================================ aggregation kernel ====================================== */
 
 
@@ -2405,7 +2556,8 @@ hipError_t prepare_group_kernels() {
         reinterpret_cast<const void*>(&k_group_dct8w<true, true>), reinterpret_cast<const void*>(&k_group_dct8w<false, true>),
         reinterpret_cast<const void*>(&k_group_bior16_haar), reinterpret_cast<const void*>(&k_group_bior16_any),
         reinterpret_cast<const void*>(&k_group_dct16_haar), reinterpret_cast<const void*>(&k_group_dct16_any),
-        reinterpret_cast<const void*>(&k_group_bior16_n1), reinterpret_cast<const void*>(&k_group_dct16_n1)};
+        reinterpret_cast<const void*>(&k_group_bior16_n1), reinterpret_cast<const void*>(&k_group_dct16_n1),
+        reinterpret_cast<const void*>(&k_group_bm3d8<2, true>), reinterpret_cast<const void*>(&k_group_bm3d8<2, false>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e != hipSuccess) return e;
@@ -2464,6 +2616,13 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         }
         if (a.step == 2) hipLaunchKernelGGL(k_group_dct8<2>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);
         else             hipLaunchKernelGGL(k_group_dct8<1>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);
+        return hipGetLastError();
+    }
+    if (a.bm3d && a.A == 1 && a.k == 8 && a.tau5 == 8 && (a.tau2 == 5 || a.tau2 == 7)) {   /* per-SAI BM3D, 8x8 patches: a group per wavefront */
+        const dim3 grid((a.n_groups + kBm3dWaves - 1) / kBm3dWaves, a.C), block(64 * kBm3dWaves);
+        const size_t lb = (size_t)kBm3dWaves * 64 * (kMaxN3 + 1) * (a.step == 2 ? sizeof(v2f) : sizeof(float));
+        if (a.step == 2) { if (a.tau2 == 7) hipLaunchKernelGGL((k_group_bm3d8<2, true>), grid, block, lb, s, a); else hipLaunchKernelGGL((k_group_bm3d8<2, false>), grid, block, lb, s, a); }
+        else             { if (a.tau2 == 7) hipLaunchKernelGGL((k_group_bm3d8<1, true>), grid, block, lb, s, a); else hipLaunchKernelGGL((k_group_bm3d8<1, false>), grid, block, lb, s, a); }
         return hipGetLastError();
     }
     const size_t lds = group_lds_bytes(a);
