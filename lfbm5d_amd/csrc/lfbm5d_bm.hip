@@ -498,7 +498,8 @@ template <int K>
 __global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
     extern __shared__ float lds[];
     /* one launch covers both searches: blocks [0, n_self) are self-similarity tables, the rest
-     * disparity tables (fewer, fuller rounds of resident waves than two launches) */
+     * disparity tables (fewer, fuller rounds of resident waves than two launches; dispatching the disparity tables first,
+     * or one self table per two disparity tables, measured 9 % slower: 2.98 / 2.99 vs 2.75 ms of block matching per pass) */
     if (blockIdx.x >= a.n_self) scan_body<K, 2>(a, (int)(blockIdx.x - a.n_self), lds);
     else if (a.refmap) scan_body<K, 1>(a, (int)blockIdx.x, lds);
     else scan_body<K, 0>(a, (int)blockIdx.x, lds);
