@@ -215,7 +215,8 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
     if (P->tau_2D != LFBM5D_ID && P->tau_2D != LFBM5D_DCT && P->tau_2D != LFBM5D_BIOR) return fail(c, "bad tau_2D");
     if (P->tau_4D != LFBM5D_ID && P->tau_4D != LFBM5D_DCT && P->tau_4D != LFBM5D_SADCT) return fail(c, "bad tau_4D");
     if (P->tau_5D != LFBM5D_HAAR && P->tau_5D != LFBM5D_HADAMARD && P->tau_5D != LFBM5D_DCT) return fail(c, "bad tau_5D");
-    if (!is_pow2(P->N) || P->N > (unsigned)kMaxN) return fail(c, "unsupported: N must be a power of two <= 16");
+    if (!is_pow2(P->N) || P->N > (unsigned)kMaxN3) return fail(c, "unsupported: N must be a power of two <= 32");
+    if (P->N > (unsigned)kMaxN && P->tau_5D == LFBM5D_DCT) return fail(c, "unsupported: tau_5D = dct needs N <= 16");
     if (P->nSim < 1 || P->nDisp < 1 || P->p < 1) return fail(c, "bad search window / step");
     /* kernel limits: the row-slot tables carry 64 entries of padding for rows y + di, di <= nSim; candidate
      * indices are divided by 2 nSim + 1 with a 20-bit reciprocal; displacement tables are (2 nDisp + 1)^2 per SAI */

@@ -948,7 +948,7 @@ __device__ __forceinline__ ShRef group_shape(const GroupArgs& a, unsigned g) {
 template <int STEP>
 __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     extern __shared__ float lds[];
-    __shared__ unsigned pos[kMaxN * kMaxA];   /* >= kMaxN3 * 1 */
+    __shared__ unsigned pos[kMaxN3 * kMaxA];
     __shared__ float red[3][kThreads / 64];
 
     const int tid = threadIdx.x;
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     const TbPtr tb = (TbPtr)a.tb;
 
     /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323): from the pre-pass */
-    if (tid < nSx * A) pos[tid] = a.gpos[(size_t)g * N * A + tid];
+    for (int i = tid; i < nSx * A; i += kThreads) pos[i] = a.gpos[(size_t)g * N * A + i];   /* up to 32 x 9 > 256 */
     ShRef sh = group_shape(a, g);
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
                 case 4:  filter5<4, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
                 case 8:  filter5<8, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
                 case 16: filter5<16, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
-                default: filter5<32, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;   /* BM3D flavour only */
+                default: filter5<32, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;   /* never with tau_5D = dct (validated) */
             }
         }
     }
@@ -2601,13 +2601,13 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         }
         return hipGetLastError();
     }
-    if (a.tau2 == 7 && a.k == 8 && a.A == 9 && a.step == 2) {   /* 8x8 bior1.5, Wiener step: the DCT kernel with the wavelet in its 2-D stage */
+    if (a.tau2 == 7 && a.k == 8 && a.A == 9 && a.step == 2 && a.N <= (unsigned)kMaxN) {   /* 8x8 bior1.5, Wiener step: the DCT kernel with the wavelet in its 2-D stage */
         const size_t l8 = (size_t)2 * 64 * ((a.N * 9) | 1) * sizeof(float);
         if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
         else             hipLaunchKernelGGL((k_group_dct8w<false, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
         return hipGetLastError();
     }
-    if (a.tau2 == 5 && a.k == 8 && a.A == 9) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
+    if (a.tau2 == 5 && a.k == 8 && a.A == 9 && a.N <= (unsigned)kMaxN) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
         const size_t l8 = (size_t)(a.step == 2 ? 2 : 1) * 64 * ((a.N * 9) | 1) * sizeof(float);
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* packed noisy/pilot pair */
             if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);

@@ -67,6 +67,10 @@ PASS_CASES = [
     ("ht-k16-dct-hw", 1, 25.0, (4, 6, 2, 16, 3, "dct", "dct", "hw"), 96, 0),
     ("ht-k16-bior-n8", 1, 10.0, (8, 8, 3, 16, 4, "bior", "sadct", "haar"), 96, 0),    # configuration 4's HT step
     ("wien-bior-n8-hw", 2, 25.0, (8, 6, 2, 8, 3, "bior", "dct", "hw"), 64, 0),
+    ("wien-n32", 2, 10.0, (32, 8, 2, 8, 4, "dct", "sadct", "haar"), 64, 0),             # N = 32: generic group kernel
+    ("ht-n32-hw", 1, 10.0, (32, 8, 2, 8, 4, "bior", "sadct", "hw"), 64, 0),
+    ("ht-n1-p5-bior", 1, 10.0, (1, 16, 3, 16, 5, "bior", "sadct", "haar"), 104, 0),     # README.md:76 (faster EPFL parameters)
+    ("wien-n8-p5", 2, 10.0, (8, 16, 3, 8, 5, "dct", "sadct", "haar"), 104, 0),
     ("ht-usesd", 1, 25.0, (4, 6, 2, 8, 3, "id", "sadct", "haar"), 64, 1),
     ("wien-dct-sadct-haar", 2, 25.0, (8, 6, 2, 8, 3, "dct", "sadct", "haar"), 64, 0),
     ("wien-id-dct-hw", 2, 25.0, (8, 6, 2, 8, 3, "id", "dct", "hw"), 64, 0),
