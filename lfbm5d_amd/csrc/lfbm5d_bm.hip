@@ -597,34 +597,49 @@ __global__ void k_self_trivial(const unsigned* __restrict__ refs, unsigned n_ref
  * (dj outer, di inner), the order the reference pushes candidates in.  grid.y = table slot. */
 struct ArgminArgs { const float* tables; size_t tstride; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp; float thr; unsigned* best; unsigned char* shape; };
 __global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
+    /* a thread takes four consecutive columns of one row (one 16-byte load per table: the tables are strip-major with
+     * 64-column strips, so groups of four never straddle a strip), eight tables in flight */
     const int W = a.W, H = a.H, nDisp = a.nDisp;
     const int span_c = W - 2 * nDisp - a.k + 1, span_r = H - 2 * nDisp - a.k + 1;
+    const int quads = (span_c + 3) / 4;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= span_c * span_r) return;
+    if (i >= quads * span_r) return;
     const unsigned slot = blockIdx.y, st = a.st_of_slot[slot];
-    const int y = nDisp + i / span_c, x = nDisp + i % span_c;
+    const int y = nDisp + i / quads, x0 = 4 * (i % quads);            /* x0: column inside the band */
     const int Ns = 2 * nDisp + 1, ncand = Ns * Ns;
     const size_t WH = (size_t)W * H;
-    const int pos = y * W + x;
-    const float* t = a.tables + (size_t)slot * ncand * a.tstride + ((size_t)((x - nDisp) / 64) * H + y) * 64 + (x - nDisp) % 64;
-    float bv = t[0]; int bo = 0, bd = 0;
-    for (int d0 = 0; d0 < ncand; d0 += 8) {   /* eight independent table reads in flight */
-        float v[8];
+    const float* t = a.tables + (size_t)slot * ncand * a.tstride + ((size_t)(x0 / 64) * H + y) * 64 + x0 % 64;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float bv[4]; int bo[4], bd[4];
+    {
+        const f4 v0 = *reinterpret_cast<const f4*>(t);
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = t[(size_t)min(d0 + u, ncand - 1) * a.tstride];
+        for (int e = 0; e < 4; e++) { bv[e] = v0[e]; bo[e] = 0; bd[e] = 0; }
+    }
+    for (int d0 = 0; d0 < ncand; d0 += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f4*>(t + (size_t)min(d0 + u, ncand - 1) * a.tstride);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int ddk = d0 + u;
             if (ddk < ncand) {
                 const int di = ddk / Ns, dj = ddk - di * Ns;
                 const int order = dj * Ns + di;
-                if (v[u] < bv || (v[u] == bv && order < bo)) { bv = v[u]; bo = order; bd = ddk; }
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (v[u][e] < bv[e] || (v[u][e] == bv[e] && order < bo[e])) { bv[e] = v[u][e]; bo[e] = order; bd[e] = ddk; }
             }
         }
     }
-    const int di = bd / Ns, dj = bd % Ns;
-    a.best[(size_t)st * WH + pos] = (unsigned)(pos + (di - nDisp) * W + (dj - nDisp));
-    a.shape[(size_t)st * WH + pos] = bv < a.thr ? 1 : 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        if (x0 + e >= span_c) break;                                    /* the band's last group may be short */
+        const int pos = y * W + nDisp + x0 + e;
+        const int di = bd[e] / Ns, dj = bd[e] % Ns;
+        a.best[(size_t)st * WH + pos] = (unsigned)(pos + (di - nDisp) * W + (dj - nDisp));
+        a.shape[(size_t)st * WH + pos] = bv[e] < a.thr ? 1 : 0;
+    }
 }
 
 __global__ void k_refmap(const unsigned* __restrict__ refs, unsigned n_refs, int* __restrict__ refmap) {
@@ -675,7 +690,7 @@ hipError_t launch_self_trivial(hipStream_t s, const unsigned* refs, unsigned n_r
 hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,
                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
                                 unsigned* best, unsigned char* shape) {
-    const unsigned n = (W - 2 * nDisp - k + 1) * (H - 2 * nDisp - k + 1);
+    const unsigned n = ((W - 2 * nDisp - k + 1 + 3) / 4) * (H - 2 * nDisp - k + 1);   /* groups of four columns */
     ArgminArgs a;
     a.tables = tables; a.tstride = stereo_table_stride(W, H, k, nDisp); a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.thr = thr; a.best = best; a.shape = shape;
     for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
