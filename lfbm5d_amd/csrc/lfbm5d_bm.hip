@@ -563,6 +563,37 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
         if (lane == 0) { out[0] = k_r; out[1] = k_r; self_cnt[ref] = 2; }
         return;
     }
+    auto wave_min = [](unsigned long long v) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long oth = __shfl_xor(v, o);
+            v = oth < v ? oth : v;
+        }
+        return v;
+    };
+    if (cnt > 128) {
+        /* Prune before selecting: the nSx-th smallest of the 64 per-lane minima bounds the nSx-th smallest key overall
+         * (there are nSx distinct keys at or below it), so only keys up to that bound can be selected.  They are
+         * compacted in place -- the write index never passes the read index, and a wavefront's reads of a round
+         * precede its writes -- and the selection rounds below walk a list of typically a few dozen keys. */
+        unsigned long long mine = ~0ull;
+        for (int e = lane; e < cnt; e += 64) { const unsigned long long kk = keys[e]; mine = kk < mine ? kk : mine; }
+        unsigned long long bound = 0, m = mine;
+        for (unsigned n = 0; n < nSx; n++) {
+            bound = wave_min(m);
+            if (m == bound) m = ~0ull;          /* keys are unique: exactly one lane drops its minimum */
+        }
+        int c2 = 0;
+        for (int e0 = 0; e0 < cnt; e0 += 64) {
+            const int e = e0 + lane;
+            const unsigned long long kk = e < cnt ? keys[e] : ~0ull;
+            const bool keep = kk <= bound;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) keys[c2 + __popcll(bal & ((1ull << lane) - 1ull))] = kk;
+            c2 += __popcll(bal);
+        }
+        cnt = c2;
+        __builtin_amdgcn_wave_barrier();
+    }
     unsigned long long last = 0;
     bool first = true;
     for (unsigned n = 0; n < nSx; n++) { /* n-th smallest (distance, scan order) key */
@@ -571,10 +602,7 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
             const unsigned long long kk = keys[e];
             if ((first || kk > last) && kk < best) best = kk;
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long oth = __shfl_xor(best, o);
-            best = oth < best ? oth : best;
-        }
+        best = wave_min(best);
         last = best; first = false;
         if (lane == 0) {
             const int e = (int)(best & 0xffffffffu);
