@@ -2575,14 +2575,17 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* geometry pre-pass: patch positions, aggregation positions, angular shapes */
     hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N * a.A), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_group_shape, grid1d(a.n_groups), dim3(256), 0, s, a);
+    /* LFBM5D_GROUP_GENERIC: test hook, every configuration through the generic LDS kernel (the dedicated kernels' cross-check) */
+    const bool generic_only = getenv("LFBM5D_GROUP_GENERIC") != nullptr && group_lds_bytes(a) <= 160 * 1024 - 4096;
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
-    if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9) {
+    if (generic_only) {}
+    else if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
         if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
         else             hipLaunchKernelGGL(k_group_id_any, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
         return hipGetLastError();
     }
-    if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
+    else if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
         const size_t lb = (size_t)a.N * 9 * 16 * 17 * sizeof(float);
         const dim3 grid(a.n_groups, a.C), block(256);
         if (a.N == 1 && a.tau5 != 5) {   /* nine patches per group: a few groups share a workgroup (Haar / Hadamard of one patch: identity) */
@@ -2601,13 +2604,13 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         }
         return hipGetLastError();
     }
-    if (a.tau2 == 7 && a.k == 8 && a.A == 9 && a.step == 2 && a.N <= (unsigned)kMaxN) {   /* 8x8 bior1.5, Wiener step: the DCT kernel with the wavelet in its 2-D stage */
+    else if (a.tau2 == 7 && a.k == 8 && a.A == 9 && a.step == 2 && a.N <= (unsigned)kMaxN) {   /* 8x8 bior1.5, Wiener step: the DCT kernel with the wavelet in its 2-D stage */
         const size_t l8 = (size_t)2 * 64 * ((a.N * 9) | 1) * sizeof(float);
         if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
         else             hipLaunchKernelGGL((k_group_dct8w<false, true>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
         return hipGetLastError();
     }
-    if (a.tau2 == 5 && a.k == 8 && a.A == 9 && a.N <= (unsigned)kMaxN) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
+    else if (a.tau2 == 5 && a.k == 8 && a.A == 9 && a.N <= (unsigned)kMaxN) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
         const size_t l8 = (size_t)(a.step == 2 ? 2 : 1) * 64 * ((a.N * 9) | 1) * sizeof(float);
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* packed noisy/pilot pair */
             if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
@@ -2618,7 +2621,7 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         else             hipLaunchKernelGGL(k_group_dct8<1>, dim3(a.n_groups, a.C), dim3(kDct8Threads), l8, s, a);
         return hipGetLastError();
     }
-    if (a.bm3d && a.A == 1 && a.k == 8 && a.tau5 == 8 && (a.tau2 == 5 || a.tau2 == 7)) {   /* per-SAI BM3D, 8x8 patches: a group per wavefront */
+    else if (a.bm3d && a.A == 1 && a.k == 8 && a.tau5 == 8 && (a.tau2 == 5 || a.tau2 == 7)) {   /* per-SAI BM3D, 8x8 patches: a group per wavefront */
         const dim3 grid((a.n_groups + kBm3dWaves - 1) / kBm3dWaves, a.C), block(64 * kBm3dWaves);
         const size_t lb = (size_t)kBm3dWaves * 64 * (kMaxN3 + 1) * (a.step == 2 ? sizeof(v2f) : sizeof(float));
         if (a.step == 2) { if (a.tau2 == 7) hipLaunchKernelGGL((k_group_bm3d8<2, true>), grid, block, lb, s, a); else hipLaunchKernelGGL((k_group_bm3d8<2, false>), grid, block, lb, s, a); }
