@@ -2056,25 +2056,6 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
     for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
     __syncthreads();
-    if (tid == 0) {
-        float w = 0.0f, m = 0.0f, q = 0.0f;
-        for (int i = 0; i < kDct8wThreads / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
-        float wx;
-        if (a.useSD) {
-            const float Nn = (float)(nSx * A);
-            const float res = (q - m * m / Nn) / (Nn - 1.0f);
-            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
-        } else {
-            const float sig = a.sigma[c];
-            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
-        }
-        a.wgt[(size_t)g * a.C + c] = wx;
-        if (c == 0) {
-            atomicAdd(&a.counters[0], (unsigned long long)nSx);
-            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
-        }
-    }
-
     PHASE_MARK();
     /* 4: 4-D inverse of the filtered stack (.y), two (n, pq) fibres per thread: pq and pq + 32 */
     if (do_dct4 || do_sa4) {
@@ -2102,6 +2083,25 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         }
     }
     __syncthreads();
+
+    if (tid == kDct8wThreads - 64) {   /* the last wave takes no part in phase 5 (NP / 2 <= 72 patch pairs): the weight costs nothing there */
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < kDct8wThreads / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(nSx * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)nSx);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
+    }
 
     PHASE_MARK();
     /* 5: inverse 2-D DCT + store, two patches per thread (patch, patch + NPh): filt[g][n][st][c][64] */
