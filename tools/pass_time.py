@@ -47,7 +47,8 @@ def main():
         torch.cuda.synchronize()
         s = ctx.stats()
         print(f"step {step} {Wb}x{Hb}: bm {s.ms_bm / reps:.3f} group {s.ms_group / reps:.3f} agg {s.ms_aggregate / reps:.3f} "
-              f"other {s.ms_other / reps:.3f} ms/pass; groups {s.groups // reps} checksum {float(num.double().sum()):.6e}")
+              f"other {s.ms_other / reps:.3f} ms/pass; groups {s.groups // reps} (shape-adaptive {s.sadct_groups // reps}, mean stack {s.stack_patches / max(1, s.groups):.2f}) "
+              f"checksum {float(num.double().sum()):.6e}")
 
 
 if __name__ == "__main__":
