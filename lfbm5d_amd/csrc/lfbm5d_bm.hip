@@ -372,11 +372,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                          v4f* la1, v4f* la2, float& lb1, float& lb2,                   /* receive rows filled+(DEP-1)T .. */
                          const v4f* sa1, const v4f* sa2, float sb1, float sb2) {       /* rows filled .. go to the ring */
             /* flavour 0: steady; 1: ramp-up (lanes start one after the other, every row and index still in range);
-             * 2: general edge (ramp-down, rows past the band, short tables) */
+             * 2: general edge (ramp-down, rows past the band, short tables); 3: tail of a disparity table's ramp-down:
+             * every row of the band is in the ring already and no lane starts any more -- the steady chain without row
+             * loads and ring writes, only the hand-off column indices are range-checked */
             constexpr int FL = decltype(edge_tag)::value;
-            constexpr bool EDGE = FL != 0;          /* lane predicates */
-            constexpr bool REDGE = FL == 2;         /* row / index range handling */
-            load_chunk(std::integral_constant<bool, REDGE>{}, filled + (DEP - 1) * T, la1, la2, lb1, lb2);
+            constexpr bool TAIL = FL == 3;
+            constexpr bool EDGE = FL == 1 || FL == 2;   /* lane predicates */
+            constexpr bool REDGE = FL == 2;             /* row / index range handling */
+            if (!TAIL) load_chunk(std::integral_constant<bool, REDGE>{}, filled + (DEP - 1) * T, la1, la2, lb1, lb2);
             const float* pa = ring + oA;
             const float* pb = ring + oB;
             float d1[T], d2[T], d3[T], d4[T], lc[T], Sout[T];
@@ -384,7 +387,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             for (int s = 0; s < T; s++) {
                 d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
                 d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
-                lc[s] = lcol[REDGE ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
+                lc[s] = lcol[(REDGE || TAIL) ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
             }
             oA += T * CW; oA = oA >= RR * CW ? oA - RR * CW : oA;
             oB += T * CW; oB = oB >= RR * CW ? oB - RR * CW : oB;
@@ -436,7 +439,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 /* hand-off column for the next strip (uniform address and value) */
                 const int il = 1 + t - last_lane;
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
-                lcol[REDGE ? ((il >= 1 && il < nrows) ? il : nrows + T) : FL == 1 ? max(il, 0) : il] = hv;   /* ramp-up: rows < 1 land in slot 0... */
+                lcol[(REDGE || TAIL) ? ((il >= 1 && il < nrows) ? il : nrows + T) : FL == 1 ? max(il, 0) : il] = hv;   /* ramp-up: rows < 1 land in slot 0... */
             }
             if (stereo) {
                 /* every 16-lane group has just completed 64-byte segments of four more rows (its last lane wrote
@@ -451,9 +454,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, val), rsTb, rv ? uvo : -1, (strip * H + b + t0 + 4 * h) * 256, 0);
                 }
             }
-            write_chunk(std::integral_constant<bool, REDGE>{}, filled, wrow, sa1, sa2, sb1, sb2);
-            wrow = wrow + T == RR ? 0 : wrow + T;
-            filled += T;
+            if (!TAIL) {
+                write_chunk(std::integral_constant<bool, REDGE>{}, filled, wrow, sa1, sa2, sb1, sb2);
+                wrow = wrow + T == RR ? 0 : wrow + T;
+                filled += T;
+            }
         };
         {
             /* [0, tS0): ramp-up, [tS0, tS1): steady, [tS1, nsteps): ramp-down; all in groups of DEP chunks (the
@@ -479,7 +484,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             SCAN_MARK(3);
             for (; t0 < tS1; t0 += G) group(std::integral_constant<int, 0>{}, t0);
             SCAN_MARK(4);
-            for (; t0 < nsteps + (stereo ? 16 : 0); t0 += G) group(std::integral_constant<int, 2>{}, t0);   /* + the chunks that flush the store stage */
+            const int t_end = nsteps + (stereo ? 16 : 0);   /* + the chunks that flush the store stage */
+            if (stereo) {
+                /* a disparity table never reads past the band (nrows = band_rows - K + 1): once the band is in the ring and
+                 * the last lane has started, the rest of the ramp-down needs neither loads nor ring writes */
+                for (; t0 < t_end && (filled < band_rows || t0 <= last_lane); t0 += G) group(std::integral_constant<int, 2>{}, t0);
+                for (; t0 < t_end; t0 += G) group(std::integral_constant<int, 3>{}, t0);
+            } else
+                for (; t0 < t_end; t0 += G) group(std::integral_constant<int, 2>{}, t0);
         }
         SCAN_MARK(3);
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
