@@ -545,14 +545,8 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     HIPCK(c, c->g_den.reserve(asize * img * sizeof(float)));
     HIPCK(c, hipMemsetAsync(c->g_num.p, 0, asize * img * sizeof(float), s));
     HIPCK(c, hipMemsetAsync(c->g_den.p, 0, asize * img * sizeof(float), s));
-    HIPCK(c, c->w_noisy.reserve(Aw * imgb * sizeof(float)));
-    if (step == 2) HIPCK(c, c->w_basic.reserve(Aw * imgb * sizeof(float)));
-    HIPCK(c, c->w_num.reserve(Aw * imgb * sizeof(float)));
-    HIPCK(c, c->w_den.reserve(Aw * imgb * sizeof(float)));
     HIPCK(c, c->small.reserve((asize + 8) * sizeof(unsigned)));
     float* g_num = c->g_num.as<float>(); float* g_den = c->g_den.as<float>();
-    float* w_noisy = c->w_noisy.as<float>(); float* w_basic = c->w_basic.as<float>();
-    float* w_num = c->w_num.as<float>(); float* w_den = c->w_den.as<float>();
     unsigned* d_small = c->small.as<unsigned>();
     std::vector<unsigned> h_cnt(asize + 8, (unsigned)img), h_tmp(asize + 8), h_one(8);   /* den starts all zero */
     std::vector<unsigned> dirty;
@@ -561,76 +555,133 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
     c->last_windows.clear();
 
-    /* one angular window around SAI (ps, pt): bm5d.cpp:215-402 */
-    auto do_window = [&](unsigned ps, unsigned pt) -> int {
-        int cs_w, mins, maxs, ct_w, mint, maxt;
-        search_window((int)ps, aheight, an, cs_w, mins, maxs);
-        search_window((int)pt, awidth, an, ct_w, mint, maxt);
-        const unsigned cst_w = ang_major == LFBM5D_ROWMAJOR ? cs_w * asw + ct_w : cs_w + ct_w * asw;
-        std::vector<unsigned> st_idx(Aw), mask_w(Aw), proc_w(Aw);
+    /* One angular window around SAI (ps, pt): bm5d.cpp:215-402, in two halves so that several windows can be in flight
+     * on lanes of their own (a lane = a context with its stream, window buffers and per-pass work buffers; lane 0 is this
+     * context).  win_begin enqueues the padding, the centre pass and its coverage count; win_finish waits for the count,
+     * runs whatever further passes the window needs (greyscale light fields) and adds the window back to the light field. */
+    struct Lane { lfbm5d_ctx* x; float* w_noisy; float* w_basic; float* w_num; float* w_den; unsigned* d_small; };
+    struct WinState {
+        unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, win_bits = 0, rem_w = 0, tot_w = 0, pst_w = 0;
+        std::vector<unsigned> st_idx, mask_w, proc_w; SaiList sl; lfbm5d_params Pw; bool counted = false;
+    };
+    auto lane_buffers = [&](lfbm5d_ctx* x, Lane& L) -> int {
+        HIPCK(c, x->w_noisy.reserve(Aw * imgb * sizeof(float)));
+        if (step == 2) HIPCK(c, x->w_basic.reserve(Aw * imgb * sizeof(float)));
+        HIPCK(c, x->w_num.reserve(Aw * imgb * sizeof(float)));
+        HIPCK(c, x->w_den.reserve(Aw * imgb * sizeof(float)));
+        HIPCK(c, x->small.reserve((asize + 8) * sizeof(unsigned)));
+        L.x = x; L.w_noisy = x->w_noisy.as<float>(); L.w_basic = x->w_basic.as<float>();
+        L.w_num = x->w_num.as<float>(); L.w_den = x->w_den.as<float>(); L.d_small = x->small.as<unsigned>();
+        return 0;
+    };
+    auto lane_fail = [&](const Lane& L) { if (L.x != c) c->err = L.x->err; return 1; };
+    /* coverage count of the pass just enqueued -> the lane's pinned word (LF_denoised_percent, utilities_LF.cpp:967-995) */
+    auto enqueue_count = [&](const Lane& L, WinState& ws) -> int {
+        hipStream_t ls = L.x->stream;
+        HIPCK(c, hipMemsetAsync(L.d_small, 0, sizeof(unsigned), ls));
+        HIPCK(c, launch_count_denoised(ls, L.w_den, imgb, Aw, ws.win_bits, W, H, C, nHW, P->k, L.d_small));
+        HIPCK(c, hipMemcpyAsync(L.x->h_small, L.d_small, sizeof(unsigned), hipMemcpyDeviceToHost, ls));
+        ws.counted = true;
+        return 0;
+    };
+    auto one_pass = [&](const Lane& L, WinState& ws) -> int {
+        if (pass_impl(L.x, step, &ws.Pw, asw, asw, wb, hb, C, L.w_noisy, step == 2 ? L.w_basic : nullptr, L.w_num, L.w_den,
+                      ws.mask_w.data(), ws.proc_w.data(), ws.cst_w, ws.pst_w)) return lane_fail(L);
+        ws.proc_w[ws.pst_w] += 1;
+        const unsigned ps_w = ang_major == LFBM5D_ROWMAJOR ? ws.pst_w / asw : ws.pst_w % asw;
+        const unsigned pt_w = ang_major == LFBM5D_ROWMAJOR ? ws.pst_w % asw : ws.pst_w / asw;
+        const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (ws.mins + ps_w) * awidth + (ws.mint + pt_w)
+                                                         : (ws.mins + ps_w) + (ws.mint + pt_w) * aheight;
+        proc[st] += 1;
+        return enqueue_count(L, ws);
+    };
+    auto win_begin = [&](const Lane& L, unsigned ps, unsigned pt, unsigned tau4, WinState& ws) -> int {
+        hipStream_t ls = L.x->stream;
+        ws.ps = ps; ws.pt = pt; ws.counted = false;
+        int maxs, maxt;
+        search_window((int)ps, aheight, an, ws.cs_w, ws.mins, maxs);
+        search_window((int)pt, awidth, an, ws.ct_w, ws.mint, maxt);
+        ws.cst_w = ang_major == LFBM5D_ROWMAJOR ? ws.cs_w * asw + ws.ct_w : ws.cs_w + ws.ct_w * asw;
+        ws.st_idx.assign(Aw, 0); ws.mask_w.assign(Aw, 0); ws.proc_w.assign(Aw, 0);
         for (unsigned si = 0; si < asw; si++)
             for (unsigned ti = 0; ti < asw; ti++) {
-                const unsigned S = si + mins, T = ti + mint;
-                if (ang_major == LFBM5D_ROWMAJOR) st_idx[si * asw + ti] = S * awidth + T;
-                else st_idx[si + ti * asw] = S + T * aheight;
+                const unsigned S = si + ws.mins, T = ti + ws.mint;
+                if (ang_major == LFBM5D_ROWMAJOR) ws.st_idx[si * asw + ti] = S * awidth + T;
+                else ws.st_idx[si + ti * asw] = S + T * aheight;
             }
-        SaiList sl;
-        sl.n = Aw;
-        unsigned win_bits = 0;
+        ws.sl.n = Aw;
+        ws.win_bits = 0;
         for (unsigned i = 0; i < Aw; i++) {
-            mask_w[i] = h_mask[st_idx[i]];
-            sl.st[i] = mask_w[i] ? st_idx[i] : 0xffffffffu;
-            if (mask_w[i]) win_bits |= 1u << i;
+            ws.mask_w[i] = h_mask[ws.st_idx[i]];
+            ws.sl.st[i] = ws.mask_w[i] ? ws.st_idx[i] : 0xffffffffu;
+            if (ws.mask_w[i]) ws.win_bits |= 1u << i;
         }
-        HIPCK(c, launch_symetrize_multi(s, d_noisy, img, w_noisy, imgb, sl, W, H, C, nHW));
-        if (step == 2) HIPCK(c, launch_symetrize_multi(s, d_basic, img, w_basic, imgb, sl, W, H, C, nHW));
-        HIPCK(c, launch_symetrize_multi(s, g_num, img, w_num, imgb, sl, W, H, C, nHW));
-        HIPCK(c, launch_symetrize_multi(s, g_den, img, w_den, imgb, sl, W, H, C, nHW));
-        for (unsigned i = 0; i < Aw; i++) proc_w[i] = !mask_w[i];
-        unsigned rem_w = (unsigned)std::count(proc_w.begin(), proc_w.end(), 0u);
-        const unsigned tot_w = rem_w;
-        if (tot_w != Aw && tau_4D == LFBM5D_DCT) tau_4D = LFBM5D_SADCT; /* bm5d.cpp:276-280 */
-        lfbm5d_params Pw = *P;
-        Pw.tau_4D = tau_4D;
-        unsigned ps_w = 0, pt_w = 0, pst_w = 0;
-        while (rem_w) {
-            if (rem_w == tot_w && mask_w[cst_w]) { ps_w = cs_w; pt_w = ct_w; pst_w = cst_w; }
-            else {
-                HIPCK(c, hipMemsetAsync(d_small, 0, Aw * sizeof(unsigned), s));
-                HIPCK(c, launch_count_zeros(s, w_den, imgb, Aw, d_small));
-                HIPCK(c, hipMemcpyAsync(h_tmp.data(), d_small, Aw * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-                HIPCK(c, hipStreamSynchronize(s));
+        HIPCK(c, launch_symetrize_multi(ls, d_noisy, img, L.w_noisy, imgb, ws.sl, W, H, C, nHW));
+        if (step == 2) HIPCK(c, launch_symetrize_multi(ls, d_basic, img, L.w_basic, imgb, ws.sl, W, H, C, nHW));
+        HIPCK(c, launch_symetrize_multi(ls, g_num, img, L.w_num, imgb, ws.sl, W, H, C, nHW));
+        HIPCK(c, launch_symetrize_multi(ls, g_den, img, L.w_den, imgb, ws.sl, W, H, C, nHW));
+        for (unsigned i = 0; i < Aw; i++) ws.proc_w[i] = !ws.mask_w[i];
+        ws.rem_w = (unsigned)std::count(ws.proc_w.begin(), ws.proc_w.end(), 0u);
+        ws.tot_w = ws.rem_w;
+        ws.Pw = *P;
+        ws.Pw.tau_4D = tau4;
+        if (ws.rem_w && ws.mask_w[ws.cst_w]) {   /* the centre pass needs no device data to be chosen: enqueue it now */
+            ws.pst_w = ws.cst_w;
+            if (one_pass(L, ws)) return 1;
+        }
+        return 0;
+    };
+    auto win_finish = [&](const Lane& L, WinState& ws) -> int {
+        hipStream_t ls = L.x->stream;
+        std::vector<unsigned> h_tmp_w(Aw);
+        while (ws.rem_w) {
+            if (!ws.counted) {   /* choose the next SAI of the window from the zero-weight counts (bm5d.cpp:299-327) and process it */
+                HIPCK(c, hipMemsetAsync(L.d_small, 0, Aw * sizeof(unsigned), ls));
+                HIPCK(c, launch_count_zeros(ls, L.w_den, imgb, Aw, L.d_small));
+                HIPCK(c, hipMemcpyAsync(h_tmp_w.data(), L.d_small, Aw * sizeof(unsigned), hipMemcpyDeviceToHost, ls));
+                HIPCK(c, hipStreamSynchronize(ls));
                 long best_cnt = -1;
                 for (unsigned i = 0; i < Aw; i++) {
-                    if (proc_w[i]) continue;
-                    if ((long)h_tmp[i] >= best_cnt) { pst_w = i; best_cnt = (long)h_tmp[i]; }
+                    if (ws.proc_w[i]) continue;
+                    if ((long)h_tmp_w[i] >= best_cnt) { ws.pst_w = i; best_cnt = (long)h_tmp_w[i]; }
                 }
-                if (ang_major == LFBM5D_ROWMAJOR) { ps_w = pst_w / asw; pt_w = pst_w - ps_w * asw; }
-                else { pt_w = pst_w / asw; ps_w = pst_w - pt_w * asw; }
+                if (one_pass(L, ws)) return 1;
             }
-            if (pass_impl(c, step, &Pw, asw, asw, wb, hb, C, w_noisy, step == 2 ? w_basic : nullptr, w_num, w_den,
-                          mask_w.data(), proc_w.data(), cst_w, pst_w)) return 1;
-            proc_w[pst_w] += 1;
-            const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (mins + ps_w) * awidth + (mint + pt_w)
-                                                             : (mins + ps_w) + (mint + pt_w) * aheight;
-            proc[st] += 1;
+            HIPCK(c, hipStreamSynchronize(ls));
+            ws.counted = false;
             /* LF_denoised_percent (utilities_LF.cpp:967-995): counts (i,j,c) triples, divides without C */
-            HIPCK(c, hipMemsetAsync(d_small, 0, sizeof(unsigned), s));
-            const unsigned n_mask = (unsigned)__builtin_popcount(win_bits);
-            HIPCK(c, launch_count_denoised(s, w_den, imgb, Aw, win_bits, W, H, C, nHW, P->k, d_small));
-            HIPCK(c, hipMemcpyAsync(h_one.data(), d_small, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            HIPCK(c, hipStreamSynchronize(s));
-            const float pct = (float)h_one[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
+            const unsigned n_mask = (unsigned)__builtin_popcount(ws.win_bits);
+            const float pct = (float)L.x->h_small[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
             if (pct >= 100.0f)
                 for (unsigned i = 0; i < Aw; i++)
-                    if (proc_w[i] == 0) { proc_w[i] += 1; proc[st_idx[i]] += 1; }
-            rem_w = (unsigned)std::count(proc_w.begin(), proc_w.end(), 0u);
+                    if (ws.proc_w[i] == 0) { ws.proc_w[i] += 1; proc[ws.st_idx[i]] += 1; }
+            ws.rem_w = (unsigned)std::count(ws.proc_w.begin(), ws.proc_w.end(), 0u);
         }
-        HIPCK(c, launch_unsymetrize_multi(s, g_num, img, w_num, imgb, sl, W, H, C, nHW));
-        HIPCK(c, launch_unsymetrize_multi(s, g_den, img, w_den, imgb, sl, W, H, C, nHW));
-        for (unsigned i = 0; i < Aw; i++) if (mask_w[i]) dirty.push_back(st_idx[i]);
-        c->last_windows.push_back(ang_major == LFBM5D_ROWMAJOR ? ps * awidth + pt : ps + pt * aheight);
+        HIPCK(c, launch_unsymetrize_multi(ls, g_num, img, L.w_num, imgb, ws.sl, W, H, C, nHW));
+        HIPCK(c, launch_unsymetrize_multi(ls, g_den, img, L.w_den, imgb, ws.sl, W, H, C, nHW));
+        for (unsigned i = 0; i < Aw; i++) if (ws.mask_w[i]) dirty.push_back(ws.st_idx[i]);
         c->stats.windows += 1;
+        return 0;
+    };
+    Lane lane0;
+    if (lane_buffers(c, lane0)) return 1;
+    /* sequential form: one window after the other on this context's stream */
+    auto do_window = [&](unsigned ps, unsigned pt) -> int {
+        /* the reference switches tau_4D from DCT to SADCT for good once a window holds an empty SAI (bm5d.cpp:276-280) */
+        unsigned n_in = 0;
+        {
+            int cs_w, mins, maxs, ct_w, mint, maxt;
+            search_window((int)ps, aheight, an, cs_w, mins, maxs);
+            search_window((int)pt, awidth, an, ct_w, mint, maxt);
+            for (unsigned si = 0; si < asw; si++)
+                for (unsigned ti = 0; ti < asw; ti++)
+                    n_in += h_mask[ang_major == LFBM5D_ROWMAJOR ? (si + mins) * awidth + (ti + mint) : (si + mins) + (ti + mint) * aheight] ? 1u : 0u;
+        }
+        if (n_in != Aw && tau_4D == LFBM5D_DCT) tau_4D = LFBM5D_SADCT;
+        WinState ws;
+        if (win_begin(lane0, ps, pt, tau_4D, ws)) return 1;
+        if (win_finish(lane0, ws)) return 1;
+        c->last_windows.push_back(ang_major == LFBM5D_ROWMAJOR ? ps * awidth + pt : ps + pt * aheight);
         return 0;
     };
 
