@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Do two core passes on two HIP streams overlap on one GPU?  Runs the headline window pass (HT or Wiener) from 1 and
+"""Do core passes on several HIP streams overlap on one GPU, and do they leave each other's results alone?  Runs the headline window pass (HT or Wiener) from 1 and
 from 2 contexts (own stream each, one host thread per context) and prints passes/s: the head-room a software
 pipeline of block matching against transform+aggregation could reach.
-usage: python tools/overlap_probe.py [step] [reps]"""
+usage: python tools/overlap_probe.py [step] [reps] [H]"""
 import os
 import sys
 import threading
@@ -28,7 +28,7 @@ def worker(ctx, step, P, Wb, Hb, bufs, reps, barrier):
 def main():
     step = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-    H = 512
+    H = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     lf = synth.make_lf(3, 3, H, H).reshape(9, 3, H, H).astype(np.float32)
     lf += 25.0 * np.random.default_rng(1).standard_normal(lf.shape).astype(np.float32)
     pk = (8, 18, 6, 16, 4, "id", "sadct", "haar") if step == 1 else (16, 18, 6, 8, 4, "dct", "sadct", "haar")
@@ -53,7 +53,13 @@ def main():
         for t in th:
             t.join()
         dt = time.time() - t0
-        print(f"step {step}: {n_ctx} stream(s): {n_ctx * reps / dt:.1f} passes/s ({dt / reps * 1e3:.2f} ms per round of {n_ctx})")
+        torch.cuda.synchronize()
+        sums = [(float(bf[2].double().sum()), float(bf[3].double().sum())) for bf in bufs]
+        if n_ctx == 1:
+            ref_sums = sums[0]
+        same = all(sm == ref_sums for sm in sums)
+        print(f"step {step}: {n_ctx} stream(s): {n_ctx * reps / dt:.1f} passes/s ({dt / reps * 1e3:.2f} ms per round of {n_ctx}); "
+              f"results {'identical to the single-stream pass' if same else 'DIFFER: ' + str(sums) + ' vs ' + str(ref_sums)}")
         for c in ctxs:
             c.close()
 
