@@ -13,6 +13,12 @@
  * One host thread per context.  All compute runs on the GPU: there is no CPU fallback, creation
  * fails when no HIP device is present.
  *
+ * Stream contract: every context launches on a stream of its own (lfbm5d_stream) and is unaware of the
+ * caller's streams.  Device buffers handed to an entry point must be READY on entry (whatever the caller
+ * queued on them -- fills, copies, kernels -- has completed or the caller's stream has been synchronised);
+ * every entry point returns with its results COMPLETE (it synchronises its stream before returning).
+ * Several contexts may share a GPU and run concurrently from different host threads.
+ *
  * Light-field layout (same as the reference, utilities_LF.cpp:140-146): asize = awidth*aheight
  * sub-aperture images (SAIs), each C planes of H*W float32 (planar, values nominally 0..255),
  * SAI index st = s*awidth + t (ang_major = LFBM5D_ROWMAJOR) or s + t*aheight (LFBM5D_COLMAJOR);
@@ -190,6 +196,11 @@ int lfbm5d_bm3d_lf_host(lfbm5d_ctx* ctx, const lfbm5d_bm3d_params* hard, const l
  * Any output pointer may be NULL.  Returns the number of reference patches via n_refs. */
 int lfbm5d_last_bm(lfbm5d_ctx* ctx, unsigned* n_refs, unsigned* h_refs, unsigned* h_self_idx,
                    unsigned* h_self_cnt, unsigned* h_best, unsigned char* h_shape);
+
+/* Raw disparity distance tables of the last pass (the scratch precompute_BM_stereo's sum_table plays in the
+ * reference, core:3513-3574), layout [slot][(2 nDisp+1)^2][strip][Hb][64]: copies min(n_floats, size) floats and
+ * returns the count; h_tables == NULL returns the buffer's size in floats.  For the bit-reproducibility tests. */
+size_t lfbm5d_last_tables(lfbm5d_ctx* ctx, float* h_tables, size_t n_floats);
 
 /* ---- device memory helpers so hosts without a HIP binding (ctypes, cgo, JNI) can stage data ---- */
 int lfbm5d_malloc(void** dptr, size_t bytes);

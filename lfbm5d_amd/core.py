@@ -105,6 +105,8 @@ def lib():
     L.lfbm5d_bm3d_step_device.argtypes = [vp, C.c_int, bp, C.c_uint, C.c_uint, C.c_uint, fp, fp, fp]
     L.lfbm5d_bm3d_lf_device.argtypes = [vp, bp, bp, fp, up, fp, fp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     L.lfbm5d_bm3d_lf_host.argtypes = [vp, bp, bp, fp, up, fp, fp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
+    L.lfbm5d_last_tables.argtypes = [vp, vp, C.c_size_t]
+    L.lfbm5d_last_tables.restype = C.c_size_t
     L.lfbm5d_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.lfbm5d_free.argtypes = [vp]
     L.lfbm5d_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
@@ -150,9 +152,14 @@ def _u32(a):
 
 
 def _dev_ptr(t):
+    """Raw device pointer of a CUDA tensor.  The library launches on the context's own stream and knows nothing
+    about torch's: work torch has queued on the tensor's device (a zero-fill, a copy) must have finished before the
+    library reads the buffer, so the current torch stream is drained here (include/lfbm5d.h: "buffers are ready on
+    entry, results complete on return")."""
     import torch
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise LfBm5dError("device entry points need contiguous float32 CUDA tensors")
+    torch.cuda.current_stream(t.device).synchronize()
     return C.c_void_p(t.data_ptr())
 
 
@@ -284,6 +291,15 @@ class Context:
         self._ck(self._L.lfbm5d_last_bm(self._h, C.byref(n), refs.ctypes.data, idx.ctypes.data, cnt.ctypes.data,
                                         best.ctypes.data, shape.ctypes.data))
         return refs, idx, cnt, best, shape
+
+
+    def last_tables(self, n_floats=None):
+        """Raw disparity distance tables of the last pass (flat float32 array)."""
+        have = self._L.lfbm5d_last_tables(self._h, None, 0)
+        n = have if n_floats is None else min(have, int(n_floats))
+        out = np.zeros(n, np.float32)
+        got = self._L.lfbm5d_last_tables(self._h, out.ctypes.data, n)
+        return out[:got]
 
 
 _default_ctx = None

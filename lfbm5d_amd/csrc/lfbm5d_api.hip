@@ -250,6 +250,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     if (!bm3d && step == 1 && P->tau_2D == LFBM5D_ID && P->tau_4D == LFBM5D_DCT) lambda /= (float)kSqrt2; /* core:206-207 */
     unsigned mask_bits = 0, proc_bits = 0;
     for (unsigned st = 0; st < A; st++) { if (h_mask[st]) mask_bits |= 1u << st; if (h_proc[st]) proc_bits |= 1u << st; }
+    if (pst >= A || cst >= A) return fail(c, "cst / pst outside the angular window");
     if (!((mask_bits >> pst) & 1)) return fail(c, "processed SAI is empty");
 
     /* reference grid (core:149-156); cached while the geometry is unchanged */
@@ -324,6 +325,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
      * the first plane for the left-most displacement) and overrun the last row by less than a ring row */
     HIPCK(c, c->est.reserve((kEstLead + A * plane + 256) * sizeof(float)));
     float* const est = c->est.as<float>() + kEstLead;
+    /* the scan addresses the score table through a buffer resource with 32-bit offsets */
+    if (N > 1 && (size_t)R * NsS * NsS * sizeof(float) > 0x7fffffffull) return fail(c, "unsupported: candidate score table of 2 GiB or more (reference patches x (2 nSim + 1)^2 x 4 B)");
     if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
     HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * stereo_table_stride(Wb, Hb, k, P->nDisp) * sizeof(float)));
     HIPCK(c, c->self_idx.reserve((size_t)R * Nst * sizeof(unsigned)));
@@ -369,7 +372,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     sa.est = est; sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
     sa.nSim = P->nSim; sa.nDisp = P->nDisp; sa.nHW = nHW;
     sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p;
-    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = c->rslot.as<int>(); sa.refmap = centre ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)std::min<size_t>((size_t)R * NsS * NsS * sizeof(float), 0x7fffffffu);
+    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = c->rslot.as<int>(); sa.refmap = centre ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)((size_t)R * NsS * NsS * sizeof(float));
     sa.n_self = N > 1 ? (P->nSim + 1) * NsS : 0;
     sa.n_stereo = n_slots * NsD * NsD;
     for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
@@ -825,7 +828,7 @@ int lfbm5d_create(lfbm5d_ctx** out, int device) {
     std::memset(&c->stats, 0, sizeof(c->stats));
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return 1; }
     if ((e = prepare_group_kernels()) != hipSuccess) { g_create_error = std::string("kernel LDS limits: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return 1; }
-    if ((e = hipHostMalloc((void**)&c->h_small, 64 * sizeof(unsigned))) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return 1; }
+    if ((e = hipHostMalloc((void**)&c->h_small, 64 * sizeof(unsigned))) != hipSuccess) { g_create_error = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return 1; }
     *out = c;
     return 0;
 }
@@ -1109,6 +1112,17 @@ int lfbm5d_last_bm(lfbm5d_ctx* c, unsigned* n_refs, unsigned* h_refs, unsigned* 
     if (h_best) HIPCK(c, hipMemcpy(h_best, c->best.p, c->last_A * c->last_plane * sizeof(unsigned), hipMemcpyDeviceToHost));
     if (h_shape) HIPCK(c, hipMemcpy(h_shape, c->shape.p, c->last_A * c->last_plane, hipMemcpyDeviceToHost));
     return 0;
+}
+
+size_t lfbm5d_last_tables(lfbm5d_ctx* c, float* h_tables, size_t n_floats) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    const size_t have = c->tables.cap / sizeof(float);
+    if (!h_tables) return have;
+    const size_t n = std::min(have, n_floats);
+    if (n && hipMemcpy(h_tables, c->tables.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
 }
 
 int lfbm5d_malloc(void** dptr, size_t bytes) { return hipMalloc(dptr, bytes) == hipSuccess ? 0 : 1; }

@@ -446,12 +446,21 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                  * rows up to t0+T-1-(16g+15)+1): each lane stores one 16-byte piece of four of them.  One store
                  * instruction per four steps, 16 cache lines touched instead of 4 x 64. */
                 typedef int v4i __attribute__((ext_vector_type(4)));
+                /* The row offset goes into the VECTOR offset and the scalar offset stays a literal 0 on purpose.  A buffer
+                 * store of more than 64 bits reads its data registers a cycle or two after it issues, and a VALU write of
+                 * those registers right behind it (here: the next piece's row index, which the register allocator likes
+                 * to put into the first data register) needs two wait states.  hipcc pads that hazard only when soffset is
+                 * NOT an SGPR (LLVM's rule: the SGPR read is supposed to cover the delay).  On gfx950 it does not always:
+                 * with other kernels resident on the CU the store of round 1 (row offset in an SGPR) stored the row index
+                 * instead of the first of its four distances for lanes 12..15 of a 16-lane group -- single dwords of a
+                 * disparity table, a few passes in ten, only with T = 8 (two pieces per chunk) and only while other
+                 * lfbm5d contexts kept the GPU busy (tools/bm_stress.py, tests/test_gpu_concurrency.py). */
 #pragma unroll
                 for (int h = 0; h < T / 4; h++) {
                     const int urow = t0 + 4 * h + ucl;          /* table row, see ucl */
                     const bool rv = (unsigned)(urow - 1) <= (unsigned)(nrows - 2);
                     const v4f val = *reinterpret_cast<const v4f*>(usk + ((urow & 31) << 6) + ucol);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, val), rsTb, rv ? uvo : -1, (strip * H + b + t0 + 4 * h) * 256, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, val), rsTb, (rv && uvo >= 0) ? uvo + (strip * H + b + t0 + 4 * h) * 256 : -1, 0, 0);
                 }
             }
             if (!TAIL) {
