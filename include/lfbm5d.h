@@ -80,6 +80,7 @@ typedef struct {
     double ms_comm;                    /* RCCL all-reduce                                     */
     unsigned long long launches_group; /* launches of the transform kernel                    */
     unsigned long long launches_aggregate;
+    unsigned long long lane_windows;   /* windows that ran on a lane other than the first (pipelined steps) */
 } lfbm5d_stats;
 
 /* ---- context ---- */

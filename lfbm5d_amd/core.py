@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("stack_patches", C.c_ulonglong), ("sadct_groups", C.c_ulonglong),
                 ("algorithmic_bytes", C.c_double), ("ms_bm", C.c_double), ("ms_group", C.c_double),
                 ("ms_aggregate", C.c_double), ("ms_other", C.c_double), ("ms_comm", C.c_double),
-                ("launches_group", C.c_ulonglong), ("launches_aggregate", C.c_ulonglong)]
+                ("launches_group", C.c_ulonglong), ("launches_aggregate", C.c_ulonglong),
+                ("lane_windows", C.c_ulonglong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -67,6 +67,11 @@ struct lfbm5d_ctx {
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
+    /* window lanes (run_step, pipelined form): extra contexts on the same device, each with its own stream, window
+     * buffers and per-pass work buffers; owned by this context */
+    std::vector<lfbm5d_ctx*> lanes;
+    unsigned* h_counts = nullptr; size_t h_counts_cap = 0;   /* pinned: coverage count of every window of a step */
+    unsigned long long lane_windows = 0;   /* windows of the last step that ran on a lane other than the first */
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<PassEvents> pending;
     /* last pass (inspection) */
@@ -90,6 +95,18 @@ namespace {
     } while (0)
 
 int fail(lfbm5d_ctx* c, const std::string& m) { c->err = m; return 1; }
+
+lfbm5d_ctx* new_ctx(int device, std::string& err) {
+    hipError_t e;
+    lfbm5d_ctx* c = new lfbm5d_ctx();
+    c->device = device;
+    std::memset(&c->stats, 0, sizeof(c->stats));
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { err = hipGetErrorString(e); delete c; return nullptr; }
+    if ((e = prepare_group_kernels()) != hipSuccess) { err = std::string("kernel LDS limits: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
+    if ((e = hipHostMalloc((void**)&c->h_small, 64 * sizeof(unsigned))) != hipSuccess) { err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
+    return c;
+}
+
 
 hipEvent_t get_event(lfbm5d_ctx* c) {
     if (c->ev_used == c->ev_pool.size()) {
@@ -566,6 +583,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     struct WinState {
         unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, win_bits = 0, rem_w = 0, tot_w = 0, pst_w = 0;
         std::vector<unsigned> st_idx, mask_w, proc_w; SaiList sl; lfbm5d_params Pw; bool counted = false;
+        unsigned* h_count_dst = nullptr;   /* pinned word the coverage count is copied to (default: the lane's) */
     };
     auto lane_buffers = [&](lfbm5d_ctx* x, Lane& L) -> int {
         HIPCK(c, x->w_noisy.reserve(Aw * imgb * sizeof(float)));
@@ -583,7 +601,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         hipStream_t ls = L.x->stream;
         HIPCK(c, hipMemsetAsync(L.d_small, 0, sizeof(unsigned), ls));
         HIPCK(c, launch_count_denoised(ls, L.w_den, imgb, Aw, ws.win_bits, W, H, C, nHW, P->k, L.d_small));
-        HIPCK(c, hipMemcpyAsync(L.x->h_small, L.d_small, sizeof(unsigned), hipMemcpyDeviceToHost, ls));
+        HIPCK(c, hipMemcpyAsync(ws.h_count_dst ? ws.h_count_dst : L.x->h_small, L.d_small, sizeof(unsigned), hipMemcpyDeviceToHost, ls));
         ws.counted = true;
         return 0;
     };
@@ -713,6 +731,142 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         ~PassShard() { c->pass_rank = 0; c->pass_world = 1; c->pass_reduce = false; }
     } pass_shard(c, by_rows);
     if (by_rows && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+
+    /* ---- Pipelined form (one GPU, colour light fields): the planned windows as a dependency graph on several lanes.
+     * Two windows interact only through num/den of the SAIs they share (the running estimate block matching reads,
+     * the sums aggregation adds to), so a window has to wait exactly for the previous window that touched each of its
+     * SAIs; windows that share no SAI commute bit for bit.  In the reference's backward raster a window shares SAIs
+     * with its predecessor in the same row of windows and with three windows of the row before, which leaves a
+     * wavefront: row i may run two windows behind row i-1.  Each lane (stream + window buffers + per-pass work buffers)
+     * takes windows in plan order at the earliest slot a greedy list schedule finds; cross-lane dependencies are HIP
+     * events.  The result is bit-identical to the sequential order, the lanes only let one window's block matching
+     * overlap another's transform and aggregation on the GPU.
+     * The reference decides after every pass whether the window is complete (coverage count, bm5d.cpp:370-382); for
+     * colour light fields one centre pass always suffices.  The pipelined form assumes
+     * that, copies every window's count to pinned memory and checks them all at the end: if a window would have
+     * needed another pass the step is redone in the sequential form (never observed; greyscale light fields, where
+     * further passes are the rule, take the sequential form directly). */
+    const char* lanes_s = std::getenv("LFBM5D_LANES");
+    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : 3));
+    c->lane_windows = 0;
+    bool pipelined = planned && !by_rows && n_lanes > 1 && C == 3 && c->world == 1 && emu <= 1;
+    if (pipelined) {
+        std::vector<unsigned> plan;
+        plan_windows(h_mask, awidth, aheight, an, ang_major, plan);
+        const size_t NW = plan.size();
+        /* SAIs and 4-D transform of every window (the DCT -> SADCT switch is sticky, bm5d.cpp:276-280) */
+        std::vector<std::vector<unsigned>> sai(NW);
+        std::vector<unsigned> tau4_w(NW), wps(NW), wpt(NW);
+        unsigned t4 = tau_4D;
+        for (size_t w = 0; w < NW && pipelined; w++) {
+            wps[w] = ang_major == LFBM5D_ROWMAJOR ? plan[w] / awidth : plan[w] % aheight;
+            wpt[w] = ang_major == LFBM5D_ROWMAJOR ? plan[w] % awidth : plan[w] / aheight;
+            int cs_w, mins, maxs, ct_w, mint, maxt;
+            search_window((int)wps[w], aheight, an, cs_w, mins, maxs);
+            search_window((int)wpt[w], awidth, an, ct_w, mint, maxt);
+            unsigned n_in = 0;
+            for (unsigned si = 0; si < asw; si++)
+                for (unsigned ti = 0; ti < asw; ti++) {
+                    const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (si + mins) * awidth + (ti + mint) : (si + mins) + (ti + mint) * aheight;
+                    if (h_mask[st]) { sai[w].push_back(st); n_in++; }
+                }
+            if (n_in != Aw && t4 == LFBM5D_DCT) t4 = LFBM5D_SADCT;
+            tau4_w[w] = t4;
+            const unsigned cst_lf = ang_major == LFBM5D_ROWMAJOR ? (unsigned)(mins + cs_w) * awidth + (unsigned)(mint + ct_w) : (unsigned)(mins + cs_w) + (unsigned)(mint + ct_w) * aheight;
+            if (!h_mask[cst_lf]) pipelined = false;   /* empty window centre: the first pass is chosen from device data */
+        }
+        if (pipelined) {
+            /* predecessors: the last earlier window that touched each SAI */
+            std::vector<std::vector<unsigned>> preds(NW);
+            std::vector<int> last_touch(asize, -1);
+            for (size_t w = 0; w < NW; w++) {
+                for (unsigned st : sai[w]) {
+                    const int p = last_touch[st];
+                    if (p >= 0 && std::find(preds[w].begin(), preds[w].end(), (unsigned)p) == preds[w].end()) preds[w].push_back((unsigned)p);
+                    last_touch[st] = (int)w;
+                }
+            }
+            /* greedy list schedule with unit window cost; ties go to the lane of the latest predecessor (no event needed) */
+            std::vector<int> lane_of(NW, 0);
+            std::vector<unsigned> finish(NW, 0), lane_free(n_lanes, 0);
+            for (size_t w = 0; w < NW; w++) {
+                unsigned ready = 0; int pref = -1;
+                for (unsigned p : preds[w]) if (finish[p] >= ready) { ready = finish[p]; pref = lane_of[p]; }
+                int best_l = 0; unsigned best_t = ~0u;
+                for (int l = 0; l < n_lanes; l++) {
+                    const unsigned t = std::max(ready, lane_free[l]);
+                    if (t < best_t || (t == best_t && l == pref)) { best_t = t; best_l = l; }
+                }
+                lane_of[w] = best_l; finish[w] = best_t + 1; lane_free[best_l] = best_t + 1;
+            }
+            /* lanes */
+            while ((int)c->lanes.size() < n_lanes - 1) {
+                std::string e;
+                lfbm5d_ctx* x = new_ctx(c->device, e);
+                if (!x) return fail(c, "lane context: " + e);
+                c->lanes.push_back(x);
+            }
+            std::vector<Lane> L(n_lanes);
+            L[0] = lane0;
+            for (int l = 1; l < n_lanes; l++) if (lane_buffers(c->lanes[l - 1], L[l])) return 1;
+            if (c->h_counts_cap < NW) {
+                if (c->h_counts) (void)hipHostFree(c->h_counts);
+                c->h_counts = nullptr; c->h_counts_cap = 0;
+                HIPCK(c, hipHostMalloc((void**)&c->h_counts, NW * sizeof(unsigned)));
+                c->h_counts_cap = NW;
+            }
+            std::vector<hipEvent_t> done(NW);
+            hipEvent_t ev_setup = get_event(c);
+            HIPCK(c, hipEventRecord(ev_setup, s));   /* colour transform and the zeroed num / den */
+            for (int l = 1; l < n_lanes; l++) HIPCK(c, hipStreamWaitEvent(L[l].x->stream, ev_setup, 0));
+            std::vector<WinState> wss(NW);
+            for (size_t w = 0; w < NW; w++) {
+                const Lane& Lw = L[lane_of[w]];
+                for (unsigned p : preds[w])
+                    if (lane_of[p] != lane_of[w]) HIPCK(c, hipStreamWaitEvent(Lw.x->stream, done[p], 0));
+                WinState& ws = wss[w];
+                ws.h_count_dst = c->h_counts + w;
+                if (win_begin(Lw, wps[w], wpt[w], tau4_w[w], ws)) return 1;
+                /* optimistic completion: the window's sums go back to the light field right away */
+                HIPCK(c, launch_unsymetrize_multi(Lw.x->stream, g_num, img, Lw.w_num, imgb, ws.sl, W, H, C, nHW));
+                HIPCK(c, launch_unsymetrize_multi(Lw.x->stream, g_den, img, Lw.w_den, imgb, ws.sl, W, H, C, nHW));
+                done[w] = get_event(c);
+                HIPCK(c, hipEventRecord(done[w], Lw.x->stream));
+                if (lane_of[w] != 0) { c->lane_windows += 1; c->stats.lane_windows += 1; }
+            }
+            for (int l = 1; l < n_lanes; l++) HIPCK(c, hipStreamSynchronize(L[l].x->stream));
+            HIPCK(c, hipStreamSynchronize(s));
+            bool complete = true;
+            for (size_t w = 0; w < NW; w++) {
+                const unsigned n_mask = (unsigned)__builtin_popcount(wss[w].win_bits);
+                const float pct = (float)c->h_counts[w] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
+                if (!(pct >= 100.0f)) complete = false;
+            }
+            /* fold the lanes' counters and event times into this context */
+            for (int l = 1; l < n_lanes; l++) {
+                lfbm5d_ctx* x = L[l].x;
+                drain_events(x);
+                if (fold_counters(x, P, Aw, C, step)) { c->err = x->err; return 1; }
+                c->stats.passes += x->stats.passes; c->stats.groups += x->stats.groups;
+                c->stats.stack_patches += x->stats.stack_patches; c->stats.sadct_groups += x->stats.sadct_groups;
+                c->stats.algorithmic_bytes += x->stats.algorithmic_bytes;
+                c->stats.ms_bm += x->stats.ms_bm; c->stats.ms_group += x->stats.ms_group; c->stats.ms_aggregate += x->stats.ms_aggregate;
+                c->stats.launches_group += x->stats.launches_group; c->stats.launches_aggregate += x->stats.launches_aggregate;
+                std::memset(&x->stats, 0, sizeof(x->stats));
+            }
+            if (complete) {
+                c->stats.windows += NW;
+                for (size_t w = 0; w < NW; w++) c->last_windows.push_back(plan[w]);
+            } else {
+                /* some window needed more than its centre pass: redo the step window after window */
+                HIPCK(c, hipMemsetAsync(g_num, 0, asize * img * sizeof(float), s));
+                HIPCK(c, hipMemsetAsync(g_den, 0, asize * img * sizeof(float), s));
+                for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
+                pipelined = false;
+            }
+        }
+    }
+    if (pipelined) { /* done above */ } else
     if (!planned) {
         unsigned remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
         const unsigned total = remaining;
@@ -823,12 +977,8 @@ int lfbm5d_create(lfbm5d_ctx** out, int device) {
     }
     if (device < 0 || device >= n) { g_create_error = "device index out of range"; return 1; }
     if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return 1; }
-    lfbm5d_ctx* c = new lfbm5d_ctx();
-    c->device = device;
-    std::memset(&c->stats, 0, sizeof(c->stats));
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { g_create_error = hipGetErrorString(e); delete c; return 1; }
-    if ((e = prepare_group_kernels()) != hipSuccess) { g_create_error = std::string("kernel LDS limits: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return 1; }
-    if ((e = hipHostMalloc((void**)&c->h_small, 64 * sizeof(unsigned))) != hipSuccess) { g_create_error = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return 1; }
+    lfbm5d_ctx* c = new_ctx(device, g_create_error);
+    if (!c) return 1;
     *out = c;
     return 0;
 }
@@ -836,6 +986,9 @@ int lfbm5d_create(lfbm5d_ctx** out, int device) {
 void lfbm5d_destroy(lfbm5d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (lfbm5d_ctx* x : c->lanes) lfbm5d_destroy(x);
+    c->lanes.clear();
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) ncclCommDestroy(c->comm);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,

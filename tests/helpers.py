@@ -70,3 +70,18 @@ def tau_match(sigma, Cc, step):
     sig = np.zeros(3, np.float32)
     O.lib().orc_sigma_table(sigma, Cc, O.OPP, sig)
     return (3.0 if Cc == 1 else 1.0) * ((3000 if step == 1 else 2000) if sig[0] < 35 else 5000)
+
+
+def textured_lf(ah, aw, H, W, disparity=1):
+    """A light field with natural texture for multi-window tests: SAI (s, t) is the centre SAI of
+    tests/golden/sourceLF (a photograph) cropped at an offset that moves `disparity` pixels per view, so every SAI
+    pair has a real, sub-nDisp disparity and block matching has unambiguous minima (flat synthetic shapes do not)."""
+    src = np.load(os.path.join(GOLDEN, "sourceLF_3x3_256_u8.npy"))[4]           # [3][256][256]
+    y0 = (256 - H - disparity * (ah - 1)) // 2
+    x0 = (256 - W - disparity * (aw - 1)) // 2
+    assert y0 >= 0 and x0 >= 0
+    out = np.zeros((ah * aw, 3, H, W), np.uint8)
+    for s in range(ah):
+        for t in range(aw):
+            out[s * aw + t] = src[:, y0 + disparity * s:y0 + disparity * s + H, x0 + disparity * t:x0 + disparity * t + W]
+    return out

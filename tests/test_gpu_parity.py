@@ -355,6 +355,45 @@ def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
     monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
 
 
+@pytest.mark.parametrize("holes", [False, True], ids=["full", "empty-sais"])
+def test_window_lanes_are_bit_identical_to_the_sequential_order(ctx, monkeypatch, holes):
+    """Pipelined steps (several windows in flight on lanes, dependencies = shared SAIs) against the window-after-window
+    order: same windows, same bits, with and without empty SAIs (sticky DCT -> SADCT switch, bm5d.cpp:276-280)."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    ah, aw, Hs, Ws = 7, 9, 64, 64
+    lf = Hh.textured_lf(ah, aw, Hs, Ws)
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    if holes:
+        mask[[0, 11, 40, 62]] = 0
+    P1 = core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "dct", "haar")
+    P2 = core.make_params(25.0, 2.7, 8, 6, 2, 8, 4, "dct", "dct", "haar")
+
+    def run():
+        d_noisy = torch.from_numpy(noisy).cuda()
+        d_basic = torch.zeros_like(d_noisy)
+        d_den = torch.zeros_like(d_noisy)
+        ctx.reset_stats()
+        ctx.step1(P1, d_noisy, mask, d_basic, L.ROWMAJOR, aw, ah, 1, Ws, Hs, 3)
+        w = ctx.last_windows()
+        ctx.step2(P2, d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, 1, Ws, Hs, 3)
+        return d_basic.cpu().numpy(), d_den.cpu().numpy(), w, ctx.stats()
+
+    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_STEP_SHARDING"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LFBM5D_LANES", "1")
+    b0, d0, w0, s0 = run()
+    assert s0.lane_windows == 0 and s0.windows == 2 * len(w0)
+    for lanes in ("2", "3", "4"):
+        monkeypatch.setenv("LFBM5D_LANES", lanes)
+        b1, d1, w1, s1 = run()
+        assert np.array_equal(w1, w0) and (s1.windows, s1.passes, s1.groups) == (s0.windows, s0.passes, s0.groups)
+        assert s1.lane_windows > 0                                  # other lanes really took windows
+        assert np.array_equal(b1, b0) and np.array_equal(d1, d0)
+    assert O.psnr_lf(d0[mask != 0], clean[mask != 0]) > O.psnr_lf(noisy[mask != 0], clean[mask != 0]) + 6
+
+
 def _random_cases():
     rng = np.random.default_rng(20261002)
     cases = []
