@@ -4,21 +4,28 @@
 Metric (BASELINE.json): SAI-megapixels/s of the full HT + Wiener denoise, sigma = 25, on the
 17x17x512x512 synthetic light field with the README "Stanford" parameters.
 One "step" = run_bm5d_1st_step + run_bm5d_2nd_step over the whole light field, inputs already
-resident in HBM.  N GPUs = one process per GPU (torchrun), every rank holds the light field, the
-step's sequence of angular windows is cut into one contiguous block per rank and the per-rank
-num/den summed with one RCCL all-reduce per step (`--sharding rows`: the exact single-GPU window
-order with row-sharded core passes instead): fixed total work -> "scaling": "strong".  The PSNR of
-the run is part of the JSON line.
+resident in HBM, noise from the reference's MT19937 stream (seed 1).  The PSNR of the run is part of
+the JSON line.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is for the transform+aggregate kernels (k_group +
-k_aggregate: the SURVEY 8d algorithmic bytes cover exactly that pair), durations from HIP events
-recorded on the library's stream inside the timed region.  `cpu_baseline` times the CPU oracle
-(oracle/, a restatement of the reference: kind "port") on one centre-window pass of each step of
-the same noisy input and extrapolates by the pass count the GPU run reports.
+Prints ONE JSON line on rank 0.
+  value      whole-job throughput of the timed region (default execution: the step's windows as a dependency
+             graph on LFBM5D_LANES = 3 streams, bit-identical to the window-after-window order)
+  roofline   the transform + aggregate kernel pair (k_group* + k_aggregate; the SURVEY 8d algorithmic bytes
+             cover exactly that pair), durations from HIP events on the library's stream.  With lanes the
+             kernels of different windows overlap on the GPU, so the pair is timed in one extra, untimed step
+             with LFBM5D_LANES=1 (kernels alone on the GPU) right after the timed region; `--lanes 1` makes
+             the timed region itself that measurement (the command the rocprof summaries under profiles/ use).
+             `achieved`/`frac` follow the contract (algorithmic bytes / time / peak); `per_step` splits HT and
+             Wiener and flags fractions above 1 (the byte model credits traffic the gather-form aggregation
+             never makes); `traffic` / `frac_physical` are the PMC-measured HBM bytes of the same kernels
+             (profiles/traffic_latest.json, collected with tools/collect_profiles.sh on this workload).
+  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference: kind "port") on the GPU box's host
+             cores: the first windows of each step of the SAME noisy light field (up to 3, bounded by a
+             time limit), extrapolated by the window count; untiled parity mode.
 """
 import argparse
 import ctypes as C
@@ -58,65 +65,38 @@ WORKLOADS = {
 }
 
 
-def cpu_baseline(wl, noisy_rgb_9, basic_rgb_9, passes1, passes2, total_mp, ctx=None):
-    """Oracle (CPU restatement) on one centre-window pass per step; checker code, timed only here."""
+def cpu_baseline(wl, noisy_rgb, basic_rgb, windows_per_step, total_mp, max_windows=3, time_limit=18.0):
+    """Oracle (CPU restatement, OpenMP over reference patches, untiled) on the first windows of each step of the
+    same noisy light field.  Checker code: imported and timed only here."""
     from oracle import oracle as O
     lib = O.lib()
-    H, W = wl["H"], wl["W"]
+    ah, aw, H, W = wl["ah"], wl["aw"], wl["H"], wl["W"]
+    mask = np.ones(ah * aw, np.uint32)
     out = {"unit": "SAI-megapixels/s", "kind": "port", "cores": int(lib.orc_get_threads())}
-    secs = []
-    parity = {}
-    for step, pk, src in ((1, wl["p1"], None), (2, wl["p2"], basic_rgb_9)):
-        P = O.make_params(wl["sigma"], 2.7, *pk)
-        nHW = pk[1] + pk[2]
-        Wb, Hb = W + 2 * nHW, H + 2 * nHW
-
-        def pad(arr):
-            o = np.zeros((9, 3 * Wb * Hb), np.float32)
-            for st in range(9):
-                im = np.ascontiguousarray(arr[st]).copy()
-                lib.orc_color_transform(im, O.OPP, W, H, 3, 1)
-                lib.orc_symetrize(im, o[st], W, H, 3, nHW)
-            return o
-        wn = pad(noisy_rgb_9)
-        wb = pad(src) if src is not None else None
-        num = np.zeros_like(wn)
-        den = np.zeros_like(wn)
-        mask = np.ones(9, np.uint32)
-        proc = np.zeros(9, np.uint32)
-        st = O.Stats()
-        t0 = time.time()
-        rc = lib.orc_pass(step, C.byref(P), 3, 3, Wb, Hb, 3, wn.reshape(-1), wb.ctypes.data if wb is not None else None,
-                          num.reshape(-1), den.reshape(-1), mask, proc, 4, 4, 0, -1, C.byref(st))
-        secs.append(time.time() - t0)
-        if rc:
-            raise RuntimeError("oracle pass failed")
-        if ctx is not None:   # the same pass through the C-ABI on the same padded window: the checker's verdict in the bench line
-            import torch
-            from lfbm5d_amd import core
-            d_n = torch.from_numpy(wn).cuda()
-            d_b = torch.from_numpy(wb).cuda() if wb is not None else None
-            g_num = torch.zeros_like(d_n); g_den = torch.zeros_like(d_n)
-            ctx.core_pass(step, core.make_params(wl["sigma"], 2.7, *pk), 3, 3, Wb, Hb, 3, d_n, d_b, g_num, g_den, mask, proc, 4, 4)
-            gn, gd = g_num.cpu().numpy(), g_den.cpu().numpy()
-            both = (den > 0) & (gd > 0)
-            eo = num[both] / den[both]; eg = gn[both] / gd[both]
-            d = np.abs(eo - eg)
-            # float32 transforms on the GPU, double accumulation in the oracle: a hard-threshold decision on a coefficient
-            # within round-off of the threshold can differ (a few hundred of the ~1e9 coefficients of a 512x512 HT pass)
-            parity["ht" if step == 1 else "wiener"] = {
-                "coverage_identical": bool(np.array_equal(den > 0, gd > 0)),
-                "mean_abs_estimate_diff": float(d.mean()), "p999_abs_estimate_diff": float(np.quantile(d, 0.999)),
-                "max_abs_estimate_diff": float(d.max()),
-                "psnr_between_estimates_db": float(10 * np.log10(255.0 ** 2 / max(float((d.astype(np.float64) ** 2).mean()), 1e-30)))}
-    est_total = secs[0] * passes1 + secs[1] * passes2
+    lib.orc_set_time_limit(float(time_limit))
+    per_window, overhead, sampled = [], [], []
+    try:
+        for step, pk in ((1, wl["p1"]), (2, wl["p2"])):
+            P = O.make_params(wl["sigma"], 2.7, *pk)
+            t0 = time.time()
+            if step == 1:
+                _, _, st = O.run_step1(P, noisy_rgb.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, H, 3, max_windows=max_windows)
+            else:
+                _, _, _, st = O.run_step2(P, noisy_rgb.copy(), basic_rgb.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, H, 3,
+                                          max_windows=max_windows)
+            wall = time.time() - t0
+            n = max(1, int(st.windows))
+            per_window.append(st.total_seconds / n)      # core passes (block matching + transforms + aggregation)
+            overhead.append(max(0.0, wall - st.total_seconds))   # whole-LF colour transforms, padding, window choice
+            sampled.append(n)
+    finally:
+        lib.orc_set_time_limit(0.0)
+    est_total = sum(pw * windows_per_step for pw in per_window) + sum(overhead)
     out["value"] = total_mp / est_total
-    out["sample"] = (f"one 3x3x{H}x{W} centre-window core pass per step on the same noisy input "
-                     f"(HT {secs[0]:.1f} s, Wiener {secs[1]:.1f} s), extrapolated to {passes1}+{passes2} passes")
-    if parity:
-        parity["note"] = ("same padded window through the C-ABI; the maximum belongs to the few hard-threshold decisions that fall "
-                          "within float round-off of the threshold (float32 on the GPU, double accumulation in the oracle)")
-        out["parity_vs_gpu"] = parity
+    out["sample"] = (f"first {sampled[0]} (HT) + {sampled[1]} (Wiener) angular windows of the {ah}x{aw}x{H}x{W} steps on the same noisy "
+                     f"light field: {per_window[0]:.2f} / {per_window[1]:.2f} s per window pass, + {sum(overhead):.1f} s of whole-LF work, "
+                     f"extrapolated to {windows_per_step} windows per step (untiled parity mode, OpenMP over reference patches)")
+    out["seconds_per_window_pass"] = {"ht": per_window[0], "wiener": per_window[1]}
     return out
 
 
@@ -127,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="lf17x17x512x512_sigma25", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 3)")
+    ap.add_argument("--noise", default="mt19937", choices=["mt19937", "torch"],
+                    help="mt19937: the reference's noise stream, seed 1 (default); torch: quick GPU noise for kernel iteration")
     ap.add_argument("--sharding", default="windows", choices=["windows", "rows"],
                     help="multi-GPU step scheme: blocks of angular windows per rank (default) or row-sharded passes")
     args = ap.parse_args()
@@ -139,6 +122,9 @@ def main():
         os.environ["LFBM5D_STEP_SHARDING"] = "rows"
     else:
         os.environ.pop("LFBM5D_STEP_SHARDING", None)
+    if args.lanes > 0:
+        os.environ["LFBM5D_LANES"] = str(args.lanes)
+    lanes_timed = int(os.environ.get("LFBM5D_LANES", "3"))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,34 +150,51 @@ def main():
 
     # synthetic input, identical on every rank (the read-only light field is replicated)
     clean_u8 = synth.make_lf(ah, aw, H, W)
-    clean = torch.from_numpy(clean_u8.reshape(asize, -1)).cuda().float()
+    clean_h = clean_u8.reshape(asize, -1).astype(np.float32)
     del clean_u8
-    g = torch.Generator(device="cuda")
-    g.manual_seed(1)
-    noisy0 = clean + sigma * torch.randn(clean.shape, generator=g, device="cuda")
+    clean = torch.from_numpy(clean_h).cuda()
+    noisy_h = None
+    if args.noise == "mt19937":
+        noisy_h = synth.add_noise_mt19937(clean_h, sigma, seed=1)     # utilities.cpp:176-183, one stream, st order
+        noisy0 = torch.from_numpy(noisy_h).cuda()
+    else:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1)
+        noisy0 = clean + sigma * torch.randn(clean.shape, generator=g, device="cuda")
+    del clean_h
     noisy = torch.empty_like(noisy0)
     basic = torch.zeros_like(noisy0)
     den = torch.zeros_like(noisy0)
     mask = np.ones(asize, np.uint32)
     P1 = core.make_params(sigma, 2.7, *wl["p1"])
     P2 = core.make_params(sigma, 2.7, *wl["p2"])
+    FIELDS = ("windows", "passes", "groups", "stack_patches", "algorithmic_bytes", "ms_bm", "ms_group", "ms_aggregate",
+              "ms_comm", "launches_group", "launches_aggregate", "lane_windows")
 
-    def one_step():
+    def one_step(acc=None):
+        """HT + Wiener; acc: {"ht": {...}, "wiener": {...}} accumulates the library's counters per step kind."""
         noisy.copy_(noisy0)
         torch.cuda.synchronize()
-        ctx.step1(P1, noisy, mask, basic, L.ROWMAJOR, aw, ah, 1, W, H, 3)
-        ctx.step2(P2, noisy, mask, basic, den, L.ROWMAJOR, aw, ah, 1, W, H, 3)
+        for kind, call in (("ht", lambda: ctx.step1(P1, noisy, mask, basic, L.ROWMAJOR, aw, ah, 1, W, H, 3)),
+                           ("wiener", lambda: ctx.step2(P2, noisy, mask, basic, den, L.ROWMAJOR, aw, ah, 1, W, H, 3))):
+            if acc is not None:
+                ctx.reset_stats()
+            call()
+            if acc is not None:
+                st = ctx.stats()
+                for f in FIELDS:
+                    acc[kind][f] = acc[kind].get(f, 0) + getattr(st, f)
 
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
-    ctx.reset_stats()
+    timed = {"ht": {}, "wiener": {}}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
+        one_step(timed)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -200,30 +203,58 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    s = ctx.stats()
+
+    # roofline measurement: the kernel pair alone on the GPU (one lane).  Outside the timed region.
+    roof, roof_steps = timed, args.steps
+    if lanes_timed != 1 and world == 1:
+        os.environ["LFBM5D_LANES"] = "1"
+        roof, roof_steps = {"ht": {}, "wiener": {}}, 1
+        one_step(roof)
+        torch.cuda.synchronize()
+        os.environ["LFBM5D_LANES"] = str(lanes_timed)
 
     if rank == 0:
         total_mp = asize * H * W / 1e6
         ms_per_step = 1e3 * elapsed / max(1, args.steps)
         value = total_mp * args.steps / elapsed
-        # quality: PSNR against the clean light field (mean over SAIs), this run
-        def psnr_lf(x):
+
+        def psnr_lf(x):   # quality: PSNR against the clean light field (mean over SAIs), this run
             mse = ((x - clean) ** 2).mean(dim=1)
             return float((20 * torch.log10(255.0 / torch.sqrt(mse))).mean().item())
-        launches = max(1, int(s.launches_group))
-        pair_ms = (s.ms_group + s.ms_aggregate) / launches
-        # rank 0 processes 1/world of the groups; its bytes and its kernel time describe one GPU
-        alg_bytes = s.algorithmic_bytes / launches
-        achieved = alg_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if args.workload in tj.get("applies_to", [tj.get("workload")]):
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if args.workload == tj.get("workload"):
+                    traffic = tj
             except Exception:
                 traffic = None
+
+        def pair(kind):
+            a = roof[kind]
+            n = max(1, int(a.get("launches_group", 0)))
+            ms = (a.get("ms_group", 0.0) + a.get("ms_aggregate", 0.0)) / n
+            by = a.get("algorithmic_bytes", 0.0) / n
+            ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            d = {"algorithmic_bytes_per_launch": by, "avg_launch_ms": ms, "ms_group": a.get("ms_group", 0.0) / n,
+                 "ms_aggregate": a.get("ms_aggregate", 0.0) / n, "launches": n, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+            if d["frac"] > 1.0:
+                d["flag"] = ("above 1: the SURVEY 8d byte model charges 16 B of num/den read-modify-write per stacked pixel, "
+                             "the gather-form aggregation moves 8 B (filt written once, read once) and the stack gathers hit L2")
+            if traffic and kind in traffic.get("per_step", {}):
+                tb = traffic["per_step"][kind]["hbm_bytes_per_launch"]
+                d["traffic"] = tb
+                d["frac_physical"] = tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None
+            return d
+        ph, pw = pair("ht"), pair("wiener")
+        n_all = ph["launches"] + pw["launches"]
+        alg_bytes = (ph["algorithmic_bytes_per_launch"] * ph["launches"] + pw["algorithmic_bytes_per_launch"] * pw["launches"]) / n_all
+        pair_ms = (ph["avg_launch_ms"] * ph["launches"] + pw["avg_launch_ms"] * pw["launches"]) / n_all
+        achieved = alg_bytes / (pair_ms * 1e-3) / 1e9 if pair_ms > 0 else 0.0
+        t_bytes = traffic.get("hbm_bytes_per_launch") if traffic else None
+        tot = {f: timed["ht"].get(f, 0) + timed["wiener"].get(f, 0) for f in FIELDS}
         out = {
             "metric": "SAI-megapixels/sec (HT+Wiener, sigma=25)",
             "value": value, "unit": "SAI-megapixels/s", "n_gpus": world, "steps": args.steps,
@@ -231,29 +262,35 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "light_field": f"{ah}x{aw}x{H}x{W}x3", "sigma": sigma,
                        "params_ht": list(map(str, wl["p1"])), "params_wiener": list(map(str, wl["p2"])),
-                       "asw": 1, "color_space": "opp", "parallelism": ("single GPU" if world == 1 else
+                       "asw": 1, "color_space": "opp", "noise": ("MT19937 seed 1 (utilities.cpp:176-183)" if args.noise == "mt19937" else "torch.randn seed 1"),
+                       "window_lanes": lanes_timed if world == 1 else 1,
+                       "parallelism": ("single GPU" if world == 1 else
                                        f"{world} x blocks of angular windows + 1 RCCL all-reduce of num/den per step"
                                        if args.sharding == "windows" else
                                        f"{world} x reference-patch rows of every pass + RCCL all-reduce per pass")},
-            "roofline": {"bound": "hbm", "kernel": "k_group+k_aggregate (transform + shrink + aggregate)",
+            "roofline": {"bound": "hbm", "kernel": "k_group* + k_aggregate (5-D transform + shrinkage + aggregation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pair_ms,
-                         "launches": launches},
-            "kernel_ms_per_step": {"block_matching": s.ms_bm / args.steps, "group": s.ms_group / args.steps,
-                                   "aggregate": s.ms_aggregate / args.steps, "comm": s.ms_comm / args.steps},
-            "passes_per_step": s.passes / args.steps, "windows_per_step": s.windows / args.steps,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": t_bytes,
+                         "frac_physical": (t_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (t_bytes and pair_ms > 0) else None,
+                         "traffic_source": (traffic or {}).get("source"),
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pair_ms, "launches": n_all,
+                         "measured_with": ("the timed region (one lane)" if roof is timed else
+                                           f"{roof_steps} extra untimed step with LFBM5D_LANES=1 (kernels alone on the GPU); the timed region ran {lanes_timed} lanes"),
+                         "per_step": {"ht": ph, "wiener": pw}},
+            "kernel_ms_per_step": {"block_matching": tot["ms_bm"] / args.steps, "group": tot["ms_group"] / args.steps,
+                                   "aggregate": tot["ms_aggregate"] / args.steps, "comm": tot["ms_comm"] / args.steps,
+                                   "note": ("HIP-event intervals on each lane's stream; with several lanes the intervals of different windows "
+                                            "overlap, so they add up to more than the step time") if lanes_timed != 1 and world == 1 else
+                                           "HIP-event intervals on the library's stream"},
+            "passes_per_step": tot["passes"] / args.steps, "windows_per_step": tot["windows"] / args.steps,
+            "lane_windows_per_step": tot["lane_windows"] / args.steps,
             "psnr": {"noisy": psnr_lf(noisy0), "basic": psnr_lf(basic), "denoised": psnr_lf(den)},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             try:
-                c = (ah // 2) * aw + aw // 2
-                idx = [c + ds * aw + dt for ds in (-1, 0, 1) for dt in (-1, 0, 1)]
-                n9 = noisy0[idx].cpu().numpy()
-                b9 = basic[idx].cpu().numpy()
-                half = s.passes / args.steps / 2
-                ctx.reset_stats()
-                out["cpu_baseline"] = cpu_baseline(wl, n9, b9, int(round(half)), int(round(half)), total_mp, ctx)
+                n_h = noisy_h if noisy_h is not None else noisy0.cpu().numpy()
+                out["cpu_baseline"] = cpu_baseline(wl, n_h, basic.cpu().numpy(), int(round(tot["windows"] / args.steps / 2)), total_mp)
             except Exception as e:  # the baseline is a reported aside, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "SAI-megapixels/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}

@@ -79,3 +79,34 @@ def make_lf(aheight, awidth, H, W, seed=12345):
             img = np.where(m[None], fg[:, y2:y2 + H, x2:x2 + W], img)
             out[s * awidth + t] = img
     return out
+
+
+def add_noise_mt19937(clean, sigma, seed=1, out=None):
+    """Additive white Gaussian noise exactly as the reference's add_noise draws it (utilities.cpp:176-183 with
+    mt19937ar.c): ONE MT19937 stream seeded with init_genrand(seed), samples in memory order (SAIs in st order,
+    planar pixels), per sample a = genrand_res53(), b = genrand_res53(), z = sigma * sqrt(-2 ln a) * cos(2 pi b)
+    in double, added as float.  numpy's legacy RandomState(seed) is that generator (init_genrand seeding, and
+    random_sample() is genrand_res53), so no C code is needed.  clean: float32 array of any shape; returns float32.
+    """
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    clean = np.ascontiguousarray(clean, dtype=np.float32)
+    res = np.empty_like(clean) if out is None else out
+    flat_in, flat_out = clean.reshape(-1), res.reshape(-1)
+    rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+    workers = max(1, min(32, (os.cpu_count() or 1)))
+    piece = 1 << 18
+
+    def box_muller(args):          # numpy releases the GIL inside log / sqrt / cos
+        u, i, n = args
+        z = float(sigma) * np.sqrt(-2.0 * np.log(u[0:2 * n:2])) * np.cos(2.0 * np.pi * u[1:2 * n:2])
+        flat_out[i:i + n] = flat_in[i:i + n] + z.astype(np.float32)
+
+    with ThreadPoolExecutor(workers) as pool:
+        chunk = piece * workers
+        for i0 in range(0, flat_in.size, chunk):      # the stream itself is drawn sequentially, in order
+            n0 = min(chunk, flat_in.size - i0)
+            u = rs.random_sample(2 * n0)
+            jobs = [(u[2 * j:2 * min(j + piece, n0)], i0 + j, min(piece, n0 - j)) for j in range(0, n0, piece)]
+            list(pool.map(box_muller, jobs))
+    return res

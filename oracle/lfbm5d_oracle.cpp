@@ -27,6 +27,7 @@ const double kSqrt2Inv = 0.7071067811865475;  /* core:34 */
 const double kPi = 3.14159265358979323846;
 
 int g_threads = 0; /* 0 = OpenMP default */
+double g_time_limit = 0.0; /* run API: stop after the window that exceeds it (0 = none) */
 
 double now_s() {
     using namespace std::chrono;
@@ -1061,8 +1062,10 @@ int run_step(int step, const orc_params* P, float* LF_noisy, const unsigned* mas
     int windows = 0;
     const unsigned Aw = asw * asw;
     std::vector<float> w_noisy(Aw * imgb), w_basic(step == 2 ? Aw * imgb : 0), w_num(Aw * imgb), w_den(Aw * imgb);
+    const double t_run0 = now_s();
     while (remaining) {
         if (max_windows > 0 && windows >= max_windows) break;
+        if (g_time_limit > 0.0 && windows > 0 && now_s() - t_run0 > g_time_limit) break;   /* bounded timing samples (bench.py) */
         if (remaining == total && mask[cst]) { ps = cs; pt = ct; }
         else { /* bm5d.cpp:187-213: most exact-zero weights, last index wins ties */
             long best_cnt = -1;
@@ -1490,6 +1493,7 @@ void orc_psnr(const float* a, const float* b, unsigned long long n, float* psnr,
     *psnr = 20.0f * std::log10(255.0f / *rmse);
 }
 void orc_set_threads(int n) { g_threads = n; }
+void orc_set_time_limit(double seconds) { g_time_limit = seconds; }
 int orc_get_threads(void) {
 #ifdef _OPENMP
     return g_threads > 0 ? g_threads : omp_get_max_threads();

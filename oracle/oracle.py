@@ -103,6 +103,7 @@ def lib():
     L.orc_denoised_percent.restype = C.c_float
     L.orc_psnr.argtypes = [_f32p, _f32p, C.c_ulonglong, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.orc_set_threads.argtypes = [C.c_int]
+    L.orc_set_time_limit.argtypes = [C.c_double]
     L.orc_get_threads.restype = C.c_int
     _lib = L
     return L

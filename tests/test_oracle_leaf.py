@@ -156,3 +156,15 @@ def test_search_window_matches_reference_semantics():
     for aidx, exp in ((0, (0, 0, 2)), (8, (1, 7, 9)), (16, (2, 14, 16))):
         L.orc_search_window(aidx, 17, 1, C.byref(c), C.byref(mn), C.byref(mx))
         assert (c.value, mn.value, mx.value) == exp
+
+
+def test_product_noise_generator_is_the_reference_stream():
+    """lfbm5d_amd.synth.add_noise_mt19937 (what bench.py feeds the GPU) against the oracle's add_noise, which is pinned
+    to the compiled mt19937ar.c above: same MT19937 stream, same Box-Muller arithmetic, bit for bit."""
+    from lfbm5d_amd import synth
+    rng = np.random.default_rng(3)
+    clean = rng.integers(0, 256, size=(4, 3, 37, 53)).astype(np.float32)
+    for seed, sigma in ((1, 25.0), (7, 50.0)):
+        a = O.add_noise_lf(clean.reshape(4, -1), sigma, seed=seed).reshape(clean.shape)
+        b = synth.add_noise_mt19937(clean, sigma, seed=seed)
+        assert np.array_equal(a, b)

@@ -1,15 +1,32 @@
 """Turn two rocprofv3 --pmc runs (FETCH_SIZE, WRITE_SIZE; separate passes as MI355X_MICROARCH.md
-prescribes) of `bench.py --steps 1 --warmup 0` into profiles/traffic_latest.json:
-HBM bytes per launch of the roofline kernels (k_group* + k_aggregate).
+prescribes) of `bench.py --steps 1 --warmup 0 --lanes 1` into profiles/traffic_latest.json:
+HBM bytes per launch of the roofline kernels (k_group* + k_aggregate), for the whole step and split
+into the HT and the Wiener pass.
 
-gfx950 corrections applied (MI355X_MICROARCH.md, HBM section): the counters are in KiB... they are
-reported in units of 1 KB by rocprofv3 (bytes = value * 1024); FETCH_SIZE reports half the bytes of
-wide coalesced streaming reads, so the read side is given both raw and doubled.
-usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json>"""
+gfx950 corrections applied (MI355X_MICROARCH.md, HBM section): rocprofv3 reports the two counters in
+units of 1 KB (bytes = value * 1024); FETCH_SIZE reports half the bytes of wide coalesced streaming
+reads (16 B per lane), so the group kernels' 16-byte gathers are doubled; the aggregation's 4-byte
+gathers are taken raw (calibrated: it reads `filt` exactly once and the raw figure equals the
+buffer's size).
+usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json> [source-tag]"""
 import csv
 import glob
 import json
 import sys
+
+
+def classify(name):
+    if "k_group_pos" in name or "k_group_shape" in name:
+        return None
+    if "k_group" in name:
+        return ("group", "wiener" if "dct8w" in name else "ht")
+    if "k_aggregate" in name:
+        return ("aggregate", "wiener" if ", 8, 8," in name else "ht")
+    if "k_bm_scan" in name:
+        return ("scan", "wiener" if "<8>" in name else "ht")
+    if "argmin" in name:
+        return ("argmin", "both")
+    return None
 
 
 def per_kernel(d, counter):
@@ -18,9 +35,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") != counter:
                 continue
-            name = r["Kernel_Name"]
-            key = "group" if ("k_group" in name and "k_group_pos" not in name and "k_group_shape" not in name) else \
-                  "aggregate" if "k_aggregate" in name else "scan" if "k_bm_scan" in name else "argmin" if "argmin" in name else None
+            key = classify(r["Kernel_Name"])
             if key is None:
                 continue
             e = out.setdefault(key, [0.0, set()])
@@ -30,23 +45,23 @@ def per_kernel(d, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {"workload": sys.argv[3], "applies_to": ["lf17x17x512x512_sigma25", "lf9x9x512x512_sigma25"],
-       "note": "per-pass figures depend on the 3x3x560x560 window only, not on the number of windows", "unit": "bytes", "kernels": {}}
-pair_raw = pair_corr = 0.0
+res = {"workload": sys.argv[3], "source": sys.argv[5] if len(sys.argv) > 5 else None, "unit": "bytes", "kernels": {}, "per_step": {}}
+tot = {"ht": [0.0, 0.0, 0], "wiener": [0.0, 0.0, 0]}
 for k in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(k, (0.0, 1))
     w, nw = write.get(k, (0.0, 1))
     fb, wb = f * 1024 / max(nf, 1), w * 1024 / max(nw, 1)
-    res["kernels"][k] = {"launches": nf, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb,
-                         "write_bytes_per_launch": wb}
-    if k == "group":        # gather of window pixels: coalesced row segments -> the 1/2 rule applies
-        pair_raw += fb + wb
-        pair_corr += 2 * fb + wb
-    if k == "aggregate":    # calibrated on a known byte count: filt is read exactly once and the raw
-        pair_raw += fb + wb  # FETCH_SIZE equals its size (4 B/lane row-segment reads are not halved)
-        pair_corr += fb + wb
-# one pass launches one group kernel and one aggregate kernel: the pair's traffic per pass
-res["hbm_bytes_per_launch"] = pair_corr
-res["hbm_bytes_per_launch_fetch_uncorrected"] = pair_raw
+    res["kernels"]["%s/%s" % k] = {"launches": nf, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb,
+                                   "write_bytes_per_launch": wb}
+    if k[0] == "group" and k[1] in tot:        # gather of window pixels: coalesced 16-byte row segments -> the 1/2 rule applies
+        tot[k[1]][0] += fb + wb; tot[k[1]][1] += 2 * fb + wb; tot[k[1]][2] = max(tot[k[1]][2], nf)
+    if k[0] == "aggregate" and k[1] in tot:    # 4 B/lane row-segment reads are not halved (calibrated on filt's size)
+        tot[k[1]][0] += fb + wb; tot[k[1]][1] += fb + wb; tot[k[1]][2] = max(tot[k[1]][2], nf)
+for kind, (raw, corr, n) in tot.items():
+    res["per_step"][kind] = {"hbm_bytes_per_launch": corr, "hbm_bytes_per_launch_fetch_uncorrected": raw, "launches": n}
+n = tot["ht"][2] + tot["wiener"][2]
+# one pass launches one group kernel and one aggregate kernel: the pair's traffic per pass, averaged over the step
+res["hbm_bytes_per_launch"] = (tot["ht"][1] * tot["ht"][2] + tot["wiener"][1] * tot["wiener"][2]) / max(n, 1)
+res["hbm_bytes_per_launch_fetch_uncorrected"] = (tot["ht"][0] * tot["ht"][2] + tot["wiener"][0] * tot["wiener"][2]) / max(n, 1)
 json.dump(res, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(res, indent=1))
