@@ -746,6 +746,10 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
      * that, copies every window's count to pinned memory and checks them all at the end: if a window would have
      * needed another pass the step is redone in the sequential form (never observed; greyscale light fields, where
      * further passes are the rule, take the sequential form directly). */
+    /* LFBM5D_MAX_WINDOWS: stop after that many windows of the planned sequence (what the oracle's max_windows does:
+     * bisecting a multi-window difference, bounded timing samples); the estimate is still formed */
+    const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
+    const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
     const char* lanes_s = std::getenv("LFBM5D_LANES");
     const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : 3));
     c->lane_windows = 0;
@@ -753,6 +757,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     if (pipelined) {
         std::vector<unsigned> plan;
         plan_windows(h_mask, awidth, aheight, an, ang_major, plan);
+        if (max_windows > 0 && plan.size() > (size_t)max_windows) plan.resize((size_t)max_windows);
         const size_t NW = plan.size();
         /* SAIs and 4-D transform of every window (the DCT -> SADCT switch is sticky, bm5d.cpp:276-280) */
         std::vector<std::vector<unsigned>> sai(NW);
@@ -896,6 +901,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     } else {
         std::vector<unsigned> plan;
         plan_windows(h_mask, awidth, aheight, an, ang_major, plan);
+        if (max_windows > 0 && plan.size() > (size_t)max_windows) plan.resize((size_t)max_windows);
         const int nranks = emu > 1 ? emu : c->world;
         float* t_num = nullptr; float* t_den = nullptr;
         if (emu > 1) {

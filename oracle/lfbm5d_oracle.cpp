@@ -27,6 +27,7 @@ const double kSqrt2Inv = 0.7071067811865475;  /* core:34 */
 const double kPi = 3.14159265358979323846;
 
 int g_threads = 0; /* 0 = OpenMP default */
+std::vector<unsigned> g_last_windows; /* run API: processed SAI of every window of the last step, in order */
 double g_time_limit = 0.0; /* run API: stop after the window that exceeds it (0 = none) */
 
 double now_s() {
@@ -1063,6 +1064,7 @@ int run_step(int step, const orc_params* P, float* LF_noisy, const unsigned* mas
     const unsigned Aw = asw * asw;
     std::vector<float> w_noisy(Aw * imgb), w_basic(step == 2 ? Aw * imgb : 0), w_num(Aw * imgb), w_den(Aw * imgb);
     const double t_run0 = now_s();
+    g_last_windows.clear();
     while (remaining) {
         if (max_windows > 0 && windows >= max_windows) break;
         if (g_time_limit > 0.0 && windows > 0 && now_s() - t_run0 > g_time_limit) break;   /* bounded timing samples (bench.py) */
@@ -1077,6 +1079,7 @@ int run_step(int step, const orc_params* P, float* LF_noisy, const unsigned* mas
             if (ang_major == ORC_ROWMAJOR) { ps = pst / awidth; pt = pst - ps * awidth; }
             else { pt = pst / aheight; ps = pst - pt * aheight; }
         }
+        g_last_windows.push_back(ang_major == ORC_ROWMAJOR ? ps * awidth + pt : ps + pt * aheight);
         int cs_w, mins, maxs, ct_w, mint, maxt;
         search_window((int)ps, aheight, an, cs_w, mins, maxs);
         search_window((int)pt, awidth, an, ct_w, mint, maxt);
@@ -1493,6 +1496,10 @@ void orc_psnr(const float* a, const float* b, unsigned long long n, float* psnr,
     *psnr = 20.0f * std::log10(255.0f / *rmse);
 }
 void orc_set_threads(int n) { g_threads = n; }
+int orc_last_windows(unsigned* out, unsigned cap) {
+    for (size_t i = 0; i < g_last_windows.size() && i < cap && out; i++) out[i] = g_last_windows[i];
+    return (int)g_last_windows.size();
+}
 void orc_set_time_limit(double seconds) { g_time_limit = seconds; }
 int orc_get_threads(void) {
 #ifdef _OPENMP

@@ -161,6 +161,8 @@ float orc_denoised_percent(const float* den, const unsigned* mask, unsigned A, u
                            unsigned H, unsigned C, unsigned N, unsigned k);
 void orc_psnr(const float* a, const float* b, unsigned long long n, float* psnr, float* rmse);
 void orc_set_threads(int n);
+/* processed SAI (index in ang_major order) of every window the last orc_run_step* call visited, in order (bm5d.cpp:187-213) */
+int orc_last_windows(unsigned* out, unsigned cap);
 /* run API: stop visiting windows once this many seconds have passed (after at least one window); 0 = no limit */
 void orc_set_time_limit(double seconds);
 int  orc_get_threads(void);

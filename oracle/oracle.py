@@ -104,6 +104,8 @@ def lib():
     L.orc_psnr.argtypes = [_f32p, _f32p, C.c_ulonglong, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_set_time_limit.argtypes = [C.c_double]
+    L.orc_last_windows.argtypes = [C.c_void_p, C.c_uint]
+    L.orc_last_windows.restype = C.c_int
     L.orc_get_threads.restype = C.c_int
     _lib = L
     return L
@@ -159,6 +161,15 @@ def psnr(a, b):
 def psnr_lf(a, b):
     """Mean over SAIs of the per-SAI PSNR (compute_psnr_LF, utilities_LF.cpp:639-692)."""
     return float(np.mean([psnr(a[i], b[i]) for i in range(a.shape[0])]))
+
+
+def last_windows():
+    """Processed SAI of every window the last run_step* call visited (the reference's data-driven choice)."""
+    L = lib()
+    n = L.orc_last_windows(None, 0)
+    out = np.zeros(max(n, 1), np.uint32)
+    L.orc_last_windows(out.ctypes.data, out.size)
+    return out[:n].copy()
 
 
 def run_step1(P, noisy, mask, ang_major, aw, ah, an, W, H, Cc, max_windows=0):
