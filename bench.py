@@ -110,16 +110,18 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 3)")
     ap.add_argument("--noise", default="mt19937", choices=["mt19937", "torch"],
                     help="mt19937: the reference's noise stream, seed 1 (default); torch: quick GPU noise for kernel iteration")
-    ap.add_argument("--sharding", default="windows", choices=["windows", "rows"],
-                    help="multi-GPU step scheme: blocks of angular windows per rank (default) or row-sharded passes")
+    ap.add_argument("--sharding", default="graph", choices=["graph", "rows", "blocks"],
+                    help="multi-GPU step scheme: graph = windows as a dependency graph, chains of windows per rank, one message per SAI "
+                         "between ranks (default; bit-identical to one GPU); rows = row-sharded passes (exact); blocks = round 1's "
+                         "contiguous window blocks + one all-reduce (scales, but not the reference's result)")
     args = ap.parse_args()
 
     import torch
     import lfbm5d_amd as L
     from lfbm5d_amd import core, synth
 
-    if args.sharding == "rows":
-        os.environ["LFBM5D_STEP_SHARDING"] = "rows"
+    if args.sharding in ("rows", "blocks"):
+        os.environ["LFBM5D_STEP_SHARDING"] = args.sharding
     else:
         os.environ.pop("LFBM5D_STEP_SHARDING", None)
     if args.lanes > 0:
@@ -169,7 +171,7 @@ def main():
     P1 = core.make_params(sigma, 2.7, *wl["p1"])
     P2 = core.make_params(sigma, 2.7, *wl["p2"])
     FIELDS = ("windows", "passes", "groups", "stack_patches", "algorithmic_bytes", "ms_bm", "ms_group", "ms_aggregate",
-              "ms_comm", "launches_group", "launches_aggregate", "lane_windows")
+              "ms_comm", "launches_group", "launches_aggregate", "lane_windows", "messages")
 
     def one_step(acc=None):
         """HT + Wiener; acc: {"ht": {...}, "wiener": {...}} accumulates the library's counters per step kind."""
@@ -263,10 +265,12 @@ def main():
             "config": {"workload": args.workload, "light_field": f"{ah}x{aw}x{H}x{W}x3", "sigma": sigma,
                        "params_ht": list(map(str, wl["p1"])), "params_wiener": list(map(str, wl["p2"])),
                        "asw": 1, "color_space": "opp", "noise": ("MT19937 seed 1 (utilities.cpp:176-183)" if args.noise == "mt19937" else "torch.randn seed 1"),
-                       "window_lanes": lanes_timed if world == 1 else 1,
+                       "window_lanes": lanes_timed,
                        "parallelism": ("single GPU" if world == 1 else
-                                       f"{world} x blocks of angular windows + 1 RCCL all-reduce of num/den per step"
-                                       if args.sharding == "windows" else
+                                       f"{world} ranks x chains of angular windows (dependency graph), RCCL send/recv of num/den per shared SAI, "
+                                       f"final broadcast of the estimates; bit-identical to one GPU" if args.sharding == "graph" else
+                                       f"{world} x blocks of angular windows + 1 RCCL all-reduce of num/den per step (NOT the reference's result)"
+                                       if args.sharding == "blocks" else
                                        f"{world} x reference-patch rows of every pass + RCCL all-reduce per pass")},
             "roofline": {"bound": "hbm", "kernel": "k_group* + k_aggregate (5-D transform + shrinkage + aggregation)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -284,7 +288,7 @@ def main():
                                             "overlap, so they add up to more than the step time") if lanes_timed != 1 and world == 1 else
                                            "HIP-event intervals on the library's stream"},
             "passes_per_step": tot["passes"] / args.steps, "windows_per_step": tot["windows"] / args.steps,
-            "lane_windows_per_step": tot["lane_windows"] / args.steps,
+            "lane_windows_per_step": tot["lane_windows"] / args.steps, "messages_per_step": tot["messages"] / args.steps,
             "psnr": {"noisy": psnr_lf(noisy0), "basic": psnr_lf(basic), "denoised": psnr_lf(den)},
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only

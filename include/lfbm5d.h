@@ -81,6 +81,7 @@ typedef struct {
     unsigned long long launches_group; /* launches of the transform kernel                    */
     unsigned long long launches_aggregate;
     unsigned long long lane_windows;   /* windows that ran on a lane other than the first (pipelined steps) */
+    unsigned long long messages;       /* SAI messages (num + den of one SAI) exchanged between ranks, graph form   */
 } lfbm5d_stats;
 
 /* ---- context ---- */
@@ -94,15 +95,22 @@ void lfbm5d_get_stats(const lfbm5d_ctx* ctx, lfbm5d_stats* out);
 /* The HIP stream (hipStream_t) the context launches on, for callers that time with events. */
 void* lfbm5d_stream(lfbm5d_ctx* ctx);
 
-/* ---- multi-GPU: one process per GPU, every rank holds the whole light field.
- * Whole steps (lfbm5d_step*): the sequence of angular windows of the reference's schedule
- * (bm5d.cpp:165-407; a pure function of the SAI mask, see lfbm5d_plan_windows) is cut into one
- * contiguous block per rank and the per-rank aggregation buffers (num, den of the whole light field)
- * are summed with ONE RCCL all-reduce per step over xGMI; every rank ends with the full result.
- * A rank's block matching sees the running estimate of its own earlier windows only, which moves the
- * final PSNR by about -0.01 / -0.03 / -0.07 dB on 2 / 4 / 8 ranks (the reference's own parallel mode,
- * spatial tiles, costs 0.5 dB).  Environment LFBM5D_STEP_SHARDING=rows keeps the single-GPU order
- * exactly instead: every core pass row-sharded as below (two all-reduces per pass, little speed-up).
+/* ---- multi-GPU: one process per GPU, every rank holds the whole (read-only) light field.
+ * Whole steps (lfbm5d_step*): the windows of the reference's schedule (bm5d.cpp:165-407; a pure function of the SAI
+ * mask, see lfbm5d_plan_windows) form a dependency graph -- a window has to wait exactly for the previous window
+ * that touched each of its SAIs, because windows interact only through num / den of shared SAIs (the running
+ * estimate block matching reads, the sums aggregation adds to).  Ranks own chains of windows (runs of consecutive
+ * windows in one row of SAIs), dealt round-robin; what a window needs from a window of another rank travels as one
+ * RCCL send / recv per SAI (num and den of that SAI, xGMI point-to-point); at the end every SAI's estimate is
+ * formed on the rank that touched it last and broadcast.  Every window sees exactly the sums the single-GPU order
+ * shows it: the result is BIT-IDENTICAL to one GPU for any rank count (lfbm5d_plan_graph / lfbm5d_plan_messages
+ * expose the assignment and the message list).  The reference's backward raster leaves a wavefront -- a row of
+ * windows may run two windows behind the row before it -- so the speed-up is bounded by the graph's critical path
+ * (22 of 64 window slots on a 17x17 light field), not by the rank count.  Environment LFBM5D_STEP_SHARDING selects
+ * the alternatives: "rows" = single-GPU window order with every core pass row-sharded as below (exact, two
+ * all-reduces per pass; also what greyscale light fields need); "blocks" = round 1's contiguous blocks of windows
+ * per rank + ONE all-reduce per step, which scales with the rank count but is NOT the reference's result (a rank's
+ * block matching only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks).
  * Single core passes (lfbm5d_pass_device): the reference patches are sharded by rows over the ranks and
  * the window's num/den all-reduced.
  * Replaces the reference's only parallelism, the OpenMP tile loop + undivide_LF merge
@@ -123,6 +131,16 @@ void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, un
  * only, needs no GPU.  Returns the number of windows (-1 on bad arguments); writes min(n, cap) entries. */
 int lfbm5d_plan_windows(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask,
                         unsigned* out_sai, unsigned cap);
+/* The graph form of a step for `world` ranks with `lanes` lanes each (host only, needs no GPU): owner rank, lane and
+ * unit-time start slot of every window of lfbm5d_plan_windows' sequence.  Returns the number of windows (-1 on bad
+ * arguments); writes min(n, cap) entries to each non-NULL array. */
+int lfbm5d_plan_graph(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask, int world, int lanes,
+                      unsigned* out_rank, unsigned* out_lane, unsigned* out_start, unsigned cap);
+/* The messages of that graph in the order every rank issues them: out[4 i] = {producer window, consumer window, SAI,
+ * channel}; the producer's rank sends num and den of the SAI to the consumer's rank once the producer window is done.
+ * Returns the number of messages (-1 on bad arguments); writes min(n, cap) quadruples. */
+int lfbm5d_plan_messages(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask, int world,
+                         unsigned* out, unsigned cap);
 /* The windows the last lfbm5d_step* call on this context actually ran (same encoding). */
 int lfbm5d_last_windows(const lfbm5d_ctx* ctx, unsigned* out_sai, unsigned cap);
 

@@ -43,7 +43,7 @@ class Stats(C.Structure):
                 ("algorithmic_bytes", C.c_double), ("ms_bm", C.c_double), ("ms_group", C.c_double),
                 ("ms_aggregate", C.c_double), ("ms_other", C.c_double), ("ms_comm", C.c_double),
                 ("launches_group", C.c_ulonglong), ("launches_aggregate", C.c_ulonglong),
-                ("lane_windows", C.c_ulonglong)]
+                ("lane_windows", C.c_ulonglong), ("messages", C.c_ulonglong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -94,6 +94,8 @@ def lib():
     L.lfbm5d_shard_rows.restype = None
     L.lfbm5d_plan_windows.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, up, C.c_uint]
     L.lfbm5d_last_windows.argtypes = [vp, up, C.c_uint]
+    L.lfbm5d_plan_graph.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, C.c_int, C.c_int, up, up, up, C.c_uint]
+    L.lfbm5d_plan_messages.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, C.c_int, up, C.c_uint]
     tail = [C.c_uint] * 7
     L.lfbm5d_step1_device.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
     L.lfbm5d_step2_device.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
@@ -127,6 +129,33 @@ def plan_windows(awidth, aheight, an=1, ang_major=None, mask=None):
     if n < 0:
         raise LfBm5dError("lfbm5d_plan_windows: bad arguments")
     return out[:n].copy()
+
+
+def plan_graph(awidth, aheight, world, lanes=1, an=1, ang_major=None, mask=None):
+    """Graph form of a step (host only): (rank, lane, start slot) of every planned window, as uint32 arrays."""
+    ang_major = ROWMAJOR if ang_major is None else ang_major
+    m = np.ones(awidth * aheight, np.uint32) if mask is None else _u32(mask)
+    mp = m.ctypes.data_as(C.POINTER(C.c_uint))
+    n = lib().lfbm5d_plan_graph(awidth, aheight, an, ang_major, mp, world, lanes, None, None, None, 0)
+    if n < 0:
+        raise LfBm5dError("lfbm5d_plan_graph: bad arguments")
+    r, l, t = (np.zeros(max(n, 1), np.uint32) for _ in range(3))
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint))
+    lib().lfbm5d_plan_graph(awidth, aheight, an, ang_major, mp, world, lanes, p(r), p(l), p(t), n)
+    return r[:n], l[:n], t[:n]
+
+
+def plan_messages(awidth, aheight, world, an=1, ang_major=None, mask=None):
+    """Messages of the graph form in issue order: rows of (producer window, consumer window, SAI, channel)."""
+    ang_major = ROWMAJOR if ang_major is None else ang_major
+    m = np.ones(awidth * aheight, np.uint32) if mask is None else _u32(mask)
+    mp = m.ctypes.data_as(C.POINTER(C.c_uint))
+    n = lib().lfbm5d_plan_messages(awidth, aheight, an, ang_major, mp, world, None, 0)
+    if n < 0:
+        raise LfBm5dError("lfbm5d_plan_messages: bad arguments")
+    out = np.zeros((max(n, 1), 4), np.uint32)
+    lib().lfbm5d_plan_messages(awidth, aheight, an, ang_major, mp, world, out.ctypes.data_as(C.POINTER(C.c_uint)), n)
+    return out[:n]
 
 
 def shard_rows(n_rows, rank, world):

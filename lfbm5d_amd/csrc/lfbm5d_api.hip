@@ -55,6 +55,8 @@ struct lfbm5d_ctx {
     std::string err;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
+    ncclComm_t comm2 = nullptr;            /* second channel of the window-graph exchange (ncclCommSplit of comm) */
+    hipStream_t cs[2] = {nullptr, nullptr}; /* exchange streams, one per channel */
     /* sharding actually applied inside a core pass: rows of reference patches over pass_world ranks (direct
      * lfbm5d_pass_device calls use rank/world; whole steps on several GPUs shard by WINDOWS instead and run
      * every pass unsharded) */
@@ -65,7 +67,7 @@ struct lfbm5d_ctx {
     /* per-pass work buffers (grow only) */
     DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den, d_mask;
     /* step-level buffers */
-    DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out;
+    DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
     /* window lanes (run_step, pipelined form): extra contexts on the same device, each with its own stream, window
      * buffers and per-pass work buffers; owned by this context */
@@ -530,6 +532,121 @@ void plan_windows(const unsigned* h_mask, unsigned awidth, unsigned aheight, uns
     }
 }
 
+/* The windows of a step as a dependency graph.  Two windows interact only through num / den of
+ * the SAIs they share -- the running estimate block matching reads, the sums aggregation adds to -- so a window has to
+ * wait exactly for the previous window that touched each of its SAIs; windows that share no SAI commute bit for bit.
+ * Ranks own CHAINS of windows (maximal runs of consecutive windows in the same row of SAIs: every window of a chain
+ * depends on its predecessor, so a chain is serial anyway), dealt round-robin; a window's inputs that a window of
+ * another rank produced travel as one point-to-point message per SAI (num and den of that SAI). */
+struct StepGraph {
+    std::vector<unsigned> plan, ps, pt, tau4, chain;
+    std::vector<int> rank, lane, start;              /* owner rank, lane within the owner, unit-time start slot */
+    std::vector<std::vector<unsigned>> sai;          /* non-empty SAIs (light-field indices) of every window */
+    std::vector<std::vector<int>> prev, next;        /* per window and SAI: previous / next window touching it (-1: none) */
+    std::vector<int> last_touch;                     /* per SAI of the light field: last window touching it (-1: none) */
+    bool centre_ok = true;                           /* every window's centre SAI is non-empty */
+    struct Xfer { unsigned from_w, to_w, sai; int channel; };
+    std::vector<Xfer> xfers;                         /* in issue order: producer window, then SAI slot */
+};
+
+void build_graph(const unsigned* h_mask, unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, unsigned tau_4D,
+                 int world, int n_lanes, int max_windows, StepGraph& G) {
+    const unsigned asize = awidth * aheight, asw = 2 * an + 1, Aw = asw * asw;
+    plan_windows(h_mask, awidth, aheight, an, ang_major, G.plan);
+    if (max_windows > 0 && G.plan.size() > (size_t)max_windows) G.plan.resize((size_t)max_windows);
+    const size_t NW = G.plan.size();
+    G.ps.assign(NW, 0); G.pt.assign(NW, 0); G.tau4.assign(NW, 0); G.chain.assign(NW, 0);
+    G.rank.assign(NW, 0); G.lane.assign(NW, 0); G.start.assign(NW, 0);
+    G.sai.assign(NW, {}); G.prev.assign(NW, {}); G.next.assign(NW, {});
+    G.last_touch.assign(asize, -1);
+    G.centre_ok = true;
+    G.xfers.clear();
+    unsigned t4 = tau_4D;
+    for (size_t w = 0; w < NW; w++) {
+        G.ps[w] = ang_major == LFBM5D_ROWMAJOR ? G.plan[w] / awidth : G.plan[w] % aheight;
+        G.pt[w] = ang_major == LFBM5D_ROWMAJOR ? G.plan[w] % awidth : G.plan[w] / aheight;
+        int cs_w, mins, maxs, ct_w, mint, maxt;
+        search_window((int)G.ps[w], aheight, an, cs_w, mins, maxs);
+        search_window((int)G.pt[w], awidth, an, ct_w, mint, maxt);
+        for (unsigned si = 0; si < asw; si++)
+            for (unsigned ti = 0; ti < asw; ti++) {
+                const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (si + mins) * awidth + (ti + mint) : (si + mins) + (ti + mint) * aheight;
+                if (h_mask[st]) G.sai[w].push_back(st);
+            }
+        if (G.sai[w].size() != Aw && t4 == LFBM5D_DCT) t4 = LFBM5D_SADCT;   /* sticky switch, bm5d.cpp:276-280 */
+        G.tau4[w] = t4;
+        const unsigned cst_lf = ang_major == LFBM5D_ROWMAJOR ? (unsigned)(mins + cs_w) * awidth + (unsigned)(mint + ct_w)
+                                                             : (unsigned)(mins + cs_w) + (unsigned)(mint + ct_w) * aheight;
+        if (!h_mask[cst_lf]) G.centre_ok = false;
+        G.chain[w] = w == 0 ? 0 : (G.ps[w] == G.ps[w - 1] ? G.chain[w - 1] : G.chain[w - 1] + 1);
+        G.prev[w].assign(G.sai[w].size(), -1);
+        G.next[w].assign(G.sai[w].size(), -1);
+        for (size_t i = 0; i < G.sai[w].size(); i++) {
+            const unsigned st = G.sai[w][i];
+            const int p = G.last_touch[st];
+            G.prev[w][i] = p;
+            if (p >= 0) {
+                const size_t j = std::find(G.sai[p].begin(), G.sai[p].end(), st) - G.sai[p].begin();
+                G.next[p][j] = (int)w;
+            }
+            G.last_touch[st] = (int)w;
+        }
+    }
+    /* Owner of every chain: chains in plan order, each to the rank on which it would finish first in unit window time
+     * (one lane per rank in this model); ties go to the rank that already owns most of the chain's predecessors (fewer
+     * messages), then to the lowest rank.  A pure function of the mask and the rank count: every rank computes the same. */
+    {
+        const int Gn = std::max(1, world);
+        std::vector<unsigned> fin(NW, 0), rank_free((size_t)Gn, 0);
+        size_t a = 0;
+        while (a < NW) {
+            size_t b = a;
+            while (b + 1 < NW && G.chain[b + 1] == G.chain[a]) b++;
+            int best_r = 0; unsigned best_f = ~0u; int best_aff = -1;
+            for (int r = 0; r < Gn; r++) {
+                unsigned t = rank_free[(size_t)r]; int aff = 0;
+                for (size_t w = a; w <= b; w++) {
+                    unsigned ready = t;
+                    for (int p : G.prev[w]) if (p >= 0) { if ((size_t)p < a) { ready = std::max(ready, fin[(size_t)p]); if (G.rank[(size_t)p] == r) aff++; } }
+                    t = ready + 1;
+                }
+                if (t < best_f || (t == best_f && aff > best_aff)) { best_f = t; best_r = r; best_aff = aff; }
+            }
+            unsigned t = rank_free[(size_t)best_r];
+            for (size_t w = a; w <= b; w++) {
+                unsigned ready = t;
+                for (int p : G.prev[w]) if (p >= 0 && (size_t)p < a) ready = std::max(ready, fin[(size_t)p]);
+                t = ready + 1; fin[w] = t; G.rank[w] = best_r;
+            }
+            rank_free[(size_t)best_r] = t;
+            a = b + 1;
+        }
+    }
+    /* greedy list schedule in unit window time: every window on the lane of its owner that is free first; ties go to
+     * the lane of its latest predecessor (no event needed) */
+    std::vector<unsigned> finish(NW, 0), lane_free((size_t)std::max(1, world) * (size_t)n_lanes, 0);
+    for (size_t w = 0; w < NW; w++) {
+        unsigned ready = 0; int pref = -1;
+        for (int p : G.prev[w]) if (p >= 0 && finish[p] >= ready) { ready = finish[p]; pref = G.rank[p] == G.rank[w] ? G.lane[p] : -1; }
+        int best_l = 0; unsigned best_t = ~0u;
+        for (int l = 0; l < n_lanes; l++) {
+            const unsigned t = std::max(ready, lane_free[(size_t)G.rank[w] * n_lanes + l]);
+            if (t < best_t || (t == best_t && l == pref)) { best_t = t; best_l = l; }
+        }
+        G.lane[w] = best_l; G.start[w] = (int)best_t; finish[w] = best_t + 1;
+        lane_free[(size_t)G.rank[w] * n_lanes + best_l] = best_t + 1;
+    }
+    /* messages, in the order every rank issues them: by producer window, then SAI slot.  Two channels (communicator +
+     * stream) alternate with the producer's chain: a rank receives its inputs from the chain before its own on one
+     * channel and sends its outputs on the other, so a send that is ready early never queues behind a receive that
+     * completes late (plan order is not time order once rows of windows overlap) */
+    for (size_t w = 0; w < NW; w++)
+        for (size_t i = 0; i < G.sai[w].size(); i++) {
+            const int n = G.next[w][i];
+            if (n >= 0 && G.rank[n] != G.rank[w]) G.xfers.push_back({(unsigned)w, (unsigned)n, G.sai[w][i], (int)(G.chain[w] & 1u)});
+        }
+}
+
 int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
              float* d_basic, float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight,
              unsigned an, unsigned W, unsigned H, unsigned C) {
@@ -579,7 +696,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
      * on lanes of their own (a lane = a context with its stream, window buffers and per-pass work buffers; lane 0 is this
      * context).  win_begin enqueues the padding, the centre pass and its coverage count; win_finish waits for the count,
      * runs whatever further passes the window needs (greyscale light fields) and adds the window back to the light field. */
-    struct Lane { lfbm5d_ctx* x; float* w_noisy; float* w_basic; float* w_num; float* w_den; unsigned* d_small; };
+    struct Lane { lfbm5d_ctx* x; float* w_noisy; float* w_basic; float* w_num; float* w_den; unsigned* d_small; float* g_num; float* g_den; };
     struct WinState {
         unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, win_bits = 0, rem_w = 0, tot_w = 0, pst_w = 0;
         std::vector<unsigned> st_idx, mask_w, proc_w; SaiList sl; lfbm5d_params Pw; bool counted = false;
@@ -593,6 +710,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         HIPCK(c, x->small.reserve((asize + 8) * sizeof(unsigned)));
         L.x = x; L.w_noisy = x->w_noisy.as<float>(); L.w_basic = x->w_basic.as<float>();
         L.w_num = x->w_num.as<float>(); L.w_den = x->w_den.as<float>(); L.d_small = x->small.as<unsigned>();
+        L.g_num = g_num; L.g_den = g_den;   /* the light field's sums this lane's windows read and update */
         return 0;
     };
     auto lane_fail = [&](const Lane& L) { if (L.x != c) c->err = L.x->err; return 1; };
@@ -639,8 +757,8 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         }
         HIPCK(c, launch_symetrize_multi(ls, d_noisy, img, L.w_noisy, imgb, ws.sl, W, H, C, nHW));
         if (step == 2) HIPCK(c, launch_symetrize_multi(ls, d_basic, img, L.w_basic, imgb, ws.sl, W, H, C, nHW));
-        HIPCK(c, launch_symetrize_multi(ls, g_num, img, L.w_num, imgb, ws.sl, W, H, C, nHW));
-        HIPCK(c, launch_symetrize_multi(ls, g_den, img, L.w_den, imgb, ws.sl, W, H, C, nHW));
+        HIPCK(c, launch_symetrize_multi(ls, L.g_num, img, L.w_num, imgb, ws.sl, W, H, C, nHW));
+        HIPCK(c, launch_symetrize_multi(ls, L.g_den, img, L.w_den, imgb, ws.sl, W, H, C, nHW));
         for (unsigned i = 0; i < Aw; i++) ws.proc_w[i] = !ws.mask_w[i];
         ws.rem_w = (unsigned)std::count(ws.proc_w.begin(), ws.proc_w.end(), 0u);
         ws.tot_w = ws.rem_w;
@@ -678,8 +796,8 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
                     if (ws.proc_w[i] == 0) { ws.proc_w[i] += 1; proc[ws.st_idx[i]] += 1; }
             ws.rem_w = (unsigned)std::count(ws.proc_w.begin(), ws.proc_w.end(), 0u);
         }
-        HIPCK(c, launch_unsymetrize_multi(ls, g_num, img, L.w_num, imgb, ws.sl, W, H, C, nHW));
-        HIPCK(c, launch_unsymetrize_multi(ls, g_den, img, L.w_den, imgb, ws.sl, W, H, C, nHW));
+        HIPCK(c, launch_unsymetrize_multi(ls, L.g_num, img, L.w_num, imgb, ws.sl, W, H, C, nHW));
+        HIPCK(c, launch_unsymetrize_multi(ls, L.g_den, img, L.w_den, imgb, ws.sl, W, H, C, nHW));
         for (unsigned i = 0; i < Aw; i++) if (ws.mask_w[i]) dirty.push_back(ws.st_idx[i]);
         c->stats.windows += 1;
         return 0;
@@ -722,9 +840,19 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     /* "rows": keep the reference's window-after-window order on several GPUs too and shard every core pass by
      * reference-patch rows (bit-for-bit the single-GPU schedule, two all-reduces per pass, little speed-up) */
     const bool by_rows = c->world > 1 && shard_s && std::strcmp(shard_s, "rows") == 0;
+    /* "blocks": the round-1 scheme -- the planned sequence cut into one contiguous block of windows per rank, ONE
+     * all-reduce of num / den per step.  It scales with the rank count but is NOT the reference's result: a rank's block
+     * matching only sees its own earlier windows' estimates (-0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks).  Opt-in. */
+    const bool by_blocks = (c->world > 1 || emu > 1) && shard_s && std::strcmp(shard_s, "blocks") == 0;
+    /* LFBM5D_MAX_WINDOWS: stop after that many windows of the planned sequence (for
+     * bisecting a multi-window difference, bounded timing samples); the estimate is still formed */
+    const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
+    const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
+    const char* lanes_s = std::getenv("LFBM5D_LANES");
+    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : 3));
     /* LFBM5D_DATA_DRIVEN_SCHEDULE: select every window from the zero-weight counts like the reference does (one
      * device round trip per window); the default takes the same sequence from plan_windows() */
-    const bool planned = (c->world > 1 && !by_rows) || emu > 1 || std::getenv("LFBM5D_DATA_DRIVEN_SCHEDULE") == nullptr;
+    const bool planned = (c->world > 1 && !by_rows) || emu > 1 || std::getenv("LFBM5D_DATA_DRIVEN_SCHEDULE") == nullptr;   /* several ranks always plan */
     struct PassShard {   /* restores the unsharded default whatever way the function returns */
         lfbm5d_ctx* c;
         PassShard(lfbm5d_ctx* cc, bool on) : c(cc) { if (on) { c->pass_rank = c->rank; c->pass_world = c->world; c->pass_reduce = c->comm != nullptr; } }
@@ -732,145 +860,224 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     } pass_shard(c, by_rows);
     if (by_rows && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
 
-    /* ---- Pipelined form (one GPU, colour light fields): the planned windows as a dependency graph on several lanes.
-     * Two windows interact only through num/den of the SAIs they share (the running estimate block matching reads,
-     * the sums aggregation adds to), so a window has to wait exactly for the previous window that touched each of its
-     * SAIs; windows that share no SAI commute bit for bit.  In the reference's backward raster a window shares SAIs
-     * with its predecessor in the same row of windows and with three windows of the row before, which leaves a
-     * wavefront: row i may run two windows behind row i-1.  Each lane (stream + window buffers + per-pass work buffers)
-     * takes windows in plan order at the earliest slot a greedy list schedule finds; cross-lane dependencies are HIP
-     * events.  The result is bit-identical to the sequential order, the lanes only let one window's block matching
-     * overlap another's transform and aggregation on the GPU.
+    /* ---- Graph form (colour light fields; the default on one GPU and on several): the planned windows as a dependency
+     * graph (StepGraph above) executed on lanes -- a lane = stream + window buffers + per-pass work buffers.  On one
+     * GPU the lanes only let one window's block matching overlap another window's transform and aggregation; on
+     * several GPUs each rank runs the chains of windows it owns and the SAIs a window needs from another rank's window
+     * arrive as point-to-point messages (RCCL send / recv over xGMI).  Either way every window sees exactly the num /
+     * den the window-after-window order would show it: the result is bit-identical to one lane on one GPU.
      * The reference decides after every pass whether the window is complete (coverage count, bm5d.cpp:370-382); for
-     * colour light fields one centre pass always suffices.  The pipelined form assumes
-     * that, copies every window's count to pinned memory and checks them all at the end: if a window would have
-     * needed another pass the step is redone in the sequential form (never observed; greyscale light fields, where
-     * further passes are the rule, take the sequential form directly). */
-    /* LFBM5D_MAX_WINDOWS: stop after that many windows of the planned sequence (what the oracle's max_windows does:
-     * bisecting a multi-window difference, bounded timing samples); the estimate is still formed */
-    const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
-    const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
-    const char* lanes_s = std::getenv("LFBM5D_LANES");
-    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : 3));
+     * colour light fields one centre pass always suffices.  The graph form assumes that,
+     * copies every window's count to pinned memory and checks them all at the end: if a window would have needed
+     * another pass, a single-GPU step is redone in the sequential form (never observed) and a multi-GPU step fails
+     * with a message; greyscale light fields, where further passes are the rule, take the sequential / row-sharded
+     * forms directly. */
+    const int nranks = emu > 1 ? emu : c->world;
     c->lane_windows = 0;
-    bool pipelined = planned && !by_rows && n_lanes > 1 && C == 3 && c->world == 1 && emu <= 1;
-    if (pipelined) {
-        std::vector<unsigned> plan;
-        plan_windows(h_mask, awidth, aheight, an, ang_major, plan);
-        if (max_windows > 0 && plan.size() > (size_t)max_windows) plan.resize((size_t)max_windows);
-        const size_t NW = plan.size();
-        /* SAIs and 4-D transform of every window (the DCT -> SADCT switch is sticky, bm5d.cpp:276-280) */
-        std::vector<std::vector<unsigned>> sai(NW);
-        std::vector<unsigned> tau4_w(NW), wps(NW), wpt(NW);
-        unsigned t4 = tau_4D;
-        for (size_t w = 0; w < NW && pipelined; w++) {
-            wps[w] = ang_major == LFBM5D_ROWMAJOR ? plan[w] / awidth : plan[w] % aheight;
-            wpt[w] = ang_major == LFBM5D_ROWMAJOR ? plan[w] % awidth : plan[w] / aheight;
-            int cs_w, mins, maxs, ct_w, mint, maxt;
-            search_window((int)wps[w], aheight, an, cs_w, mins, maxs);
-            search_window((int)wpt[w], awidth, an, ct_w, mint, maxt);
-            unsigned n_in = 0;
-            for (unsigned si = 0; si < asw; si++)
-                for (unsigned ti = 0; ti < asw; ti++) {
-                    const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (si + mins) * awidth + (ti + mint) : (si + mins) + (ti + mint) * aheight;
-                    if (h_mask[st]) { sai[w].push_back(st); n_in++; }
-                }
-            if (n_in != Aw && t4 == LFBM5D_DCT) t4 = LFBM5D_SADCT;
-            tau4_w[w] = t4;
-            const unsigned cst_lf = ang_major == LFBM5D_ROWMAJOR ? (unsigned)(mins + cs_w) * awidth + (unsigned)(mint + ct_w) : (unsigned)(mins + cs_w) + (unsigned)(mint + ct_w) * aheight;
-            if (!h_mask[cst_lf]) pipelined = false;   /* empty window centre: the first pass is chosen from device data */
+    StepGraph G;
+    bool graph_mode = planned && !by_rows && !by_blocks && C == 3 && (n_lanes > 1 || nranks > 1);
+    if (graph_mode) {
+        build_graph(h_mask, awidth, aheight, an, ang_major, tau_4D, nranks, emu > 1 ? 1 : n_lanes, max_windows, G);
+        if (!G.centre_ok) graph_mode = false;   /* empty window centre: the first pass is chosen from device data */
+    }
+    if (!graph_mode && nranks > 1 && !by_rows && !by_blocks)
+        return fail(c, "whole steps on several ranks: this light field needs data-driven passes (greyscale, or an empty SAI at a "
+                       "window centre); set LFBM5D_STEP_SHARDING=rows");
+    if (graph_mode && c->world > 1 && emu <= 1 && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+    bool graph_done = false;
+    if (graph_mode) {
+        const size_t NW = G.plan.size();
+        const bool emulate = emu > 1;
+        const int lanes_per_rank = emulate ? 1 : n_lanes;
+        const size_t need_ctx = emulate ? (size_t)emu - 1 : (size_t)n_lanes - 1;
+        while (c->lanes.size() < need_ctx) {
+            std::string e;
+            lfbm5d_ctx* x = new_ctx(c->device, e);
+            if (!x) return fail(c, "lane context: " + e);
+            c->lanes.push_back(x);
         }
-        if (pipelined) {
-            /* predecessors: the last earlier window that touched each SAI */
-            std::vector<std::vector<unsigned>> preds(NW);
-            std::vector<int> last_touch(asize, -1);
-            for (size_t w = 0; w < NW; w++) {
-                for (unsigned st : sai[w]) {
-                    const int p = last_touch[st];
-                    if (p >= 0 && std::find(preds[w].begin(), preds[w].end(), (unsigned)p) == preds[w].end()) preds[w].push_back((unsigned)p);
-                    last_touch[st] = (int)w;
+        struct RankState { int rank; lfbm5d_ctx* x; float* g_num; float* g_den; std::vector<Lane> lanes; };
+        std::vector<RankState> states(emulate ? (size_t)emu : 1);
+        hipEvent_t ev_setup = get_event(c);
+        HIPCK(c, hipEventRecord(ev_setup, s));   /* colour transform and the zeroed num / den */
+        for (size_t r = 0; r < states.size(); r++) {
+            RankState& S = states[r];
+            S.rank = emulate ? (int)r : c->rank;
+            S.x = r == 0 ? c : c->lanes[r - 1];
+            S.g_num = g_num; S.g_den = g_den;
+            if (r > 0) {   /* an emulated rank keeps light-field sums of its own, like a real one */
+                HIPCK(c, S.x->g_num.reserve(asize * img * sizeof(float)));
+                HIPCK(c, S.x->g_den.reserve(asize * img * sizeof(float)));
+                S.g_num = S.x->g_num.as<float>(); S.g_den = S.x->g_den.as<float>();
+                HIPCK(c, hipMemsetAsync(S.g_num, 0, asize * img * sizeof(float), S.x->stream));
+                HIPCK(c, hipMemsetAsync(S.g_den, 0, asize * img * sizeof(float), S.x->stream));
+            }
+            S.lanes.resize((size_t)lanes_per_rank);
+            for (int l = 0; l < lanes_per_rank; l++) {
+                lfbm5d_ctx* lx = emulate ? S.x : (l == 0 ? c : c->lanes[(size_t)l - 1]);
+                if (lane_buffers(lx, S.lanes[(size_t)l])) return 1;
+                S.lanes[(size_t)l].g_num = S.g_num; S.lanes[(size_t)l].g_den = S.g_den;
+                if (lx != c) HIPCK(c, hipStreamWaitEvent(lx->stream, ev_setup, 0));
+            }
+            if (nranks > 1)
+                for (int ch = 0; ch < 2; ch++) {
+                    if (!S.x->cs[ch]) HIPCK(c, hipStreamCreateWithFlags(&S.x->cs[ch], hipStreamNonBlocking));
+                    HIPCK(c, hipStreamWaitEvent(S.x->cs[ch], ev_setup, 0));
                 }
-            }
-            /* greedy list schedule with unit window cost; ties go to the lane of the latest predecessor (no event needed) */
-            std::vector<int> lane_of(NW, 0);
-            std::vector<unsigned> finish(NW, 0), lane_free(n_lanes, 0);
-            for (size_t w = 0; w < NW; w++) {
-                unsigned ready = 0; int pref = -1;
-                for (unsigned p : preds[w]) if (finish[p] >= ready) { ready = finish[p]; pref = lane_of[p]; }
-                int best_l = 0; unsigned best_t = ~0u;
-                for (int l = 0; l < n_lanes; l++) {
-                    const unsigned t = std::max(ready, lane_free[l]);
-                    if (t < best_t || (t == best_t && l == pref)) { best_t = t; best_l = l; }
+        }
+        auto local = [&](int r) -> RankState* { return emulate ? &states[(size_t)r] : (r == c->rank ? &states[0] : nullptr); };
+        if (c->h_counts_cap < NW) {
+            if (c->h_counts) (void)hipHostFree(c->h_counts);
+            c->h_counts = nullptr; c->h_counts_cap = 0;
+            HIPCK(c, hipHostMalloc((void**)&c->h_counts, NW * sizeof(unsigned)));
+            c->h_counts_cap = NW;
+        }
+        std::vector<hipEvent_t> done(NW, nullptr);
+        std::vector<std::vector<hipEvent_t>> arrived(NW);   /* [producer window][SAI slot]: the message reached its consumer's rank */
+        for (size_t w = 0; w < NW; w++) arrived[w].assign(G.sai[w].size(), nullptr);
+        std::vector<WinState> wss(NW);
+        std::vector<char> mine(NW, 0);
+        ncclComm_t comms[2] = {c->comm, c->comm2 ? c->comm2 : c->comm};
+        size_t xi = 0, n_msgs = 0;
+        for (size_t w = 0; w < NW; w++) {
+            const int r = G.rank[w];
+            RankState* S = local(r);
+            if (S) {
+                const Lane& Lw = S->lanes[(size_t)G.lane[w]];
+                hipStream_t ls = Lw.x->stream;
+                for (size_t i = 0; i < G.sai[w].size(); i++) {
+                    const int pw = G.prev[w][i];
+                    if (pw < 0) continue;
+                    if (G.rank[pw] == r) { if (G.lane[pw] != G.lane[w]) HIPCK(c, hipStreamWaitEvent(ls, done[(size_t)pw], 0)); }
+                    else {
+                        const size_t j = (size_t)(std::find(G.sai[(size_t)pw].begin(), G.sai[(size_t)pw].end(), G.sai[w][i]) - G.sai[(size_t)pw].begin());
+                        HIPCK(c, hipStreamWaitEvent(ls, arrived[(size_t)pw][j], 0));
+                    }
                 }
-                lane_of[w] = best_l; finish[w] = best_t + 1; lane_free[best_l] = best_t + 1;
-            }
-            /* lanes */
-            while ((int)c->lanes.size() < n_lanes - 1) {
-                std::string e;
-                lfbm5d_ctx* x = new_ctx(c->device, e);
-                if (!x) return fail(c, "lane context: " + e);
-                c->lanes.push_back(x);
-            }
-            std::vector<Lane> L(n_lanes);
-            L[0] = lane0;
-            for (int l = 1; l < n_lanes; l++) if (lane_buffers(c->lanes[l - 1], L[l])) return 1;
-            if (c->h_counts_cap < NW) {
-                if (c->h_counts) (void)hipHostFree(c->h_counts);
-                c->h_counts = nullptr; c->h_counts_cap = 0;
-                HIPCK(c, hipHostMalloc((void**)&c->h_counts, NW * sizeof(unsigned)));
-                c->h_counts_cap = NW;
-            }
-            std::vector<hipEvent_t> done(NW);
-            hipEvent_t ev_setup = get_event(c);
-            HIPCK(c, hipEventRecord(ev_setup, s));   /* colour transform and the zeroed num / den */
-            for (int l = 1; l < n_lanes; l++) HIPCK(c, hipStreamWaitEvent(L[l].x->stream, ev_setup, 0));
-            std::vector<WinState> wss(NW);
-            for (size_t w = 0; w < NW; w++) {
-                const Lane& Lw = L[lane_of[w]];
-                for (unsigned p : preds[w])
-                    if (lane_of[p] != lane_of[w]) HIPCK(c, hipStreamWaitEvent(Lw.x->stream, done[p], 0));
                 WinState& ws = wss[w];
                 ws.h_count_dst = c->h_counts + w;
-                if (win_begin(Lw, wps[w], wpt[w], tau4_w[w], ws)) return 1;
+                if (win_begin(Lw, G.ps[w], G.pt[w], G.tau4[w], ws)) return 1;
                 /* optimistic completion: the window's sums go back to the light field right away */
-                HIPCK(c, launch_unsymetrize_multi(Lw.x->stream, g_num, img, Lw.w_num, imgb, ws.sl, W, H, C, nHW));
-                HIPCK(c, launch_unsymetrize_multi(Lw.x->stream, g_den, img, Lw.w_den, imgb, ws.sl, W, H, C, nHW));
+                HIPCK(c, launch_unsymetrize_multi(ls, Lw.g_num, img, Lw.w_num, imgb, ws.sl, W, H, C, nHW));
+                HIPCK(c, launch_unsymetrize_multi(ls, Lw.g_den, img, Lw.w_den, imgb, ws.sl, W, H, C, nHW));
                 done[w] = get_event(c);
-                HIPCK(c, hipEventRecord(done[w], Lw.x->stream));
-                if (lane_of[w] != 0) { c->lane_windows += 1; c->stats.lane_windows += 1; }
+                HIPCK(c, hipEventRecord(done[w], ls));
+                mine[w] = 1;
+                if (Lw.x != c) { c->lane_windows += 1; c->stats.lane_windows += 1; }
             }
-            for (int l = 1; l < n_lanes; l++) HIPCK(c, hipStreamSynchronize(L[l].x->stream));
-            HIPCK(c, hipStreamSynchronize(s));
-            bool complete = true;
-            for (size_t w = 0; w < NW; w++) {
-                const unsigned n_mask = (unsigned)__builtin_popcount(wss[w].win_bits);
-                const float pct = (float)c->h_counts[w] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
-                if (!(pct >= 100.0f)) complete = false;
-            }
-            /* fold the lanes' counters and event times into this context */
-            for (int l = 1; l < n_lanes; l++) {
-                lfbm5d_ctx* x = L[l].x;
-                drain_events(x);
-                if (fold_counters(x, P, Aw, C, step)) { c->err = x->err; return 1; }
-                c->stats.passes += x->stats.passes; c->stats.groups += x->stats.groups;
-                c->stats.stack_patches += x->stats.stack_patches; c->stats.sadct_groups += x->stats.sadct_groups;
-                c->stats.algorithmic_bytes += x->stats.algorithmic_bytes;
-                c->stats.ms_bm += x->stats.ms_bm; c->stats.ms_group += x->stats.ms_group; c->stats.ms_aggregate += x->stats.ms_aggregate;
-                c->stats.launches_group += x->stats.launches_group; c->stats.launches_aggregate += x->stats.launches_aggregate;
-                std::memset(&x->stats, 0, sizeof(x->stats));
-            }
-            if (complete) {
-                c->stats.windows += NW;
-                for (size_t w = 0; w < NW; w++) c->last_windows.push_back(plan[w]);
-            } else {
-                /* some window needed more than its centre pass: redo the step window after window */
-                HIPCK(c, hipMemsetAsync(g_num, 0, asize * img * sizeof(float), s));
-                HIPCK(c, hipMemsetAsync(g_den, 0, asize * img * sizeof(float), s));
-                for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
-                pipelined = false;
+            /* the messages this window's result feeds, in the order every rank issues them */
+            for (; xi < G.xfers.size() && G.xfers[xi].from_w == w; xi++) {
+                const StepGraph::Xfer& X = G.xfers[xi];
+                const int ra = r, rb = G.rank[X.to_w], ch = X.channel;
+                RankState* Sa = local(ra); RankState* Sb = local(rb);
+                const size_t j = (size_t)(std::find(G.sai[w].begin(), G.sai[w].end(), X.sai) - G.sai[w].begin());
+                const size_t off = (size_t)X.sai * img;
+                if (emulate) {   /* both ends live here: the message is a device copy between the two ranks' sums */
+                    hipStream_t xs = Sb->x->cs[ch];
+                    HIPCK(c, hipStreamWaitEvent(xs, done[w], 0));
+                    HIPCK(c, hipMemcpyAsync(Sb->g_num + off, Sa->g_num + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                    HIPCK(c, hipMemcpyAsync(Sb->g_den + off, Sa->g_den + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                    arrived[w][j] = get_event(c);
+                    HIPCK(c, hipEventRecord(arrived[w][j], xs));
+                    n_msgs++;
+                } else if (Sa || Sb) {
+                    hipStream_t xs = c->cs[ch];
+                    if (Sa) HIPCK(c, hipStreamWaitEvent(xs, done[w], 0));
+                    bool ok = ncclGroupStart() == ncclSuccess;
+                    if (Sa) ok = ok && ncclSend(g_num + off, img, ncclFloat, rb, comms[ch], xs) == ncclSuccess
+                                    && ncclSend(g_den + off, img, ncclFloat, rb, comms[ch], xs) == ncclSuccess;
+                    else    ok = ok && ncclRecv(g_num + off, img, ncclFloat, ra, comms[ch], xs) == ncclSuccess
+                                    && ncclRecv(g_den + off, img, ncclFloat, ra, comms[ch], xs) == ncclSuccess;
+                    ok = ncclGroupEnd() == ncclSuccess && ok;
+                    if (!ok) return fail(c, "RCCL send / recv of a window's SAI failed");
+                    if (Sb) { arrived[w][j] = get_event(c); HIPCK(c, hipEventRecord(arrived[w][j], xs)); }
+                    n_msgs++;
+                }
             }
         }
+        /* drain: every lane, every exchange stream */
+        for (RankState& S : states) {
+            for (Lane& Lq : S.lanes) HIPCK(c, hipStreamSynchronize(Lq.x->stream));
+            for (int ch = 0; ch < 2; ch++) if (S.x->cs[ch]) HIPCK(c, hipStreamSynchronize(S.x->cs[ch]));
+        }
+        HIPCK(c, hipStreamSynchronize(s));
+        int complete = 1;
+        for (size_t w = 0; w < NW; w++) {
+            if (!mine[w]) continue;
+            const unsigned n_mask = (unsigned)__builtin_popcount(wss[w].win_bits);
+            const float pct = (float)c->h_counts[w] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
+            if (!(pct >= 100.0f)) complete = 0;
+        }
+        /* fold the other lanes' / emulated ranks' counters and event times into this context */
+        for (lfbm5d_ctx* x : c->lanes) {
+            if (x->pending.empty() && x->stats.passes == 0) continue;
+            drain_events(x);
+            if (fold_counters(x, P, Aw, C, step)) { c->err = x->err; return 1; }
+            c->stats.passes += x->stats.passes; c->stats.groups += x->stats.groups;
+            c->stats.stack_patches += x->stats.stack_patches; c->stats.sadct_groups += x->stats.sadct_groups;
+            c->stats.algorithmic_bytes += x->stats.algorithmic_bytes;
+            c->stats.ms_bm += x->stats.ms_bm; c->stats.ms_group += x->stats.ms_group; c->stats.ms_aggregate += x->stats.ms_aggregate;
+            c->stats.launches_group += x->stats.launches_group; c->stats.launches_aggregate += x->stats.launches_aggregate;
+            std::memset(&x->stats, 0, sizeof(x->stats));
+        }
+        if (nranks > 1 && !emulate) {   /* all ranks must agree before the collective below */
+            HIPCK(c, c->small.reserve((asize + 8) * sizeof(unsigned)));
+            int* d_flag = reinterpret_cast<int*>(c->small.as<unsigned>());
+            HIPCK(c, hipMemcpyAsync(d_flag, &complete, sizeof(int), hipMemcpyHostToDevice, s));
+            if (ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(flag) failed");
+            HIPCK(c, hipMemcpyAsync(&complete, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCK(c, hipStreamSynchronize(s));
+        }
+        if (complete) {
+            for (size_t w = 0; w < NW; w++) { c->last_windows.push_back(G.plan[w]); if (mine[w]) c->stats.windows += 1; }
+            graph_done = true;
+            if (nranks > 1) {
+                /* Every SAI's final sums live on the rank of the last window that touched it: that rank forms the SAI's
+                 * estimate (bm5d.cpp:405), then the estimates are broadcast so that every rank ends with the whole result */
+                std::vector<unsigned> own(asize);
+                const float* sub = step == 1 ? d_noisy : d_basic;
+                for (RankState& S : states) {
+                    for (unsigned st = 0; st < asize; st++)
+                        own[st] = (h_mask[st] && G.last_touch[st] >= 0 && G.rank[(size_t)G.last_touch[st]] == S.rank) ? 1u : 0u;
+                    HIPCK(c, S.x->d_own.reserve(asize * sizeof(unsigned)));
+                    HIPCK(c, hipMemcpyAsync(S.x->d_own.p, own.data(), asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
+                    HIPCK(c, launch_estimate_lf(s, S.g_num, S.g_den, sub, d_out, img, asize, S.x->d_own.as<unsigned>()));
+                    HIPCK(c, hipStreamSynchronize(s));   /* own is reused */
+                }
+                if (!emulate) {
+                    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+                    HIPCK(c, hipEventRecord(e0, s));
+                    bool ok = ncclGroupStart() == ncclSuccess;
+                    for (unsigned st = 0; st < asize && ok; st++) {
+                        if (!h_mask[st] || G.last_touch[st] < 0) continue;
+                        ok = ncclBroadcast(d_out + (size_t)st * img, d_out + (size_t)st * img, img, ncclFloat, G.rank[(size_t)G.last_touch[st]], c->comm, s) == ncclSuccess;
+                    }
+                    ok = ncclGroupEnd() == ncclSuccess && ok;
+                    if (!ok) return fail(c, "ncclBroadcast of the estimates failed");
+                    HIPCK(c, hipEventRecord(e1, s));
+                    HIPCK(c, hipStreamSynchronize(s));
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->stats.ms_comm += ms;
+                }
+                /* SAIs no window touched (LFBM5D_MAX_WINDOWS) keep the step's input, like the single-rank estimate */
+                for (unsigned st = 0; st < asize; st++) own[st] = (h_mask[st] && G.last_touch[st] < 0) ? 1u : 0u;
+                if (std::count(own.begin(), own.end(), 1u)) {
+                    HIPCK(c, hipMemcpyAsync(c->d_own.p, own.data(), asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
+                    HIPCK(c, launch_estimate_lf(s, g_num, g_den, sub, d_out, img, asize, c->d_own.as<unsigned>()));
+                    HIPCK(c, hipStreamSynchronize(s));
+                }
+            }
+            c->stats.messages += n_msgs;
+        } else if (nranks > 1) {
+            return fail(c, "a window needed more than its centre pass: set LFBM5D_STEP_SHARDING=rows for this light field");
+        } else {
+            /* some window needed more than its centre pass: redo the step window after window */
+            HIPCK(c, hipMemsetAsync(g_num, 0, asize * img * sizeof(float), s));
+            HIPCK(c, hipMemsetAsync(g_den, 0, asize * img * sizeof(float), s));
+            for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
+        }
     }
+    const bool pipelined = graph_done;
     if (pipelined) { /* done above */ } else
     if (!planned) {
         unsigned remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
@@ -902,36 +1109,38 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         std::vector<unsigned> plan;
         plan_windows(h_mask, awidth, aheight, an, ang_major, plan);
         if (max_windows > 0 && plan.size() > (size_t)max_windows) plan.resize((size_t)max_windows);
-        const int nranks = emu > 1 ? emu : c->world;
+        /* one rank (sequential planned form), or the opt-in window blocks */
+        const bool emu_b = by_blocks && emu > 1;
+        const int nb = by_blocks ? (emu > 1 ? emu : c->world) : 1, rb = by_blocks && !emu_b ? c->rank : 0;
         float* t_num = nullptr; float* t_den = nullptr;
-        if (emu > 1) {
+        if (emu_b) {
             HIPCK(c, c->t_num.reserve(asize * img * sizeof(float)));
             HIPCK(c, c->t_den.reserve(asize * img * sizeof(float)));
             t_num = c->t_num.as<float>(); t_den = c->t_den.as<float>();
             HIPCK(c, hipMemsetAsync(t_num, 0, asize * img * sizeof(float), s));
             HIPCK(c, hipMemsetAsync(t_den, 0, asize * img * sizeof(float), s));
         }
-        for (int r = (emu > 1 ? 0 : c->rank); r < (emu > 1 ? emu : c->rank + 1); r++) {
+        for (int r = (emu_b ? 0 : rb); r < (emu_b ? emu : rb + 1); r++) {
             /* contiguous blocks of the sequence: consecutive windows overlap, so most of a window's already
              * processed SAIs (whose running estimate the matching uses) were processed by the same rank */
-            const size_t w_begin = plan.size() * (size_t)r / (size_t)nranks, w_end = plan.size() * (size_t)(r + 1) / (size_t)nranks;
+            const size_t w_begin = plan.size() * (size_t)r / (size_t)nb, w_end = plan.size() * (size_t)(r + 1) / (size_t)nb;
             for (size_t wi = w_begin; wi < w_end; wi++) {
                 const unsigned pst = plan[wi];
                 const unsigned ps = ang_major == LFBM5D_ROWMAJOR ? pst / awidth : pst % aheight;
                 const unsigned pt = ang_major == LFBM5D_ROWMAJOR ? pst % awidth : pst / aheight;
                 if (do_window(ps, pt)) return 1;
             }
-            if (emu > 1) { /* what the all-reduce does, rank by rank */
+            if (emu_b) { /* what the all-reduce does, rank by rank */
                 HIPCK(c, launch_add(s, t_num, g_num, asize * img));
                 HIPCK(c, launch_add(s, t_den, g_den, asize * img));
                 HIPCK(c, hipMemsetAsync(g_num, 0, asize * img * sizeof(float), s));
                 HIPCK(c, hipMemsetAsync(g_den, 0, asize * img * sizeof(float), s));
             }
         }
-        if (emu > 1) {
+        if (emu_b) {
             HIPCK(c, hipMemcpyAsync(g_num, t_num, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
             HIPCK(c, hipMemcpyAsync(g_den, t_den, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
-        } else if (c->comm) {
+        } else if (by_blocks && c->comm) {
             hipEvent_t e0, e1;
             HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
             HIPCK(c, hipEventRecord(e0, s));
@@ -942,13 +1151,14 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             float ms = 0.0f;
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->stats.ms_comm += ms;
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-        } else if (c->world > 1) {
+        } else if (by_blocks && c->world > 1) {
             return fail(c, "whole steps on several ranks need lfbm5d_comm_init (lfbm5d_set_shard only shards core passes)");
         }
     }
     /* final estimate (bm5d.cpp:405) and inverse colour transforms (bm5d.cpp:711-714 / :1414-1418) */
     const float* sub = step == 1 ? d_noisy : d_basic;
-    HIPCK(c, launch_estimate_lf(s, g_num, g_den, sub, d_out, img, asize, d_mask));
+    if (!(graph_done && nranks > 1))   /* (the multi-rank graph form has formed and exchanged the estimates already) */
+        HIPCK(c, launch_estimate_lf(s, g_num, g_den, sub, d_out, img, asize, d_mask));
     if (C == 3 && P->color_space != LFBM5D_RGB) {
         HIPCK(c, launch_color_lf(s, d_out, img, asize, d_mask, P->color_space, W * H, 0));
         if (step == 2) HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P->color_space, W * H, 0));
@@ -996,10 +1206,12 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     c->lanes.clear();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm2) ncclCommDestroy(c->comm2);
     if (c->comm) ncclCommDestroy(c->comm);
+    for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
                       &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
-                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out};
+                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1036,6 +1248,8 @@ int lfbm5d_comm_init(lfbm5d_ctx* c, const void* idb, int rank, int world) {
     ncclUniqueId id;
     std::memcpy(&id, idb, sizeof(id));
     if (ncclCommInitRank(&c->comm, world, id, rank) != ncclSuccess) return fail(c, "ncclCommInitRank failed");
+    /* second channel of the window-graph exchange: same ranks, independent progress.  Optional (one channel is only slower) */
+    if (ncclCommSplit(c->comm, 0, rank, &c->comm2, nullptr) != ncclSuccess) c->comm2 = nullptr;
     return 0;
 }
 
@@ -1047,6 +1261,32 @@ int lfbm5d_plan_windows(unsigned awidth, unsigned aheight, unsigned an, unsigned
     plan_windows(mask, awidth, aheight, an, ang_major, plan);
     for (size_t i = 0; i < plan.size() && i < cap && out_sai; i++) out_sai[i] = plan[i];
     return (int)plan.size();
+}
+
+int lfbm5d_plan_graph(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask, int world, int lanes,
+                      unsigned* out_rank, unsigned* out_lane, unsigned* out_start, unsigned cap) {
+    if (!mask || !awidth || !aheight || 2 * an + 1 > awidth || 2 * an + 1 > aheight || world < 1 || lanes < 1) return -1;
+    if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return -1;
+    StepGraph G;
+    build_graph(mask, awidth, aheight, an, ang_major, LFBM5D_SADCT, world, lanes, 0, G);
+    for (size_t i = 0; i < G.plan.size() && i < cap; i++) {
+        if (out_rank) out_rank[i] = (unsigned)G.rank[i];
+        if (out_lane) out_lane[i] = (unsigned)G.lane[i];
+        if (out_start) out_start[i] = (unsigned)G.start[i];
+    }
+    return (int)G.plan.size();
+}
+
+int lfbm5d_plan_messages(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask, int world,
+                         unsigned* out, unsigned cap) {
+    if (!mask || !awidth || !aheight || 2 * an + 1 > awidth || 2 * an + 1 > aheight || world < 1) return -1;
+    if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return -1;
+    StepGraph G;
+    build_graph(mask, awidth, aheight, an, ang_major, LFBM5D_SADCT, world, 1, 0, G);
+    for (size_t i = 0; i < G.xfers.size() && i < cap && out; i++) {
+        out[4 * i] = G.xfers[i].from_w; out[4 * i + 1] = G.xfers[i].to_w; out[4 * i + 2] = G.xfers[i].sai; out[4 * i + 3] = (unsigned)G.xfers[i].channel;
+    }
+    return (int)G.xfers.size();
 }
 
 int lfbm5d_last_windows(const lfbm5d_ctx* c, unsigned* out_sai, unsigned cap) {
@@ -1079,6 +1319,35 @@ int lfbm5d_comm_selftest(lfbm5d_ctx* c, unsigned n) {
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "stream failed");
     for (unsigned i = 0; i < n && !rc; i++)
         if (r[i] != h[i] * (float)world) rc = fail(c, "all-reduce returned a wrong sum");
+    /* the graph form's primitives: a split communicator, grouped send / recv (to this rank itself: the only peer a
+     * one-GPU box has) and a grouped broadcast, on the exchange path's kind of stream */
+    if (!rc && n >= 2) {
+        ncclComm_t comm2 = nullptr;
+        float* d2 = nullptr;
+        const unsigned half = n / 2;
+        int me = 0;
+        if (ncclCommUserRank(comm, &me) != ncclSuccess) rc = fail(c, "ncclCommUserRank failed");
+        if (!rc && ncclCommSplit(comm, 0, me, &comm2, nullptr) != ncclSuccess) rc = fail(c, "ncclCommSplit failed");
+        if (!rc && hipMalloc(&d2, half * sizeof(float)) != hipSuccess) rc = fail(c, "hipMalloc failed");
+        if (!rc && hipMemsetAsync(d2, 0, half * sizeof(float), c->stream) != hipSuccess) rc = fail(c, "memset failed");
+        if (!rc) {
+            bool ok = ncclGroupStart() == ncclSuccess;
+            ok = ok && ncclSend(d, half, ncclFloat, me, comm2, c->stream) == ncclSuccess;
+            ok = ok && ncclRecv(d2, half, ncclFloat, me, comm2, c->stream) == ncclSuccess;
+            ok = ncclGroupEnd() == ncclSuccess && ok;
+            ok = ok && ncclGroupStart() == ncclSuccess;
+            ok = ok && ncclBroadcast(d + half, d + half, n - half, ncclFloat, 0, comm, c->stream) == ncclSuccess;
+            ok = ncclGroupEnd() == ncclSuccess && ok;
+            if (!ok) rc = fail(c, "RCCL send / recv / broadcast failed");
+        }
+        std::vector<float> r2(half);
+        if (!rc && hipMemcpyAsync(r2.data(), d2, half * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(c, "copy failed");
+        if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "stream failed");
+        for (unsigned i = 0; i < half && !rc; i++)
+            if (r2[i] != r[i]) rc = fail(c, "send / recv returned wrong data");
+        if (d2) (void)hipFree(d2);
+        if (comm2) ncclCommDestroy(comm2);
+    }
     if (d) (void)hipFree(d);
     if (own) ncclCommDestroy(comm);
     return rc;

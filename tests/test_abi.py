@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(core.Params) == 12 * 4
-    assert C.sizeof(core.Stats) == 5 * 8 + 6 * 8 + 3 * 8
+    assert C.sizeof(core.Stats) == 5 * 8 + 6 * 8 + 4 * 8
 
 
 def test_shard_rows_partition():

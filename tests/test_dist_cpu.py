@@ -1,7 +1,8 @@
-"""world_size-2 gloo test (CPU) of the multi-GPU scheme: each rank runs the core pass on its shard
-of reference-patch rows (here with the oracle standing in for the device kernels), rank > 0
-starts from zeroed aggregation buffers, an all-reduce(sum) of num/den restores base + all
-contributions -- exactly what lfbm5d_pass_device does with RCCL."""
+"""world_size-2 gloo tests (CPU) of the multi-GPU schemes, with the oracle standing in for the device kernels:
+ * whole steps, graph form: windows owned per rank + one message per SAI a window needs from another rank's window
+   (lfbm5d_plan_graph / lfbm5d_plan_messages) -- bit-identical to the single-process step;
+ * single core passes: each rank runs its shard of reference-patch rows, rank > 0 starts from zeroed aggregation
+   buffers, an all-reduce(sum) of num/den restores base + all contributions -- what lfbm5d_pass_device does with RCCL."""
 import os
 import socket
 import sys
@@ -67,50 +68,146 @@ def test_row_sharded_pass_all_reduce_equals_full_pass():
     assert all(ok for _, ok, _ in res), res
 
 
-def _window_worker(rank, world, port, q):
+def _graph_worker(rank, world, port, q):
+    """One rank of the graph form of a step, with the oracle's core pass standing in for the device kernels and gloo
+    send / recv for RCCL's: the rank runs the windows lfbm5d_plan_graph gives it, in plan order, on num / den of its
+    own, and handles the messages of lfbm5d_plan_messages in their issue order."""
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    import helpers as Hh
+    from oracle import oracle as O
     from lfbm5d_amd import core
-    aw, ah = 7, 5
-    plan = core.plan_windows(aw, ah, 1)                       # host-only entry point of the C-ABI library
-    b, e = len(plan) * rank // world, len(plan) * (rank + 1) // world   # run_step's block of this rank
-    # stand-in for the per-rank aggregation buffers: every window adds 1 to the 3x3 SAIs it covers
-    num = np.zeros((ah, aw), np.float32)
-    for pst in plan[b:e]:
+    lib = O.lib()
+    ah, aw, H, W, Cc, sigma = 5, 7, 40, 40, 3, 25.0
+    pk = (4, 5, 2, 8, 4, "id", "sadct", "haar")
+    nHW = pk[1] + pk[2]
+    A = ah * aw
+    clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, H, W), sigma)
+    mask = np.ones(A, np.uint32)
+    plan = core.plan_windows(aw, ah, 1)                       # host-only entry points of the C-ABI library
+    ranks, _, _ = core.plan_graph(aw, ah, world)
+    msgs = core.plan_messages(aw, ah, world)
+    # what run_bm5d_1st_step does before the windows (bm5d.cpp:133): forward colour transform
+    lf = noisy.copy()
+    for st in range(A):
+        lib.orc_color_transform(lf[st], O.OPP, W, H, Cc, 1)
+    num, den = np.zeros_like(lf), np.zeros_like(lf)
+    Wb, Hb = W + 2 * nHW, H + 2 * nHW
+    mi = 0
+    n_sent = n_recv = 0
+    for w, pst in enumerate(plan):
+        if ranks[w] == rank:
+            ps, pt = int(pst) // aw, int(pst) % aw
+            cs_w, mins, maxs, ct_w, mint, maxt = (C.c_int() for _ in range(6))
+            lib.orc_search_window(ps, ah, 1, C.byref(cs_w), C.byref(mins), C.byref(maxs))
+            lib.orc_search_window(pt, aw, 1, C.byref(ct_w), C.byref(mint), C.byref(maxt))
+            idx = [(mins.value + s) * aw + (mint.value + t) for s in range(3) for t in range(3)]
+            wn, wnum, wden = (np.zeros((9, Cc * Wb * Hb), np.float32) for _ in range(3))
+            for i, st in enumerate(idx):
+                lib.orc_symetrize(lf[st], wn[i], W, H, Cc, nHW)
+                lib.orc_symetrize(num[st], wnum[i], W, H, Cc, nHW)
+                lib.orc_symetrize(den[st], wden[i], W, H, Cc, nHW)
+            cst_w = cs_w.value * 3 + ct_w.value
+            Hh.oracle_pass(1, sigma, pk, wn, None, Wb, Hb, Cc, num=wnum, den=wden, cst=cst_w, pst=cst_w)
+            for i, st in enumerate(idx):
+                lib.orc_unsymetrize(num[st], wnum[i], W, H, Cc, nHW)
+                lib.orc_unsymetrize(den[st], wden[i], W, H, Cc, nHW)
+        while mi < len(msgs) and msgs[mi][0] == w:            # the messages this window's result feeds
+            _, to_w, st, _ = (int(v) for v in msgs[mi])
+            mi += 1
+            if ranks[w] == rank:
+                dist.send(torch.from_numpy(num[st]), int(ranks[to_w])); dist.send(torch.from_numpy(den[st]), int(ranks[to_w]))
+                n_sent += 1
+            elif ranks[to_w] == rank:
+                dist.recv(torch.from_numpy(num[st]), int(ranks[w])); dist.recv(torch.from_numpy(den[st]), int(ranks[w]))
+                n_recv += 1
+    # every SAI's final sums live on the rank of the last window that touched it
+    last = {}
+    for w, pst in enumerate(plan):
         ps, pt = int(pst) // aw, int(pst) % aw
         s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
-        num[s0:s0 + 3, t0:t0 + 3] += 1
-    tn = torch.from_numpy(num)
-    dist.all_reduce(tn)                                        # the one all-reduce of a step
-    full = np.zeros((ah, aw), np.float32)
-    for pst in plan:
-        ps, pt = int(pst) // aw, int(pst) % aw
-        s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
-        full[s0:s0 + 3, t0:t0 + 3] += 1
-    q.put((rank, bool(np.array_equal(tn.numpy(), full)), bool((full > 0).all()), len(plan), e - b))
+        for s in range(3):
+            for t in range(3):
+                last[(s0 + s) * aw + (t0 + t)] = w
+    est = np.zeros_like(lf)
+    for st in range(A):
+        if ranks[last[st]] == rank:
+            est[st] = np.where(den[st] != 0, num[st] / np.where(den[st] != 0, den[st], 1), lf[st])
+        t = torch.from_numpy(est[st])
+        dist.broadcast(t, int(ranks[last[st]]))
+        lib.orc_color_transform(est[st], O.OPP, W, H, Cc, 0)
+    # the single-process oracle (data-driven windows, one rank)
+    _, b_o, st1 = O.run_step1(O.make_params(sigma, 2.7, *pk), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
+    q.put((rank, bool(np.array_equal(est, b_o)), float(np.abs(est - b_o).max()), int(sum(1 for r in ranks if r == rank)), n_sent, n_recv,
+           len(msgs), bool(np.array_equal(O.last_windows(), plan))))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_window_blocks_all_reduce_covers_every_sai():
-    """world_size-2 gloo run of the step-level scheme: contiguous blocks of the planned window sequence per
-    rank, one all-reduce of the per-rank sums."""
+def test_graph_form_with_messages_equals_the_single_rank_step():
+    """world_size-2 gloo run of the step-level multi-GPU scheme (graph form): windows owned per rank, one message per
+    SAI a window needs from another rank's window, estimates formed by the last toucher -- bit-identical to the
+    oracle's single-process step, and every planned message is used exactly once."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_window_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert all(ok and covered for _, ok, covered, _, _ in res)
-    assert sum(n for *_, n in res) == res[0][3]
+    assert all(ok and same_plan for _, ok, _, _, _, _, _, same_plan in res), res
+    assert all(n_win > 0 for _, _, _, n_win, *_ in res)                    # both ranks own windows
+    assert sum(r[4] for r in res) == sum(r[5] for r in res) == res[0][6] > 0   # every message sent once, received once
+
+
+def test_graph_plan_properties():
+    """Host-side properties of the graph form for 1..8 ranks: every window has an owner, chains stay on one rank, the
+    unit-time schedule respects the dependencies (a window starts after every earlier window it shares an SAI with),
+    and messages connect exactly the consecutive touchers of an SAI that live on different ranks."""
+    from lfbm5d_amd import core
+    for (ah, aw) in ((17, 17), (9, 9), (15, 15), (5, 7), (3, 3)):
+        plan = core.plan_windows(aw, ah, 1)
+        cover = []
+        for pst in plan:
+            ps, pt = int(pst) // aw, int(pst) % aw
+            s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
+            cover.append({(s0 + s) * aw + (t0 + t) for s in range(3) for t in range(3)})
+        for world in (1, 2, 3, 4, 8):
+            for lanes in (1, 3):
+                ranks, lane, start = core.plan_graph(aw, ah, world, lanes)
+                assert len(ranks) == len(plan) and ranks.max() < world and lane.max() < lanes
+                for w in range(len(plan)):
+                    for p in range(w):
+                        if cover[w] & cover[p]:
+                            assert start[p] < start[w], (ah, aw, world, lanes, p, w)
+                    if w and int(plan[w]) // aw == int(plan[w - 1]) // aw:
+                        assert ranks[w] == ranks[w - 1]               # a chain (same row of SAIs) stays on one rank
+                # no two windows at once on one lane
+                assert len({(int(ranks[w]), int(lane[w]), int(start[w])) for w in range(len(plan))}) == len(plan)
+            msgs = core.plan_messages(aw, ah, world)
+            ranks, _, _ = core.plan_graph(aw, ah, world)
+            expect = []
+            for w in range(len(plan)):
+                for st in sorted(cover[w]):
+                    nxt = next((n for n in range(w + 1, len(plan)) if st in cover[n]), None)
+                    if nxt is not None and ranks[nxt] != ranks[w]:
+                        expect.append((w, nxt, st))
+            assert sorted((int(a), int(b), int(c)) for a, b, c, _ in msgs) == sorted(expect)
+            assert [int(m[0]) for m in msgs] == sorted(int(m[0]) for m in msgs)   # issued by producer window
+            if world == 1:
+                assert len(msgs) == 0
+    r17, _, t17 = core.plan_graph(17, 17, 8)
+    assert t17.max() + 1 <= 24                                        # critical path of the 17x17 backward raster
 
 
 def test_plan_windows_matches_the_reference_rule():

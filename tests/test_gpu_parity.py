@@ -365,14 +365,16 @@ def test_multi_window_steps_with_empty_sais_match_oracle(ctx):
                      O.ROWMAJOR, L.ROWMAJOR, mask=mask)
 
 
-def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
-    """Multi-GPU step scheme with all ranks played in turn on this GPU (LFBM5D_EMULATE_WORLD): the planned
-    window sequence is the data-driven one (bit-identical results), and
-    2 / 4 ranks stay within the documented PSNR distance of the single-GPU result."""
+def test_multi_rank_graph_played_on_one_gpu_is_bit_identical(ctx, monkeypatch):
+    """The multi-GPU step scheme with all ranks played on this GPU (LFBM5D_EMULATE_WORLD): every rank keeps num / den
+    of its own, runs the chains of windows the graph gives it and receives the SAIs it needs from other ranks' windows
+    as messages (device copies here, RCCL send / recv between real ranks).  The planned sequence is the reference's
+    data-driven one, and 2 / 3 / 4 / 8 ranks reproduce the single-rank result BIT FOR BIT.  The opt-in window blocks
+    of round 1 (one all-reduce per step) are checked to be what their documentation says: close, not identical."""
     import lfbm5d_amd as L
-    from lfbm5d_amd import core, synth
-    ah, aw, Hh_, Ww = 5, 7, 64, 64
-    lf = synth.make_lf(ah, aw, Hh_, Ww)
+    from lfbm5d_amd import core
+    ah, aw, Hh_, Ww = 7, 9, 64, 64
+    lf = Hh.textured_lf(ah, aw, Hh_, Ww)
     clean, noisy = Hh.noisy_lf(lf, 25.0)
     mask = np.ones(ah * aw, np.uint32)
     P1 = core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "sadct", "haar")
@@ -382,29 +384,39 @@ def test_window_sharded_steps_played_on_one_gpu(ctx, monkeypatch):
         d_noisy = torch.from_numpy(noisy).cuda()
         d_basic = torch.zeros_like(d_noisy)
         d_den = torch.zeros_like(d_noisy)
+        ctx.reset_stats()
         ctx.step1(P1, d_noisy, mask, d_basic, L.ROWMAJOR, aw, ah, 1, Ww, Hh_, 3)
         w = ctx.last_windows()
         ctx.step2(P2, d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, 1, Ww, Hh_, 3)
-        return d_basic.cpu().numpy(), d_den.cpu().numpy(), w
+        return d_basic.cpu().numpy(), d_den.cpu().numpy(), w, ctx.stats()
 
-    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_STEP_SHARDING"):
+    for k in ("LFBM5D_EMULATE_WORLD", "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_STEP_SHARDING", "LFBM5D_LANES"):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("LFBM5D_DATA_DRIVEN_SCHEDULE", "1")     # the reference's selection from zero-weight counts
-    b0, d0, w0 = run()
+    b0, d0, w0, _ = run()
     monkeypatch.delenv("LFBM5D_DATA_DRIVEN_SCHEDULE")
     plan = core.plan_windows(aw, ah, 1, L.ROWMAJOR)
     assert np.array_equal(plan, w0) and w0[0] == (ah // 2) * aw + aw // 2
-    b1, d1, w1 = run()                                            # default: the planned sequence
-    assert np.array_equal(w1, w0) and np.array_equal(b1, b0) and np.array_equal(d1, d0)
+    b1, d1, w1, s1 = run()                                        # default: the planned sequence on three lanes
+    assert np.array_equal(w1, w0) and np.array_equal(b1, b0) and np.array_equal(d1, d0) and s1.messages == 0
+    for n in (2, 3, 4, 8):
+        monkeypatch.setenv("LFBM5D_EMULATE_WORLD", str(n))
+        b, d, w, st = run()
+        ranks, _, _ = core.plan_graph(aw, ah, n)
+        msgs = core.plan_messages(aw, ah, n)
+        assert np.array_equal(w, w0) and st.windows == 2 * len(w0) and st.messages == 2 * len(msgs) > 0
+        assert len(set(ranks.tolist())) > 1                        # several ranks really own windows
+        assert np.array_equal(b, b0) and np.array_equal(d, d0), n
+    # round 1's window blocks: one all-reduce per step, a rank's matching only sees its own earlier windows
+    monkeypatch.setenv("LFBM5D_STEP_SHARDING", "blocks")
     p0 = O.psnr_lf(d0, clean)
     for n in (2, 4):
         monkeypatch.setenv("LFBM5D_EMULATE_WORLD", str(n))
-        b, d, w = run()
-        assert sorted(w.tolist()) == sorted(w0.tolist())          # every window exactly once
-        # tiny SAIs: a few tenths of a dB either way (block matching of a rank's first windows runs on noisy
-        # instead of already denoised neighbours); 0.01-0.07 dB on the 17x17x512x512 workload, see DESIGN.md
-        assert abs(O.psnr_lf(d, clean) - p0) < 0.5 and O.psnr_lf(d, clean) > O.psnr_lf(noisy, clean) + 8
+        b, d, w, _ = run()
+        assert sorted(w.tolist()) == sorted(w0.tolist()) and not np.array_equal(d, d0)
+        assert abs(O.psnr_lf(d, clean) - p0) < 0.5
     monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
+    monkeypatch.delenv("LFBM5D_STEP_SHARDING")
 
 
 @pytest.mark.parametrize("holes", [False, True], ids=["full", "empty-sais"])
