@@ -2155,6 +2155,244 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Wiener step, 8x8 DCT, second generation: the same arithmetic as k_group_dct8w with the 2-D stages dealt to ALL
+ * threads.  k_group_dct8w runs the forward 2-D DCT with one thread per patch (144 of 256 threads busy, fed through an
+ * LDS staging area) and the inverse with one thread per patch PAIR (72 of 256): those two phases were 63 % of its time
+ * at a quarter to a half of the lanes.  Here a 2-D DCT is two passes over the LDS stack with an item = one 8-point
+ * packed transform:
+ *   1a  item = (row i, patch): the thread loads its 32-byte row of both images straight from the window (no staging),
+ *       transforms the noisy / pilot pair, writes 8 float2 into the stack [coefficient][patch]
+ *   1b  item = (column j, patch): 8-point transform down the column, in place
+ *   2-4 as before (3x3 angular DCT per (n, pq) fibre; Haar + Wiener + inverse Haar per (st, pq) fibre; inverse 3x3)
+ *   5a  item = (column j, patch pair): inverse transform of the filtered stack, two patches packed
+ *   5b  item = (row i, patch pair): inverse transform along the row, two 32-byte stores
+ * With N = 16 every phase divides evenly over 192 threads (1152 / 576 items = 6 / 3 per thread): three wavefronts per
+ * workgroup, all lanes busy.  Items are numbered patch-fastest so that the stack accesses of a wavefront are
+ * consecutive float2 (no bank conflicts); the global accesses are 32-byte row segments either way.
+ * ------------------------------------------------------------------------------------------ */
+constexpr int kDct8w2Threads = 256;
+
+template <bool HAAR>
+__global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[3][kDct8w2Threads / 64];
+    __shared__ unsigned pos[kMaxN * kMaxA];
+    constexpr int TH = kDct8w2Threads;
+    const int tid = threadIdx.x;
+    const unsigned g = a.ref_begin + blockIdx.x;
+    const int c = blockIdx.y;
+    constexpr int A = 9, K2 = 64;
+    const int N = a.N;
+    const int nSx = (int)a.self_cnt[g];
+    const size_t plane = (size_t)a.Wb * a.Hb;
+    const int NP = nSx * A;               /* patches per stack */
+    const int NPp = (N * A) | 1;          /* row stride of the [pq][patch] stack (float2 units), odd */
+    v2f* stack = reinterpret_cast<v2f*>(lds);
+    float* stackf = lds;
+    const TbPtr tb = (TbPtr)a.tb;
+
+    ShRef sh = group_shape(a, g);
+    for (int i = tid; i < NP; i += TH) pos[i] = a.gpos[(size_t)g * N * A + i];
+    __syncthreads();
+#ifdef LFBM5D_PHASE_TIMING
+    long long tc[6]; int tci = 0;
+    PHASE_MARK();
+#endif
+
+    /* 1a: rows.  All loads of a thread's items are issued before the first transform */
+    {
+        constexpr int kIt = (kMaxN * kMaxA * 8 + TH - 1) / TH;   /* 6 */
+        f4u n0[kIt], n1[kIt], b0[kIt], b1[kIt];
+#pragma unroll
+        for (int q = 0; q < kIt; q++) {
+            const int it = tid + q * TH;
+            const int i = it / NP, patch = it - i * NP;
+            if (it < NP * 8) {
+                const unsigned p = pos[patch];
+                const size_t off = ((size_t)(patch % A) * a.C + c) * plane + (p != 0xffffffffu ? p : 0u) + (size_t)i * a.Wb;
+                n0[q] = *reinterpret_cast<const f4u*>(a.noisy + off); n1[q] = *reinterpret_cast<const f4u*>(a.noisy + off + 4);
+                b0[q] = *reinterpret_cast<const f4u*>(a.basic + off); b1[q] = *reinterpret_cast<const f4u*>(a.basic + off + 4);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kIt; q++) {
+            const int it = tid + q * TH;
+            const int i = it / NP, patch = it - i * NP;
+            if (it < NP * 8) {
+                const bool ok = pos[patch] != 0xffffffffu;     /* empty SAI / never-filled table column: zeros */
+                v2f x[8];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    x[j] = ok ? v2f{n0[q].v[j], b0[q].v[j]} : v2f{0.f, 0.f};
+                    x[4 + j] = ok ? v2f{n1[q].v[j], b1[q].v[j]} : v2f{0.f, 0.f};
+                }
+                dct8_fwd_t(x);
+                v2f* dst = stack + (i * 8) * NPp + patch;
+#pragma unroll
+                for (int j = 0; j < 8; j++) dst[j * NPp] = x[j];
+            }
+        }
+    }
+    __syncthreads();
+    PHASE_MARK();
+    /* 1b: columns, in place */
+    for (int it = tid; it < NP * 8; it += TH) {
+        const int j = it / NP, patch = it - j * NP;
+        v2f* col = stack + j * NPp + patch;
+        v2f x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = col[(i * 8) * NPp];
+        dct8_fwd_t(x);
+#pragma unroll
+        for (int i = 0; i < 8; i++) col[(i * 8) * NPp] = x[i];
+    }
+    __syncthreads();
+    PHASE_MARK();
+
+    /* 2: 4-D forward, one (n, pq) fibre of 9 float2 per thread */
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
+    const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < nSx * K2; f += TH) {
+            const int n = f / K2, pq = f % K2;
+            v2f* base = stack + pq * NPp + n * A;
+            v2f x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = base[st];
+            if (do_dct4) dct9_fwd2(x, tb);
+            else {   /* rare: shape-adaptive transform on the scalar path */
+                float t9[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) t9[i] = x[i].x;
+                sadct9_fwd(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
+                sadct9_fwd(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) x[i].y = t9[i];
+            }
+#pragma unroll
+            for (int st = 0; st < 9; st++) base[st] = x[st];
+        }
+        __syncthreads();
+    }
+
+    /* 3: 5th dimension + Wiener shrinkage, one (st, pq) fibre of nSx float2 per thread; result -> .y */
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    {
+        const float sig = a.sigma[c];
+        const float sig2 = sig * sig;
+        const bool useSD = a.useSD != 0;
+        for (int f = tid; f < A * K2; f += TH) {
+            const int st = f / K2, pq = f % K2;
+            const bool in_shape = !use_sadct || sh.mask_dct[st];
+            const int base = pq * NPp + st;
+            switch (nSx) {
+                case 1:  wiener_fibre2<1, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                case 2:  wiener_fibre2<2, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                case 4:  wiener_fibre2<4, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                case 8:  wiener_fibre2<8, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+                default: wiener_fibre2<16, HAAR>(stack, base, A, a.tau5, sig2, in_shape, useSD, wacc, s1, s2, tb); break;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    /* 4: 4-D inverse of the filtered stack (.y), two (n, pq) fibres per thread: pq and pq + 32 */
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < nSx * (K2 / 2); f += TH) {
+            const int n = f / (K2 / 2), pq = f % (K2 / 2);
+            float* b0 = stackf + 2 * (pq * NPp + n * A) + 1;
+            float* b1 = stackf + 2 * ((pq + K2 / 2) * NPp + n * A) + 1;
+            v2f x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = v2f{b0[2 * st], b1[2 * st]};
+            if (do_dct4) dct9_inv2(x, tb);
+            else {
+                float t9[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) t9[i] = x[i].x;
+                sadct9_inv(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
+                sadct9_inv(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) x[i].y = t9[i];
+            }
+#pragma unroll
+            for (int st = 0; st < 9; st++) { b0[2 * st] = x[st].x; b1[2 * st] = x[st].y; }
+        }
+    }
+    __syncthreads();
+
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < TH / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(nSx * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            const float sig = a.sigma[c];
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)nSx);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
+    }
+
+    PHASE_MARK();
+    /* 5a: inverse transform down the columns of the filtered stack (.y), two patches (pa, pa + NPh) packed, in place */
+    const int NPh = (NP + 1) / 2;
+    for (int it = tid; it < NPh * 8; it += TH) {
+        const int j = it / NPh, pa = it - j * NPh;
+        const int pb = pa + NPh < NP ? pa + NPh : pa;
+        float* ca = stackf + 2 * (j * NPp + pa) + 1;
+        float* cb = stackf + 2 * (j * NPp + pb) + 1;
+        v2f x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = v2f{ca[2 * (i * 8) * NPp], cb[2 * (i * 8) * NPp]};
+        dct8_inv_t(x);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { ca[2 * (i * 8) * NPp] = x[i].x; if (pb != pa) cb[2 * (i * 8) * NPp] = x[i].y; }
+    }
+    __syncthreads();
+    PHASE_MARK();
+    /* 5b: inverse transform along the rows + store: filt[g][n][st][c][64] */
+    for (int it = tid; it < NPh * 8; it += TH) {
+        const int i = it / NPh, pa = it - i * NPh;
+        const int pb = pa + NPh;
+        const bool has_b = pb < NP;
+        const float* ra = stackf + 2 * ((i * 8) * NPp + pa) + 1;
+        const float* rb = stackf + 2 * ((i * 8) * NPp + (has_b ? pb : pa)) + 1;
+        v2f x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = v2f{ra[2 * j * NPp], rb[2 * j * NPp]};
+        dct8_inv_t(x);
+        float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
+        oa[0] = make_float4(x[0].x, x[1].x, x[2].x, x[3].x);
+        oa[1] = make_float4(x[4].x, x[5].x, x[6].x, x[7].x);
+        if (has_b) {
+            float4* ob = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pb) * a.C * K2 + (size_t)c * K2 + i * 8);
+            ob[0] = make_float4(x[0].y, x[1].y, x[2].y, x[3].y);
+            ob[1] = make_float4(x[4].y, x[5].y, x[6].y, x[7].y);
+        }
+    }
+#ifdef LFBM5D_PHASE_TIMING
+    PHASE_MARK();
+    if (tid == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&a.counters[4 + i], (unsigned long long)(tc[i + 1] - tc[i]));
+        atomicAdd(&a.counters[9], 1ull);
+    }
+#endif
+}
+
+/* ------------------------------------------------------------------------------------------
  * Per-SAI BM3D flavour, 8x8 patches (LFBM3Ddenoising's parameters: bm3d.cpp:315-690 with kHard = kWien = 8).
  * A group is nSx <= 32 patches of ONE image, so a whole group fits a WAVEFRONT: four groups per workgroup, no
  * workgroup barrier anywhere.  Lane = patch for the 2-D stages (the 8x8 patch and its transform in registers, the
@@ -2553,6 +2791,7 @@ hipError_t prepare_group_kernels() {
         reinterpret_cast<const void*>(&k_group<1>), reinterpret_cast<const void*>(&k_group<2>),
         reinterpret_cast<const void*>(&k_group_dct8<1>), reinterpret_cast<const void*>(&k_group_dct8<2>),
         reinterpret_cast<const void*>(&k_group_dct8w<true, false>), reinterpret_cast<const void*>(&k_group_dct8w<false, false>),
+        reinterpret_cast<const void*>(&k_group_dct8w2<true>), reinterpret_cast<const void*>(&k_group_dct8w2<false>),
         reinterpret_cast<const void*>(&k_group_dct8w<true, true>), reinterpret_cast<const void*>(&k_group_dct8w<false, true>),
         reinterpret_cast<const void*>(&k_group_bior16_haar), reinterpret_cast<const void*>(&k_group_bior16_any),
         reinterpret_cast<const void*>(&k_group_dct16_haar), reinterpret_cast<const void*>(&k_group_dct16_any),
@@ -2612,7 +2851,12 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     }
     else if (a.tau2 == 5 && a.k == 8 && a.A == 9 && a.N <= (unsigned)kMaxN) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
         const size_t l8 = (size_t)(a.step == 2 ? 2 : 1) * 64 * ((a.N * 9) | 1) * sizeof(float);
-        if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* packed noisy/pilot pair */
+        if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR") && !getenv("LFBM5D_DCT8W_V1")) {   /* packed noisy/pilot pair, 2-D stages dealt to all threads */
+            if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w2<true>), dim3(a.n_groups, a.C), dim3(kDct8w2Threads), l8, s, a);
+            else             hipLaunchKernelGGL((k_group_dct8w2<false>), dim3(a.n_groups, a.C), dim3(kDct8w2Threads), l8, s, a);
+            return hipGetLastError();
+        }
+        if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* round 1's packed kernel (one thread per patch in the 2-D stages) */
             if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w<true, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
             else             hipLaunchKernelGGL((k_group_dct8w<false, false>), dim3(a.n_groups, a.C), dim3(kDct8wThreads), l8, s, a);
             return hipGetLastError();
