@@ -1433,6 +1433,10 @@ void orc_sadct_forward(float* v, const unsigned* mask, unsigned aw, unsigned ah,
 void orc_sadct_inverse(float* v, const unsigned* mask, unsigned aw, unsigned ah) {
     Shape sh; sh.build(mask, aw, ah); sadct_inv(v, sh);
 }
+void orc_ht_filter_slab(float* X, unsigned nSx, unsigned A, unsigned C, const float* sigma, float lambda, float* weight,
+                        const unsigned* mask_dct, unsigned tau5) { ht_filter_slab(X, nSx, A, C, sigma, lambda, weight, mask_dct, tau5); }
+void orc_wiener_filter_slab(float* Xo, float* Xe, unsigned nSx, unsigned A, unsigned C, const float* sigma, float* weight,
+                            const unsigned* mask_dct, unsigned tau5) { wiener_filter_slab(Xo, Xe, nSx, A, C, sigma, weight, mask_dct, tau5); }
 void orc_kaiser_window(float* out, unsigned k) {
     std::vector<float> w; kaiser_window(k, w); std::memcpy(out, w.data(), sizeof(float) * k * k);
 }

@@ -94,6 +94,14 @@ void orc_dct4d_inverse(float* v, unsigned aw, unsigned ah);
 /* shape-adaptive DCT; mask[aw*ah] in {0,1}; mask_dct receives the coefficient support */
 void orc_sadct_forward(float* v, const unsigned* mask, unsigned aw, unsigned ah, unsigned* mask_dct);
 void orc_sadct_inverse(float* v, const unsigned* mask, unsigned aw, unsigned ah);
+/* 5th-dimension filters on one coefficient slab X[c][st][n] (in place): forward transform along n, hard threshold
+ * (core:2281-2690) / Wiener shrinkage with the pilot slab Xe (core:2706-3123; the result is left in Xe), inverse
+ * transform; weight[c] accumulates the retained-coefficient count / the sum of Wiener coefficients.  mask_dct
+ * (A entries, or NULL) selects the in-shape SAIs of the masked variants. */
+void orc_ht_filter_slab(float* X, unsigned nSx, unsigned A, unsigned C, const float* sigma, float lambda, float* weight,
+                        const unsigned* mask_dct, unsigned tau5);
+void orc_wiener_filter_slab(float* Xo, float* Xe, unsigned nSx, unsigned A, unsigned C, const float* sigma, float* weight,
+                            const unsigned* mask_dct, unsigned tau5);
 void orc_kaiser_window(float* out, unsigned k);
 
 /* ---- block matching ---- */

@@ -102,6 +102,8 @@ def lib():
                                        C.c_uint, C.c_uint]
     L.orc_denoised_percent.restype = C.c_float
     L.orc_psnr.argtypes = [_f32p, _f32p, C.c_ulonglong, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_ht_filter_slab.argtypes = [_f32p, C.c_uint, C.c_uint, C.c_uint, _f32p, C.c_float, _f32p, C.c_void_p, C.c_uint]
+    L.orc_wiener_filter_slab.argtypes = [_f32p, _f32p, C.c_uint, C.c_uint, C.c_uint, _f32p, _f32p, C.c_void_p, C.c_uint]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_set_time_limit.argtypes = [C.c_double]
     L.orc_last_windows.argtypes = [C.c_void_p, C.c_uint]
