@@ -28,6 +28,7 @@ const double kPi = 3.14159265358979323846;
 
 int g_threads = 0; /* 0 = OpenMP default */
 std::vector<unsigned> g_last_windows; /* run API: processed SAI of every window of the last step, in order */
+int g_tiles = 1; /* run API: 1 = untiled (nb_threads == 1 semantics), > 1 = the reference's OpenMP tile mode with that many tiles */
 double g_time_limit = 0.0; /* run API: stop after the window that exceeds it (0 = none) */
 
 double now_s() {
@@ -1033,6 +1034,80 @@ float denoised_percent(const float* den, const unsigned* mask, unsigned A, unsig
 }
 
 /* bm5d.cpp:165-407 (step 1) and :861-1106 (step 2), nb_threads == 1 */
+/* One pass over a window in the reference's OpenMP tile mode (bm5d.cpp:411-708): every SAI of the (mirror-padded) window
+ * is cut into nb_tiles sub-images with a halo of N = nSim + nDisp pixels (sub_divide, utilities.cpp:312-395: the image
+ * is halved along its longer side until there are nb_tiles pieces; the last row / column of tiles takes the remainder),
+ * each tile runs the core pass on its own, only the tiles' interiors are kept (undivide_LF, utilities_LF.cpp:438-515:
+ * whatever a tile aggregated into its halo is DISCARDED, which is what costs the tiled mode about 0.5 dB) and the window's
+ * num / den are padded again for the next pass.  w_* are the padded window buffers [Aw][C*hb*wb], updated in place.
+ * pct receives the sum of the tiles' LF_denoised_percent (bm5d.cpp:666-668). */
+int tiled_pass(int step, const orc_params* Pw, unsigned asw, unsigned W, unsigned H, unsigned C, unsigned N,
+               const std::vector<float>& w_noisy, const std::vector<float>& w_basic, std::vector<float>& w_num,
+               std::vector<float>& w_den, const std::vector<unsigned>& mask_w, const std::vector<unsigned>& proc_w,
+               unsigned cst_w, unsigned pst_w, int nb_tiles, float* pct, orc_stats* stats) {
+    const unsigned Aw = asw * asw, hb = H + 2 * N, wb = W + 2 * N;
+    const size_t imgb = (size_t)C * wb * hb, img = (size_t)C * W * H;
+    unsigned w_small = W, h_small = H, nw = 1, nh = 1;
+    for (int n = nb_tiles; n > 1; n /= 2) {
+        if (w_small > h_small) { w_small = (unsigned)std::floor((float)w_small * 0.5f); nw *= 2; }
+        else { h_small = (unsigned)std::floor((float)h_small * 0.5f); nh *= 2; }
+    }
+    const unsigned h_bound = nh > 1 ? H - (nh - 1) * h_small : h_small;
+    const unsigned w_bound = nw > 1 ? W - (nw - 1) * w_small : w_small;
+    const int nt = (int)(nw * nh);
+    std::vector<std::vector<float> > und_num(Aw, std::vector<float>(img, 0.0f)), und_den(Aw, std::vector<float>(img, 0.0f));
+    std::vector<orc_stats> tstats((size_t)nt);
+    std::vector<float> tpct((size_t)nt, 0.0f);
+    std::vector<int> trc((size_t)nt, 0);
+    for (orc_stats& ts : tstats) std::memset(&ts, 0, sizeof(ts));
+    const double t0 = now_s();
+    #pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads > 0 ? g_threads : omp_get_max_threads())
+    for (int kt = 0; kt < nt; kt++) {
+        const unsigned i = (unsigned)kt / nw, j = (unsigned)kt % nw;
+        const unsigned h = (i == nh - 1 ? h_bound : h_small) + 2 * N, w = (j == nw - 1 ? w_bound : w_small) + 2 * N;
+        const size_t timg = (size_t)C * w * h;
+        std::vector<float> t_noisy(Aw * timg), t_basic(step == 2 ? Aw * timg : 0), t_num(Aw * timg), t_den(Aw * timg);
+        auto cut = [&](const std::vector<float>& src, std::vector<float>& dst) {
+            for (unsigned a = 0; a < Aw; a++) {
+                if (!mask_w[a]) continue;
+                for (unsigned c = 0; c < C; c++)
+                    for (unsigned p = 0; p < h; p++)
+                        std::memcpy(&dst[a * timg + ((size_t)c * h + p) * w],
+                                    &src[a * imgb + ((size_t)c * hb + i * h_small + p) * wb + j * w_small], w * sizeof(float));
+            }
+        };
+        cut(w_noisy, t_noisy); if (step == 2) cut(w_basic, t_basic); cut(w_num, t_num); cut(w_den, t_den);
+        if (h < 2 * N + Pw->k + 1 || w < 2 * N + Pw->k + 1) { trc[kt] = 2; continue; }   /* tile smaller than the search range */
+        trc[kt] = pass_impl(step, Pw, asw, asw, w, h, C, t_noisy.data(), step == 2 ? t_basic.data() : nullptr, t_num.data(), t_den.data(),
+                            mask_w.data(), proc_w.data(), cst_w, pst_w, 0, -1, &tstats[(size_t)kt]);
+        tpct[kt] = denoised_percent(t_den.data(), mask_w.data(), Aw, w - 2 * N, h - 2 * N, C, N, Pw->k);
+        for (unsigned a = 0; a < Aw; a++) {   /* interiors only */
+            if (!mask_w[a]) continue;
+            for (unsigned c = 0; c < C; c++)
+                for (unsigned p = 0; p < h - 2 * N; p++) {
+                    const size_t so = a * timg + ((size_t)c * h + N + p) * w + N;
+                    const size_t dof = ((size_t)c * H + i * h_small + p) * W + j * w_small;
+                    std::memcpy(&und_num[a][dof], &t_num[so], (w - 2 * N) * sizeof(float));
+                    std::memcpy(&und_den[a][dof], &t_den[so], (w - 2 * N) * sizeof(float));
+                }
+        }
+    }
+    *pct = 0.0f;
+    for (int kt = 0; kt < nt; kt++) {
+        if (trc[kt]) return 1;
+        *pct += tpct[kt];
+        if (stats) { stats->groups += tstats[kt].groups; stats->sadct_groups += tstats[kt].sadct_groups; stats->stack_patches += tstats[kt].stack_patches;
+                     stats->bm_seconds += tstats[kt].bm_seconds; }
+    }
+    if (stats) { stats->passes += 1; stats->total_seconds += now_s() - t0; }
+    for (unsigned a = 0; a < Aw; a++) {
+        if (!mask_w[a]) continue;
+        symetrize(und_num[a].data(), &w_num[a * imgb], W, H, C, N);
+        symetrize(und_den[a].data(), &w_den[a * imgb], W, H, C, N);
+    }
+    return 0;
+}
+
 int run_step(int step, const orc_params* P, float* LF_noisy, const unsigned* mask, float* LF_basic,
              float* LF_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
              unsigned W, unsigned H, unsigned C, int max_windows, orc_stats* stats) {
@@ -1119,14 +1194,20 @@ int run_step(int step, const orc_params* P, float* LF_noisy, const unsigned* mas
                 if (ang_major == ORC_ROWMAJOR) { ps_w = pst_w / asw; pt_w = pst_w - ps_w * asw; }
                 else { pt_w = pst_w / asw; ps_w = pst_w - pt_w * asw; }
             }
-            if (pass_impl(step, &Pw, asw, asw, wb, hb, C, w_noisy.data(), step == 2 ? w_basic.data() : nullptr,
-                          w_num.data(), w_den.data(), mask_w.data(), proc_w.data(), cst_w, pst_w, 0, -1, stats))
+            float pct_tiles = 0.0f;
+            if (g_tiles <= 1) {
+                if (pass_impl(step, &Pw, asw, asw, wb, hb, C, w_noisy.data(), step == 2 ? w_basic.data() : nullptr,
+                              w_num.data(), w_den.data(), mask_w.data(), proc_w.data(), cst_w, pst_w, 0, -1, stats))
+                    return 1;
+            } else if (tiled_pass(step, &Pw, asw, W, H, C, nHW, w_noisy, w_basic, w_num, w_den, mask_w, proc_w, cst_w, pst_w, g_tiles,
+                                  &pct_tiles, stats))
                 return 1;
             proc_w[pst_w] += 1;
             const unsigned st = ang_major == ORC_ROWMAJOR ? (mins + ps_w) * awidth + (mint + pt_w)
                                                           : (mins + ps_w) + (mint + pt_w) * aheight;
             proc[st] += 1;
-            if (denoised_percent(w_den.data(), mask_w.data(), Aw, W, H, C, nHW, P->k) >= 100.0f)
+            if (g_tiles <= 1 ? denoised_percent(w_den.data(), mask_w.data(), Aw, W, H, C, nHW, P->k) >= 100.0f
+                             : pct_tiles >= 100.0f * (float)g_tiles)   /* bm5d.cpp:668-672 */
                 for (unsigned i = 0; i < Aw; i++)
                     if (proc_w[i] == 0) { proc_w[i] += 1; proc[st_idx[i]] += 1; }
             rem_w = (unsigned)std::count(proc_w.begin(), proc_w.end(), 0u);
@@ -1505,6 +1586,7 @@ int orc_last_windows(unsigned* out, unsigned cap) {
     return (int)g_last_windows.size();
 }
 void orc_set_time_limit(double seconds) { g_time_limit = seconds; }
+void orc_set_tiles(int n) { g_tiles = n > 1 ? n : 1; }
 int orc_get_threads(void) {
 #ifdef _OPENMP
     return g_threads > 0 ? g_threads : omp_get_max_threads();

@@ -173,6 +173,9 @@ void orc_set_threads(int n);
 int orc_last_windows(unsigned* out, unsigned cap);
 /* run API: stop visiting windows once this many seconds have passed (after at least one window); 0 = no limit */
 void orc_set_time_limit(double seconds);
+/* run API: n > 1 selects the reference's OpenMP tile mode (bm5d.cpp:411-708; n = its nb_threads, a power of two): every SAI is cut
+ * into n sub-images with a halo, tiles run independently, halo output is discarded.  1 = untiled (the parity mode). */
+void orc_set_tiles(int n);
 int  orc_get_threads(void);
 
 #ifdef __cplusplus

@@ -106,6 +106,7 @@ def lib():
     L.orc_wiener_filter_slab.argtypes = [_f32p, _f32p, C.c_uint, C.c_uint, C.c_uint, _f32p, _f32p, C.c_void_p, C.c_uint]
     L.orc_set_threads.argtypes = [C.c_int]
     L.orc_set_time_limit.argtypes = [C.c_double]
+    L.orc_set_tiles.argtypes = [C.c_int]
     L.orc_last_windows.argtypes = [C.c_void_p, C.c_uint]
     L.orc_last_windows.restype = C.c_int
     L.orc_get_threads.restype = C.c_int

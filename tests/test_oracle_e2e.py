@@ -86,3 +86,22 @@ def test_sharded_passes_sum_to_the_full_pass():
     nb, db, _ = Hh.oracle_pass(1, 25.0, pk, win, None, Wb, Hb, 3, rows=(b1, e1))
     np.testing.assert_allclose(na + nb, num, rtol=1e-5, atol=1e-3)
     np.testing.assert_allclose(da + db, den, rtol=1e-5, atol=1e-6)
+
+
+def test_reference_tile_mode_costs_half_a_db():
+    """The reference's OpenMP mode (bm5d.cpp:411-708: every SAI cut into nb_threads tiles with a halo whose output is
+    discarded) restated in the oracle: on the README command with 8 tiles it loses about 0.5 dB against the untiled
+    result, as the stock CLI did in the survey's probe run (33.72 / 35.21 dB with its own noise
+    draw against 34.20 / 35.72 untiled)."""
+    clean, noisy = Hh.noisy_lf(Hh.source_lf(), 25.0)
+    mask = np.ones(9, np.uint32)
+    lib = O.lib()
+    lib.orc_set_tiles(8)
+    try:
+        n1, b, st1 = O.run_step1(O.make_params(25.0, 2.7, *Hh.README_HT), noisy.copy(), mask, O.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+        _, _, d, st2 = O.run_step2(O.make_params(25.0, 2.7, *Hh.README_WIEN), n1.copy(), b.copy(), mask, O.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+    finally:
+        lib.orc_set_tiles(1)
+    pb, pd = O.psnr_lf(b, clean), O.psnr_lf(d, clean)
+    assert 33.5 < pb < 33.85 and 35.0 < pd < 35.35, (pb, pd)          # untiled: 34.2073 / 35.7082
+    assert st1.windows == st2.windows == 1 and st1.passes == 1
