@@ -67,7 +67,7 @@ struct lfbm5d_ctx {
     /* per-pass work buffers (grow only) */
     DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den, d_mask;
     /* step-level buffers */
-    DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own;
+    DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
     /* window lanes (run_step, pipelined form): extra contexts on the same device, each with its own stream, window
      * buffers and per-pass work buffers; owned by this context */
@@ -189,7 +189,9 @@ void build_tables(GroupTables& t, unsigned k, unsigned aw, unsigned ah) {
         }
     for (unsigned u = 0; u < 3; u++)
         for (unsigned j = 0; j < 3; j++) t.cos3[u * 3 + j] = (float)std::cos(kPi * (j + 0.5) * u / 3.0);
-    for (unsigned n = 1; n <= 3; n++) {
+    for (unsigned u = 0; u < aw && aw <= (unsigned)kMaxAw; u++)
+        for (unsigned j = 0; j < aw; j++) t.cosw[u * aw + j] = (float)std::cos(kPi * (j + 0.5) * u / (double)aw);
+    for (unsigned n = 1; n <= (unsigned)kMaxAw; n++) {
         for (unsigned u = 0; u < n; u++)
             for (unsigned j = 0; j < n; j++) t.cos1[n][u * n + j] = (float)std::cos(kPi * (j + 0.5) * u / n);
         const float c1 = (float)((float)kSqrt2 / std::sqrt((double)n));
@@ -227,7 +229,7 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
         if (P->nSim < 1 || P->nSim > 48 || P->p < 1) return fail(c, "bad search window / step");
         return 0;
     }
-    if (aw != 3 || ah != 3) return fail(c, "unsupported: angular search window must be 3x3 (aswSize 1)");
+    if (aw != ah || (aw != 3 && aw != 5)) return fail(c, "unsupported: angular search window must be 3x3 or 5x5 (aswSize 1 or 2)");
     if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
     if (P->k != 8 && P->k != 12 && P->k != 16) return fail(c, "unsupported: patch size k must be 8, 12 or 16");
     if (P->tau_2D == LFBM5D_BIOR && !is_pow2(P->k)) return fail(c, "bior1.5 needs a power-of-two patch size");
@@ -432,7 +434,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.step = step; ga.lambda = lambda; ga.fill_quirk = centre ? 1u : 0u;
     for (int i = 0; i < 3; i++) ga.sigma[i] = sig[i];
     ga.bm3d = bm3d ? 1u : 0u;
-    if (group_lds_bytes(ga) > 160 * 1024 - 4096) return fail(c, "unsupported: N*k*k stack does not fit the 160 KiB LDS");
+    if (const size_t sb = group_scratch_bytes(ga)) {   /* generic path with stacks beyond the 160 KiB LDS: HBM scratch slices */
+        HIPCK(c, c->gscratch.reserve(sb));
+        ga.scratch = c->gscratch.as<float>(); ga.scratch_floats = sb / sizeof(float);
+    }
     if (n_groups) HIPCK(c, launch_group(s, ga));
     HIPCK(c, hipEventRecord(pe.e[2], s));
 
@@ -1211,7 +1216,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
                       &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
-                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own};
+                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_small) (void)hipHostFree(c->h_small);

@@ -11,7 +11,9 @@
 namespace lfbm5d {
 
 constexpr int kMaxK = 16;       /* patch side supported by the group kernel */
-constexpr int kMaxA = 9;        /* SAIs per angular window (an = 1) */
+constexpr int kMaxA = 25;       /* SAIs per angular window: 3x3 (an = 1, every dedicated kernel) or 5x5 (an = 2, generic kernel) */
+constexpr int kA3 = 9;          /* ... of the 3x3 window the dedicated kernels are written for */
+constexpr int kMaxAw = 5;       /* side of the largest window */
 constexpr int kMaxN = 16;      /* max similar patches (power of two) of the light-field core and its dedicated kernels */
 constexpr int kMaxN3 = 32;     /* ... of the per-SAI BM3D flavour (generic group kernel only) */
 
@@ -26,10 +28,11 @@ struct GroupTables {
     float cn4[kMaxA];           /* coef_norm_4d */
     float cni4[kMaxA];
     float cos3[9];              /* cos(pi (j+1/2) u / 3) */
-    float cos1[4][9];           /* SADCT: cos(pi (j+1/2) u / n) at [n][u*n + j], n = 1..3 */
-    float cn1[4][3];            /* SADCT 1-D norms for length n (core:3229-3252) */
-    float cni1[4][3];
-    float c1inv[4];             /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
+    float cosw[kMaxA];          /* cos(pi (j+1/2) u / aw) at [u*aw + j] for the window side aw (general angular DCT) */
+    float cos1[kMaxAw + 1][kMaxA]; /* SADCT: cos(pi (j+1/2) u / n) at [n][u*n + j], n = 1..5 */
+    float cn1[kMaxAw + 1][kMaxAw]; /* SADCT 1-D norms for length n (core:3229-3252) */
+    float cni1[kMaxAw + 1][kMaxAw];
+    float c1inv[kMaxAw + 1];    /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
     float cos5[5][256];         /* 5th-dimension DCT: cos(pi (j+1/2) u / n) at [log2 n][u*n + j], n = 1..16 */
     float cn5_0[5], cn5[5];     /* coef_norm of preProcess_5d (core:3262-3276) */
     float c5inv[5];             /* 0.5 * SQRT2_INV / sqrt(n) (core:2591) */
@@ -38,7 +41,7 @@ struct GroupTables {
     float coef4inv;             /* 1 / (2 sqrt(aw) sqrt(ah))      (core:1945)     */
 };
 
-constexpr unsigned kShapeInfoBytes = 208;
+constexpr unsigned kShapeInfoBytes = (5 * kMaxA + 2 * kMaxAw + 1) * 4;
 
 struct GroupArgs {
     const float* noisy;         /* [A][C][Hb][Wb] */
@@ -66,6 +69,8 @@ struct GroupArgs {
     int step;
     float lambda;
     float sigma[3];
+    float* scratch;             /* generic path, stacks beyond the LDS: HBM slices for k_group_big (or NULL) */
+    unsigned long long scratch_floats;   /* size of scratch */
     unsigned bm3d;              /* per-SAI BM3D arithmetic (bm3d.cpp:914-1027, :1345-1373): threshold without sqrt2, SD weight over nSx*k^2 */
 };
 
@@ -131,7 +136,7 @@ hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsig
 hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub,
                            float* est, size_t n);
 /* all SAIs of an angular window in one launch: slot i of the window <-> SAI L.st[i] of the light field */
-struct SaiList { unsigned st[16]; unsigned n; };
+struct SaiList { unsigned st[32]; unsigned n; };
 hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,
                                   const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride, const float* src, size_t src_stride,
@@ -160,6 +165,8 @@ hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsign
 hipError_t prepare_group_kernels();   /* once per device: LDS limits of the group kernels */
 hipError_t launch_group(hipStream_t s, const GroupArgs& a);
 size_t group_lds_bytes(const GroupArgs& a);
+/* HBM scratch (bytes) launch_group needs for this configuration: 0 unless the generic path's stacks exceed the LDS */
+size_t group_scratch_bytes(const GroupArgs& a);
 hipError_t launch_aggregate(hipStream_t s, const AggArgs& a);
 
 } /* namespace lfbm5d */

@@ -22,6 +22,8 @@
  */
 #include "lfbm5d_kernels.h"
 
+#include <algorithm>
+
 #include <type_traits>
 
 namespace lfbm5d {
@@ -193,30 +195,31 @@ __global__ void k_count_denoised(const float* __restrict__ den, size_t sai_strid
 constexpr int kThreads = 256;
 
 struct ShapeInfo {           /* SADCT bookkeeping of one group (core:302-323, :2036-2049, :2102-2104) */
-    int mask[kMaxA], idx[kMaxA], mask_col[kMaxA], idx_col[kMaxA], mask_dct[kMaxA];
-    int row_n[3], col_n[3];
+    int mask[kMaxA], idx[kMaxA], mask_col[kMaxA], idx_col[kMaxA], mask_dct[kMaxA];   /* [s * aw + t], aw = window side */
+    int row_n[kMaxAw], col_n[kMaxAw];
     int use_sadct;
 };
 static_assert(sizeof(ShapeInfo) == kShapeInfoBytes, "GroupArgs::gshape stride");
 /* the per-group ShapeInfo written by the pre-pass is constant during the group kernels: scalar loads */
 typedef const __attribute__((address_space(4))) ShapeInfo& ShRef;
 
-__device__ void build_shape(ShapeInfo& sh, const int* m) {
+__device__ void build_shape(ShapeInfo& sh, const int* m, int aw) {
+    const int A = aw * aw;
     int size = 0;
-    for (int i = 0; i < 9; i++) { sh.mask[i] = m[i]; sh.idx[i] = 0; sh.mask_col[i] = 0; sh.idx_col[i] = 0; sh.mask_dct[i] = 0; size += m[i]; }
-    for (int s = 0; s < 3; s++) {
+    for (int i = 0; i < A; i++) { sh.mask[i] = m[i]; sh.idx[i] = 0; sh.mask_col[i] = 0; sh.idx_col[i] = 0; sh.mask_dct[i] = 0; size += m[i]; }
+    for (int s = 0; s < aw; s++) {
         int r = 0;
-        for (int t = 0; t < 3; t++) if (m[s * 3 + t]) sh.idx[s * 3 + r++] = t;
+        for (int t = 0; t < aw; t++) if (m[s * aw + t]) sh.idx[s * aw + r++] = t;
         sh.row_n[s] = r;
-        for (int t = 0; t < r; t++) sh.mask_col[s * 3 + t] = 1;
+        for (int t = 0; t < r; t++) sh.mask_col[s * aw + t] = 1;
     }
-    for (int t = 0; t < 3; t++) {
+    for (int t = 0; t < aw; t++) {
         int r = 0;
-        for (int s = 0; s < 3; s++) if (sh.mask_col[s * 3 + t]) sh.idx_col[(r++) * 3 + t] = s;
+        for (int s = 0; s < aw; s++) if (sh.mask_col[s * aw + t]) sh.idx_col[(r++) * aw + t] = s;
         sh.col_n[t] = r;
-        for (int s = 0; s < r; s++) sh.mask_dct[s * 3 + t] = 1;
+        for (int s = 0; s < r; s++) sh.mask_dct[s * aw + t] = 1;
     }
-    sh.use_sadct = size != 9;
+    sh.use_sadct = size != A;
 }
 
 /* orthonormalised 3x3 angular DCT as the reference applies it (core:1862-1954) */
@@ -375,6 +378,86 @@ __device__ __noinline__ void sadct9_inv(float* v, ShRef sh, TbPtr tb) {
         }
     }
     for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask[i];
+}
+
+/* General aw x aw angular window (aswSize 2: 5x5): the same transforms with run-time sizes, generic kernel only.
+ * dct_4d_process / dct_4d_inverse (core:1862-1954) and sadct_4d_process / _inverse (core:1969-2264) on one vector. */
+__device__ __noinline__ void dctw_fwd(float* x, int aw, TbPtr tb) {
+    float t[kMaxA];
+    for (int s = 0; s < aw; s++)
+        for (int u = 0; u < aw; u++) {
+            float acc = 0.0f;
+            for (int j = 0; j < aw; j++) acc += x[s * aw + j] * tb->cosw[u * aw + j];
+            t[s * aw + u] = 2.0f * acc;
+        }
+    for (int v = 0; v < aw; v++)
+        for (int u = 0; u < aw; u++) {
+            float acc = 0.0f;
+            for (int j = 0; j < aw; j++) acc += t[j * aw + u] * tb->cosw[v * aw + j];
+            x[v * aw + u] = 2.0f * acc * tb->cn4[v * aw + u];
+        }
+}
+__device__ __noinline__ void dctw_inv(float* x, int aw, TbPtr tb) {
+    float t[kMaxA];
+    for (int i = 0; i < aw * aw; i++) x[i] *= tb->cni4[i];
+    for (int s = 0; s < aw; s++)
+        for (int j = 0; j < aw; j++) {
+            float acc = 0.0f;
+            for (int u = 1; u < aw; u++) acc += x[s * aw + u] * tb->cosw[u * aw + j];
+            t[s * aw + j] = x[s * aw] + 2.0f * acc;
+        }
+    for (int i = 0; i < aw; i++)
+        for (int j = 0; j < aw; j++) {
+            float acc = 0.0f;
+            for (int v = 1; v < aw; v++) acc += t[v * aw + j] * tb->cosw[v * aw + i];
+            x[i * aw + j] = (t[j] + 2.0f * acc) * tb->coef4inv;
+        }
+}
+__device__ __noinline__ void sadctw_fwd(float* v, int aw, ShRef sh, TbPtr tb) {
+    float x[kMaxAw], y[kMaxAw];
+    for (int s = 0; s < aw; s++) {
+        const int n = sh.row_n[s];
+        if (n == 1) v[s * aw] = v[s * aw + sh.idx[s * aw]];
+        else if (n > 1) {
+            for (int t = 0; t < n; t++) x[t] = v[s * aw + sh.idx[s * aw + t]];
+            r10_small(x, y, n, tb);
+            for (int t = 0; t < n; t++) v[s * aw + t] = y[t] * tb->cn1[n][t];
+        }
+    }
+    for (int t = 0; t < aw; t++) {
+        const int n = sh.col_n[t];
+        if (n == 1) v[t] = v[sh.idx_col[t] * aw + t];
+        else if (n > 1) {
+            for (int s = 0; s < n; s++) x[s] = v[sh.idx_col[s * aw + t] * aw + t];
+            r10_small(x, y, n, tb);
+            for (int s = 0; s < n; s++) v[s * aw + t] = y[s] * tb->cn1[n][s];
+        }
+    }
+    const float coef = 0.5f * 0.70710678118654752f;
+    for (int i = 0; i < aw * aw; i++) v[i] *= (float)sh.mask_dct[i] * coef;
+}
+__device__ __noinline__ void sadctw_inv(float* v, int aw, ShRef sh, TbPtr tb) {
+    float x[kMaxAw], y[kMaxAw];
+    const float coef = 2.0f * 1.41421356237309505f;
+    for (int t = 0; t < aw; t++) {
+        const int n = sh.col_n[t];
+        if (n == 1) v[sh.idx_col[t] * aw + t] = v[t] * coef;
+        else if (n > 1) {
+            for (int s = 0; s < n; s++) x[s] = v[s * aw + t] * tb->cni1[n][s] * coef;
+            r01_small(x, y, n, tb);
+            for (int s = 0; s < n; s++) v[sh.idx_col[s * aw + t] * aw + t] = y[s] * tb->c1inv[n];
+        }
+    }
+    for (int s = 0; s < aw; s++) {
+        const int n = sh.row_n[s];
+        if (n == 1) v[s * aw + sh.idx[s * aw]] = v[s * aw];
+        else if (n > 1) {
+            for (int t = 0; t < n; t++) x[t] = v[s * aw + t] * tb->cni1[n][t];
+            r01_small(x, y, n, tb);
+            for (int t = 0; t < n; t++) v[s * aw + sh.idx[s * aw + t]] = y[t] * tb->c1inv[n];
+        }
+    }
+    for (int i = 0; i < aw * aw; i++) v[i] *= (float)sh.mask[i];
 }
 
 /* lib_transforms.cpp:403-471 / :290-321 on a register vector of compile-time length */
@@ -928,12 +1011,12 @@ __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     const unsigned k_r = a.refs[g];
     ShapeInfo sh;
     if (a.tau4 == 6) {
-        int m[9];
-        for (int st = 0; st < 9; st++) {
+        int m[kMaxA];
+        for (int st = 0; st < (int)a.A; st++) {
             const bool masked = (a.mask_bits >> st) & 1;
             m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
         }
-        build_shape(sh, m);
+        build_shape(sh, m, a.A == 9 ? 3 : 5);
     } else {
         for (int q = 0; q < (int)(sizeof(ShapeInfo) / sizeof(int)); q++) reinterpret_cast<int*>(&sh)[q] = 0;
     }
@@ -945,22 +1028,18 @@ __device__ __forceinline__ ShRef group_shape(const GroupArgs& a, unsigned g) {
         (const __attribute__((address_space(4))) char*)a.gshape + (size_t)g * sizeof(ShapeInfo));
 }
 
+/* One (group, channel) of the generic path.  S0 / S1: the group's stack(s) [n][st][pq] -- in LDS (k_group) or, when the
+ * stacks do not fit the 160 KiB, in a per-workgroup slice of an HBM scratch buffer (k_group_big); tmp: the 2-D stage's
+ * LDS work area.  Any patch size, any transform combination, 3x3 and 5x5 angular windows. */
 template <int STEP>
-__global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
-    extern __shared__ float lds[];
-    __shared__ unsigned pos[kMaxN3 * kMaxA];
-    __shared__ float red[3][kThreads / 64];
-
+__device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned g, const int c, float* S0, float* S1, float* tmp,
+                                              unsigned* pos, float (*red)[kThreads / 64]) {
     const int tid = threadIdx.x;
-    const unsigned g = a.ref_begin + blockIdx.x;
-    const int c = blockIdx.y;
     const int k = a.k, k2 = k * k, A = a.A, N = a.N;
+    const int aw = A == 9 ? 3 : 5;
     const int nSx = (int)a.self_cnt[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int stack = nSx * A * k2;
-    float* S0 = lds;
-    float* S1 = STEP == 2 ? lds + stack : nullptr;
-    float* tmp = lds + (STEP == 2 ? 2 : 1) * stack;
     const TbPtr tb = (TbPtr)a.tb;
 
     /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323): from the pre-pass */
@@ -1012,12 +1091,19 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
             const int n = f / k2, pq = f % k2;
             for (int s = 0; s < (STEP == 2 ? 2 : 1); s++) {
                 float* S = s ? S1 : S0;
-                float x[9];
+                if (A == 9) {
+                    float x[9];
 #pragma unroll
-                for (int st = 0; st < 9; st++) x[st] = S[(n * A + st) * k2 + pq];
-                if (do_dct4) dct9_fwd(x, tb); else sadct9_fwd(x, sh, tb);
+                    for (int st = 0; st < 9; st++) x[st] = S[(n * A + st) * k2 + pq];
+                    if (do_dct4) dct9_fwd(x, tb); else sadct9_fwd(x, sh, tb);
 #pragma unroll
-                for (int st = 0; st < 9; st++) S[(n * A + st) * k2 + pq] = x[st];
+                    for (int st = 0; st < 9; st++) S[(n * A + st) * k2 + pq] = x[st];
+                } else {   /* 5x5 window */
+                    float x[kMaxA];
+                    for (int st = 0; st < A; st++) x[st] = S[(n * A + st) * k2 + pq];
+                    if (do_dct4) dctw_fwd(x, aw, tb); else sadctw_fwd(x, aw, sh, tb);
+                    for (int st = 0; st < A; st++) S[(n * A + st) * k2 + pq] = x[st];
+                }
             }
         }
         __syncthreads();
@@ -1071,12 +1157,19 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * k2; f += kThreads) {
             const int n = f / k2, pq = f % k2;
-            float x[9];
+            if (A == 9) {
+                float x[9];
 #pragma unroll
-            for (int st = 0; st < 9; st++) x[st] = F[(n * A + st) * k2 + pq];
-            if (do_dct4) dct9_inv(x, tb); else sadct9_inv(x, sh, tb);
+                for (int st = 0; st < 9; st++) x[st] = F[(n * A + st) * k2 + pq];
+                if (do_dct4) dct9_inv(x, tb); else sadct9_inv(x, sh, tb);
 #pragma unroll
-            for (int st = 0; st < 9; st++) F[(n * A + st) * k2 + pq] = x[st];
+                for (int st = 0; st < 9; st++) F[(n * A + st) * k2 + pq] = x[st];
+            } else {
+                float x[kMaxA];
+                for (int st = 0; st < A; st++) x[st] = F[(n * A + st) * k2 + pq];
+                if (do_dct4) dctw_inv(x, aw, tb); else sadctw_inv(x, aw, sh, tb);
+                for (int st = 0; st < A; st++) F[(n * A + st) * k2 + pq] = x[st];
+            }
         }
     }
     __syncthreads();
@@ -1087,6 +1180,35 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
     for (int e = tid; e < stack; e += kThreads) {
         const int pq = e % k2, ns = e / k2;
         out[((size_t)ns * a.C + c) * k2 + pq] = F[e];
+    }
+}
+
+template <int STEP>
+__global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ unsigned pos[kMaxN3 * kMaxA];
+    __shared__ float red[3][kThreads / 64];
+    const unsigned g = a.ref_begin + blockIdx.x;
+    const int stack = (int)a.self_cnt[g] * (int)a.A * (int)(a.k * a.k);
+    group_generic<STEP>(a, g, (int)blockIdx.y, lds, STEP == 2 ? lds + stack : nullptr, lds + (STEP == 2 ? 2 : 1) * stack, pos, red);
+}
+
+/* Stacks beyond the LDS (a 5x5 window with the README's 16x16 patches: 8 x 25 x 256 floats = 200 KiB per stack; N = 32
+ * with 16x16 patches): a persistent launch, every workgroup owns a slice of an HBM scratch buffer for its stack(s) and
+ * walks over (group, channel) items.  Global memory written by a workgroup is visible to it after a barrier (one CU, one
+ * vector L1), so the phases are the LDS kernel's, only slower; the 2-D stage's work area stays in LDS. */
+template <int STEP>
+__global__ __launch_bounds__(kThreads) void k_group_big(GroupArgs a, float* scratch, unsigned long long slice_floats) {
+    extern __shared__ float lds[];
+    __shared__ unsigned pos[kMaxN3 * kMaxA];
+    __shared__ float red[3][kThreads / 64];
+    float* S0 = scratch + (size_t)blockIdx.x * slice_floats;
+    const unsigned items = a.n_groups * a.C;
+    for (unsigned it = blockIdx.x; it < items; it += gridDim.x) {
+        const unsigned g = a.ref_begin + it / a.C;
+        const int stack = (int)a.self_cnt[g] * (int)a.A * (int)(a.k * a.k);
+        group_generic<STEP>(a, g, (int)(it % a.C), S0, STEP == 2 ? S0 + stack : nullptr, lds, pos, red);
+        __syncthreads();   /* pos / red / the scratch slice are reused by the next item */
     }
 }
 
@@ -1585,7 +1707,7 @@ constexpr int kDct8Threads = 320;
 template <int STEP>
 __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
     extern __shared__ float lds[];
-    __shared__ unsigned pos[kMaxN * kMaxA];
+    __shared__ unsigned pos[kMaxN * kA3];
     __shared__ float red[3][kDct8Threads / 64];
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x;
@@ -1936,10 +2058,10 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
      * patch.  The pieces are parked in LDS, [image][patch][16 pieces], piece index XOR-ed with the patch
      * index so that phase 1b reads them without bank conflicts; the area is reused by the stack afterwards. */
     {
-        __shared__ unsigned pos[kMaxN * kMaxA];
+        __shared__ unsigned pos[kMaxN * kA3];
         for (int i = tid; i < NP; i += kDct8wThreads) pos[i] = a.gpos[(size_t)g * N * A + i];
         __syncthreads();
-        constexpr int kItems = (kMaxN * kMaxA * 16 + kDct8wThreads - 1) / kDct8wThreads;   /* 9 */
+        constexpr int kItems = (kMaxN * kA3 * 16 + kDct8wThreads - 1) / kDct8wThreads;   /* 9 */
         f4u v0[kItems], v1[kItems];
 #pragma unroll
         for (int j = 0; j < kItems; j++) {
@@ -2176,7 +2298,7 @@ template <bool HAAR>
 __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
     extern __shared__ float lds[];
     __shared__ float red[3][kDct8w2Threads / 64];
-    __shared__ unsigned pos[kMaxN * kMaxA];
+    __shared__ unsigned pos[kMaxN * kA3];
     constexpr int TH = kDct8w2Threads;
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x;
@@ -2201,7 +2323,7 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
 
     /* 1a: rows.  All loads of a thread's items are issued before the first transform */
     {
-        constexpr int kIt = (kMaxN * kMaxA * 8 + TH - 1) / TH;   /* 6 */
+        constexpr int kIt = (kMaxN * kA3 * 8 + TH - 1) / TH;   /* 6 */
         f4u n0[kIt], n1[kIt], b0[kIt], b1[kIt];
 #pragma unroll
         for (int q = 0; q < kIt; q++) {
@@ -2804,18 +2926,35 @@ hipError_t prepare_group_kernels() {
     return hipSuccess;
 }
 
+constexpr unsigned kBigBlocks = 1024;   /* persistent workgroups of k_group_big (four per CU) */
+static size_t group_tmp_floats(const GroupArgs& a) {
+    /* the 2-D stage's work area: one patch per wave-quarter for the generic path, [patch][k][k+1] for bior1.5 */
+    return (a.tau2 == 7 && (a.k == 8 || a.k == 16)) ? (size_t)(kThreads / a.k) * a.k * (a.k + 1) : 256;
+}
 size_t group_lds_bytes(const GroupArgs& a) {
     const size_t stack = (size_t)a.N * a.A * a.k * a.k;
-    /* + the 2-D stage's work area: one patch per wave-quarter for the generic path, [patch][k][k+1] for bior1.5 */
-    const size_t tmp = (a.tau2 == 7 && (a.k == 8 || a.k == 16)) ? (size_t)(kThreads / a.k) * a.k * (a.k + 1) : 256;
-    return ((a.step == 2 ? 2 : 1) * stack + tmp) * sizeof(float);
+    return ((a.step == 2 ? 2 : 1) * stack + group_tmp_floats(a)) * sizeof(float);
+}
+static bool group_uses_generic(const GroupArgs& a) {   /* mirrors launch_group's dispatch */
+    if (getenv("LFBM5D_GROUP_GENERIC") != nullptr) return true;
+    if (a.A != 9) return true;
+    if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) return false;
+    if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1) return false;
+    if (a.tau2 == 7 && a.k == 8 && a.step == 2 && a.N <= (unsigned)kMaxN) return false;
+    if (a.tau2 == 5 && a.k == 8 && a.N <= (unsigned)kMaxN) return false;
+    if (a.bm3d && a.A == 1 && a.k == 8 && a.tau5 == 8 && (a.tau2 == 5 || a.tau2 == 7)) return false;
+    return true;
+}
+size_t group_scratch_bytes(const GroupArgs& a) {
+    if (!group_uses_generic(a) || group_lds_bytes(a) <= 160 * 1024 - 4096) return 0;
+    return (size_t)kBigBlocks * (a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);
 }
 hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* geometry pre-pass: patch positions, aggregation positions, angular shapes */
     hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N * a.A), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_group_shape, grid1d(a.n_groups), dim3(256), 0, s, a);
     /* LFBM5D_GROUP_GENERIC: test hook, every configuration through the generic LDS kernel (the dedicated kernels' cross-check) */
-    const bool generic_only = getenv("LFBM5D_GROUP_GENERIC") != nullptr && group_lds_bytes(a) <= 160 * 1024 - 4096;
+    const bool generic_only = getenv("LFBM5D_GROUP_GENERIC") != nullptr;
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
     if (generic_only) {}
     else if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9) {
@@ -2873,6 +3012,15 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         return hipGetLastError();
     }
     const size_t lds = group_lds_bytes(a);
+    if (lds > 160 * 1024 - 4096) {   /* stacks in HBM scratch slices, persistent workgroups */
+        const unsigned long long slice = (unsigned long long)(a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k;
+        if (!a.scratch || a.scratch_floats < slice * kBigBlocks) return hipErrorInvalidValue;
+        const unsigned blocks = std::min<unsigned>(kBigBlocks, a.n_groups * a.C);
+        const size_t ltmp = group_tmp_floats(a) * sizeof(float);
+        if (a.step == 2) hipLaunchKernelGGL(k_group_big<2>, dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice);
+        else             hipLaunchKernelGGL(k_group_big<1>, dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice);
+        return hipGetLastError();
+    }
     if (a.step == 2) hipLaunchKernelGGL(k_group<2>, dim3(a.n_groups, a.C), dim3(kThreads), lds, s, a);
     else             hipLaunchKernelGGL(k_group<1>, dim3(a.n_groups, a.C), dim3(kThreads), lds, s, a);
     return hipGetLastError();

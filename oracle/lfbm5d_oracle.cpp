@@ -914,7 +914,7 @@ int pass_impl(int step, const orc_params* P, unsigned aw, unsigned ah, unsigned 
             process_group(cx, row_start[r] + jj, rows[r] * Wb + cols[r][jj], outs[jj]);
         /* aggregation in the reference's order: st, then group, then c, n, p, q (core:484-528) */
         for (unsigned st = 0; st < A; st++) {
-            if (procSAI[st]) continue;
+            if (procSAI[st] || !mask[st]) continue;   /* (the schedule marks empty SAIs processed, bm5d.cpp:268-270) */
             float* num_st = num + (size_t)st * C * plane;
             float* den_st = den + (size_t)st * C * plane;
             for (unsigned jj = 0; jj < ncols; jj++) {

@@ -47,7 +47,7 @@ def padded_window(arr, W, H, Cc, nHW, cs=O.OPP, color=True):
 
 
 def oracle_pass(step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, mask=None, proc=None,
-                rows=(0, -1), cst=4, pst=4, useSD=0):
+                rows=(0, -1), cst=4, pst=4, useSD=0, aw=3):
     A = win.shape[0]
     num = np.zeros_like(win) if num is None else num
     den = np.zeros_like(win) if den is None else den
@@ -55,7 +55,7 @@ def oracle_pass(step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, mas
     proc = np.zeros(A, np.uint32) if proc is None else proc
     st = O.Stats()
     P = O.make_params(sigma, 2.7, *pk, useSD=useSD)
-    rc = O.lib().orc_pass(step, C.byref(P), 3, 3, Wb, Hb, Cc, win.reshape(-1),
+    rc = O.lib().orc_pass(step, C.byref(P), aw, aw, Wb, Hb, Cc, win.reshape(-1),
                           basic.ctypes.data if basic is not None else None, num.reshape(-1), den.reshape(-1),
                           mask, proc, cst, pst, rows[0], rows[1], C.byref(st))
     assert rc == 0

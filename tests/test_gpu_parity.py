@@ -27,7 +27,7 @@ def ctx():
     c.close()
 
 
-def gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, mask=None, proc=None, useSD=0, cst=4, pst=4):
+def gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, mask=None, proc=None, useSD=0, cst=4, pst=4, aw=3):
     from lfbm5d_amd import core
     A = win.shape[0]
     d_win = torch.from_numpy(win).cuda()
@@ -37,7 +37,7 @@ def gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, num=None, den=None, m
     mask = np.ones(A, np.uint32) if mask is None else mask
     proc = np.zeros(A, np.uint32) if proc is None else proc
     torch.cuda.synchronize()
-    ctx.core_pass(step, core.make_params(sigma, 2.7, *pk, useSD=useSD), 3, 3, Wb, Hb, Cc, d_win, d_basic, d_num, d_den,
+    ctx.core_pass(step, core.make_params(sigma, 2.7, *pk, useSD=useSD), aw, aw, Wb, Hb, Cc, d_win, d_basic, d_num, d_den,
                   mask, proc, cst, pst)
     return d_num.cpu().numpy(), d_den.cpu().numpy()
 
@@ -458,6 +458,91 @@ def test_window_lanes_are_bit_identical_to_the_sequential_order(ctx, monkeypatch
     assert O.psnr_lf(d0[mask != 0], clean[mask != 0]) > O.psnr_lf(noisy[mask != 0], clean[mask != 0]) + 6
 
 
+# ------------------------------------------------------------------------------------------------
+# 5x5 angular windows (aswSize 2; bm5d.cpp:215-218, utilities_LF.cpp:881-901, core:1862-2264 with awidth = aheight = 5)
+# ------------------------------------------------------------------------------------------------
+ASW2_CASES = [
+    # name, step, params, crop, empty SAIs of the window
+    ("ht-id-sadct-haar", 1, (4, 6, 2, 8, 4, "id", "sadct", "haar"), 64, ()),
+    ("ht-id-dct-haar", 1, (4, 6, 2, 8, 4, "id", "dct", "haar"), 64, ()),
+    ("ht-dct-sadct-hw-holes", 1, (8, 6, 2, 8, 4, "dct", "sadct", "hw"), 64, (0, 7, 18)),
+    ("wien-dct-sadct-haar", 2, (8, 6, 2, 8, 4, "dct", "sadct", "haar"), 64, ()),
+    ("wien-bior-dct-haar-holes", 2, (4, 6, 2, 8, 4, "bior", "dct", "haar"), 64, (3, 24)),
+    # 16x16 patches, N = 8: 8 x 25 x 256 floats = 200 KiB per stack -> the HBM-scratch form of the generic kernel
+    ("ht-bior-sadct-haar-k16", 1, (8, 6, 2, 16, 4, "bior", "sadct", "haar"), 72, ()),
+    ("wien-dct-sadct-haar-n16", 2, (16, 6, 2, 8, 4, "dct", "sadct", "haar"), 64, ()),
+]
+
+
+@pytest.mark.parametrize("case", ASW2_CASES, ids=[c[0] for c in ASW2_CASES])
+def test_5x5_window_pass_matches_oracle(ctx, case):
+    """One core pass on a 5x5 angular window (25 SAIs, 24 disparity searches, general 5x5 angular DCT / SADCT):
+    identical block matching, coverage and group statistics, estimate within the float tolerance of a 3x3 pass."""
+    name, step, pk, crop, holes = case
+    sigma = 25.0
+    lf = Hh.textured_lf(5, 5, crop, crop)
+    _, noisy = Hh.noisy_lf(lf, sigma)
+    N, nSim, nDisp, k = pk[0], pk[1], pk[2], pk[3]
+    win, Wb, Hb = Hh.padded_window(noisy, crop, crop, 3, nSim + nDisp)
+    mask = np.ones(25, np.uint32)
+    for h in holes:
+        mask[h] = 0
+        win[h] = 0
+    proc = (mask == 0).astype(np.uint32)      # the schedule marks empty SAIs as processed (bm5d.cpp:268-270)
+    basic = None
+    if step == 2:
+        n1, d1, _ = Hh.oracle_pass(1, sigma, (4,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, 3, mask=mask, proc=proc, cst=12, pst=12, aw=5)
+        basic = np.ascontiguousarray(Hh.estimate(n1, d1, win).astype(np.float32))
+    num_o, den_o, st = Hh.oracle_pass(step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=12, pst=12, aw=5)
+    ctx.reset_stats()
+    num_g, den_g = gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=12, pst=12, aw=5)
+    s = ctx.stats()
+    assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
+    if holes:
+        assert st.sadct_groups == st.groups or pk[6] == "dct"
+    refs, idx, cnt, best, shape = ctx.last_bm(N, 25, Wb * Hb)
+    est = (win if step == 1 else basic)[:, :Wb * Hb]
+    tau = Hh.tau_match(sigma, 3, step)
+    regr, regc = slice(nDisp, Hb - k - nDisp + 1), slice(nDisp, Wb - k - nDisp + 1)
+    for st_i in (0, 6, 13, 24):
+        if not mask[st_i]:
+            continue
+        ob, osh = np.zeros(Wb * Hb, np.uint32), np.zeros(Wb * Hb, np.uint8)
+        O.lib().orc_bm_stereo(np.ascontiguousarray(est[12]), np.ascontiguousarray(est[st_i]), Wb, Hb, k, nDisp, tau, ob, osh)
+        assert np.array_equal(ob.reshape(Hb, Wb)[regr, regc], best[st_i].reshape(Hb, Wb)[regr, regc])
+        assert np.array_equal(osh.reshape(Hb, Wb)[regr, regc], shape[st_i].reshape(Hb, Wb)[regr, regc])
+    assert np.array_equal(den_o != 0, den_g != 0)
+    np.testing.assert_allclose(den_g, den_o, rtol=1e-4, atol=1e-6)
+    eo, eg = Hh.estimate(num_o, den_o, win), Hh.estimate(num_g, den_g, win)
+    assert np.abs(eo - eg).max() < 3e-3
+
+
+@pytest.mark.parametrize("ah,aw", [(5, 5), (7, 6)])
+def test_whole_steps_with_5x5_windows_match_oracle(ctx, ah, aw):
+    """aswSize 2: the window schedule with 5x5 windows (compute_LF_angular_search_window's clamping at the borders),
+    both steps against the oracle: same windows, PSNR within 0.01 dB."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    Hs = Ws = 72
+    lf = Hh.textured_lf(ah, aw, Hs, Ws)
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    p1, p2 = (4, 6, 2, 8, 4, "id", "sadct", "haar"), (8, 6, 2, 8, 4, "dct", "sadct", "haar")
+    n1, b_o, st1 = O.run_step1(O.make_params(25.0, 2.7, *p1), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    w1 = O.last_windows()
+    _, _, d_o, st2 = O.run_step2(O.make_params(25.0, 2.7, *p2), n1.copy(), b_o.copy(), mask, O.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    d_noisy = torch.from_numpy(noisy).cuda()
+    d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+    ctx.reset_stats()
+    ctx.step1(core.make_params(25.0, 2.7, *p1), d_noisy, mask, d_basic, L.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    assert np.array_equal(ctx.last_windows(), w1) and ctx.stats().windows == st1.windows
+    pb = O.psnr_lf(d_basic.cpu().numpy(), clean)
+    ctx.step2(core.make_params(25.0, 2.7, *p2), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    pd = O.psnr_lf(d_den.cpu().numpy(), clean)
+    assert abs(pb - O.psnr_lf(b_o, clean)) < 0.01 and abs(pd - O.psnr_lf(d_o, clean)) < 0.01
+    assert pd > O.psnr_lf(noisy, clean) + 6
+
+
 def _random_cases():
     rng = np.random.default_rng(20261002)
     cases = []
@@ -512,7 +597,7 @@ def test_unsupported_configurations_fail_loudly(ctx):
     t = torch.zeros((25, 3 * 32 * 32), device="cuda")
     with pytest.raises(L.LfBm5dError, match="angular search window"):
         ctx.step1(core.make_params(25, 2.7, 4, 4, 2, 8, 4, "id", "sadct", "haar"), t, np.ones(25, np.uint32), t.clone(),
-                  L.ROWMAJOR, 5, 5, 2, 32, 32, 3)
+                  L.ROWMAJOR, 5, 5, 3, 32, 32, 3)
     with pytest.raises(L.LfBm5dError, match="power of two"):
         ctx.step1(core.make_params(25, 2.7, 6, 4, 2, 8, 4, "id", "sadct", "haar"), t, np.ones(25, np.uint32), t.clone(),
                   L.ROWMAJOR, 5, 5, 1, 32, 32, 3)
