@@ -2292,7 +2292,10 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
  * workgroup, all lanes busy.  Items are numbered patch-fastest so that the stack accesses of a wavefront are
  * consecutive float2 (no bank conflicts); the global accesses are 32-byte row segments either way.
  * ------------------------------------------------------------------------------------------ */
-constexpr int kDct8w2Threads = 256;
+#ifndef LFBM5D_DCT8W2_THREADS
+#define LFBM5D_DCT8W2_THREADS 512
+#endif
+constexpr int kDct8w2Threads = LFBM5D_DCT8W2_THREADS;
 
 template <bool HAAR>
 __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
