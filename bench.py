@@ -125,6 +125,52 @@ def cpu_baseline(wl, noisy_rgb, basic_rgb, windows_per_step, total_mp, max_windo
     return out
 
 
+def parity_vs_gpu(wl, noisy_rgb_9, basic_rgb_9, ctx):
+    """--parity-check: the centre 3x3 window of the workload through the oracle AND through the C-ABI on the same padded
+    window, one core pass per step: the checker's verdict in the bench line (coverage, estimate differences)."""
+    import torch
+    from oracle import oracle as O
+    from lfbm5d_amd import core
+    lib = O.lib()
+    H, W = wl["H"], wl["W"]
+    out = {}
+    for step, pk, src in ((1, wl["p1"], None), (2, wl["p2"], basic_rgb_9)):
+        P = O.make_params(wl["sigma"], 2.7, *pk)
+        nHW = pk[1] + pk[2]
+        Wb, Hb = W + 2 * nHW, H + 2 * nHW
+
+        def pad(arr):
+            o = np.zeros((9, 3 * Wb * Hb), np.float32)
+            for st in range(9):
+                im = np.ascontiguousarray(arr[st]).copy()
+                lib.orc_color_transform(im, O.OPP, W, H, 3, 1)
+                lib.orc_symetrize(im, o[st], W, H, 3, nHW)
+            return o
+        wn = pad(noisy_rgb_9)
+        wb = pad(src) if src is not None else None
+        num, den = np.zeros_like(wn), np.zeros_like(wn)
+        mask, proc = np.ones(9, np.uint32), np.zeros(9, np.uint32)
+        st = O.Stats()
+        if lib.orc_pass(step, C.byref(P), 3, 3, Wb, Hb, 3, wn.reshape(-1), wb.ctypes.data if wb is not None else None,
+                        num.reshape(-1), den.reshape(-1), mask, proc, 4, 4, 0, -1, C.byref(st)):
+            raise RuntimeError("oracle pass failed")
+        d_n = torch.from_numpy(wn).cuda()
+        d_b = torch.from_numpy(wb).cuda() if wb is not None else None
+        g_num, g_den = torch.zeros_like(d_n), torch.zeros_like(d_n)
+        ctx.core_pass(step, core.make_params(wl["sigma"], 2.7, *pk), 3, 3, Wb, Hb, 3, d_n, d_b, g_num, g_den, mask, proc, 4, 4)
+        gn, gd = g_num.cpu().numpy(), g_den.cpu().numpy()
+        both = (den > 0) & (gd > 0)
+        d = np.abs(num[both] / den[both] - gn[both] / gd[both])
+        out["ht" if step == 1 else "wiener"] = {
+            "coverage_identical": bool(np.array_equal(den > 0, gd > 0)),
+            "mean_abs_estimate_diff": float(d.mean()), "p999_abs_estimate_diff": float(np.quantile(d, 0.999)),
+            "max_abs_estimate_diff": float(d.max()),
+            "psnr_between_estimates_db": float(10 * np.log10(255.0 ** 2 / max(float((d.astype(np.float64) ** 2).mean()), 1e-30)))}
+    out["note"] = ("same padded window through the oracle and the C-ABI; the maximum belongs to the few hard-threshold decisions that fall "
+                   "within float round-off of the threshold (float32 on the GPU, double accumulation in the oracle)")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,6 +178,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="lf17x17x512x512_sigma25", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-check", action="store_true",
+                    help="also run the centre window of each step through the oracle and the C-ABI and report the differences (+20 s)")
     ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 3)")
     ap.add_argument("--noise", default="mt19937", choices=["mt19937", "torch"],
                     help="mt19937: the reference's noise stream, seed 1 (default); torch: quick GPU noise for kernel iteration")
@@ -320,6 +368,10 @@ def main():
             try:
                 n_h = noisy_h if noisy_h is not None else noisy0.cpu().numpy()
                 out["cpu_baseline"] = cpu_baseline(wl, n_h, basic.cpu().numpy(), int(round(tot["windows"] / args.steps / 2)), total_mp)
+                if args.parity_check:
+                    cc = (ah // 2) * aw + aw // 2
+                    idx = [cc + ds * aw + dt for ds in (-1, 0, 1) for dt in (-1, 0, 1)]
+                    out["cpu_baseline"]["parity_vs_gpu"] = parity_vs_gpu(wl, n_h[idx], basic[idx].cpu().numpy(), ctx)
             except Exception as e:  # the baseline is a reported aside, never a reason to lose the bench line
                 out["cpu_baseline"] = {"value": None, "unit": "SAI-megapixels/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e}"}
