@@ -10,8 +10,9 @@
  *   src/bm5d_core_processing.cpp  bm5d_1st_step :90-822, bm5d_2nd_step :859-1659, transforms
  *                                 :1679-2264, 5D filters :2281-3123, weights :3140-3173,
  *                                 normalisation tables :3191-3276, block matching :3301-3945
- *   src/bm5d.cpp                  run_bm5d_1st_step :88-747, run_bm5d_2nd_step :782-1452
- *                                 (nb_threads == 1 branch only)
+ *   src/bm5d.cpp                  run_bm5d_1st_step :88-747, run_bm5d_2nd_step :782-1452: the nb_threads == 1 branch
+ *                                 (parity mode) and the OpenMP tile mode :411-708 with sub_divide / undivide_LF
+ *                                 (utilities.cpp:312-395, utilities_LF.cpp:438-515; orc_set_tiles: second CPU baseline)
  *   src/bm3d.cpp                  preProcess :1101-1169, dct_2d_inverse :1039-1071; the per-SAI BM3D of
  *                                 LFBM3Ddenoising: run_bm3d :86-300, bm3d_1st_step :315-505,
  *                                 bm3d_2nd_step :507-690, Hadamard filters :914-1027, precompute_BM :1187-1343,
@@ -34,8 +35,11 @@
  * (needs FFTW3 + libpng headers that the image lacks).  Pinned against compiled reference code:
  * Haar / Hadamard / bior1.5 / MT19937 (oracle/_ref, built from lib_transforms.cpp and mt19937ar.c).
  * Pinned against an independent implementation of the published definition: DCT-II/III (scipy).
- * Everything else (BM, SADCT, filters, schedule): restated from the source, checked against the
- * end-to-end PSNRs recorded in SURVEY.md section 6 -- "parity unpinned" for those parts.
+ * Everything else (BM, SADCT, filters, aggregation, schedule, tile mode): restated from the source -- "parity unpinned"
+ * for those parts.  What stands in for a pin there: numpy models written from the published definitions for both
+ * block-matching searches (brute-force float64 SSD), the SADCT (values on every mask) and the Haar slab filters
+ * (tests/test_oracle_pins.py), and the end-to-end PSNRs recorded in SURVEY.md section 6 (a survey-time probe that
+ * linked an FFTW stand-in: indicative, not a pin).
  *
  * Where the reference leaves behaviour unspecified the oracle fixes it (and the HIP path follows):
  *   - std::partial_sort / std::sort tie order in block matching: ties keep candidate scan order.
