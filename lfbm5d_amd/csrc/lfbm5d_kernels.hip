@@ -2315,6 +2315,8 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
     v2f* stack = reinterpret_cast<v2f*>(lds);
     float* stackf = lds;
     const TbPtr tb = (TbPtr)a.tb;
+    /* item index -> (row or column, patch): division by NP / NPh through a 32-bit reciprocal (exact for items < 2^16) */
+    const unsigned rcpNP = 0xffffffffu / (unsigned)NP + 1u, rcpNPh = 0xffffffffu / (unsigned)((NP + 1) / 2) + 1u;
 
     ShRef sh = group_shape(a, g);
     for (int i = tid; i < NP; i += TH) pos[i] = a.gpos[(size_t)g * N * A + i];
@@ -2331,7 +2333,11 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
 #pragma unroll
         for (int q = 0; q < kIt; q++) {
             const int it = tid + q * TH;
-            const int i = it / NP, patch = it - i * NP;
+#ifndef LFBM5D_W2_LOAD_ROWFAST
+            const int i = (int)__umulhi((unsigned)it, rcpNP), patch = it - i * NP;
+#else
+            const int patch = it >> 3, i = it & 7;     /* row-fastest (measured: the stack writes then conflict, 1.46 vs 1.44 ms) */
+#endif
             if (it < NP * 8) {
                 const unsigned p = pos[patch];
                 const size_t off = ((size_t)(patch % A) * a.C + c) * plane + (p != 0xffffffffu ? p : 0u) + (size_t)i * a.Wb;
@@ -2342,7 +2348,11 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
 #pragma unroll
         for (int q = 0; q < kIt; q++) {
             const int it = tid + q * TH;
-            const int i = it / NP, patch = it - i * NP;
+#ifndef LFBM5D_W2_LOAD_ROWFAST
+            const int i = (int)__umulhi((unsigned)it, rcpNP), patch = it - i * NP;
+#else
+            const int patch = it >> 3, i = it & 7;
+#endif
             if (it < NP * 8) {
                 const bool ok = pos[patch] != 0xffffffffu;     /* empty SAI / never-filled table column: zeros */
                 v2f x[8];
@@ -2362,7 +2372,7 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
     PHASE_MARK();
     /* 1b: columns, in place */
     for (int it = tid; it < NP * 8; it += TH) {
-        const int j = it / NP, patch = it - j * NP;
+        const int j = (int)__umulhi((unsigned)it, rcpNP), patch = it - j * NP;
         v2f* col = stack + j * NPp + patch;
         v2f x[8];
 #pragma unroll
@@ -2475,7 +2485,7 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
     /* 5a: inverse transform down the columns of the filtered stack (.y), two patches (pa, pa + NPh) packed, in place */
     const int NPh = (NP + 1) / 2;
     for (int it = tid; it < NPh * 8; it += TH) {
-        const int j = it / NPh, pa = it - j * NPh;
+        const int j = (int)__umulhi((unsigned)it, rcpNPh), pa = it - j * NPh;
         const int pb = pa + NPh < NP ? pa + NPh : pa;
         float* ca = stackf + 2 * (j * NPp + pa) + 1;
         float* cb = stackf + 2 * (j * NPp + pb) + 1;
@@ -2488,7 +2498,9 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
     }
     __syncthreads();
     PHASE_MARK();
-    /* 5b: inverse transform along the rows + store: filt[g][n][st][c][64] */
+    /* 5b: inverse transform along the rows + store: filt[g][n][st][c][64].  Items are numbered row-fastest: the eight
+     * lanes that hold the rows of one patch write its 256 contiguous bytes */
+#ifdef LFBM5D_W2_ROWS_PAIRED
     for (int it = tid; it < NPh * 8; it += TH) {
         const int i = it / NPh, pa = it - i * NPh;
         const int pb = pa + NPh;
@@ -2508,6 +2520,19 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
             ob[1] = make_float4(x[4].y, x[5].y, x[6].y, x[7].y);
         }
     }
+#else
+    for (int it = tid; it < NP * 8; it += TH) {
+        const int patch = it >> 3, i = it & 7;
+        const float* ra = stackf + 2 * ((i * 8) * NPp + patch) + 1;
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = ra[2 * j * NPp];
+        dct8_inv_t(x);
+        float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + patch) * a.C * K2 + (size_t)c * K2 + i * 8);
+        oa[0] = make_float4(x[0], x[1], x[2], x[3]);
+        oa[1] = make_float4(x[4], x[5], x[6], x[7]);
+    }
+#endif
 #ifdef LFBM5D_PHASE_TIMING
     PHASE_MARK();
     if (tid == 0) {
