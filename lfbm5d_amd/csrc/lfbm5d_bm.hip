@@ -19,6 +19,8 @@
 #include "lfbm5d_kernels.h"
 
 #include <type_traits>
+#include <algorithm>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -63,15 +65,15 @@ __device__ __forceinline__ int grid_index(int v, int n, int last, int nHW, int p
  * column to the next strip through `lcol`.
  */
 #ifndef LFBM5D_SCAN_DEPTH
-#define LFBM5D_SCAN_DEPTH(T) ((T) == 4 ? 7 : 4)
+#define LFBM5D_SCAN_DEPTH(T) 4   /* with two waves per SIMD a shallower pipeline suffices, and it keeps the kernel under 256 VGPRs */
 #endif
 typedef float v4f __attribute__((ext_vector_type(4)));
-template <int K, int MODE>   /* MODE 0: self search on the regular grid, 1: self search on an irregular list, 2: disparity */
+template <int K, int MODE, bool WIDE>   /* MODE 0: self search on the regular grid, 1: self search on an irregular list, 2: disparity */
 __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, float* lds) {
     /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows (+ T-1 mirror rows).  With the hand-off column,
      * the row-slot table and the straightening buffer a wave takes just under 40 KiB at 560-wide windows: four
      * waves per CU, one per SIMD */
-    constexpr int T = K >= 12 ? 4 : 8, RR = 64 + K + 2 * T, CW = 64 + K;
+    constexpr int T = 4, RR = 64 + K + 2 * T, CW = 64 + K;
     constexpr int DEP = LFBM5D_SCAN_DEPTH(T);   /* row-load pipeline depth in chunks */
     constexpr bool stereo = MODE == 2;
     constexpr bool irregular = MODE == 1;
@@ -114,7 +116,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     }
     D.W = W; D.H = H; D.b = b;
     const size_t tstride = stereo ? stereo_table_stride(a.W, a.H, a.k, a.nDisp) : 0;
-    float* table = stereo ? a.tables + (size_t)bid * tstride : nullptr;   /* [strip][row][64] */
+    float* table = stereo ? a.tables + (size_t)bid * tstride : nullptr;   /* [strip][row + lane][64]: skewed, see the store stage */
+    const int SR = nrows + 63;   /* rows of a strip in the skewed layout */
     const int djs = dj - half;
     const int nSim = half;
     const int ord_fwd = dj * Ns + di;
@@ -130,7 +133,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     const int lastR = H - (int)a.k - gN, lastC = W - (int)a.k - gN;
 
     auto emit = [&](int y, int x, float S) {
-        if (stereo) { table[((size_t)((x - b) / 64) * H + y) * 64 + (x - b) % 64] = S; return; }
+        if (stereo) { table[((size_t)((x - b) / 64) * SR + (y - b) + (x - b) % 64) * 64 + (x - b) % 64] = S; return; }
         if (irregular) { /* irregular reference list (subset path, core:3631-3788): slots come from a position map */
             const int r = a.refmap[y * W + x];
             if (r >= 0) a.scores[(size_t)r * ncand + ord_fwd] = S;
@@ -221,12 +224,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     /* regular grid: row -> reference-grid row slot (-1: none) as 16-bit entries in LDS (a global lookup per
      * step would make every step wait on vmcnt, i.e. on all the loads and stores in flight); like the global
      * table it has 64 entries of -1 padding behind row H-1 for the rows y + di of the mirrored candidate */
-    short* rs16 = reinterpret_cast<short*>(lcol + nrows + T + 1);
-    /* disparity tables: 32 rows x 64 columns in which the skewed results of the last steps are straightened
-     * out before they are stored (see the chunk's store stage); 16-byte aligned */
-    float* usk = lds + (((RR + T - 1) * CW + nrows + T + 1 + (H + 64 + 1) / 2 + 3) & ~3);
+    typedef typename std::conditional<WIDE, short, signed char>::type slot_t;   /* WIDE: more than 127 reference rows */
+    slot_t* rs16 = reinterpret_cast<slot_t*>(lcol + nrows + T + 1);
     if (MODE == 0)
-        for (int i = lane; i < H + 64; i += 64) rs16[i] = (short)a.rslot[i];
+        for (int i = lane; i < H + 64; i += 64) rs16[i] = (slot_t)a.rslot[i];
     __syncthreads();
 
     SCAN_MARK(0);
@@ -356,15 +357,13 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         float left_prev = row0_left;    /* lane 0: S[0][cb-1]; other lanes: overwritten before use */
         const int nsteps = (nrows - 1) + last_lane;
         const int lane_eff = col_ok ? lane : 0x40000000;   /* lanes past the last column are never active */
-        /* table stores: lane-constant offset (>= 0) + scalar row offset; the resource starts 64 rows above the
-         * table so that the scalar part stays non-negative during the ramp-up */
-        const __amdgpu_buffer_rsrc_t rsTb = __builtin_amdgcn_make_buffer_rsrc((void*)(table - 64 * 64), 0, (int)((tstride + 64 * 64) * 4), kRsrcFlags);
-        /* lane (g, j) of the store stage: row t0 - 16g - 14 + j/4 (+ 4h) of the strip, columns 16g + 4(j%4) .. +3; a piece
-         * that starts past the last column is dropped (columns past it inside a piece are never read back) */
-        const int ucl = -16 * (lane >> 4) - 14 + ((lane & 15) >> 2);
-        const int ucol = 16 * (lane >> 4) + 4 * (lane & 3);
-        const int uvo = ucol <= last_lane ? ((ucl + 64) * 64 + ucol) * 4 : -1;
-        int uo = ((((1 - lane) & 31) << 6) | lane) * 4;     /* byte offset in usk of (row 1+t-lane, column lane), t = 0 */
+        /* Disparity tables are stored SKEWED: the value lane l computes at step t -- row 1 + t - l of column l -- goes to
+         * row t + 1 = (table row) + l of the strip, column l.  Every step then stores one contiguous 256-byte row with a
+         * single 4-byte buffer store (lane offset constant, row offset scalar): no straightening buffer in LDS (round 1
+         * kept 8 KiB of it per wave, and its 16-byte stores are where the store-data hazard of DESIGN.md section 3 lived).
+         * The arg-min kernel reads the tables in the same skewed coordinates (it works position by position, the layout
+         * is irrelevant to it) and un-skews only its own small output. */
+        const __amdgpu_buffer_rsrc_t rsTb = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (int)(tstride * 4), kRsrcFlags);
         /* running LDS offsets (floats) of ring rows (t + K - lane) and (t - lane), column lane */
         int oA = ((K - lane + 64 * RR) % RR) * CW + lane, oB = ((64 * RR - lane) % RR) * CW + lane;
         int wrow = filled % RR;   /* a multiple of T, like RR: the T rows of a chunk never wrap inside the ring */
@@ -413,9 +412,8 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 const int t = t0 + s;
                 const bool act = EDGE ? (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2) : col_ok;
                 if (stereo) {
-                    /* lane l holds row 1+t-l: park it in the straightening buffer (row mod 32, column l) */
-                    *reinterpret_cast<float*>(reinterpret_cast<char*>(usk) + uo) = Sout[s];
-                    uo = (uo + 256) & 0x1fff;
+                    const bool on = (EDGE || TAIL) ? (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2) : col_ok;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsTb, on ? lane * 4 : -1, (strip * SR + t + 1) * 256, 0);
                 } else {
                     int v1, v2;
                     if (irregular) {   /* irregular list: whole-slot lookups (out-of-range offsets read 0, masked by act) */
@@ -426,7 +424,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                         v2 = (act && r2 >= 0) ? (int)(((unsigned)r2 * (unsigned)ncand + (unsigned)ord_bwd) * 4u) : -1;
                     } else {
                         /* rows of lanes that have not started / have finished are clamped into the table (masked by act) */
-                        const short* rp = rs16 + min(max(b + 1 + t0 - lane, 0), H - T);
+                        const slot_t* rp = rs16 + min(max(b + 1 + t0 - lane, 0), H - T);
                         const int r1 = rp[s], r2 = rp[s + di];                  /* -1: not a grid row */
                         const bool ok1 = (r1 | base_fwd) >= 0, ok2 = (r2 | base_bwd) >= 0;
                         v1 = (ok1 && (!EDGE || act)) ? r1 * row_bytes + base_fwd : -1;
@@ -440,28 +438,6 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 const int il = 1 + t - last_lane;
                 const float hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Sout[s]), last_lane));
                 lcol[(REDGE || TAIL) ? ((il >= 1 && il < nrows) ? il : nrows + T) : FL == 1 ? max(il, 0) : il] = hv;   /* ramp-up: rows < 1 land in slot 0... */
-            }
-            if (stereo) {
-                /* every 16-lane group has just completed 64-byte segments of four more rows (its last lane wrote
-                 * rows up to t0+T-1-(16g+15)+1): each lane stores one 16-byte piece of four of them.  One store
-                 * instruction per four steps, 16 cache lines touched instead of 4 x 64. */
-                typedef int v4i __attribute__((ext_vector_type(4)));
-                /* The row offset goes into the VECTOR offset and the scalar offset stays a literal 0 on purpose.  A buffer
-                 * store of more than 64 bits reads its data registers a cycle or two after it issues, and a VALU write of
-                 * those registers right behind it (here: the next piece's row index, which the register allocator likes
-                 * to put into the first data register) needs two wait states.  hipcc pads that hazard only when soffset is
-                 * NOT an SGPR (LLVM's rule: the SGPR read is supposed to cover the delay).  On gfx950 it does not always:
-                 * with other kernels resident on the CU the store of round 1 (row offset in an SGPR) stored the row index
-                 * instead of the first of its four distances for lanes 12..15 of a 16-lane group -- single dwords of a
-                 * disparity table, a few passes in ten, only with T = 8 (two pieces per chunk) and only while other
-                 * lfbm5d contexts kept the GPU busy (tools/bm_stress.py, tests/test_gpu_concurrency.py). */
-#pragma unroll
-                for (int h = 0; h < T / 4; h++) {
-                    const int urow = t0 + 4 * h + ucl;          /* table row, see ucl */
-                    const bool rv = (unsigned)(urow - 1) <= (unsigned)(nrows - 2);
-                    const v4f val = *reinterpret_cast<const v4f*>(usk + ((urow & 31) << 6) + ucol);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, val), rsTb, (rv && uvo >= 0) ? uvo + (strip * H + b + t0 + 4 * h) * 256 : -1, 0, 0);
-                }
             }
             if (!TAIL) {
                 write_chunk(std::integral_constant<bool, REDGE>{}, filled, wrow, sa1, sa2, sb1, sb2);
@@ -493,7 +469,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             SCAN_MARK(3);
             for (; t0 < tS1; t0 += G) group(std::integral_constant<int, 0>{}, t0);
             SCAN_MARK(4);
-            const int t_end = nsteps + (stereo ? 16 : 0);   /* + the chunks that flush the store stage */
+            const int t_end = nsteps;
             if (stereo) {
                 /* a disparity table never reads past the band (nrows = band_rows - K + 1): once the band is in the ring and
                  * the last lane has started, the rest of the ramp-down needs neither loads nor ring writes */
@@ -515,15 +491,21 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
 #endif
 }
 
-template <int K>
-__global__ __launch_bounds__(64) void k_bm_scan(ScanArgs a) {
+/* Two waves per SIMD: the scan is issue-bound with long dependent chains (0.61 of a lone wave's cycles issue), so a
+ * second wave on the SIMD is worth a quarter of the kernel's time -- if it fits: 256 VGPRs (round 1 used 298) and an
+ * LDS footprint of at most a sixth of the CU's 160 KiB (round 1: 40 KiB, a quarter). */
+#ifndef LFBM5D_SCAN_WAVES_ATTR
+#define LFBM5D_SCAN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+template <int K, bool WIDE>
+__global__ __launch_bounds__(64) LFBM5D_SCAN_WAVES_ATTR void k_bm_scan(ScanArgs a) {
     extern __shared__ float lds[];
     /* one launch covers both searches: blocks [0, n_self) are self-similarity tables, the rest
      * disparity tables (fewer, fuller rounds of resident waves than two launches; dispatching the disparity tables first,
      * or one self table per two disparity tables, measured 9 % slower: 2.98 / 2.99 vs 2.75 ms of block matching per pass) */
-    if (blockIdx.x >= a.n_self) scan_body<K, 2>(a, (int)(blockIdx.x - a.n_self), lds);
-    else if (a.refmap) scan_body<K, 1>(a, (int)blockIdx.x, lds);
-    else scan_body<K, 0>(a, (int)blockIdx.x, lds);
+    if (blockIdx.x >= a.n_self) scan_body<K, 2, WIDE>(a, (int)(blockIdx.x - a.n_self), lds);
+    else if (a.refmap) scan_body<K, 1, WIDE>(a, (int)blockIdx.x, lds);
+    else scan_body<K, 0, WIDE>(a, (int)blockIdx.x, lds);
 }
 
 /* order-preserving float -> uint map (scores can be slightly negative after cancellation) */
@@ -646,18 +628,21 @@ __global__ void k_self_trivial(const unsigned* __restrict__ refs, unsigned n_ref
  * (dj outer, di inner), the order the reference pushes candidates in.  grid.y = table slot. */
 struct ArgminArgs { const float* tables; size_t tstride; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp; float thr; unsigned* best; unsigned char* shape; };
 __global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
-    /* a thread takes four consecutive columns of one row (one 16-byte load per table: the tables are strip-major with
-     * 64-column strips, so groups of four never straddle a strip), eight tables in flight */
+    /* The tables are skewed (scan kernel, store stage): entry [strip][q][l] holds table row q - l of column 64 strip + l.
+     * A thread takes four consecutive lanes l0 .. l0+3 of one skewed row q (one 16-byte load per table), eight tables in
+     * flight; the arg-min is taken position by position, so the skew only matters when the result is written. */
     const int W = a.W, H = a.H, nDisp = a.nDisp;
     const int span_c = W - 2 * nDisp - a.k + 1, span_r = H - 2 * nDisp - a.k + 1;
-    const int quads = (span_c + 3) / 4;
+    const int SR = span_r + 63, nstrips = (span_c + 63) / 64;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= quads * span_r) return;
+    if (i >= nstrips * SR * 16) return;
     const unsigned slot = blockIdx.y, st = a.st_of_slot[slot];
-    const int y = nDisp + i / quads, x0 = 4 * (i % quads);            /* x0: column inside the band */
+    const int l0 = 4 * (i & 15), q = (i >> 4) % SR, strip = (i >> 4) / SR;
+    /* rows of the four entries: q - l0 - e; all outside the table -> nothing to do (the corners of the skew) */
+    if (q - l0 < 0 || q - l0 - 3 >= span_r) return;
     const int Ns = 2 * nDisp + 1, ncand = Ns * Ns;
     const size_t WH = (size_t)W * H;
-    const float* t = a.tables + (size_t)slot * ncand * a.tstride + ((size_t)(x0 / 64) * H + y) * 64 + x0 % 64;
+    const float* t = a.tables + (size_t)slot * ncand * a.tstride + ((size_t)strip * SR + q) * 64 + l0;
     typedef float f4 __attribute__((ext_vector_type(4)));
     float bv[4]; int bo[4], bd[4];
     {
@@ -683,8 +668,9 @@ __global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
     }
 #pragma unroll
     for (int e = 0; e < 4; e++) {
-        if (x0 + e >= span_c) break;                                    /* the band's last group may be short */
-        const int pos = y * W + nDisp + x0 + e;
+        const int r = q - l0 - e, col = 64 * strip + l0 + e;
+        if (r < 0 || r >= span_r || col >= span_c) continue;            /* entries never written hold garbage */
+        const int pos = (nDisp + r) * W + nDisp + col;
         const int di = bd[e] / Ns, dj = bd[e] % Ns;
         a.best[(size_t)st * WH + pos] = (unsigned)(pos + (di - nDisp) * W + (dj - nDisp));
         a.shape[(size_t)st * WH + pos] = bv[e] < a.thr ? 1 : 0;
@@ -706,18 +692,24 @@ hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, i
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
     const unsigned rows_self = a.n_self ? a.H - 2 * a.nHW : 0, rows_st = a.n_stereo ? a.H - 2 * a.nDisp - (a.k - 1) : 0;
     const unsigned nrows = rows_self > rows_st ? rows_self : rows_st;
-    const unsigned T = a.k >= 12 ? 4 : 8;
-    const size_t lds = (size_t)((64 + a.k + 2 * T + T - 1) * (64 + a.k) + nrows + T + 1) * sizeof(float)
-                     + (size_t)(a.H + 64 + 8) * sizeof(short)        /* row-slot table of the regular grid (+ alignment) */
-                     + (a.n_stereo ? 32 * 64 * sizeof(float) : 0);    /* straightening buffer of the disparity tables */
+    const unsigned T = 4;
+    const bool wide = a.n_ref_rows > 127;   /* row-slot table entries: bytes unless the grid has more than 127 rows */
+    size_t lds = (size_t)((64 + a.k + 2 * T + T - 1) * (64 + a.k) + nrows + T + 1) * sizeof(float)
+               + (a.n_self && !a.refmap ? (size_t)(a.H + 64 + 8) * (wide ? 2 : 1) : 0);     /* row-slot table of the regular grid (+ alignment) */
     const unsigned n = a.n_self + a.n_stereo;
     if (!n) return hipSuccess;
+#ifdef LFBM5D_SCAN_LDS_EXPERIMENT   /* development builds: timing at a smaller LDS footprint (results are garbage) */
+    if (const char* cap = getenv("LFBM5D_SCAN_LDS_CAP")) lds = std::min<size_t>(lds, (size_t)atoi(cap));
+#endif
+#define LFBM5D_SCAN(K_) do { if (wide) hipLaunchKernelGGL((k_bm_scan<K_, true>), dim3(n), dim3(64), lds, s, a); \
+                             else      hipLaunchKernelGGL((k_bm_scan<K_, false>), dim3(n), dim3(64), lds, s, a); } while (0)
     switch (a.k) {
-        case 8:  hipLaunchKernelGGL(k_bm_scan<8>,  dim3(n), dim3(64), lds, s, a); break;
-        case 12: hipLaunchKernelGGL(k_bm_scan<12>, dim3(n), dim3(64), lds, s, a); break;
-        case 16: hipLaunchKernelGGL(k_bm_scan<16>, dim3(n), dim3(64), lds, s, a); break;
+        case 8:  LFBM5D_SCAN(8); break;
+        case 12: LFBM5D_SCAN(12); break;
+        case 16: LFBM5D_SCAN(16); break;
         default: return hipErrorInvalidValue;
     }
+#undef LFBM5D_SCAN
     return hipGetLastError();
 }
 
@@ -739,7 +731,8 @@ hipError_t launch_self_trivial(hipStream_t s, const unsigned* refs, unsigned n_r
 hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,
                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
                                 unsigned* best, unsigned char* shape) {
-    const unsigned n = ((W - 2 * nDisp - k + 1 + 3) / 4) * (H - 2 * nDisp - k + 1);   /* groups of four columns */
+    const unsigned span_c = W - 2 * nDisp - k + 1, span_r = H - 2 * nDisp - k + 1;
+    const unsigned n = ((span_c + 63) / 64) * (span_r + 63) * 16;   /* groups of four lanes of every skewed row */
     ArgminArgs a;
     a.tables = tables; a.tstride = stereo_table_stride(W, H, k, nDisp); a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.thr = thr; a.best = best; a.shape = shape;
     for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];

@@ -96,11 +96,12 @@ struct AggArgs {
     unsigned wchan0;            /* every channel uses channel 0's group weight (sd_weighting of bm3d.cpp:1345-1373) */
 };
 
-/* Disparity score tables are laid out strip-major -- [strip of 64 columns][row][64] -- so that the
- * scan kernel, which walks one strip top to bottom, writes one contiguous stream per table. */
+/* Disparity score tables are laid out strip-major and SKEWED -- [strip of 64 columns][table row + lane][64] -- so that
+ * the scan kernel, whose lane l works on a row l steps behind lane 0's, writes the 64 values of a step as one contiguous
+ * 256-byte row, one contiguous stream per table.  A strip has nrows + 63 such rows (the corners hold nothing). */
 __host__ __device__ inline size_t stereo_table_stride(unsigned W, unsigned H, unsigned k, unsigned nDisp) {
-    const unsigned ncols = W - 2 * nDisp - (k - 1);
-    return (size_t)((ncols + 63) / 64) * 64 * H;
+    const unsigned ncols = W - 2 * nDisp - (k - 1), nrows = H - 2 * nDisp - (k - 1);
+    return (size_t)((ncols + 63) / 64) * 64 * (nrows + 63);
 }
 
 struct ScanArgs {
