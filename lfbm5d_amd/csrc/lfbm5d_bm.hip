@@ -73,7 +73,10 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
     /* T steps per chunk; the ring holds 63 (skew) + K + 2T + 1 rows (+ T-1 mirror rows).  With the hand-off column,
      * the row-slot table and the straightening buffer a wave takes just under 40 KiB at 560-wide windows: four
      * waves per CU, one per SIMD */
-    constexpr int T = 4, RR = 64 + K + 2 * T, CW = 64 + K;
+    /* FIFO: the operands of the band's upper edge (rows t - lane) are the lower edge's of K steps ago, kept in 2K registers
+     * instead of K more ring rows -- half the ring reads and a ring of 64 + 2T rows (the pipeline depth must be a multiple of K) */
+    constexpr bool FIFO = K == 8 || K == 16;
+    constexpr int T = 4, RR = FIFO ? 64 + 2 * T : 64 + K + 2 * T, CW = 64 + K;
     constexpr int DEP = LFBM5D_SCAN_DEPTH(T);   /* row-load pipeline depth in chunks */
     constexpr bool stereo = MODE == 2;
     constexpr bool irregular = MODE == 1;
@@ -88,6 +91,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
      * 4-byte load for the REM <= 64 entries left. */
     constexpr int E = T * CW, NA = E / 256, REM = E - 256 * NA;
     static_assert(CW % 4 == 0 && REM >= 0 && REM <= 64 && RR % T == 0 && (K + T) % T == 0, "chunk geometry");
+    static_assert(!FIFO || (DEP * T) % K == 0, "the register FIFO rotates once per group of chunks");
     int qrow[NA], qcol[NA];
 #pragma unroll
     for (int q = 0; q < NA; q++) { qrow[q] = (256 * q + 4 * lane) / CW; qcol[q] = (256 * q + 4 * lane) % CW; }
@@ -353,6 +357,14 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
          * Inactive lanes compute on garbage that no active lane ever reads.  Ring rows are addressed through
          * running pointers (mirror rows make T consecutive rows wrap-free); chunks are issued in pairs with
          * the two sets of staging registers swapped instead of copied. */
+        float F1[FIFO ? K : 1], F2[FIFO ? K : 1];   /* D[t - lane][lane + K], D[t - lane][lane] of the next K steps */
+        if (FIFO) {
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                const int row = max(m - lane, 0);   /* rows 0 .. K-1 are in the ring; lanes that start later read garbage-free junk */
+                F1[m] = ring[row * CW + lane + K]; F2[m] = ring[row * CW + lane];
+            }
+        }
         float curS = S0;
         float left_prev = row0_left;    /* lane 0: S[0][cb-1]; other lanes: overwritten before use */
         const int nsteps = (nrows - 1) + last_lane;
@@ -367,7 +379,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         /* running LDS offsets (floats) of ring rows (t + K - lane) and (t - lane), column lane */
         int oA = ((K - lane + 64 * RR) % RR) * CW + lane, oB = ((64 * RR - lane) % RR) * CW + lane;
         int wrow = filled % RR;   /* a multiple of T, like RR: the T rows of a chunk never wrap inside the ring */
-        auto chunk = [&](auto edge_tag, int t0,
+        auto chunk = [&](auto edge_tag, int t0, const int jj,   /* jj: index of the chunk in its group (a constant after unrolling) */
                          v4f* la1, v4f* la2, float& lb1, float& lb2,                   /* receive rows filled+(DEP-1)T .. */
                          const v4f* sa1, const v4f* sa2, float sb1, float sb2) {       /* rows filled .. go to the ring */
             /* flavour 0: steady; 1: ramp-up (lanes start one after the other, every row and index still in range);
@@ -385,11 +397,15 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 d1[s] = pa[s * CW + K]; d2[s] = pa[s * CW];
-                d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW];
+                if (FIFO) {
+                    const int slot = (jj * T + s) % K;
+                    d3[s] = F1[slot]; d4[s] = F2[slot];
+                    F1[slot] = d1[s]; F2[slot] = d2[s];
+                } else { d3[s] = pb[s * CW + K]; d4[s] = pb[s * CW]; }
                 lc[s] = lcol[(REDGE || TAIL) ? min(1 + t0 + s, nrows + T) : 1 + t0 + s];   /* uniform address: lane 0's left neighbour */
             }
             oA += T * CW; oA = oA >= RR * CW ? oA - RR * CW : oA;
-            oB += T * CW; oB = oB >= RR * CW ? oB - RR * CW : oB;
+            if (!FIFO) { oB += T * CW; oB = oB >= RR * CW ? oB - RR * CW : oB; }
 #pragma unroll
             for (int s = 0; s < T; s++) {
                 if (EDGE) curS = (lane_eff == t0 + s) ? S0 : curS;      /* becomes active: start from its row-0 value */
@@ -460,7 +476,7 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             auto group = [&](auto tag, int tg) {
 #pragma unroll
                 for (int j = 0; j < DEP; j++)
-                    chunk(tag, tg + j * T, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
+                    chunk(tag, tg + j * T, j, A1[(j + DEP - 1) % DEP], A2[(j + DEP - 1) % DEP], Bq1[(j + DEP - 1) % DEP], Bq2[(j + DEP - 1) % DEP],
                           A1[j], A2[j], Bq1[j], Bq2[j]);
             };
             SCAN_MARK(2);
@@ -694,7 +710,8 @@ hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
     const unsigned nrows = rows_self > rows_st ? rows_self : rows_st;
     const unsigned T = 4;
     const bool wide = a.n_ref_rows > 127;   /* row-slot table entries: bytes unless the grid has more than 127 rows */
-    size_t lds = (size_t)((64 + a.k + 2 * T + T - 1) * (64 + a.k) + nrows + T + 1) * sizeof(float)
+    const unsigned ring_rows = (a.k == 8 || a.k == 16) ? 64 + 2 * T : 64 + a.k + 2 * T;   /* scan_body: FIFO */
+    size_t lds = (size_t)((ring_rows + T - 1) * (64 + a.k) + nrows + T + 1) * sizeof(float)
                + (a.n_self && !a.refmap ? (size_t)(a.H + 64 + 8) * (wide ? 2 : 1) : 0);     /* row-slot table of the regular grid (+ alignment) */
     const unsigned n = a.n_self + a.n_stereo;
     if (!n) return hipSuccess;
