@@ -1031,6 +1031,15 @@ __device__ __forceinline__ ShRef group_shape(const GroupArgs& a, unsigned g) {
 /* One (group, channel) of the generic path.  S0 / S1: the group's stack(s) [n][st][pq] -- in LDS (k_group) or, when the
  * stacks do not fit the 160 KiB, in a per-workgroup slice of an HBM scratch buffer (k_group_big); tmp: the 2-D stage's
  * LDS work area.  Any patch size, any transform combination, 3x3 and 5x5 angular windows. */
+/* XCD-aware group numbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with an L2 of its
+ * own), so workgroup b takes group (b % 8) * per_xcd + b / 8: an XCD works its way through a contiguous band of reference
+ * patches and its L2 fetches that band's window rows once instead of every XCD fetching every row.  The launch rounds
+ * grid.x up to 8 * per_xcd; indices past the last group return. */
+__device__ __forceinline__ unsigned xcd_group_index(const GroupArgs& a) {
+    const unsigned per_xcd = (a.n_groups + 7) / 8;
+    return (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+}
+
 template <int STEP>
 __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned g, const int c, float* S0, float* S1, float* tmp,
                                               unsigned* pos, float (*red)[kThreads / 64]) {
@@ -1354,7 +1363,9 @@ template <bool HAAR>
 __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
     __shared__ float red[3][4];
     const int tid = threadIdx.x;
-    const unsigned g = a.ref_begin + blockIdx.x;
+    const unsigned gi = xcd_group_index(a);
+    if (gi >= a.n_groups) return;
+    const unsigned g = a.ref_begin + gi;
     const int c = blockIdx.y;
     const int A = 9, N = a.N;
     const int nSx = (int)a.self_cnt[g];
@@ -2304,7 +2315,9 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
     __shared__ unsigned pos[kMaxN * kA3];
     constexpr int TH = kDct8w2Threads;
     const int tid = threadIdx.x;
-    const unsigned g = a.ref_begin + blockIdx.x;
+    const unsigned gi = xcd_group_index(a);
+    if (gi >= a.n_groups) return;
+    const unsigned g = a.ref_begin + gi;
     const int c = blockIdx.y;
     constexpr int A = 9, K2 = 64;
     const int N = a.N;
@@ -2987,8 +3000,9 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     if (generic_only) {}
     else if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9) {
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
-        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
-        else             hipLaunchKernelGGL(k_group_id_any, dim3(a.n_groups, a.C), dim3(threads), 0, s, a);
+        const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
+        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(gx, a.C), dim3(threads), 0, s, a);
+        else             hipLaunchKernelGGL(k_group_id_any, dim3(gx, a.C), dim3(threads), 0, s, a);
         return hipGetLastError();
     }
     else if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
@@ -3019,8 +3033,9 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     else if (a.tau2 == 5 && a.k == 8 && a.A == 9 && a.N <= (unsigned)kMaxN) {   /* 8x8 DCT: one thread per patch for the 2-D stage */
         const size_t l8 = (size_t)(a.step == 2 ? 2 : 1) * 64 * ((a.N * 9) | 1) * sizeof(float);
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR") && !getenv("LFBM5D_DCT8W_V1")) {   /* packed noisy/pilot pair, 2-D stages dealt to all threads */
-            if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w2<true>), dim3(a.n_groups, a.C), dim3(kDct8w2Threads), l8, s, a);
-            else             hipLaunchKernelGGL((k_group_dct8w2<false>), dim3(a.n_groups, a.C), dim3(kDct8w2Threads), l8, s, a);
+            const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
+            if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w2<true>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);
+            else             hipLaunchKernelGGL((k_group_dct8w2<false>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);
             return hipGetLastError();
         }
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR")) {   /* round 1's packed kernel (one thread per patch in the 2-D stages) */
