@@ -893,8 +893,11 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     if (graph_mode) {
         const size_t NW = G.plan.size();
         const bool emulate = emu > 1;
-        const int lanes_per_rank = emulate ? 1 : n_lanes;
-        const size_t need_ctx = emulate ? (size_t)emu - 1 : (size_t)n_lanes - 1;
+        /* lanes the schedule actually uses (a 3x3 light field is one window: no extra lane, no extra buffers) */
+        int lanes_used = 1;
+        for (size_t w = 0; w < NW; w++) lanes_used = std::max(lanes_used, G.lane[w] + 1);
+        const int lanes_per_rank = emulate ? 1 : lanes_used;
+        const size_t need_ctx = emulate ? (size_t)emu - 1 : (size_t)lanes_used - 1;
         while (c->lanes.size() < need_ctx) {
             std::string e;
             lfbm5d_ctx* x = new_ctx(c->device, e);
