@@ -183,6 +183,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 3)")
     ap.add_argument("--noise", default="mt19937", choices=["mt19937", "torch"],
                     help="mt19937: the reference's noise stream, seed 1 (default); torch: quick GPU noise for kernel iteration")
+    ap.add_argument("--watchdog-s", type=int, default=1500,
+                    help="several GPUs: print an error line and exit if the run has not finished after this many seconds "
+                         "(the RCCL exchange of the window graph has never run between real ranks: a hang should not be silent)")
     ap.add_argument("--sharding", default="graph", choices=["graph", "rows", "blocks"],
                     help="multi-GPU step scheme: graph = windows as a dependency graph, chains of windows per rank, one message per SAI "
                          "between ranks (default; bit-identical to one GPU); rows = row-sharded passes (exact); blocks = round 1's "
@@ -209,7 +212,18 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
+        import threading
         import torch.distributed as dist
+
+        def _give_up():
+            if rank == 0:
+                print(json.dumps({"metric": "SAI-megapixels/sec (HT+Wiener, sigma=25)", "value": None, "unit": "SAI-megapixels/s",
+                                  "n_gpus": world, "error": f"no result after {args.watchdog_s} s with --sharding {args.sharding}: "
+                                  "the multi-GPU exchange did not complete"}), flush=True)
+            os._exit(3)
+        wd = threading.Timer(args.watchdog_s, _give_up)
+        wd.daemon = True
+        wd.start()
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     wl = WORKLOADS[args.workload]

@@ -976,7 +976,9 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             /* the messages this window's result feeds, in the order every rank issues them */
             for (; xi < G.xfers.size() && G.xfers[xi].from_w == w; xi++) {
                 const StepGraph::Xfer& X = G.xfers[xi];
-                const int ra = r, rb = G.rank[X.to_w], ch = X.channel;
+                /* one channel when the second communicator could not be created: two streams on one communicator would
+                 * break the common issue order the exchange relies on */
+                const int ra = r, rb = G.rank[X.to_w], ch = (emulate || c->comm2) ? X.channel : 0;
                 RankState* Sa = local(ra); RankState* Sb = local(rb);
                 const size_t j = (size_t)(std::find(G.sai[w].begin(), G.sai[w].end(), X.sai) - G.sai[w].begin());
                 const size_t off = (size_t)X.sai * img;
