@@ -200,7 +200,9 @@ int lfbm5d_bm3d_step_device(lfbm5d_ctx* ctx, int step, const lfbm5d_bm3d_params*
                             unsigned C, const float* d_noisy, const float* d_basic, float* d_out);
 /* == run_bm3d_LF (src/bm3d_LF.h:10-35; run_bm3d src/bm3d.h:11-34 with nb_threads == 1 for every SAI of the mask).
  * Buffers [asize][C*H*W]; d_noisy is colour-transformed at entry and back at exit like the reference mutates
- * LF_noisy (bm3d.cpp:115, :290); d_basic and d_denoised are outputs (RGB).  nHard must equal nWien. */
+ * LF_noisy (bm3d.cpp:115, :290); d_basic and d_denoised are outputs (RGB).  nHard != nWien reproduces the reference's
+ * crop of the second step at offset nWien of the nHard-padded image (bm3d.cpp:181-189: a shifted picture); nWien <= nHard
+ * (beyond that the reference itself returns 0 / 0 in the border). */
 int lfbm5d_bm3d_lf_device(lfbm5d_ctx* ctx, const lfbm5d_bm3d_params* hard, const lfbm5d_bm3d_params* wien,
                           float* d_noisy, const unsigned* h_mask, float* d_basic, float* d_denoised,
                           unsigned asize, unsigned W, unsigned H, unsigned C);

@@ -199,10 +199,11 @@ void build_tables(GroupTables& t, unsigned k, unsigned aw, unsigned ah) {
         for (unsigned i = 1; i < n; i++) { t.cn1[n][i] = c1; t.cni1[n][i] = 1.0f; }
         t.c1inv[n] = 0.5f * (float)kSqrt2Inv / std::sqrt((float)n);
     }
-    for (unsigned l = 0; l < 5; l++) {
+    for (unsigned l = 0; l < 6; l++) {
         const unsigned n = 1u << l;
+        float* ct = l < 5 ? t.cos5[l] : t.cos5x;
         for (unsigned uu = 0; uu < n; uu++)
-            for (unsigned j = 0; j < n; j++) t.cos5[l][uu * n + j] = (float)std::cos(kPi * (j + 0.5) * uu / n);
+            for (unsigned j = 0; j < n; j++) ct[uu * n + j] = (float)std::cos(kPi * (j + 0.5) * uu / n);
         const float c5 = (float)((float)kSqrt2 / std::sqrt((double)n));
         t.cn5_0[l] = (float)(kSqrt2Inv * c5); t.cn5[l] = c5;
         t.c5inv[l] = 0.5f * (float)kSqrt2Inv / std::sqrt((float)n);
@@ -237,7 +238,6 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
     if (P->tau_4D != LFBM5D_ID && P->tau_4D != LFBM5D_DCT && P->tau_4D != LFBM5D_SADCT) return fail(c, "bad tau_4D");
     if (P->tau_5D != LFBM5D_HAAR && P->tau_5D != LFBM5D_HADAMARD && P->tau_5D != LFBM5D_DCT) return fail(c, "bad tau_5D");
     if (!is_pow2(P->N) || P->N > (unsigned)kMaxN3) return fail(c, "unsupported: N must be a power of two <= 32");
-    if (P->N > (unsigned)kMaxN && P->tau_5D == LFBM5D_DCT) return fail(c, "unsupported: tau_5D = dct needs N <= 16");
     if (P->nSim < 1 || P->nDisp < 1 || P->p < 1) return fail(c, "bad search window / step");
     /* kernel limits: the row-slot tables carry 64 entries of padding for rows y + di, di <= nSim; candidate
      * indices are divided by 2 nSim + 1 with a 20-bit reciprocal; displacement tables are (2 nDisp + 1)^2 per SAI */
@@ -1467,8 +1467,11 @@ int bm3d_fold(lfbm5d_ctx* c, const lfbm5d_bm3d_params* B, unsigned C, int step) 
 /* run_bm3d_LF (bm3d_LF.cpp:75-125) -> run_bm3d (bm3d.cpp:86-300, nb_threads == 1) on device-resident buffers */
 int run_bm3d_lf(lfbm5d_ctx* c, const lfbm5d_bm3d_params* Hd, const lfbm5d_bm3d_params* Wn, float* d_noisy, const unsigned* h_mask,
                 float* d_basic, float* d_denoised, unsigned asize, unsigned W, unsigned H, unsigned C) {
-    if (Hd->nHW != Wn->nHW)   /* the reference pads both steps by nHard but crops the second by nWien (bm3d.cpp:126-189) */
-        return fail(c, "unsupported: BM3D needs nHard == nWien (the reference's crop is only right then)");
+    /* the reference pads both steps by nHard, searches the second within nWien and crops it at offset nWien of the nHard-padded
+     * image (bm3d.cpp:126-189): a shifted picture unless the two are equal -- reproduced as is for nWien <= nHard.  With
+     * nWien > nHard the crop reaches rows and columns the second step never aggregates into, which the reference returns
+     * as 0 / 0: no result to reproduce */
+    if (Wn->nHW > Hd->nHW) return fail(c, "unsupported: BM3D with nWien > nHard (the reference's own result is undefined there: 0 / 0 in the cropped border)");
     if (Hd->color_space != Wn->color_space || Hd->sigma != Wn->sigma) return fail(c, "BM3D: both steps share sigma and colour space");
     hipStream_t s = c->stream;
     const unsigned nP = Hd->nHW, Wb = W + 2 * nP, Hb = H + 2 * nP;
@@ -1486,7 +1489,7 @@ int run_bm3d_lf(lfbm5d_ctx* c, const lfbm5d_bm3d_params* Hd, const lfbm5d_bm3d_p
         HIPCK(c, launch_unsymetrize(s, basic, wo, W, H, C, nP));
         HIPCK(c, launch_symetrize(s, basic, wb, W, H, C, nP));
         if (bm3d_step(c, 2, Wn, Wb, Hb, C, wn, wb, wo)) return 1;
-        HIPCK(c, launch_unsymetrize(s, deno, wo, W, H, C, nP));
+        HIPCK(c, launch_crop(s, deno, wo, W, H, C, nP, Wn->nHW));
         if (C == 3) {
             HIPCK(c, launch_color(s, deno, Hd->color_space, W * H, 0));
             HIPCK(c, launch_color(s, noisy, Hd->color_space, W * H, 0));

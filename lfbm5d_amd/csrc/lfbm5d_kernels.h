@@ -34,8 +34,9 @@ struct GroupTables {
     float cni1[kMaxAw + 1][kMaxAw];
     float c1inv[kMaxAw + 1];    /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
     float cos5[5][256];         /* 5th-dimension DCT: cos(pi (j+1/2) u / n) at [log2 n][u*n + j], n = 1..16 */
-    float cn5_0[5], cn5[5];     /* coef_norm of preProcess_5d (core:3262-3276) */
-    float c5inv[5];             /* 0.5 * SQRT2_INV / sqrt(n) (core:2591) */
+    float cos5x[1024];          /* ... and for n = 32 (generic kernel only) */
+    float cn5_0[6], cn5[6];     /* coef_norm of preProcess_5d (core:3262-3276), [log2 n] */
+    float c5inv[6];             /* 0.5 * SQRT2_INV / sqrt(n) (core:2591) */
     float lpd[10], hpd[10], lpr[10], hpr[10];
     float coef2inv;             /* 1 / (2k)                       (bm3d.cpp:1064) */
     float coef4inv;             /* 1 / (2 sqrt(aw) sqrt(ah))      (core:1945)     */
@@ -133,6 +134,8 @@ hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigne
                             unsigned C, unsigned N);
 hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsigned W, unsigned H,
                               unsigned C, unsigned N);
+/* W x H crop at offset (off, off) of an image padded by N (off == N: unsymetrize) */
+hipError_t launch_crop(hipStream_t s, float* dst, const float* src, unsigned W, unsigned H, unsigned C, unsigned N, unsigned off);
 /* est = den ? num/den : sub on `n` elements */
 hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub,
                            float* est, size_t n);

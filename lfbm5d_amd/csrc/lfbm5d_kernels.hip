@@ -73,13 +73,14 @@ __global__ void k_symetrize(const float* __restrict__ src, float* __restrict__ d
     dst[i] = src[(size_t)c * W * H + (size_t)y * W + x];
 }
 
-__global__ void k_unsymetrize(float* __restrict__ dst, const float* __restrict__ src, int W, int H, int C, int N) {
+__global__ void k_unsymetrize(float* __restrict__ dst, const float* __restrict__ src, int W, int H, int C, int N, int off) {
+    /* N: padding of src; off: offset of the crop (== N except for the reference's BM3D second-step crop, bm3d.cpp:181-189) */
     const int w = W + 2 * N, h = H + 2 * N;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)W * H * C) return;
     const int c = (int)(i / ((size_t)W * H));
     const int r = (int)(i % ((size_t)W * H));
-    dst[i] = src[(size_t)c * w * h + (size_t)(r / W + N) * w + r % W + N];
+    dst[i] = src[(size_t)c * w * h + (size_t)(r / W + off) * w + r % W + off];
 }
 
 /* the same for all SAIs of an angular window in one launch: blockIdx.y = window slot, L.st[slot] = SAI
@@ -502,9 +503,9 @@ template <int NS> __device__ __forceinline__ void hadamard(float* v) {
  * HT: core:2408-2505 / :2281-2391; Wiener: core:2826-2925 / :2706-2810. */
 /* 5th-dimension DCT of a fibre (tau_5D = dct): REDFT10 * coef_norm / coef_norm_inv * REDFT01 * coef
  * (core:2546-2593, norms preProcess_5d core:3262-3276) */
-template <int NS> __device__ __forceinline__ int log2c() { return NS == 1 ? 0 : NS == 2 ? 1 : NS == 4 ? 2 : NS == 8 ? 3 : 4; }
+template <int NS> __device__ __forceinline__ int log2c() { return NS == 1 ? 0 : NS == 2 ? 1 : NS == 4 ? 2 : NS == 8 ? 3 : NS == 16 ? 4 : 5; }
 template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, TbPtr tb) {
-    TbFloats ct = tb->cos5[log2c<NS>()];
+    TbFloats ct = NS == 32 ? tb->cos5x : tb->cos5[NS == 32 ? 0 : log2c<NS>()];
     float y[NS];
 #pragma unroll
     for (int u = 0; u < NS; u++) {
@@ -517,7 +518,7 @@ template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, TbPtr tb) {
     for (int u = 0; u < NS; u++) v[u] = y[u];
 }
 template <int NS> __device__ __forceinline__ void dct5_inv(float* v, TbPtr tb) {
-    TbFloats ct = tb->cos5[log2c<NS>()];
+    TbFloats ct = NS == 32 ? tb->cos5x : tb->cos5[NS == 32 ? 0 : log2c<NS>()];
     float y[NS];
     const float x0 = v[0] * 1.41421356237309505f;   /* coef_norm_inv[0] = sqrt2, others 1 */
 #pragma unroll
@@ -1134,7 +1135,7 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
                 case 4:  filter5<4, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
                 case 8:  filter5<8, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
                 case 16: filter5<16, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
-                default: filter5<32, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;   /* never with tau_5D = dct (validated) */
+                default: filter5<32, STEP>(S0, S1, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;   
             }
         }
     }
@@ -2897,8 +2898,12 @@ hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigne
     hipLaunchKernelGGL(k_symetrize, grid1d((size_t)(W + 2 * N) * (H + 2 * N) * C), dim3(256), 0, s, src, dst, (int)W, (int)H, (int)C, (int)N);
     return hipGetLastError();
 }
+hipError_t launch_crop(hipStream_t s, float* dst, const float* src, unsigned W, unsigned H, unsigned C, unsigned N, unsigned off) {
+    hipLaunchKernelGGL(k_unsymetrize, grid1d((size_t)W * H * C), dim3(256), 0, s, dst, src, (int)W, (int)H, (int)C, (int)N, (int)off);
+    return hipGetLastError();
+}
 hipError_t launch_unsymetrize(hipStream_t s, float* dst, const float* src, unsigned W, unsigned H, unsigned C, unsigned N) {
-    hipLaunchKernelGGL(k_unsymetrize, grid1d((size_t)W * H * C), dim3(256), 0, s, dst, src, (int)W, (int)H, (int)C, (int)N);
+    hipLaunchKernelGGL(k_unsymetrize, grid1d((size_t)W * H * C), dim3(256), 0, s, dst, src, (int)W, (int)H, (int)C, (int)N, (int)N);
     return hipGetLastError();
 }
 hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,

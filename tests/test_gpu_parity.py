@@ -69,6 +69,8 @@ PASS_CASES = [
     ("wien-bior-n8-hw", 2, 25.0, (8, 6, 2, 8, 3, "bior", "dct", "hw"), 64, 0),
     ("wien-n32", 2, 10.0, (32, 8, 2, 8, 4, "dct", "sadct", "haar"), 64, 0),             # N = 32: generic group kernel
     ("ht-n32-hw", 1, 10.0, (32, 8, 2, 8, 4, "bior", "sadct", "hw"), 64, 0),
+    ("ht-n32-dct5", 1, 10.0, (32, 8, 2, 8, 4, "bior", "sadct", "dct"), 64, 0),          # 32-point DCT along the stack
+    ("wien-n32-dct5", 2, 10.0, (32, 8, 2, 8, 4, "dct", "sadct", "dct"), 64, 0),
     ("ht-n1-p5-bior", 1, 10.0, (1, 16, 3, 16, 5, "bior", "sadct", "haar"), 104, 0),     # README.md:76 (faster EPFL parameters)
     ("wien-n8-p5", 2, 10.0, (8, 16, 3, 8, 5, "dct", "sadct", "haar"), 104, 0),
     ("ht-usesd", 1, 25.0, (4, 6, 2, 8, 3, "id", "sadct", "haar"), 64, 1),
@@ -732,9 +734,27 @@ def test_bm3d_rejects_what_is_not_built(ctx):
     with pytest.raises(core.LfBm5dError, match="dct or bior"):
         ctx.bm3d_step(1, core.make_bm3d_params(25, 2.7, 8, 8, 8, 3, "id"), 64, 64, 3, t, None, t.clone())
     z = np.zeros((1, 3 * 32 * 32), np.float32)
-    with pytest.raises(core.LfBm5dError, match="nHard == nWien"):
-        ctx.bm3d_lf(core.make_bm3d_params(25, 2.7, 8, 8, 8, 3, "bior"), core.make_bm3d_params(25, 2.7, 8, 6, 8, 3, "dct"),
+    with pytest.raises(core.LfBm5dError, match="nWien > nHard"):      # the reference itself returns 0 / 0 there
+        ctx.bm3d_lf(core.make_bm3d_params(25, 2.7, 8, 4, 8, 3, "bior"), core.make_bm3d_params(25, 2.7, 8, 6, 8, 3, "dct"),
                     z.copy(), np.ones(1, np.uint32), z.copy(), z.copy(), 32, 32, 3)
+
+
+@pytest.mark.parametrize("nHard,nWien", [(12, 8), (16, 6)])
+def test_bm3d_lf_with_different_search_windows_matches_oracle(ctx, nHard, nWien):
+    """run_bm3d pads both steps by nHard, searches the second within nWien and crops it at offset nWien of the
+    nHard-padded image (bm3d.cpp:126-189): a shifted picture unless the two are equal.  Reproduced as it is."""
+    from lfbm5d_amd import core
+    lf = Hh.source_lf(crop=72)[[0, 4]]
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(2, np.uint32)
+    hard, wien = (8, nHard, 8, 3, "bior", 0), (16, nWien, 8, 3, "dct", 0)
+    _, b_o, d_o, _ = O.run_bm3d_lf(25.0, 2.7, noisy, mask, 72, 72, 3, hard, wien)
+    h_noisy, h_basic, h_den = noisy.copy(), np.zeros_like(noisy), np.zeros_like(noisy)
+    ctx.bm3d_lf(core.make_bm3d_params(25.0, 2.7, 8, nHard, 8, 3, "bior"), core.make_bm3d_params(25.0, 2.7, 16, nWien, 8, 3, "dct"),
+                h_noisy, mask, h_basic, h_den, 72, 72, 3)
+    assert np.abs(h_basic - b_o).max() < 5e-3
+    assert np.abs(h_den - d_o).max() < 2e-2 and abs(O.psnr_lf(h_den, clean) - O.psnr_lf(d_o, clean)) < 0.01
+    assert O.psnr_lf(h_den, clean) < O.psnr_lf(h_basic, clean)      # the reference's shifted crop: worse than its own first step
 
 
 # ------------------------------------------------------------------------------------------------
