@@ -369,11 +369,17 @@ def main():
                          "measured_with": ("the timed region (one lane)" if roof is timed else
                                            f"{roof_steps} extra untimed step with LFBM5D_LANES=1 (kernels alone on the GPU); the timed region ran {lanes_timed} lanes"),
                          "per_step": {"ht": ph, "wiener": pw}},
-            "kernel_ms_per_step": {"block_matching": tot["ms_bm"] / args.steps, "group": tot["ms_group"] / args.steps,
-                                   "aggregate": tot["ms_aggregate"] / args.steps, "comm": tot["ms_comm"] / args.steps,
-                                   "note": ("HIP-event intervals on each lane's stream; with several lanes the intervals of different windows "
-                                            "overlap, so they add up to more than the step time") if lanes_timed != 1 and world == 1 else
-                                           "HIP-event intervals on the library's stream"},
+            # kernel classes alone on the GPU (the one-lane measurement step); with several lanes the HIP-event intervals of
+            # different windows overlap and add up to more than the step, so those are reported under their own key
+            "kernel_ms_per_step": {"block_matching": (roof["ht"].get("ms_bm", 0.0) + roof["wiener"].get("ms_bm", 0.0)) / roof_steps,
+                                   "group": (roof["ht"].get("ms_group", 0.0) + roof["wiener"].get("ms_group", 0.0)) / roof_steps,
+                                   "aggregate": (roof["ht"].get("ms_aggregate", 0.0) + roof["wiener"].get("ms_aggregate", 0.0)) / roof_steps,
+                                   "comm": (roof["ht"].get("ms_comm", 0.0) + roof["wiener"].get("ms_comm", 0.0)) / roof_steps,
+                                   "measured_with": "the timed region" if roof is timed else "the one-lane measurement step (kernels alone on the GPU)"},
+            "kernel_ms_per_step_overlapped": {"block_matching": tot["ms_bm"] / args.steps, "group": tot["ms_group"] / args.steps,
+                                              "aggregate": tot["ms_aggregate"] / args.steps, "comm": tot["ms_comm"] / args.steps,
+                                              "note": "HIP-event intervals on each lane's stream during the timed region; intervals of "
+                                                      "different windows overlap and add up to more than the step time"},
             "passes_per_step": tot["passes"] / args.steps, "windows_per_step": tot["windows"] / args.steps,
             "lane_windows_per_step": tot["lane_windows"] / args.steps, "messages_per_step": tot["messages"] / args.steps,
             "psnr": {"noisy": psnr_lf(noisy0), "basic": psnr_lf(basic), "denoised": psnr_lf(den)},
