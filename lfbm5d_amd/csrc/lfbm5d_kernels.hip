@@ -1887,33 +1887,39 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
  *   5  thread = two patches: packed inverse 8x8 DCT, 16-byte stores of the filtered patches
  * ------------------------------------------------------------------------------------------ */
 
+/* 8-point orthonormal DCT-II / DCT-III of the Wiener kernels (T = float or a packed pair).  The 1/2 of the orthonormal
+ * scaling is folded into the cosines (round 1 multiplied by it separately: a seventh more instructions, no effect then
+ * because the kernel was latency-bound; at 60 % VALU utilisation it counts).  No threshold follows these transforms, so
+ * the last-bit differences against the unfolded form stay far inside the Wiener step's tolerance. */
 template <class T> __device__ __forceinline__ void dct8_fwd_t(T* x) {
-    const float a0 = 0.35355339059327376f, h = 0.5f;
-    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
-                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
+    const float a0 = 0.35355339059327376f;
+    const float c1 = 0.5f * 0.98078528040323044f, c2 = 0.5f * 0.92387953251128674f, c3 = 0.5f * 0.83146961230254524f,
+                c4 = 0.5f * 0.70710678118654752f, c5 = 0.5f * 0.55557023301960222f, c6 = 0.5f * 0.38268343236508977f,
+                c7 = 0.5f * 0.19509032201612827f;
     const T s0 = x[0] + x[7], s1 = x[1] + x[6], s2 = x[2] + x[5], s3 = x[3] + x[4];
     const T d0 = x[0] - x[7], d1 = x[1] - x[6], d2 = x[2] - x[5], d3 = x[3] - x[4];
     const T p0 = s0 + s3, p1 = s1 + s2, m0 = s0 - s3, m1 = s1 - s2;
     x[0] = a0 * (p0 + p1);
-    x[4] = (h * c4) * (p0 - p1);
-    x[2] = h * (c2 * m0 + c6 * m1);
-    x[6] = h * (c6 * m0 - c2 * m1);
-    x[1] = h * (c1 * d0 + c3 * d1 + c5 * d2 + c7 * d3);
-    x[3] = h * (c3 * d0 - c7 * d1 - c1 * d2 - c5 * d3);
-    x[5] = h * (c5 * d0 - c1 * d1 + c7 * d2 + c3 * d3);
-    x[7] = h * (c7 * d0 - c5 * d1 + c3 * d2 - c1 * d3);
+    x[4] = c4 * (p0 - p1);
+    x[2] = c2 * m0 + c6 * m1;
+    x[6] = c6 * m0 - c2 * m1;
+    x[1] = c1 * d0 + c3 * d1 + c5 * d2 + c7 * d3;
+    x[3] = c3 * d0 - c7 * d1 - c1 * d2 - c5 * d3;
+    x[5] = c5 * d0 - c1 * d1 + c7 * d2 + c3 * d3;
+    x[7] = c7 * d0 - c5 * d1 + c3 * d2 - c1 * d3;
 }
 template <class T> __device__ __forceinline__ void dct8_inv_t(T* X) {
-    const float a0 = 0.35355339059327376f, h = 0.5f;
-    const float c1 = 0.98078528040323044f, c2 = 0.92387953251128674f, c3 = 0.83146961230254524f, c4 = 0.70710678118654752f,
-                c5 = 0.55557023301960222f, c6 = 0.38268343236508977f, c7 = 0.19509032201612827f;
-    const T e0 = a0 * X[0] + (h * c4) * X[4], e1 = a0 * X[0] - (h * c4) * X[4];
-    const T f0 = h * (c2 * X[2] + c6 * X[6]), f1 = h * (c6 * X[2] - c2 * X[6]);
+    const float a0 = 0.35355339059327376f;
+    const float c1 = 0.5f * 0.98078528040323044f, c2 = 0.5f * 0.92387953251128674f, c3 = 0.5f * 0.83146961230254524f,
+                c4 = 0.5f * 0.70710678118654752f, c5 = 0.5f * 0.55557023301960222f, c6 = 0.5f * 0.38268343236508977f,
+                c7 = 0.5f * 0.19509032201612827f;
+    const T e0 = a0 * X[0] + c4 * X[4], e1 = a0 * X[0] - c4 * X[4];
+    const T f0 = c2 * X[2] + c6 * X[6], f1 = c6 * X[2] - c2 * X[6];
     const T E0 = e0 + f0, E1 = e1 + f1, E2 = e1 - f1, E3 = e0 - f0;
-    const T O0 = h * (c1 * X[1] + c3 * X[3] + c5 * X[5] + c7 * X[7]);
-    const T O1 = h * (c3 * X[1] - c7 * X[3] - c1 * X[5] - c5 * X[7]);
-    const T O2 = h * (c5 * X[1] - c1 * X[3] + c7 * X[5] + c3 * X[7]);
-    const T O3 = h * (c7 * X[1] - c5 * X[3] + c3 * X[5] - c1 * X[7]);
+    const T O0 = c1 * X[1] + c3 * X[3] + c5 * X[5] + c7 * X[7];
+    const T O1 = c3 * X[1] - c7 * X[3] - c1 * X[5] - c5 * X[7];
+    const T O2 = c5 * X[1] - c1 * X[3] + c7 * X[5] + c3 * X[7];
+    const T O3 = c7 * X[1] - c5 * X[3] + c3 * X[5] - c1 * X[7];
     X[0] = E0 + O0; X[7] = E0 - O0;
     X[1] = E1 + O1; X[6] = E1 - O1;
     X[2] = E2 + O2; X[5] = E2 - O2;
@@ -1935,9 +1941,13 @@ template <int NS> __device__ __forceinline__ void haar_fwd2(v2f* v) {
  * one correction step instead of the IEEE division sequence -- within one ulp of the quotient, which is well inside
  * the float tolerance of this stage (the division was a tenth of the kernel's instructions) */
 __device__ __forceinline__ float wiener_div(float a, float b) {
+#ifdef LFBM5D_WIENER_DIV_REFINED
     const float r = __builtin_amdgcn_rcpf(b);
     const float q = a * r;
     return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+#else
+    return a * __builtin_amdgcn_rcpf(b);   /* v_rcp_f32 is good to 1 ulp: the quotient to 2 ulp, a Wiener coefficient needs no more */
+#endif
 }
 
 /* phase 3 of k_group_dct8w on one (st, pq) fibre of nSx = NS float2 entries (x: noisy, y: pilot) */
