@@ -219,7 +219,7 @@ int lfbm5d_last_bm(lfbm5d_ctx* ctx, unsigned* n_refs, unsigned* h_refs, unsigned
                    unsigned* h_self_cnt, unsigned* h_best, unsigned char* h_shape);
 
 /* Raw disparity distance tables of the last pass (the scratch precompute_BM_stereo's sum_table plays in the
- * reference, core:3513-3574), layout [slot][(2 nDisp+1)^2][strip][Hb][64]: copies min(n_floats, size) floats and
+ * reference, core:3513-3574), layout [slot][(2 nDisp+1)^2][strip][table row + lane][64] (skewed: lfbm5d_kernels.h, stereo_table_stride): copies min(n_floats, size) floats and
  * returns the count; h_tables == NULL returns the buffer's size in floats.  For the bit-reproducibility tests. */
 size_t lfbm5d_last_tables(lfbm5d_ctx* ctx, float* h_tables, size_t n_floats);
 

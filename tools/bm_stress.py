@@ -25,9 +25,12 @@ num = torch.zeros_like(noisy); den = torch.zeros_like(noisy)
 mask = np.ones(9, np.uint32); proc = np.zeros(9, np.uint32)
 ctx = L.Context(0)
 NSTRIP = (Wb - 2 * nDisp - (k - 1) + 63) // 64
-TS = NSTRIP * 64 * Hb
 NT = 8 * (2 * nDisp + 1) ** 2
 NR, NC = Hb - 2 * nDisp - (k - 1), Wb - 2 * nDisp - (k - 1)
+SR = NR + 63                   # rows of a strip in the skewed layout: entry [strip][q][l] = table row q - l, column 64 strip + l
+TS = NSTRIP * 64 * SR
+qq, ll = np.arange(SR)[:, None], np.arange(64)[None, :]
+VALID = np.stack([((qq - ll) >= 0) & ((qq - ll) < NR) & (64 * sp + ll < NC) for sp in range(NSTRIP)])   # [strip][q][l]
 
 
 def one():
@@ -36,7 +39,7 @@ def one():
     torch.cuda.synchronize()
     refs, idx, cnt, best, shape = ctx.last_bm(pk[0], 9, Wb * Hb)
     valid = np.arange(pk[0])[None, :] < cnt[:, None]
-    tab = ctx.last_tables(NT * TS).reshape(NT, NSTRIP, Hb, 64).copy()
+    tab = ctx.last_tables(NT * TS).reshape(NT, NSTRIP, SR, 64).copy()
     return np.where(valid, idx, 0), cnt.copy(), best.reshape(9, Hb, Wb).copy(), shape.reshape(9, Hb, Wb).copy(), tab
 
 
@@ -71,12 +74,9 @@ for mode in ("quiet", "busy"):
             bad_best += 1
             for (sl, r, c) in d[:12]:
                 diffs.append((it, int(sl), int(r), int(c), int(a[sl, r, c]) - int(b[sl, r, c])))
-        # raw tables: valid region rows [nDisp, nDisp+NR), strip columns < NC
-        ta, tb = o[4][:, :, nDisp:nDisp + NR, :], ref[4][:, :, nDisp:nDisp + NR, :]
-        neq = ta.view(np.uint32) != tb.view(np.uint32)
-        for sp in range(NSTRIP):
-            w = min(64, NC - 64 * sp)
-            neq[:, sp, :, w:] = False
+        # raw tables, the entries that hold table values (the corners of the skew and the columns past the band do not)
+        ta, tb = o[4], ref[4]
+        neq = (ta.view(np.uint32) != tb.view(np.uint32)) & VALID[None]
         td = np.argwhere(neq)
         if len(td):
             bad_tab += 1
@@ -85,7 +85,7 @@ for mode in ("quiet", "busy"):
                 refv = [float(v) for v in tb[tbl, sp, r, max(c - 1, 0):c + 3]]
                 # where else in the reference table does the wrong value occur?
                 hit = np.argwhere(ref[4][tbl].view(np.uint32) == ta[tbl, sp, r, c].view(np.uint32))[:3].tolist()
-                tdiffs.append({"pass": it, "table": int(tbl), "strip": int(sp), "row": int(r), "col": int(c), "got": ctxv, "exp": refv, "got_found_at(strip,y,col)": hit, "n": int(len(td))})
+                tdiffs.append({"pass": it, "table": int(tbl), "strip": int(sp), "row": int(r - c), "col": int(64 * sp + c), "got": ctxv, "exp": refv, "got_found_at(strip,q,lane)": hit, "n": int(len(td))})
     if mode == "busy":
         stop = True
         for t in ths: t.join()
