@@ -1018,6 +1018,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             const float pct = (float)c->h_counts[w] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
             if (!(pct >= 100.0f)) complete = 0;
         }
+        if (std::getenv("LFBM5D_FORCE_REDO") && nranks == 1) complete = 0;   /* test hook: exercise the sequential redo */
         /* fold the other lanes' / emulated ranks' counters and event times into this context */
         for (lfbm5d_ctx* x : c->lanes) {
             if (x->pending.empty() && x->stats.passes == 0) continue;
