@@ -192,6 +192,11 @@ def main():
                          "contiguous window blocks + one all-reduce (scales, but not the reference's result)")
     args = ap.parse_args()
 
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # several ranks: a rank's lanes (3 streams) and the two exchange streams should not share hardware queues -- a send
+        # that waits for its peer must never sit in front of a compute stream on the same queue (ROCm maps streams onto
+        # GPU_MAX_HW_QUEUES queues, 4 by default).  Must be set before the HIP runtime starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import lfbm5d_amd as L
     from lfbm5d_amd import core, synth
