@@ -379,6 +379,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
         /* running LDS offsets (floats) of ring rows (t + K - lane) and (t - lane), column lane */
         int oA = ((K - lane + 64 * RR) % RR) * CW + lane, oB = ((64 * RR - lane) % RR) * CW + lane;
         int wrow = filled % RR;   /* a multiple of T, like RR: the T rows of a chunk never wrap inside the ring */
+        /* fast steady flavour (regular grid): next step with a forward / mirrored store (uniform), the lanes' byte offsets
+         * at that step (-1: the lane never stores) and their increment per grid row */
+        int nextF = 0x7fffffff, nextB = 0x7fffffff, offF = -1, offB = -1, incF = 0, incB = 0;
         auto chunk = [&](auto edge_tag, int t0, const int jj,   /* jj: index of the chunk in its group (a constant after unrolling) */
                          v4f* la1, v4f* la2, float& lb1, float& lb2,                   /* receive rows filled+(DEP-1)T .. */
                          const v4f* sa1, const v4f* sa2, float sb1, float sb2) {       /* rows filled .. go to the ring */
@@ -386,7 +389,11 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
              * 2: general edge (ramp-down, rows past the band, short tables); 3: tail of a disparity table's ramp-down:
              * every row of the band is in the ring already and no lane starts any more -- the steady chain without row
              * loads and ring writes, only the hand-off column indices are range-checked */
+            /* 4: steady chunk of a self-similarity table on the regular grid, rows and columns all on the grid's pattern:
+             * the lanes that store are the same 64 / p lanes on one step in p (see fast_init below), so the slot
+             * arithmetic of the steady flavour shrinks to two scalar compares per step */
             constexpr int FL = decltype(edge_tag)::value;
+            constexpr bool FAST = FL == 4;
             constexpr bool TAIL = FL == 3;
             constexpr bool EDGE = FL == 1 || FL == 2;   /* lane predicates */
             constexpr bool REDGE = FL == 2;             /* row / index range handling */
@@ -430,6 +437,9 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
                 if (stereo) {
                     const bool on = (EDGE || TAIL) ? (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2) : col_ok;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsTb, on ? lane * 4 : -1, (strip * SR + t + 1) * 256, 0);
+                } else if (FAST) {
+                    if (t == nextF) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, offF, 0, 0); offF += incF; nextF += gP; }
+                    if (t == nextB) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, Sout[s]), rsS, offB, 0, 0); offB += incB; nextB += gP; }
                 } else {
                     int v1, v2;
                     if (irregular) {   /* irregular list: whole-slot lookups (out-of-range offsets read 0, masked by act) */
@@ -483,6 +493,33 @@ __device__ __forceinline__ void scan_body(const ScanArgs& a, const int bid, floa
             if (light_up) for (; t0 < min(tS0, nsteps); t0 += G) group(std::integral_constant<int, 1>{}, t0);
             else          for (; t0 < min(tS0, nsteps); t0 += G) group(std::integral_constant<int, 2>{}, t0);
             SCAN_MARK(3);
+            if (MODE == 0) {
+                /* A reference row / column is "on the pattern" when (coordinate - nHW) % p == 0 and its slot is below the
+                 * forced last one.  If every grid column of this strip is (all but a forced last column that is not), the
+                 * storing lanes share l mod p, hence also the residue mod p of the steps on which their row 1 + t - l is a
+                 * grid row: one store step in p, the same lanes every time, slot = row / p.  Groups whose rows (plus di for
+                 * the mirrored candidate) stay below the forced last row take that flavour; the rest of the steady range and
+                 * strips with an off-pattern column keep the table look-ups. */
+                const bool offpat = (base_fwd >= 0 && (x - gN) % gP != 0) || (base_bwd >= 0 && (x + djs - gN) % gP != 0);
+                const unsigned long long mF = __builtin_amdgcn_ballot_w64(base_fwd >= 0), mB = __builtin_amdgcn_ballot_w64(base_bwd >= 0);
+                int tF1 = (gR - 1) * gP - 1 - G - di;                       /* last group start whose rows are all regular */
+                tF1 = tF1 >= t0 ? t0 + ((tF1 - t0) / G + 1) * G : t0;       /* -> end of the fast range (exclusive) */
+                tF1 = min(tF1, tS1);
+                if (!__builtin_amdgcn_ballot_w64(offpat) && t0 < tF1) {
+                    nextF = nextB = 0x7fffffff; offF = offB = -1; incF = incB = 0;
+                    if (mF) {
+                        const int l1 = (int)__builtin_ctzll(mF);
+                        nextF = t0 + (((l1 - 1 - t0) % gP) + gP) % gP;          /* 1 + t - l1 = 0 (mod p) */
+                        if (base_fwd >= 0) { offF = ((1 + nextF - lane) / gP) * row_bytes + base_fwd; incF = row_bytes; }
+                    }
+                    if (mB) {
+                        const int l2 = (int)__builtin_ctzll(mB);
+                        nextB = t0 + (((l2 - 1 - di - t0) % gP) + gP) % gP;     /* 1 + t - l2 + di = 0 (mod p) */
+                        if (base_bwd >= 0) { offB = ((1 + nextB - lane + di) / gP) * row_bytes + base_bwd; incB = row_bytes; }
+                    }
+                    for (; t0 < tF1; t0 += G) group(std::integral_constant<int, 4>{}, t0);
+                }
+            }
             for (; t0 < tS1; t0 += G) group(std::integral_constant<int, 0>{}, t0);
             SCAN_MARK(4);
             const int t_end = nsteps;
