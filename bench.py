@@ -241,6 +241,21 @@ def main():
             idt.copy_(torch.frombuffer(bytearray(L.Context.unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        if args.sharding == "graph":
+            # pre-flight of the exchange between the real peers (all-reduce, split communicator, grouped send / recv on both
+            # channels at once, broadcast).  An error on any rank moves every rank to the all-reduce scheme ("rows": exact,
+            # slower) rather than losing the line; a hang ends in the watchdog above.
+            try:
+                ctx.comm_selftest(1 << 20)
+                bad = 0
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: exchange pre-flight failed: {e}", file=sys.stderr, flush=True)
+                bad = 1
+            flag = torch.tensor([bad], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                args.sharding = "rows"
+                os.environ["LFBM5D_STEP_SHARDING"] = "rows"
 
     # synthetic input, identical on every rank (the read-only light field is replicated)
     clean_u8 = synth.make_lf(ah, aw, H, W)

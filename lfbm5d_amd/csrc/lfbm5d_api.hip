@@ -1359,6 +1359,42 @@ int lfbm5d_comm_selftest(lfbm5d_ctx* c, unsigned n) {
         if (d2) (void)hipFree(d2);
         if (comm2) ncclCommDestroy(comm2);
     }
+    /* several ranks: the exchange pattern of the window graph between real peers -- both channels at once, each on its
+     * exchange stream, channel 0 passing a block to the next rank while channel 1 passes one to the previous rank */
+    if (!rc && !own && world > 1 && c->comm2 && n >= 4) {
+        int me = c->rank;
+        const int nxt = (me + 1) % world, prv = (me + world - 1) % world;
+        const unsigned q = n / 4;
+        float* e = nullptr;
+        hipStream_t xs[2] = {nullptr, nullptr};
+        if (hipMalloc(&e, (size_t)4 * q * sizeof(float)) != hipSuccess) rc = fail(c, "hipMalloc failed");
+        for (int ch = 0; ch < 2 && !rc; ch++)
+            if (hipStreamCreateWithFlags(&xs[ch], hipStreamNonBlocking) != hipSuccess) rc = fail(c, "hipStreamCreate failed");
+        std::vector<float> hs(2 * q);
+        for (unsigned i = 0; i < 2 * q; i++) hs[i] = (float)(me * 1000) + (float)(i % 97);     /* [0,q): for next, [q,2q): for prev */
+        if (!rc && hipMemcpyAsync(e, hs.data(), 2 * q * sizeof(float), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(c, "copy failed");
+        if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, "stream failed");
+        if (!rc) {
+            bool ok = ncclGroupStart() == ncclSuccess;
+            ok = ok && ncclSend(e, q, ncclFloat, nxt, c->comm, xs[0]) == ncclSuccess;
+            ok = ok && ncclRecv(e + 2 * q, q, ncclFloat, prv, c->comm, xs[0]) == ncclSuccess;
+            ok = ncclGroupEnd() == ncclSuccess && ok;
+            ok = ok && ncclGroupStart() == ncclSuccess;
+            ok = ok && ncclSend(e + q, q, ncclFloat, prv, c->comm2, xs[1]) == ncclSuccess;
+            ok = ok && ncclRecv(e + 3 * q, q, ncclFloat, nxt, c->comm2, xs[1]) == ncclSuccess;
+            ok = ncclGroupEnd() == ncclSuccess && ok;
+            if (!ok) rc = fail(c, "RCCL two-channel exchange failed");
+        }
+        for (int ch = 0; ch < 2 && !rc; ch++)
+            if (hipStreamSynchronize(xs[ch]) != hipSuccess) rc = fail(c, "exchange stream failed");
+        std::vector<float> hr(2 * q);
+        if (!rc && hipMemcpy(hr.data(), e + 2 * q, 2 * q * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(c, "copy failed");
+        for (unsigned i = 0; i < q && !rc; i++)
+            if (hr[i] != (float)(prv * 1000) + (float)(i % 97) || hr[q + i] != (float)(nxt * 1000) + (float)((q + i) % 97))
+                rc = fail(c, "two-channel exchange returned wrong data");
+        for (int ch = 0; ch < 2; ch++) if (xs[ch]) (void)hipStreamDestroy(xs[ch]);
+        if (e) (void)hipFree(e);
+    }
     if (d) (void)hipFree(d);
     if (own) ncclCommDestroy(comm);
     return rc;
