@@ -230,7 +230,7 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
         if (P->nSim < 1 || P->nSim > 48 || P->p < 1) return fail(c, "bad search window / step");
         return 0;
     }
-    if (aw != ah || (aw != 3 && aw != 5)) return fail(c, "unsupported: angular search window must be 3x3 or 5x5 (aswSize 1 or 2)");
+    if (aw != ah || (aw != 3 && aw != 5 && aw != 7)) return fail(c, "unsupported: angular search window must be 3x3, 5x5 or 7x7 (aswSize 1 to 3)");
     if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
     if (P->k != 8 && P->k != 12 && P->k != 16) return fail(c, "unsupported: patch size k must be 8, 12 or 16");
     if (P->tau_2D == LFBM5D_BIOR && !is_pow2(P->k)) return fail(c, "bior1.5 needs a power-of-two patch size");
@@ -269,8 +269,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     const float thr = tauMatch * k * k;                                                                  /* core:3315 */
     float lambda = P->lambda;
     if (!bm3d && step == 1 && P->tau_2D == LFBM5D_ID && P->tau_4D == LFBM5D_DCT) lambda /= (float)kSqrt2; /* core:206-207 */
-    unsigned mask_bits = 0, proc_bits = 0;
-    for (unsigned st = 0; st < A; st++) { if (h_mask[st]) mask_bits |= 1u << st; if (h_proc[st]) proc_bits |= 1u << st; }
+    unsigned long long mask_bits = 0, proc_bits = 0;
+    for (unsigned st = 0; st < A; st++) { if (h_mask[st]) mask_bits |= 1ull << st; if (h_proc[st]) proc_bits |= 1ull << st; }
     if (pst >= A || cst >= A) return fail(c, "cst / pst outside the angular window");
     if (!((mask_bits >> pst) & 1)) return fail(c, "processed SAI is empty");
 
@@ -703,7 +703,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
      * runs whatever further passes the window needs (greyscale light fields) and adds the window back to the light field. */
     struct Lane { lfbm5d_ctx* x; float* w_noisy; float* w_basic; float* w_num; float* w_den; unsigned* d_small; float* g_num; float* g_den; };
     struct WinState {
-        unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, win_bits = 0, rem_w = 0, tot_w = 0, pst_w = 0;
+        unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, rem_w = 0, tot_w = 0, pst_w = 0; unsigned long long win_bits = 0;
         std::vector<unsigned> st_idx, mask_w, proc_w; SaiList sl; lfbm5d_params Pw; bool counted = false;
         unsigned* h_count_dst = nullptr;   /* pinned word the coverage count is copied to (default: the lane's) */
     };
@@ -758,7 +758,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         for (unsigned i = 0; i < Aw; i++) {
             ws.mask_w[i] = h_mask[ws.st_idx[i]];
             ws.sl.st[i] = ws.mask_w[i] ? ws.st_idx[i] : 0xffffffffu;
-            if (ws.mask_w[i]) ws.win_bits |= 1u << i;
+            if (ws.mask_w[i]) ws.win_bits |= 1ull << i;
         }
         HIPCK(c, launch_symetrize_multi(ls, d_noisy, img, L.w_noisy, imgb, ws.sl, W, H, C, nHW));
         if (step == 2) HIPCK(c, launch_symetrize_multi(ls, d_basic, img, L.w_basic, imgb, ws.sl, W, H, C, nHW));
@@ -794,7 +794,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             HIPCK(c, hipStreamSynchronize(ls));
             ws.counted = false;
             /* LF_denoised_percent (utilities_LF.cpp:967-995): counts (i,j,c) triples, divides without C */
-            const unsigned n_mask = (unsigned)__builtin_popcount(ws.win_bits);
+            const unsigned n_mask = (unsigned)__builtin_popcountll(ws.win_bits);
             const float pct = (float)L.x->h_small[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
             if (pct >= 100.0f)
                 for (unsigned i = 0; i < Aw; i++)
@@ -1014,7 +1014,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         int complete = 1;
         for (size_t w = 0; w < NW; w++) {
             if (!mine[w]) continue;
-            const unsigned n_mask = (unsigned)__builtin_popcount(wss[w].win_bits);
+            const unsigned n_mask = (unsigned)__builtin_popcountll(wss[w].win_bits);
             const float pct = (float)c->h_counts[w] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
             if (!(pct >= 100.0f)) complete = 0;
         }

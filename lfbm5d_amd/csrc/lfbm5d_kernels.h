@@ -11,9 +11,9 @@
 namespace lfbm5d {
 
 constexpr int kMaxK = 16;       /* patch side supported by the group kernel */
-constexpr int kMaxA = 25;       /* SAIs per angular window: 3x3 (an = 1, every dedicated kernel) or 5x5 (an = 2, generic kernel) */
+constexpr int kMaxA = 49;       /* SAIs per angular window: 3x3 (an = 1, every dedicated kernel), 5x5 or 7x7 (an = 2, 3: generic kernel) */
 constexpr int kA3 = 9;          /* ... of the 3x3 window the dedicated kernels are written for */
-constexpr int kMaxAw = 5;       /* side of the largest window */
+constexpr int kMaxAw = 7;       /* side of the largest window */
 constexpr int kMaxN = 16;      /* max similar patches (power of two) of the light-field core and its dedicated kernels */
 constexpr int kMaxN3 = 32;     /* ... of the per-SAI BM3D flavour (generic group kernel only) */
 
@@ -29,7 +29,7 @@ struct GroupTables {
     float cni4[kMaxA];
     float cos3[9];              /* cos(pi (j+1/2) u / 3) */
     float cosw[kMaxA];          /* cos(pi (j+1/2) u / aw) at [u*aw + j] for the window side aw (general angular DCT) */
-    float cos1[kMaxAw + 1][kMaxA]; /* SADCT: cos(pi (j+1/2) u / n) at [n][u*n + j], n = 1..5 */
+    float cos1[kMaxAw + 1][kMaxA]; /* SADCT: cos(pi (j+1/2) u / n) at [n][u*n + j], n = 1..7 */
     float cn1[kMaxAw + 1][kMaxAw]; /* SADCT 1-D norms for length n (core:3229-3252) */
     float cni1[kMaxAw + 1][kMaxAw];
     float c1inv[kMaxAw + 1];    /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
@@ -64,7 +64,7 @@ struct GroupArgs {
     unsigned long long* counters; /* [0] sum nSx, [1] sadct groups */
     unsigned ref_begin, n_groups;
     unsigned Wb, Hb, C, A, k, N, pst;
-    unsigned mask_bits, proc_bits;
+    unsigned long long mask_bits, proc_bits;   /* bit st: SAI st of the window is there / already processed */
     unsigned tau2, tau4, tau5, useSD;
     unsigned fill_quirk;        /* 1 on the centre path: patches at column Wb-k read as zeros (core:1697) */
     int step;
@@ -92,7 +92,7 @@ struct AggArgs {
     unsigned ref_begin, n_groups;   /* groups [ref_begin, ref_begin + n_groups) of this rank */
     unsigned n_ref_rows, n_ref_cols;
     unsigned Wb, Hb, C, A, k, N, pst, p, nHW, nSim, nDisp;
-    unsigned mask_bits, proc_bits, tau4;
+    unsigned long long mask_bits, proc_bits; unsigned tau4;
     unsigned irregular;         /* reference list is not the regular grid (subset path): scan every reference */
     unsigned wchan0;            /* every channel uses channel 0's group weight (sd_weighting of bm3d.cpp:1345-1373) */
 };
@@ -140,13 +140,13 @@ hipError_t launch_crop(hipStream_t s, float* dst, const float* src, unsigned W, 
 hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub,
                            float* est, size_t n);
 /* all SAIs of an angular window in one launch: slot i of the window <-> SAI L.st[i] of the light field */
-struct SaiList { unsigned st[32]; unsigned n; };
+struct SaiList { unsigned st[kMaxA]; unsigned n; };
 hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,
                                   const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride, const float* src, size_t src_stride,
                                     const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
-                                 size_t plane, unsigned C, unsigned A, unsigned mask_bits);
+                                 size_t plane, unsigned C, unsigned A, unsigned long long mask_bits);
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n);
 hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n);
 hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   /* dst += src */
@@ -154,7 +154,7 @@ hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   
 hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsigned n_seg,
                               unsigned* counts);
 /* LF_denoised_percent numerator on a padded window image (utilities_LF.cpp:985-992) */
-hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned mask_bits,
+hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned long long mask_bits,
                                  unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count);
 hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, int* refmap);
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a);

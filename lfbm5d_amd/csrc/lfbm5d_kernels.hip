@@ -120,7 +120,7 @@ __global__ void k_estimate(const float* __restrict__ num, const float* __restric
 
 /* matching estimate (channel 0) of every non-empty SAI of a window: blockIdx.y = SAI */
 __global__ void k_estimate_multi(const float* __restrict__ num, const float* __restrict__ den, const float* __restrict__ sub,
-                                 float* __restrict__ est, size_t plane, unsigned C, unsigned mask_bits) {
+                                 float* __restrict__ est, size_t plane, unsigned C, unsigned long long mask_bits) {
     const unsigned st = blockIdx.y;
     if (!((mask_bits >> st) & 1)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,7 +173,7 @@ __global__ void k_count_zeros(const float* __restrict__ den, size_t seg, unsigne
     if (threadIdx.x == 0 && t) atomicAdd(&counts[blockIdx.y], t);
 }
 
-__global__ void k_count_denoised(const float* __restrict__ den, size_t sai_stride, unsigned mask_bits, int W, int H, int C, int N, int k,
+__global__ void k_count_denoised(const float* __restrict__ den, size_t sai_stride, unsigned long long mask_bits, int W, int H, int C, int N, int k,
                                  unsigned* __restrict__ count) {
     __shared__ unsigned red[4];
     if (!((mask_bits >> blockIdx.y) & 1)) return;      /* blockIdx.y = window slot */
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
             const bool masked = (a.mask_bits >> st) & 1;
             m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
         }
-        build_shape(sh, m, a.A == 9 ? 3 : 5);
+        build_shape(sh, m, a.A == 9 ? 3 : a.A == 25 ? 5 : 7);
     } else {
         for (int q = 0; q < (int)(sizeof(ShapeInfo) / sizeof(int)); q++) reinterpret_cast<int*>(&sh)[q] = 0;
     }
@@ -1046,7 +1046,7 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
                                               unsigned* pos, float (*red)[kThreads / 64]) {
     const int tid = threadIdx.x;
     const int k = a.k, k2 = k * k, A = a.A, N = a.N;
-    const int aw = A == 9 ? 3 : 5;
+    const int aw = A == 9 ? 3 : A == 25 ? 5 : 7;
     const int nSx = (int)a.self_cnt[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int stack = nSx * A * k2;
@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
                     if (do_dct4) dct9_fwd(x, tb); else sadct9_fwd(x, sh, tb);
 #pragma unroll
                     for (int st = 0; st < 9; st++) S[(n * A + st) * k2 + pq] = x[st];
-                } else {   /* 5x5 window */
+                } else {   /* 5x5 / 7x7 window */
                     float x[kMaxA];
                     for (int st = 0; st < A; st++) x[st] = S[(n * A + st) * k2 + pq];
                     if (do_dct4) dctw_fwd(x, aw, tb); else sadctw_fwd(x, aw, sh, tb);
@@ -2929,7 +2929,7 @@ hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride
     return hipGetLastError();
 }
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
-                                 size_t plane, unsigned C, unsigned A, unsigned mask_bits) {
+                                 size_t plane, unsigned C, unsigned A, unsigned long long mask_bits) {
     hipLaunchKernelGGL(k_estimate_multi, dim3(grid1d(plane).x, A), dim3(256), 0, s, num, den, sub, est, plane, C, mask_bits);
     return hipGetLastError();
 }
@@ -2955,7 +2955,7 @@ hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsig
     hipLaunchKernelGGL(k_count_zeros, dim3(gx, n_seg), dim3(256), 0, s, den, seg, counts);
     return hipGetLastError();
 }
-hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned mask_bits,
+hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned long long mask_bits,
                                  unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count) {
     hipLaunchKernelGGL(k_count_denoised, dim3(128, n_slots), dim3(256), 0, s, den, sai_stride, mask_bits, (int)W, (int)H, (int)C, (int)N, (int)k, count);
     return hipGetLastError();
@@ -2963,6 +2963,7 @@ hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_str
 
 /* Kernels whose LDS stack can exceed the 64 KiB a launch gets by default: raise the limit once per device
  * (called from lfbm5d_create after hipSetDevice; the attribute belongs to the device's code object). */
+constexpr int kGenericLdsLimit = 160 * 1024 - 8192;   /* dynamic LDS of k_group: its static part (positions of up to 32 x 49 patches) is 6.3 KB */
 hipError_t prepare_group_kernels() {
     const int lim = 160 * 1024 - 4096;
     const void* fns[] = {
@@ -2976,7 +2977,8 @@ hipError_t prepare_group_kernels() {
         reinterpret_cast<const void*>(&k_group_bior16_n1), reinterpret_cast<const void*>(&k_group_dct16_n1),
         reinterpret_cast<const void*>(&k_group_bm3d8<2, true>), reinterpret_cast<const void*>(&k_group_bm3d8<2, false>)};
     for (const void* f : fns) {
-        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        const bool generic = f == reinterpret_cast<const void*>(&k_group<1>) || f == reinterpret_cast<const void*>(&k_group<2>);
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, generic ? kGenericLdsLimit : lim);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -3002,7 +3004,7 @@ static bool group_uses_generic(const GroupArgs& a) {   /* mirrors launch_group's
     return true;
 }
 size_t group_scratch_bytes(const GroupArgs& a) {
-    if (!group_uses_generic(a) || group_lds_bytes(a) <= 160 * 1024 - 4096) return 0;
+    if (!group_uses_generic(a) || group_lds_bytes(a) <= (size_t)kGenericLdsLimit) return 0;
     return (size_t)kBigBlocks * (a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);
 }
 hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
@@ -3070,7 +3072,7 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         return hipGetLastError();
     }
     const size_t lds = group_lds_bytes(a);
-    if (lds > 160 * 1024 - 4096) {   /* stacks in HBM scratch slices, persistent workgroups */
+    if (lds > (size_t)kGenericLdsLimit) {   /* stacks in HBM scratch slices, persistent workgroups */
         const unsigned long long slice = (unsigned long long)(a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k;
         if (!a.scratch || a.scratch_floats < slice * kBigBlocks) return hipErrorInvalidValue;
         const unsigned blocks = std::min<unsigned>(kBigBlocks, a.n_groups * a.C);

@@ -476,41 +476,39 @@ ASW2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", ASW2_CASES, ids=[c[0] for c in ASW2_CASES])
-def test_5x5_window_pass_matches_oracle(ctx, case):
-    """One core pass on a 5x5 angular window (25 SAIs, 24 disparity searches, general 5x5 angular DCT / SADCT):
-    identical block matching, coverage and group statistics, estimate within the float tolerance of a 3x3 pass."""
+def _wide_window_pass(ctx, case, aw):
     name, step, pk, crop, holes = case
     sigma = 25.0
-    lf = Hh.textured_lf(5, 5, crop, crop)
+    A, cc = aw * aw, (aw * aw) // 2
+    lf = Hh.textured_lf(aw, aw, crop, crop)
     _, noisy = Hh.noisy_lf(lf, sigma)
     N, nSim, nDisp, k = pk[0], pk[1], pk[2], pk[3]
     win, Wb, Hb = Hh.padded_window(noisy, crop, crop, 3, nSim + nDisp)
-    mask = np.ones(25, np.uint32)
+    mask = np.ones(A, np.uint32)
     for h in holes:
         mask[h] = 0
         win[h] = 0
     proc = (mask == 0).astype(np.uint32)      # the schedule marks empty SAIs as processed (bm5d.cpp:268-270)
     basic = None
     if step == 2:
-        n1, d1, _ = Hh.oracle_pass(1, sigma, (4,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, 3, mask=mask, proc=proc, cst=12, pst=12, aw=5)
+        n1, d1, _ = Hh.oracle_pass(1, sigma, (4,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, 3, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
         basic = np.ascontiguousarray(Hh.estimate(n1, d1, win).astype(np.float32))
-    num_o, den_o, st = Hh.oracle_pass(step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=12, pst=12, aw=5)
+    num_o, den_o, st = Hh.oracle_pass(step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
     ctx.reset_stats()
-    num_g, den_g = gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=12, pst=12, aw=5)
+    num_g, den_g = gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
     s = ctx.stats()
     assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
     if holes:
         assert st.sadct_groups == st.groups or pk[6] == "dct"
-    refs, idx, cnt, best, shape = ctx.last_bm(N, 25, Wb * Hb)
+    refs, idx, cnt, best, shape = ctx.last_bm(N, A, Wb * Hb)
     est = (win if step == 1 else basic)[:, :Wb * Hb]
     tau = Hh.tau_match(sigma, 3, step)
     regr, regc = slice(nDisp, Hb - k - nDisp + 1), slice(nDisp, Wb - k - nDisp + 1)
-    for st_i in (0, 6, 13, 24):
+    for st_i in (0, aw + 1, cc + 1, A - 1):
         if not mask[st_i]:
             continue
         ob, osh = np.zeros(Wb * Hb, np.uint32), np.zeros(Wb * Hb, np.uint8)
-        O.lib().orc_bm_stereo(np.ascontiguousarray(est[12]), np.ascontiguousarray(est[st_i]), Wb, Hb, k, nDisp, tau, ob, osh)
+        O.lib().orc_bm_stereo(np.ascontiguousarray(est[cc]), np.ascontiguousarray(est[st_i]), Wb, Hb, k, nDisp, tau, ob, osh)
         assert np.array_equal(ob.reshape(Hb, Wb)[regr, regc], best[st_i].reshape(Hb, Wb)[regr, regc])
         assert np.array_equal(osh.reshape(Hb, Wb)[regr, regc], shape[st_i].reshape(Hb, Wb)[regr, regc])
     assert np.array_equal(den_o != 0, den_g != 0)
@@ -519,27 +517,49 @@ def test_5x5_window_pass_matches_oracle(ctx, case):
     assert np.abs(eo - eg).max() < 3e-3
 
 
-@pytest.mark.parametrize("ah,aw", [(5, 5), (7, 6)])
-def test_whole_steps_with_5x5_windows_match_oracle(ctx, ah, aw):
-    """aswSize 2: the window schedule with 5x5 windows (compute_LF_angular_search_window's clamping at the borders),
-    both steps against the oracle: same windows, PSNR within 0.01 dB."""
+@pytest.mark.parametrize("case", ASW2_CASES, ids=[c[0] for c in ASW2_CASES])
+def test_5x5_window_pass_matches_oracle(ctx, case):
+    """One core pass on a 5x5 angular window (25 SAIs, 24 disparity searches, general 5x5 angular DCT / SADCT):
+    identical block matching, coverage and group statistics, estimate within the float tolerance of a 3x3 pass."""
+    _wide_window_pass(ctx, case, 5)
+
+
+# 7x7 angular windows (aswSize 3): 49 SAIs, 48 disparity searches, 7-point angular DCT / SADCT rows and columns
+ASW3_CASES = [
+    ("ht-id-sadct-haar-holes", 1, (4, 5, 2, 8, 4, "id", "sadct", "haar"), 56, (0, 10, 30, 48)),
+    ("ht-dct-dct-hw", 1, (8, 5, 2, 8, 4, "dct", "dct", "hw"), 56, ()),
+    ("wien-dct-sadct-haar", 2, (8, 5, 2, 8, 4, "dct", "sadct", "haar"), 56, ()),
+    ("wien-bior-sadct-dct5-holes", 2, (4, 5, 2, 8, 4, "bior", "sadct", "dct"), 56, (8, 40)),
+]
+
+
+@pytest.mark.parametrize("case", ASW3_CASES, ids=[c[0] for c in ASW3_CASES])
+def test_7x7_window_pass_matches_oracle(ctx, case):
+    """aswSize 3: one core pass on a 7x7 angular window against the oracle."""
+    _wide_window_pass(ctx, case, 7)
+
+
+@pytest.mark.parametrize("ah,aw,an", [(5, 5, 2), (7, 6, 2), (8, 7, 3)])
+def test_whole_steps_with_5x5_windows_match_oracle(ctx, ah, aw, an):
+    """aswSize 2 and 3: the window schedule with 5x5 / 7x7 windows (compute_LF_angular_search_window's clamping at the
+    borders), both steps against the oracle: same windows, PSNR within 0.01 dB."""
     import lfbm5d_amd as L
     from lfbm5d_amd import core
-    Hs = Ws = 72
+    Hs = Ws = 72 if an == 2 else 64
     lf = Hh.textured_lf(ah, aw, Hs, Ws)
     clean, noisy = Hh.noisy_lf(lf, 25.0)
     mask = np.ones(ah * aw, np.uint32)
     p1, p2 = (4, 6, 2, 8, 4, "id", "sadct", "haar"), (8, 6, 2, 8, 4, "dct", "sadct", "haar")
-    n1, b_o, st1 = O.run_step1(O.make_params(25.0, 2.7, *p1), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    n1, b_o, st1 = O.run_step1(O.make_params(25.0, 2.7, *p1), noisy.copy(), mask, O.ROWMAJOR, aw, ah, an, Ws, Hs, 3)
     w1 = O.last_windows()
-    _, _, d_o, st2 = O.run_step2(O.make_params(25.0, 2.7, *p2), n1.copy(), b_o.copy(), mask, O.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    _, _, d_o, st2 = O.run_step2(O.make_params(25.0, 2.7, *p2), n1.copy(), b_o.copy(), mask, O.ROWMAJOR, aw, ah, an, Ws, Hs, 3)
     d_noisy = torch.from_numpy(noisy).cuda()
     d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
     ctx.reset_stats()
-    ctx.step1(core.make_params(25.0, 2.7, *p1), d_noisy, mask, d_basic, L.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    ctx.step1(core.make_params(25.0, 2.7, *p1), d_noisy, mask, d_basic, L.ROWMAJOR, aw, ah, an, Ws, Hs, 3)
     assert np.array_equal(ctx.last_windows(), w1) and ctx.stats().windows == st1.windows
     pb = O.psnr_lf(d_basic.cpu().numpy(), clean)
-    ctx.step2(core.make_params(25.0, 2.7, *p2), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, 2, Ws, Hs, 3)
+    ctx.step2(core.make_params(25.0, 2.7, *p2), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, an, Ws, Hs, 3)
     pd = O.psnr_lf(d_den.cpu().numpy(), clean)
     assert abs(pb - O.psnr_lf(b_o, clean)) < 0.01 and abs(pd - O.psnr_lf(d_o, clean)) < 0.01
     assert pd > O.psnr_lf(noisy, clean) + 6
