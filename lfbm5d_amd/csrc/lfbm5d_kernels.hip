@@ -1010,18 +1010,24 @@ __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     const unsigned g = a.ref_begin + i;
     const size_t plane = (size_t)a.Wb * a.Hb;
     const unsigned k_r = a.refs[g];
+    /* only what the group kernels read is written: the first A entries of each array (the record is sized for a 7x7
+     * window, a 3x3 one uses a fifth of it), and nothing but the flag when the angular transform is not shape-adaptive */
+    ShapeInfo* out = reinterpret_cast<ShapeInfo*>(a.gshape) + g;
+    if (a.tau4 != 6) { out->use_sadct = 0; return; }
     ShapeInfo sh;
-    if (a.tau4 == 6) {
-        int m[kMaxA];
-        for (int st = 0; st < (int)a.A; st++) {
-            const bool masked = (a.mask_bits >> st) & 1;
-            m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
-        }
-        build_shape(sh, m, a.A == 9 ? 3 : a.A == 25 ? 5 : 7);
-    } else {
-        for (int q = 0; q < (int)(sizeof(ShapeInfo) / sizeof(int)); q++) reinterpret_cast<int*>(&sh)[q] = 0;
+    const int A = (int)a.A, aw = A == 9 ? 3 : A == 25 ? 5 : 7;
+    int m[kMaxA];
+    for (int st = 0; st < A; st++) {
+        const bool masked = (a.mask_bits >> st) & 1;
+        m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
     }
-    reinterpret_cast<ShapeInfo*>(a.gshape)[g] = sh;
+    build_shape(sh, m, aw);
+    for (int q = 0; q < A; q++) {
+        out->mask[q] = sh.mask[q]; out->idx[q] = sh.idx[q]; out->mask_col[q] = sh.mask_col[q];
+        out->idx_col[q] = sh.idx_col[q]; out->mask_dct[q] = sh.mask_dct[q];
+    }
+    for (int q = 0; q < aw; q++) { out->row_n[q] = sh.row_n[q]; out->col_n[q] = sh.col_n[q]; }
+    out->use_sadct = sh.use_sadct;
 }
 /* SADCT bookkeeping of group g (pre-pass output) */
 __device__ __forceinline__ ShRef group_shape(const GroupArgs& a, unsigned g) {
