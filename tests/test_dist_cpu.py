@@ -5,6 +5,8 @@
    buffers, an all-reduce(sum) of num/den restores base + all contributions -- what lfbm5d_pass_device does with RCCL."""
 import os
 import socket
+
+import pytest
 import sys
 
 import numpy as np
@@ -83,7 +85,9 @@ def _graph_worker(rank, world, port, q):
     from oracle import oracle as O
     from lfbm5d_amd import core
     lib = O.lib()
-    ah, aw, H, W, Cc, sigma = 5, 7, 40, 40, 3, 25.0
+    # two rows of windows for two ranks, three for three (a chain = a row of windows is the unit dealt to ranks)
+    ah, aw = (5, 7) if world == 2 else (7, 11)
+    H, W, Cc, sigma = 40, 40, 3, 25.0
     pk = (4, 5, 2, 8, 4, "id", "sadct", "haar")
     nHW = pk[1] + pk[2]
     A = ah * aw
@@ -149,8 +153,9 @@ def _graph_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_graph_form_with_messages_equals_the_single_rank_step():
-    """world_size-2 gloo run of the step-level multi-GPU scheme (graph form): windows owned per rank, one message per
+@pytest.mark.parametrize("world", [2, 3])
+def test_graph_form_with_messages_equals_the_single_rank_step(world):
+    """world_size-2 / -3 gloo run of the step-level multi-GPU scheme (graph form): windows owned per rank, one message per
     SAI a window needs from another rank's window, estimates formed by the last toucher -- bit-identical to the
     oracle's single-process step, and every planned message is used exactly once."""
     s = socket.socket()
@@ -159,14 +164,14 @@ def test_graph_form_with_messages_equals_the_single_rank_step():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(ok and same_plan for _, ok, _, _, _, _, _, same_plan in res), res
-    assert all(n_win > 0 for _, _, _, n_win, *_ in res)                    # both ranks own windows
+    assert all(n_win > 0 for _, _, _, n_win, *_ in res)                    # every rank owns windows
     assert sum(r[4] for r in res) == sum(r[5] for r in res) == res[0][6] > 0   # every message sent once, received once
 
 
