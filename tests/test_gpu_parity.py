@@ -9,6 +9,7 @@ Tolerances (float32 path; BASELINE.json north_star: PSNR within +-0.01 dB of the
     (transforms accumulate in float32 on the GPU, in double in the oracle);
   * whole steps: step 1 within 2e-3 grey levels, mean PSNR of either step within 0.01 dB.
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -125,6 +126,14 @@ def _check_pass(ctx, case, strict):
         assert np.array_equal(osh.reshape(Hb, Wb)[regr, regc], shape[st_i].reshape(Hb, Wb)[regr, regc])
     # aggregation buffers
     assert np.array_equal(den_o != 0, den_g != 0)
+    # A Wiener group whose shrinkage coefficients sum to a denormal (a pilot with values around 1e-20, as a hard-threshold
+    # pass leaves them where it kills nearly everything) gets the weight 1 / (sigma^2 * sum) = inf
+    # (core:1219, :1544): the reference then carries inf / NaN in num and den.  Same entries here, everything else compared.
+    nf = ~(np.isfinite(num_o) & np.isfinite(den_o))
+    assert np.array_equal(nf, ~(np.isfinite(num_g) & np.isfinite(den_g)))
+    if nf.any():
+        assert step == 2 and nf.mean() < 0.01
+        num_o, den_o, num_g, den_g = (np.where(nf, 0.0, a).astype(np.float32) for a in (num_o, den_o, num_g, den_g))
     eo, eg = Hh.estimate(num_o, den_o, win), Hh.estimate(num_g, den_g, win)
     if strict:
         np.testing.assert_allclose(den_g, den_o, rtol=2e-5, atol=1e-7)
@@ -134,7 +143,8 @@ def _check_pass(ctx, case, strict):
         # arbitrary configurations: the transforms accumulate in float here and in double in the oracle, so a hard
         # threshold decision can flip for a coefficient within ~1e-6 of the threshold (one weight count changes by
         # one) -- a few groups in a thousand with a 16x16 DCT; everything else stays at float round-off
-        bad = ~np.isclose(den_g, den_o, rtol=1e-4, atol=1e-7)
+        # (weights are float sums of up to N A k^2 = 36 864 shrinkage coefficients: relative round-off up to ~1.3e-4 measured)
+        bad = ~np.isclose(den_g, den_o, rtol=2e-4, atol=1e-7)
         assert bad.mean() < (0.03 if step == 1 else 1e-4), bad.mean()
         assert np.abs(eo - eg).mean() < 2e-4 and np.quantile(np.abs(eo - eg), 0.999) < 5e-2
 
@@ -566,9 +576,10 @@ def test_whole_steps_with_5x5_windows_match_oracle(ctx, ah, aw, an):
 
 
 def _random_cases():
-    rng = np.random.default_rng(20261002)
+    # LFBM5D_TEST_SEED / LFBM5D_TEST_CASES: wider sweeps by hand (the committed default keeps the suite short)
+    rng = np.random.default_rng(int(os.environ.get("LFBM5D_TEST_SEED", "20261002")))
     cases = []
-    while len(cases) < 12:
+    while len(cases) < int(os.environ.get("LFBM5D_TEST_CASES", "12")):
         step = int(rng.integers(1, 3))
         k = int(rng.choice([8, 12, 16]))
         N = int(rng.choice([1, 2, 4, 8, 16] if step == 2 else [1, 2, 4, 8]))
@@ -578,8 +589,7 @@ def _random_cases():
         tau5 = str(rng.choice(["haar", "hw", "dct"]))
         ch, cw = int(rng.integers(k + 2 * (nSim + nDisp) + 6, 110)), int(rng.integers(k + 2 * (nSim + nDisp) + 6, 140))
         sigma = float(rng.choice([10.0, 25.0, 50.0]))
-        if step * N * 9 * k * k * 4 > 150 * 1024:      # stack(s) beyond the LDS: refused loudly, see the unsupported test
-            continue
+        # (stacks beyond the 160 KiB LDS -- e.g. step 2, N = 16, k = 16 -- run on the HBM-scratch form of the generic kernel)
         # useSD stays 0 here: the reference's sd_weighting_5d (core:3140-3173) subtracts two float sums of k^2 N
         # terms that nearly cancel, so its value depends on the summation order to ~1e-3; the two dedicated
         # useSD cases above pin well-conditioned inputs
