@@ -218,6 +218,35 @@ def test_subset_pass_matches_oracle(ctx):
         assert np.array_equal(num_g[4], num0[4])   # the processed centre SAI is not aggregated into again
 
 
+@pytest.mark.parametrize("pk,sigma", [((8, 6, 2, 8, 4, "dct", "sadct", "haar"), 20.0), ((4, 5, 2, 12, 3, "dct", "sadct", "hw"), 50.0),
+                                      ((8, 6, 1, 8, 3, "bior", "id", "haar"), 50.0)])
+def test_subset_pass_of_the_wiener_step_matches_oracle(ctx, pk, sigma):
+    """The same for step 2 (core:1332-1658): the pilot-driven matching on the irregular list, the den-aware list on the
+    Wiener weights' den, two subset passes one after the other (the second sees the first one's sums)."""
+    win, Wb, Hb, Cc = window(sigma, pk, 72, grey=True)
+    n1, d1, _ = Hh.oracle_pass(1, sigma, (4,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, Cc)
+    basic = np.ascontiguousarray(Hh.estimate(n1, d1, win).astype(np.float32))
+    num_o, den_o, st0 = Hh.oracle_pass(2, sigma, pk, win, basic, Wb, Hb, Cc)
+    num_g, den_g = gpu_pass(ctx, 2, sigma, pk, win, basic, Wb, Hb, Cc)
+    assert np.array_equal(den_o != 0, den_g != 0)
+    proc = np.zeros(9, np.uint32)
+    proc[4] = 1
+    for pst in (8, 1, 6):
+        # both sides start from the SAME sums (the oracle's): block matching runs on num / den, and sums that differ in
+        # the last bits re-order near-tied candidates now and then
+        num_in, den_in = num_o.copy(), den_o.copy()
+        num_o, den_o, st = Hh.oracle_pass(2, sigma, pk, win, basic, Wb, Hb, Cc, num=num_o, den=den_o, proc=proc.copy(), pst=pst)
+        ctx.reset_stats()
+        num_g, den_g = gpu_pass(ctx, 2, sigma, pk, win, basic, Wb, Hb, Cc, num=num_in, den=den_in, proc=proc.copy(), pst=pst)
+        s = ctx.stats()
+        assert st.groups < st0.groups
+        assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups), pst
+        assert np.array_equal(den_o != 0, den_g != 0), pst
+        np.testing.assert_allclose(den_g, den_o, rtol=1e-4, atol=1e-7)
+        assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 5e-3
+        proc[pst] = 1
+
+
 def test_greyscale_light_field_whole_steps(ctx):
     """C == 1: windows are not finished by their centre pass, the subset path runs."""
     import lfbm5d_amd as L
