@@ -67,6 +67,25 @@ for ci in range(ncases):
         ctx.step2(core.make_params(sigma, 2.7, *p2), d_noisy, mask, d_basic, d_den, mg, aw, ah, an, Ws, Hs, Cc)
         w2_g, s2 = ctx.last_windows(), ctx.stats()
         d_g = d_den.cpu().numpy()
+        if os.environ.get("SWEEP_LANES_CHECK"):   # the same steps on the other lane count: bit-identical?
+            os.environ["LFBM5D_LANES"] = "1" if lanes == 3 else "3"
+            e_basic, e_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+            e_noisy = torch.from_numpy(noisy).cuda()
+            ctx.step1(core.make_params(sigma, 2.7, *p1), e_noisy, mask, e_basic, mg, aw, ah, an, Ws, Hs, Cc)
+            ctx.step2(core.make_params(sigma, 2.7, *p2), e_noisy, mask, e_basic, e_den, mg, aw, ah, an, Ws, Hs, Cc)
+            print("   other lane count: basic identical", bool(torch.equal(e_basic, d_basic)), "denoised identical", bool(torch.equal(e_den, d_den)),
+                  "| max |basic gpu - oracle|", float(np.abs(b_g - b_o).max()), "max |den gpu - oracle|", float(np.abs(d_g - d_o).max()),
+                  "mean", float(np.abs(d_g - d_o).mean()))
+            eo_, eg_ = np.abs(d_o - clean)[mask != 0], np.abs(d_g - clean)[mask != 0]
+            print("   |denoised - clean| > 15 grey levels: oracle %d px (max %.1f), gpu %d px (max %.1f); noisy max err %.1f; both wrong at the same px: %d"
+                  % ((eo_ > 15).sum(), eo_.max(), (eg_ > 15).sum(), eg_.max(), np.abs(noisy - clean)[mask != 0].max(), ((eo_ > 15) & (eg_ > 15)).sum()))
+            bo_ = np.abs(b_o - clean)[mask != 0]
+            print("   basic: |basic - clean| > 15: oracle %d px; exact zeros in oracle basic: %d, tiny (<1e-10, != 0): %d"
+                  % ((bo_ > 15).sum(), (b_o[mask != 0] == 0).sum(), ((np.abs(b_o[mask != 0]) < 1e-10) & (b_o[mask != 0] != 0)).sum()))
+            for st in range(0):
+                if mask[st]:
+                    print("    SAI", st, "PSNR gpu %.4f oracle %.4f" % (O.psnr_lf(d_g[st:st+1], clean[st:st+1]), O.psnr_lf(d_o[st:st+1], clean[st:st+1])),
+                          "max|d|", float(np.abs(d_g[st] - d_o[st]).max()))
         m = mask != 0
         okw = np.array_equal(w1_g, w1_o) and np.array_equal(w2_g, w2_o)
         okp = (s1.windows, s1.passes) == (st1.windows, st1.passes) and (s2.windows, s2.passes) == (st2.windows, st2.passes)
