@@ -538,7 +538,7 @@ def _wide_window_pass(ctx, case, aw):
     s = ctx.stats()
     assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
     if holes:
-        assert st.sadct_groups == st.groups or pk[6] == "dct"
+        assert st.sadct_groups == st.groups or pk[6] in ("dct", "id")
     refs, idx, cnt, best, shape = ctx.last_bm(N, A, Wb * Hb)
     est = (win if step == 1 else basic)[:, :Wb * Hb]
     tau = Hh.tau_match(sigma, 3, step)
