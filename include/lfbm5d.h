@@ -123,6 +123,12 @@ int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);
 int lfbm5d_comm_selftest(lfbm5d_ctx* ctx, unsigned n);
 /* Shard without a communicator (tests): this rank only processes its rows; no reduction. */
 int lfbm5d_set_shard(lfbm5d_ctx* ctx, int rank, int world);
+/* The reference's OpenMP tile mode for whole steps (bm5d.cpp:411-708, run_bm5d_* with nb_threads > 1): every window pass
+ * runs tile by tile (sub_divide, utilities.cpp:312-395) and keeps the tiles' interiors only (undivide_LF,
+ * utilities_LF.cpp:438-515).  nb_tiles is floored to a power of two like main.cpp:101-102 does with nbThreads; 0 / 1 =
+ * off (the default: the untiled result, which is what nb_threads == 1 gives and about 0.5 dB better).  A compatibility
+ * mode for reproducing a tiled reference run; one GPU, one window after the other.  Returns 0. */
+int lfbm5d_set_tiles(lfbm5d_ctx* ctx, int nb_tiles);
 /* Row range [begin,end) of n_rows reference-patch rows owned by `rank` of `world`. */
 void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, unsigned* end);
 /* The window schedule of a step as the processed SAI (index in `ang_major` order) of each window, in

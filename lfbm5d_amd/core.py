@@ -89,6 +89,7 @@ def lib():
     L.lfbm5d_comm_unique_id.argtypes = [vp]
     L.lfbm5d_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.lfbm5d_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.lfbm5d_set_tiles.argtypes = [vp, C.c_int]
     L.lfbm5d_comm_selftest.argtypes = [vp, C.c_uint]
     L.lfbm5d_shard_rows.argtypes = [C.c_uint, C.c_int, C.c_int, up, up]
     L.lfbm5d_shard_rows.restype = None
@@ -237,6 +238,10 @@ class Context:
 
     def set_shard(self, rank, world):
         self._ck(self._L.lfbm5d_set_shard(self._h, rank, world))
+
+    def set_tiles(self, nb_tiles):
+        """The reference's tile mode (run_bm5d_* with nb_threads > 1) for whole steps; 0 / 1 switches it off."""
+        self._ck(self._L.lfbm5d_set_tiles(self._h, int(nb_tiles)))
 
     # ---- stats ----
     def reset_stats(self):

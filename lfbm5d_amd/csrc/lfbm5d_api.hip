@@ -54,6 +54,7 @@ struct lfbm5d_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     int rank = 0, world = 1;
+    int tiles = 1;                         /* > 1: the reference's OpenMP tile mode (lfbm5d_set_tiles) */
     ncclComm_t comm = nullptr;
     ncclComm_t comm2 = nullptr;            /* second channel of the window-graph exchange (ncclCommSplit of comm) */
     hipStream_t cs[2] = {nullptr, nullptr}; /* exchange streams, one per channel */
@@ -65,6 +66,7 @@ struct lfbm5d_ctx {
     std::vector<unsigned> last_windows;   /* processed SAI of every window of the last step, in order */
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
+    DevBuf t_noisy, t_basic, t_tnum, t_tden, und_num, und_den;   /* tile mode: one tile of the window, the tiles' interiors */
     DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den, d_mask;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
@@ -706,6 +708,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, rem_w = 0, tot_w = 0, pst_w = 0; unsigned long long win_bits = 0;
         std::vector<unsigned> st_idx, mask_w, proc_w; SaiList sl; lfbm5d_params Pw; bool counted = false;
         unsigned* h_count_dst = nullptr;   /* pinned word the coverage count is copied to (default: the lane's) */
+        float tile_pct = 0.0f;             /* tile mode: sum of the tiles' LF_denoised_percent of the last pass */
     };
     auto lane_buffers = [&](lfbm5d_ctx* x, Lane& L) -> int {
         HIPCK(c, x->w_noisy.reserve(Aw * imgb * sizeof(float)));
@@ -728,7 +731,69 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         ws.counted = true;
         return 0;
     };
+    /* The reference's OpenMP tile mode (bm5d.cpp:411-708), opt-in through lfbm5d_set_tiles: every SAI of the padded window
+     * is cut into tiles with a halo of nHW pixels (sub_divide, utilities.cpp:312-395: halved along its longer side until
+     * there are `tiles` pieces, the last row / column takes the remainder), each tile runs the core pass on its own, only
+     * the tiles' interiors are kept (undivide_LF, utilities_LF.cpp:438-515 -- what a tile aggregated into its halo is
+     * discarded, about 0.5 dB) and the window's num / den are padded again.  A compatibility mode: tile after tile. */
+    const int n_tiles = c->tiles;
+    unsigned tl_w = W, tl_h = H, tl_nw = 1, tl_nh = 1;
+    for (int n = n_tiles; n > 1; n /= 2) {
+        if (tl_w > tl_h) { tl_w = (unsigned)std::floor((float)tl_w * 0.5f); tl_nw *= 2; }
+        else { tl_h = (unsigned)std::floor((float)tl_h * 0.5f); tl_nh *= 2; }
+    }
+    const unsigned tl_hb = tl_nh > 1 ? H - (tl_nh - 1) * tl_h : tl_h, tl_wb = tl_nw > 1 ? W - (tl_nw - 1) * tl_w : tl_w;
+    auto tiled_pass = [&](const Lane& L, WinState& ws) -> int {
+        lfbm5d_ctx* x = L.x;
+        hipStream_t ls = x->stream;
+        const unsigned hmax = std::max(tl_h, tl_hb) + 2 * nHW, wmax = std::max(tl_w, tl_wb) + 2 * nHW;
+        const size_t tmax = (size_t)C * hmax * wmax;
+        HIPCK(c, x->t_noisy.reserve(Aw * tmax * sizeof(float)));
+        if (step == 2) HIPCK(c, x->t_basic.reserve(Aw * tmax * sizeof(float)));
+        HIPCK(c, x->t_tnum.reserve(Aw * tmax * sizeof(float)));
+        HIPCK(c, x->t_tden.reserve(Aw * tmax * sizeof(float)));
+        HIPCK(c, x->und_num.reserve(Aw * img * sizeof(float)));
+        HIPCK(c, x->und_den.reserve(Aw * img * sizeof(float)));
+        float* tn = x->t_noisy.as<float>(); float* tb = x->t_basic.as<float>();
+        float* tu = x->t_tnum.as<float>(); float* td = x->t_tden.as<float>();
+        const unsigned n_mask = (unsigned)__builtin_popcountll(ws.win_bits);
+        ws.tile_pct = 0.0f;
+        const unsigned long long passes0 = x->stats.passes;   /* a window pass counts once, not once per tile */
+        for (unsigned kt = 0; kt < tl_nw * tl_nh; kt++) {
+            const unsigned i = kt / tl_nw, j = kt % tl_nw;
+            const unsigned h = (i == tl_nh - 1 ? tl_hb : tl_h) + 2 * nHW, w = (j == tl_nw - 1 ? tl_wb : tl_w) + 2 * nHW;
+            const size_t timg = (size_t)C * w * h;
+            if (h < 2 * nHW + P->k + 1 || w < 2 * nHW + P->k + 1) return fail(c, "tile smaller than the search range");
+            auto cut = [&](const float* src, float* dst) {
+                return launch_copy_rect(ls, dst, timg, w, h, 0, 0, src, imgb, wb, hb, j * tl_w, i * tl_h, w, h, C, Aw, ws.win_bits);
+            };
+            HIPCK(c, cut(L.w_noisy, tn));
+            if (step == 2) HIPCK(c, cut(L.w_basic, tb));
+            HIPCK(c, cut(L.w_num, tu));
+            HIPCK(c, cut(L.w_den, td));
+            if (pass_impl(x, step, &ws.Pw, asw, asw, w, h, C, tn, step == 2 ? tb : nullptr, tu, td,
+                          ws.mask_w.data(), ws.proc_w.data(), ws.cst_w, ws.pst_w)) return lane_fail(L);
+            HIPCK(c, hipMemsetAsync(L.d_small, 0, sizeof(unsigned), ls));
+            HIPCK(c, launch_count_denoised(ls, td, timg, Aw, ws.win_bits, w - 2 * nHW, h - 2 * nHW, C, nHW, P->k, L.d_small));
+            HIPCK(c, hipMemcpyAsync(x->h_small, L.d_small, sizeof(unsigned), hipMemcpyDeviceToHost, ls));
+            HIPCK(c, launch_copy_rect(ls, x->und_num.as<float>(), img, W, H, j * tl_w, i * tl_h, tu, timg, w, h, nHW, nHW,
+                                      w - 2 * nHW, h - 2 * nHW, C, Aw, ws.win_bits));
+            HIPCK(c, launch_copy_rect(ls, x->und_den.as<float>(), img, W, H, j * tl_w, i * tl_h, td, timg, w, h, nHW, nHW,
+                                      w - 2 * nHW, h - 2 * nHW, C, Aw, ws.win_bits));
+            HIPCK(c, hipStreamSynchronize(ls));
+            ws.tile_pct += (float)x->h_small[0] * 100.0f / (float)n_mask / (float)(h - 2 * nHW - P->k + 1) / (float)(w - 2 * nHW - P->k + 1);
+        }
+        x->stats.passes = passes0 + 1;
+        SaiList slots; slots.n = Aw;
+        for (unsigned a = 0; a < Aw; a++) slots.st[a] = ws.mask_w[a] ? a : 0xffffffffu;
+        HIPCK(c, launch_symetrize_multi(ls, x->und_num.as<float>(), img, L.w_num, imgb, slots, W, H, C, nHW));
+        HIPCK(c, launch_symetrize_multi(ls, x->und_den.as<float>(), img, L.w_den, imgb, slots, W, H, C, nHW));
+        return 0;
+    };
     auto one_pass = [&](const Lane& L, WinState& ws) -> int {
+        if (n_tiles > 1) {
+            if (tiled_pass(L, ws)) return 1;
+        } else
         if (pass_impl(L.x, step, &ws.Pw, asw, asw, wb, hb, C, L.w_noisy, step == 2 ? L.w_basic : nullptr, L.w_num, L.w_den,
                       ws.mask_w.data(), ws.proc_w.data(), ws.cst_w, ws.pst_w)) return lane_fail(L);
         ws.proc_w[ws.pst_w] += 1;
@@ -737,6 +802,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (ws.mins + ps_w) * awidth + (ws.mint + pt_w)
                                                          : (ws.mins + ps_w) + (ws.mint + pt_w) * aheight;
         proc[st] += 1;
+        if (n_tiles > 1) { ws.counted = true; return 0; }
         return enqueue_count(L, ws);
     };
     auto win_begin = [&](const Lane& L, unsigned ps, unsigned pt, unsigned tau4, WinState& ws) -> int {
@@ -796,7 +862,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             /* LF_denoised_percent (utilities_LF.cpp:967-995): counts (i,j,c) triples, divides without C */
             const unsigned n_mask = (unsigned)__builtin_popcountll(ws.win_bits);
             const float pct = (float)L.x->h_small[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
-            if (pct >= 100.0f)
+            if (n_tiles > 1 ? ws.tile_pct >= 100.0f * (float)(tl_nw * tl_nh) /* bm5d.cpp:668-672 */ : pct >= 100.0f)
                 for (unsigned i = 0; i < Aw; i++)
                     if (ws.proc_w[i] == 0) { ws.proc_w[i] += 1; proc[ws.st_idx[i]] += 1; }
             ws.rem_w = (unsigned)std::count(ws.proc_w.begin(), ws.proc_w.end(), 0u);
@@ -880,7 +946,8 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     const int nranks = emu > 1 ? emu : c->world;
     c->lane_windows = 0;
     StepGraph G;
-    bool graph_mode = planned && !by_rows && !by_blocks && C == 3 && (n_lanes > 1 || nranks > 1);
+    if (c->tiles > 1 && nranks > 1) return fail(c, "the tile mode runs on one GPU");
+    bool graph_mode = planned && !by_rows && !by_blocks && C == 3 && (n_lanes > 1 || nranks > 1) && c->tiles <= 1;
     if (graph_mode) {
         build_graph(h_mask, awidth, aheight, an, ang_major, tau_4D, nranks, emu > 1 ? 1 : n_lanes, max_windows, G);
         if (!G.centre_ok) graph_mode = false;   /* empty window centre: the first pass is chosen from device data */
@@ -1221,7 +1288,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     if (c->comm) ncclCommDestroy(c->comm);
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1398,6 +1465,14 @@ int lfbm5d_comm_selftest(lfbm5d_ctx* c, unsigned n) {
     if (d) (void)hipFree(d);
     if (own) ncclCommDestroy(comm);
     return rc;
+}
+
+int lfbm5d_set_tiles(lfbm5d_ctx* c, int nb_tiles) {
+    if (!c || nb_tiles < 0) return 1;
+    int n = 1;
+    while (n * 2 <= nb_tiles) n *= 2;     /* main.cpp:101-102 floors nb_threads to a power of two */
+    c->tiles = nb_tiles <= 1 ? 1 : n;
+    return 0;
 }
 
 int lfbm5d_set_shard(lfbm5d_ctx* c, int rank, int world) {

@@ -147,6 +147,11 @@ hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride
                                     const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
                                  size_t plane, unsigned C, unsigned A, unsigned long long mask_bits);
+/* w x h rectangle of every channel of n_slots images: dst image (dW x dH, slots dst_stride apart) at (dx0, dy0) <- src image
+ * (sW x sH) at (sx0, sy0).  The reference's sub_divide / undivide_LF (utilities.cpp:312-395, utilities_LF.cpp:438-515) */
+hipError_t launch_copy_rect(hipStream_t s, float* dst, size_t dst_stride, unsigned dW, unsigned dH, unsigned dx0, unsigned dy0,
+                            const float* src, size_t src_stride, unsigned sW, unsigned sH, unsigned sx0, unsigned sy0,
+                            unsigned w, unsigned h, unsigned C, unsigned n_slots, unsigned long long mask_bits);
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n);
 hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n);
 hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   /* dst += src */

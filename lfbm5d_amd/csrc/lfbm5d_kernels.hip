@@ -141,6 +141,18 @@ __global__ void k_estimate_lf(const float* __restrict__ num, const float* __rest
     est[o] = d ? __fdiv_rn(num[o], d) : sub[o];
 }
 
+__global__ void k_copy_rect(float* __restrict__ dst, size_t dst_stride, int dW, int dH, int dx0, int dy0,
+                            const float* __restrict__ src, size_t src_stride, int sW, int sH, int sx0, int sy0,
+                            int w, int h, int C, unsigned long long mask_bits) {
+    if (!((mask_bits >> blockIdx.y) & 1)) return;      /* blockIdx.y = window slot */
+    const size_t total = (size_t)w * h * C;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i / ((size_t)w * h)), r = (int)(i % ((size_t)w * h));
+    const int y = r / w, x = r % w;
+    dst[blockIdx.y * dst_stride + ((size_t)c * dH + dy0 + y) * dW + dx0 + x] =
+        src[blockIdx.y * src_stride + ((size_t)c * sH + sy0 + y) * sW + sx0 + x];
+}
 __global__ void k_fill_f32(float* p, float v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -2908,6 +2920,13 @@ hipError_t launch_color_lf(hipStream_t s, float* lf, size_t sai_stride, unsigned
 hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t seg,
                               unsigned n_sai, const unsigned* d_mask) {
     hipLaunchKernelGGL(k_estimate_lf, dim3(grid1d(seg).x, n_sai), dim3(256), 0, s, num, den, sub, est, seg, d_mask);
+    return hipGetLastError();
+}
+hipError_t launch_copy_rect(hipStream_t s, float* dst, size_t dst_stride, unsigned dW, unsigned dH, unsigned dx0, unsigned dy0,
+                            const float* src, size_t src_stride, unsigned sW, unsigned sH, unsigned sx0, unsigned sy0,
+                            unsigned w, unsigned h, unsigned C, unsigned n_slots, unsigned long long mask_bits) {
+    hipLaunchKernelGGL(k_copy_rect, dim3(grid1d((size_t)w * h * C).x, n_slots), dim3(256), 0, s, dst, dst_stride, (int)dW, (int)dH, (int)dx0,
+                       (int)dy0, src, src_stride, (int)sW, (int)sH, (int)sx0, (int)sy0, (int)w, (int)h, (int)C, mask_bits);
     return hipGetLastError();
 }
 hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigned W, unsigned H, unsigned C, unsigned N) {

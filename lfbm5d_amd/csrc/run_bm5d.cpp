@@ -51,13 +51,21 @@ lfbm5d_params make(float sigma, float lambda, unsigned N, unsigned nSim, unsigne
 
 } // namespace
 
+/* nb_threads selects the reference's tile mode (bm5d.cpp:411-708), whose result depends on the caller's core count and is
+ * about 0.5 dB below the untiled one.  The GPU path therefore ignores it -- nb_threads == 1 semantics -- unless
+ * LFBM5D_TILED is set in the environment: then nb_threads tiles (floored to a power of two) are reproduced. */
+static int tiles_for(unsigned nb_threads) {
+    const char* e = std::getenv("LFBM5D_TILED");
+    return (e && *e && *e != '0' && nb_threads > 1) ? (int)nb_threads : 1;
+}
+
 int run_bm5d_1st_step(const float sigma, const float lambdaHard5D, std::vector<std::vector<float> >& LF_noisy,
                       std::vector<unsigned>& LF_SAI_mask, std::vector<std::vector<float> >& LF_basic,
                       const unsigned ang_major, const unsigned awidth, const unsigned aheight, const unsigned anHard,
                       const unsigned width, const unsigned height, const unsigned chnls, const unsigned NHard,
                       const unsigned nSim, const unsigned nDisp, const unsigned kHard, const unsigned pHard,
                       const bool useSD, const unsigned tau_2D, unsigned tau_4D, const unsigned tau_5D,
-                      const unsigned color_space, const unsigned /*nb_threads*/) {
+                      const unsigned color_space, const unsigned nb_threads) {
     const unsigned asize = awidth * aheight;
     if (LF_noisy.size() != asize || LF_SAI_mask.size() != asize) {
         std::cout << "run_bm5d_1st_step: light field and mask must hold awidth*aheight SAIs" << std::endl;
@@ -65,6 +73,7 @@ int run_bm5d_1st_step(const float sigma, const float lambdaHard5D, std::vector<s
     }
     lfbm5d_ctx* ctx = context();
     if (!ctx) return EXIT_FAILURE;
+    lfbm5d_set_tiles(ctx, tiles_for(nb_threads));
     if (LF_basic.size() != asize) LF_basic.resize(asize); /* bm5d.cpp:129-130 */
     const size_t img = (size_t)width * height * chnls;
     std::vector<float> noisy, basic(asize * img, 0.0f);
@@ -86,7 +95,7 @@ int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_no
                       const unsigned width, const unsigned height, const unsigned chnls, const unsigned NWien,
                       const unsigned nSim, const unsigned nDisp, const unsigned kWien, const unsigned pWien,
                       const bool useSD, const unsigned tau_2D, unsigned tau_4D, const unsigned tau_5D,
-                      const unsigned color_space, const unsigned /*nb_threads*/) {
+                      const unsigned color_space, const unsigned nb_threads) {
     const unsigned asize = awidth * aheight;
     if (LF_noisy.size() != asize || LF_basic.size() != asize || LF_SAI_mask.size() != asize) {
         std::cout << "run_bm5d_2nd_step: light fields and mask must hold awidth*aheight SAIs" << std::endl;
@@ -94,6 +103,7 @@ int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_no
     }
     lfbm5d_ctx* ctx = context();
     if (!ctx) return EXIT_FAILURE;
+    lfbm5d_set_tiles(ctx, tiles_for(nb_threads));
     if (LF_denoised.size() != asize) LF_denoised.resize(asize); /* bm5d.cpp:823-824 */
     const size_t img = (size_t)width * height * chnls;
     std::vector<float> noisy, basic, den(asize * img, 0.0f);

@@ -12,7 +12,8 @@
 //! Main function (hard-thresholding step) -- same argument list as the reference.  LF_noisy is
 //! colour-transformed and transformed back in place (lossy for OPP, like the reference),
 //! LF_basic is (re)sized and filled.  nb_threads is accepted for source compatibility; the GPU path
-//! always has the semantics of nb_threads == 1 (no tile-halo discard).
+//! has the semantics of nb_threads == 1 (no tile-halo discard) unless LFBM5D_TILED is set in the
+//! environment, in which case the reference's tile mode with nb_threads tiles is reproduced.
 int run_bm5d_1st_step(
     const float sigma
 ,   const float lambdaHard5D

@@ -247,6 +247,58 @@ def test_subset_pass_of_the_wiener_step_matches_oracle(ctx, pk, sigma):
         proc[pst] = 1
 
 
+@pytest.mark.parametrize("tiles,grey", [(4, False), (8, False), (4, True)])
+def test_tile_mode_matches_the_oracles_tile_mode(ctx, tiles, grey):
+    """lfbm5d_set_tiles: the reference's OpenMP tile mode (bm5d.cpp:411-708; what run_bm5d_* does with nb_threads > 1) --
+    tiles with a discarded halo.  Both steps against the oracle in the same mode: same windows and passes, PSNR within
+    0.01 dB, and measurably different from the untiled result (the mode is there to reproduce tiled reference runs)."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    ah, aw, Hs, Ws = 3, 5, 112, 96
+    lf = Hh.textured_lf(ah, aw, Hs, Ws)
+    if grey:
+        lf = np.ascontiguousarray(lf[:, :1])
+    Cc = lf.shape[1]
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    p1, p2 = (4, 6, 2, 8, 4, "id", "sadct", "haar"), (8, 6, 2, 8, 4, "dct", "sadct", "haar")
+    cs = "rgb" if grey else "opp"
+    lib = O.lib()
+    lib.orc_set_tiles(tiles)
+    try:
+        n1, b_o, st1 = O.run_step1(O.make_params(25.0, 2.7, *p1, cs=cs), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 1, Ws, Hs, Cc)
+        w1 = O.last_windows()
+        _, _, d_o, st2 = O.run_step2(O.make_params(25.0, 2.7, *p2, cs=cs), n1.copy(), b_o.copy(), mask, O.ROWMAJOR, aw, ah, 1, Ws, Hs, Cc)
+    finally:
+        lib.orc_set_tiles(1)
+
+    def gpu(nt):
+        d_noisy = torch.from_numpy(noisy).cuda()
+        d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+        ctx.set_tiles(nt)
+        try:
+            ctx.reset_stats()
+            ctx.step1(core.make_params(25.0, 2.7, *p1, color_space=cs), d_noisy, mask, d_basic, L.ROWMAJOR, aw, ah, 1, Ws, Hs, Cc)
+            s1, wins = ctx.stats(), ctx.last_windows()
+            ctx.reset_stats()
+            ctx.step2(core.make_params(25.0, 2.7, *p2, color_space=cs), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, aw, ah, 1, Ws, Hs, Cc)
+            s2 = ctx.stats()
+        finally:
+            ctx.set_tiles(1)
+        return d_basic.cpu().numpy(), d_den.cpu().numpy(), s1, s2, wins
+
+    b_g, d_g, s1, s2, wins = gpu(tiles)
+    assert np.array_equal(wins, w1)
+    assert (s1.windows, s1.passes) == (st1.windows, st1.passes) and s2.windows == st2.windows
+    assert np.isfinite(b_g).all() and np.isfinite(d_g).all()
+    assert abs(O.psnr_lf(b_g, clean) - O.psnr_lf(b_o, clean)) < 0.01
+    assert abs(O.psnr_lf(d_g, clean) - O.psnr_lf(d_o, clean)) < 0.01
+    if not grey:
+        b_u, d_u, *_ = gpu(1)
+        assert O.psnr_lf(d_u, clean) > O.psnr_lf(d_g, clean) + 0.05      # the halo discard costs quality
+        assert np.abs(b_u - b_g).max() > 1.0
+
+
 def test_greyscale_light_field_whole_steps(ctx):
     """C == 1: windows are not finished by their centre pass, the subset path runs."""
     import lfbm5d_amd as L
