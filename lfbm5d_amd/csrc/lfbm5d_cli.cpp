@@ -12,9 +12,10 @@
  * Differences, all opt-in through the environment so the argument list stays a drop-in:
  *   LFBM5D_SEED=<n>   seed MT19937 once with n and draw the noise SAI by SAI in st order
  *                     (reproducible); unset = time + pid seeding like the reference;
- *   LFBM5D_DEVICE=<i> HIP device index.
- * nbThreads is parsed and ignored: the GPU path has the reference's untiled (nb_threads == 1)
- * semantics.
+ *   LFBM5D_DEVICE=<i> HIP device index;
+ *   LFBM5D_TILED=1    honour nbThreads > 1 the reference's way (tiles with a discarded halo, bm5d.cpp:411-708).
+ * Without LFBM5D_TILED nbThreads is parsed and ignored: the GPU path has the reference's untiled
+ * (nb_threads == 1) semantics, half a dB better than its tiled mode.
  *
  * Compiled with -DLFBM3D_CLI the same file is `LFBM3Ddenoising` (src/main_bm3d_LF.cpp:56-272, arguments of
  * get_params_BM3D, utilities_LF.cpp:1342-1468 / README.md:85), BM3D on every SAI independently:

@@ -61,6 +61,40 @@ def test_readme_command_matches_oracle(tmp_path):
     assert 20 * np.log10(255 / np.sqrt(mse)) > 36.0
 
 
+@pytest.mark.gpu
+def test_readme_command_in_tile_mode_matches_the_oracles_tile_mode(tmp_path):
+    """nbThreads = 8 with LFBM5D_TILED=1: the drop-in reproduces the reference's OpenMP tile mode (bm5d.cpp:411-708) --
+    PSNR report within 0.01 dB of the oracle's tiled run on the same noise, half a dB below the untiled numbers."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as Hh
+    from oracle import oracle as O
+    tmp = str(tmp_path)
+    src, lf = write_source_lf(tmp)
+    for d in ("noisy", "basic", "denoised", "diff"):
+        os.makedirs(os.path.join(tmp, d))
+    res = os.path.join(tmp, "measures.txt")
+    args = [CLI, src, "SAI", "_", "3", "3", "1", "1", "1", "1", "row", "25", "2.7", f"{tmp}/noisy", f"{tmp}/basic",
+            f"{tmp}/denoised", f"{tmp}/diff", "8", "18", "6", "16", "4", "id", "sadct", "haar", "0", "16", "18", "6", "8", "4",
+            "dct", "sadct", "haar", "0", "opp", "8", res]
+    out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, LFBM5D_SEED="1", LFBM5D_TILED="1"))
+    assert out.returncode == 0, out.stdout[-2000:]
+    txt = open(res).read()
+    vals = {k: float(txt.split(f"-> Average PSNR {k} = ")[1].split()[0]) for k in ("noisy", "basic", "denoised")}
+    clean, noisy = Hh.noisy_lf(Hh.source_lf(), 25.0)
+    mask = np.ones(9, np.uint32)
+    lib = O.lib()
+    lib.orc_set_tiles(8)
+    try:
+        n1, b, _ = O.run_step1(O.make_params(25.0, 2.7, *Hh.README_HT), noisy.copy(), mask, O.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+        _, _, d, _ = O.run_step2(O.make_params(25.0, 2.7, *Hh.README_WIEN), n1.copy(), b.copy(), mask, O.ROWMAJOR, 3, 3, 1, 256, 256, 3)
+    finally:
+        lib.orc_set_tiles(1)
+    assert abs(vals["noisy"] - 20.1672) < 1e-3
+    assert abs(vals["basic"] - O.psnr_lf(b, clean)) < 0.01 and abs(vals["denoised"] - O.psnr_lf(d, clean)) < 0.01
+    assert vals["basic"] < 34.2073 - 0.3 and vals["denoised"] < 35.7082 - 0.3      # the untiled result (test above)
+
+
 CLI3 = os.path.join(ROOT, "lfbm5d_amd", "LFBM3Ddenoising")
 
 
