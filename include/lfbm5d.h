@@ -228,6 +228,13 @@ int lfbm5d_last_bm(lfbm5d_ctx* ctx, unsigned* n_refs, unsigned* h_refs, unsigned
  * reference, core:3513-3574), layout [slot][(2 nDisp+1)^2][strip][table row + lane][64] (skewed: lfbm5d_kernels.h, stereo_table_stride): copies min(n_floats, size) floats and
  * returns the count; h_tables == NULL returns the buffer's size in floats.  For the bit-reproducibility tests. */
 size_t lfbm5d_last_tables(lfbm5d_ctx* ctx, float* h_tables, size_t n_floats);
+/* Candidate scores of the self-similarity search of the last pass, [reference patch][(2 nSim+1)^2] in the scan order of
+ * core:3407-3420 (entries no table covers keep 2 * threshold): same calling convention. */
+size_t lfbm5d_last_scores(lfbm5d_ctx* ctx, float* h_scores, size_t n_floats);
+/* Which generation of the table kernel the last pass used: 2 = ring-sharing workgroups (table layout
+ * [slot][(2 nDisp+1)^2]{[strip][Q / 4][lane][Q % 4], column 0}, lfbm5d_kernels.h stereo_table_stride2), 1 = one wave per table
+ * (12x12 patches, irregular reference lists, LFBM5D_SCAN_V1=1). */
+int lfbm5d_last_scan_version(const lfbm5d_ctx* ctx);
 
 /* ---- device memory helpers so hosts without a HIP binding (ctypes, cgo, JNI) can stage data ---- */
 int lfbm5d_malloc(void** dptr, size_t bytes);

@@ -111,6 +111,10 @@ def lib():
     L.lfbm5d_bm3d_lf_host.argtypes = [vp, bp, bp, fp, up, fp, fp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     L.lfbm5d_last_tables.argtypes = [vp, vp, C.c_size_t]
     L.lfbm5d_last_tables.restype = C.c_size_t
+    L.lfbm5d_last_scores.argtypes = [vp, vp, C.c_size_t]
+    L.lfbm5d_last_scores.restype = C.c_size_t
+    L.lfbm5d_last_scan_version.argtypes = [vp]
+    L.lfbm5d_last_scan_version.restype = C.c_int
     L.lfbm5d_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.lfbm5d_free.argtypes = [vp]
     L.lfbm5d_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
@@ -335,6 +339,17 @@ class Context:
         out = np.zeros(n, np.float32)
         got = self._L.lfbm5d_last_tables(self._h, out.ctypes.data, n)
         return out[:got]
+
+    def last_scores(self, n_floats=None):
+        """Candidate scores of the self-similarity search of the last pass (flat float32 array)."""
+        have = self._L.lfbm5d_last_scores(self._h, None, 0)
+        n = have if n_floats is None else min(have, int(n_floats))
+        out = np.zeros(n, np.float32)
+        got = self._L.lfbm5d_last_scores(self._h, out.ctypes.data, n)
+        return out[:got]
+
+    def last_scan_version(self):
+        return int(self._L.lfbm5d_last_scan_version(self._h))
 
 
 _default_ctx = None

@@ -67,6 +67,9 @@ struct lfbm5d_ctx {
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
     DevBuf t_noisy, t_basic, t_tnum, t_tden, und_num, und_den;   /* tile mode: one tile of the window, the tiles' interiors */
+    DevBuf scan_wgs, scan_lcol;            /* second-generation scan: workgroup list, hand-off columns */
+    std::vector<Scan2Wg> scan_plan; unsigned scan_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t scan_lds = 0;
+    int last_scan_version = 0;
     DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den, d_mask;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
@@ -351,7 +354,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* the scan addresses the score table through a buffer resource with 32-bit offsets */
     if (N > 1 && (size_t)R * NsS * NsS * sizeof(float) > 0x7fffffffull) return fail(c, "unsupported: candidate score table of 2 GiB or more (reference patches x (2 nSim + 1)^2 x 4 B)");
     if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
-    HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * stereo_table_stride(Wb, Hb, k, P->nDisp) * sizeof(float)));
+    HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * std::max(stereo_table_stride(Wb, Hb, k, P->nDisp), stereo_table_stride2(Wb, Hb, k, P->nDisp)) * sizeof(float)));
     HIPCK(c, c->self_idx.reserve((size_t)R * Nst * sizeof(unsigned)));
     HIPCK(c, c->self_cnt.reserve((size_t)R * sizeof(unsigned)));
     HIPCK(c, c->best.reserve(A * plane * sizeof(unsigned)));
@@ -399,14 +402,36 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     sa.n_self = N > 1 ? (P->nSim + 1) * NsS : 0;
     sa.n_stereo = n_slots * NsD * NsD;
     for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
+    sa.est_planes = A;
     if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
-    HIPCK(c, launch_bm_scan(s, sa));
+    const int scan_version = bm_scan_version(sa);
+    c->last_scan_version = scan_version;
+    if (scan_version == 2) {
+        /* ring-sharing workgroups of eight tables (lfbm5d_scan2.hip): the list depends on the search geometry only */
+        const unsigned skey[8] = {sa.n_self, sa.n_stereo, sa.nSim, sa.nDisp, sa.k, Hb, Wb, 1u};
+        if (std::memcmp(skey, c->scan_key, sizeof(skey)) != 0) {
+            if (!scan2_plan(sa, c->scan_plan, &c->scan_lds)) return fail(c, "scan plan");
+            HIPCK(c, c->scan_wgs.reserve(c->scan_plan.size() * sizeof(Scan2Wg)));
+            HIPCK(c, hipMemcpyAsync(c->scan_wgs.p, c->scan_plan.data(), c->scan_plan.size() * sizeof(Scan2Wg), hipMemcpyHostToDevice, s));
+            HIPCK(c, hipStreamSynchronize(s));
+            std::memcpy(c->scan_key, skey, sizeof(skey));
+        }
+        sa.wgs = c->scan_wgs.as<Scan2Wg>(); sa.n_wgs = (unsigned)c->scan_plan.size();
+        sa.lcol_stride = scan2_lcol_stride(sa);
+        HIPCK(c, c->scan_lcol.reserve((size_t)(sa.n_self + sa.n_stereo) * sa.lcol_stride * sizeof(float)));
+        sa.lcol = c->scan_lcol.as<float>();
+        HIPCK(c, launch_bm_scan2(s, sa, c->scan_lds));
+    } else
+        HIPCK(c, launch_bm_scan(s, sa));
     if (N > 1)
         HIPCK(c, launch_self_select(s, c->scores.as<float>(), c->refs.as<unsigned>(), R, Wb, P->nSim, N, thr,
                                     c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
     else
         HIPCK(c, launch_self_trivial(s, c->refs.as<unsigned>(), R, c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
-    if (n_slots)
+    if (n_slots && scan_version == 2)
+        HIPCK(c, launch_stereo_argmin2(s, c->tables.as<float>(), slots, n_slots, Wb, Hb, k, P->nDisp, thr,
+                                       c->best.as<unsigned>(), c->shape.as<unsigned char>()));
+    else if (n_slots)
         HIPCK(c, launch_stereo_argmin(s, c->tables.as<float>(), slots, n_slots, Wb, Hb, k, P->nDisp, thr,
                                       c->best.as<unsigned>(), c->shape.as<unsigned char>()));
     HIPCK(c, hipEventRecord(pe.e[1], s));
@@ -1289,7 +1314,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
     DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
                       &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
-                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch};
+                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch, &c->scan_wgs, &c->scan_lcol};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1677,6 +1702,19 @@ size_t lfbm5d_last_tables(lfbm5d_ctx* c, float* h_tables, size_t n_floats) {
     if (n && hipMemcpy(h_tables, c->tables.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return n;
 }
+
+size_t lfbm5d_last_scores(lfbm5d_ctx* c, float* h_scores, size_t n_floats) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    const size_t have = c->scores.cap / sizeof(float);
+    if (!h_scores) return have;
+    const size_t n = std::min(have, n_floats);
+    if (n && hipMemcpy(h_scores, c->scores.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
+int lfbm5d_last_scan_version(const lfbm5d_ctx* c) { return c ? c->last_scan_version : 0; }
 
 int lfbm5d_malloc(void** dptr, size_t bytes) { return hipMalloc(dptr, bytes) == hipSuccess ? 0 : 1; }
 int lfbm5d_free(void* dptr) { return hipFree(dptr) == hipSuccess ? 0 : 1; }

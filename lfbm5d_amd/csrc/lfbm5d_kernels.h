@@ -7,6 +7,7 @@
 #define LFBM5D_KERNELS_H
 
 #include <hip/hip_runtime.h>
+#include <vector>
 
 namespace lfbm5d {
 
@@ -105,6 +106,29 @@ __host__ __device__ inline size_t stereo_table_stride(unsigned W, unsigned H, un
     return (size_t)((ncols + 63) / 64) * 64 * (nrows + 63);
 }
 
+/* Second-generation scan (lfbm5d_scan2.hip): the four values of four consecutive steps leave as one 16-byte store, so a
+ * table is [strip][Q / 4][lane][Q % 4] with Q = table row + lane + 3 (step t of a strip writes Q = t + 4; the row-0 value
+ * of lane l sits at Q = l + 3); steps are rounded up to whole groups of sixteen.  Strips start at column 1: column 0 is
+ * computed up front (the hand-off column of the first strip) and stored as a plain column behind the strips. */
+__host__ __device__ inline unsigned stereo_table_srq(unsigned H, unsigned k, unsigned nDisp) {
+    const unsigned nrows = H - 2 * nDisp - (k - 1);
+    return ((nrows - 1 + 63 + 15) / 16) * 4 + 1;
+}
+__host__ __device__ inline size_t stereo_table_stride2(unsigned W, unsigned H, unsigned k, unsigned nDisp) {
+    const unsigned ncols = W - 2 * nDisp - (k - 1);
+    return (size_t)((ncols - 1 + 63) / 64) * stereo_table_srq(H, k, nDisp) * 256 + stereo_table_srq(H, k, nDisp) * 4;
+}
+
+/* One workgroup of the second-generation scan: up to eight displacement tables of one image pair whose (di + dj) mod 4
+ * agree (16-byte alignment of the transposed ring reads), and the extent of their displacements (size of the second ring). */
+struct Scan2Wg {
+    short tab[8];               /* displacement index di * Ns + dj of each wave's table, -1: the wave has none */
+    short slot;                 /* disparity search: table slot (index into st_of_slot); self search: -1 */
+    short r2lo, c2lo;           /* smallest row / column offset of the second image's reads against the first's */
+    short rh, ch;               /* ... and how many more rows / columns the largest needs */
+    short pad[3];
+};
+
 struct ScanArgs {
     const float* est;           /* [A][Wb*Hb] channel-0 estimates (+ slack) */
     unsigned W, H, k;
@@ -122,6 +146,12 @@ struct ScanArgs {
     unsigned long long* dbg;    /* development builds (LFBM5D_PHASE_TIMING): phase clocks; else unused */
     float* tables;              /* [n_slots][Ns*Ns][stereo_table_stride]: strip-major [strip][row][64 columns] */
     unsigned st_of_slot[kMaxA];
+    /* second-generation kernel */
+    unsigned est_planes;        /* SAIs in est */
+    const Scan2Wg* wgs;         /* [n_wgs] workgroup descriptors (device) */
+    unsigned n_wgs;
+    float* lcol;                /* [n_self + n_stereo][lcol_stride] hand-off columns between the strips of a table */
+    unsigned lcol_stride;
 };
 
 hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward);
@@ -163,6 +193,15 @@ hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_str
                                  unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count);
 hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, int* refmap);
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a);
+/* second generation (lfbm5d_scan2.hip): which kernel a configuration gets (1 or 2), the workgroup list and LDS size of a
+ * launch, the hand-off row length, the launch itself and the arg-min over its table layout */
+int bm_scan_version(const ScanArgs& a);
+bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes);
+unsigned scan2_lcol_stride(const ScanArgs& a);
+hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds_bytes);
+hipError_t launch_stereo_argmin2(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,
+                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
+                                 unsigned* best, unsigned char* shape);
 hipError_t launch_self_select(hipStream_t s, const float* scores, const unsigned* refs, unsigned n_refs,
                               unsigned W, unsigned nSim, unsigned N, float thr, unsigned* self_idx,
                               unsigned* self_cnt);
