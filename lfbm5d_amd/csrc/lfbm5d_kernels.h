@@ -119,10 +119,10 @@ __host__ __device__ inline size_t stereo_table_stride2(unsigned W, unsigned H, u
     return (size_t)((ncols - 1 + 63) / 64) * stereo_table_srq(H, k, nDisp) * 256 + stereo_table_srq(H, k, nDisp) * 4;
 }
 
-/* One workgroup of the second-generation scan: up to eight displacement tables of one image pair whose (di + dj) mod 4
+/* One workgroup of the second-generation scan: up to ten displacement tables of one image pair whose (di + dj) mod 4
  * agree (16-byte alignment of the transposed ring reads), and the extent of their displacements (size of the second ring). */
 struct Scan2Wg {
-    short tab[8];               /* displacement index di * Ns + dj of each wave's table, -1: the wave has none */
+    short tab[16];              /* displacement index di * Ns + dj of each table wave's table, -1: the wave has none */
     short slot;                 /* disparity search: table slot (index into st_of_slot); self search: -1 */
     short r2lo, c2lo;           /* smallest row / column offset of the second image's reads against the first's */
     short rh, ch;               /* ... and how many more rows / columns the largest needs */

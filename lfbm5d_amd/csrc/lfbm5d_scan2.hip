@@ -4,8 +4,8 @@
  * Same arithmetic as lfbm5d_bm.hip (the reference's integral-image recurrence in the reference's association order,
  * precompute_BM core:3301-3461, precompute_BM_stereo core:3479-3611 -- bit-identical tables), different machine mapping:
  *
- *   - a WORKGROUP of eight wavefronts walks eight displacement tables of one image pair in lockstep (one barrier per
- *     chunk of eight steps).  The eight tables read the same image rows, only shifted by their displacement, so the
+ *   - a WORKGROUP of seven table waves and one loader wave walks seven displacement tables of one image pair in lockstep
+ *     (one barrier per chunk of eight steps).  The eight tables read the same image rows, only shifted by their displacement, so the
  *     workgroup keeps ONE ring of raw rows per image in LDS (round 2: one ring of squared differences per table:
  *     26.8 KiB per wave, six waves per CU) and every wave forms its squared differences on the fly (two packed
  *     subtract / multiply pairs per step);
@@ -18,8 +18,10 @@
  *   - the two operands of the band's upper edge come from a 2K-register FIFO like round 2;
  *   - the four results of four steps leave as ONE 16-byte store per lane (table layout [strip][step / 4][lane][4]),
  *     the hand-off column to the next strip as one 16-byte store of the strip's last lane into a per-table scratch row
- *     in global memory, and comes back as uniform 16-byte loads -- no LDS traffic besides the ring reads;
- *   - the row loads are dealt to all 512 threads (at most one 16-byte load per thread per chunk) two chunks ahead.
+ *     in global memory;
+ *   - the table waves issue stores only: every load -- ring rows two chunks ahead, the hand-off column values of the
+ *     next chunks into a small staging area -- belongs to the loader wave, whose vmcnt (an in-order counter of loads
+ *     AND stores) therefore never waits for a table store to be acknowledged.
  *
  * No FMA contraction in this file (it would change the rounding).
  */
@@ -41,6 +43,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kRsrcFlags = 0x00020000u;
+/* development builds (tools/build_variant.sh ... -DLFBM5D_S2_EXP=bits): timing experiments, results are garbage.
+ * 1: table stores go nowhere; 2: no hand-off column traffic; 4: no ring loads; 8 / 16: no self / no disparity tables */
+#ifndef LFBM5D_S2_EXP
+#define LFBM5D_S2_EXP 0
+#endif
+#ifndef LFBM5D_S2_HAND_AUX
+#define LFBM5D_S2_HAND_AUX 17   /* sc0 sc1 */
+#endif
 constexpr int kLeadBytes = 32;   /* the image resource starts 8 floats in front of the first plane (the estimate buffer has 64 of slack) */
 
 template <int K> struct S2Geom {
@@ -68,12 +78,162 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int K, bool STEREO>
-__device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, float* lds) {
+constexpr int kS2NW = 11;         /* tables (table waves) of a workgroup */
+constexpr int kS2NL = 1;          /* ... and its loader wave: twelve waves, three per SIMD (the loader's instruction count per chunk is about a
+                                   * table wave's, so every SIMD carries the same load and no wave idles at the chunk barrier), one workgroup per CU */
+constexpr int kS2NI = 6;          /* 16-byte pieces of a block of eight ring rows per loader lane: 64 * kS2NI >= 2 (CW1 + CW2) */
+constexpr int kS2LD = 2;          /* blocks the loader wave has in flight */
+
+/* ---- the loader wave: image rows into the two rings, hand-off column values into their staging area ---- */
+template <int K, bool STEREO, int NW, int NL>
+__device__ __forceinline__ void scan2_loader(const ScanArgs& a, const Scan2Wg& g, float* lds, int r0, const int lw) {
+    static_assert(NL == 1, "one loader wave");
+    /* the loader wave is the youngest of the workgroup and would get the issue slots the table waves leave over, with all
+     * of them waiting at the chunk barrier for the rows: it goes first */
+    __builtin_amdgcn_s_setprio(3);
     typedef S2Geom<K> G;
     constexpr int CW1 = G::CW1, RR1 = G::RR1, RRp1 = G::RRp1, LEAD1 = G::LEAD1;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   /* wave-uniform: everything derived from the wave's table stays scalar */
+    const int lane = threadIdx.x & 63;
+    const int W = a.W, H = a.H;
+    const int half = STEREO ? (int)a.nDisp : (int)a.nSim;
+    const int b = STEREO ? (int)a.nDisp : (int)a.nHW;
+    const int trim = STEREO ? K - 1 : 0;
+    const int Ns = 2 * half + 1, ncand = Ns * Ns;
+    const int nrows = H - 2 * b - trim, ncols = W - 2 * b - trim;
+    const size_t WH = (size_t)W * H;
+    const int CW2 = G::cw2(g.ch), LEAD2 = G::lead2(g.rh), RR2 = G::rr2(g.rh), RRp2 = RR2 + 13;
+    const int LEADM = LEAD2 > LEAD1 ? LEAD2 : LEAD1;
+    float* ring1 = lds;
+    float* ring2 = lds + CW1 * RRp1;
+    float* lcst = ring2 + CW2 * RRp2;            /* [2][NW][8] hand-off column values of the current / next chunk */
+    const unsigned pl1 = a.pst, pl2 = STEREO ? a.st_of_slot[g.slot] : a.pst;
+    const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.est - kLeadBytes / 4), 0, (int)(a.est_planes * WH * 4 + kLeadBytes + 1024), kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rLA = __builtin_amdgcn_make_buffer_rsrc((void*)a.lcol, 0, (int)((a.n_self + a.n_stereo) * a.lcol_stride * 4), kRsrcFlags);
+    /* piece k of a block <-> (ring, row of the block, four columns).  Every lane issues all kS2NI loads of a block, pieces past
+     * the last one at an out-of-range offset: with loads under a uniform branch the compiler can no longer count them and
+     * waits for vmcnt(0), i.e. for the block it has just asked for */
+    const int n1 = 2 * CW1, nit = n1 + 2 * CW2;
+    bool pv[kS2NI], p1[kS2NI];
+    int py0[kS2NI], pgo[kS2NI], pslot[kS2NI];
+    float* pdst[kS2NI];
+#pragma unroll
+    for (int k = 0; k < kS2NI; k++) {
+        const int item = k * 64 + lane;
+        pv[k] = item < nit; p1[k] = item < n1;
+        const int it = p1[k] ? item : item - n1;
+        const int r = it & 7, quad = it >> 3;
+        py0[k] = (p1[k] ? b : b + g.r2lo) + r;
+        /* byte offset of the piece in row 0 of its plane, relative to the strip's first column */
+        pgo[k] = (int)((p1[k] ? pl1 : pl2) * WH) * 4 + kLeadBytes + ((p1[k] ? 0 : g.c2lo) + 4 * quad - 1) * 4;
+        pdst[k] = (p1[k] ? ring1 : ring2) + 4 * quad * (p1[k] ? RRp1 : RRp2);
+        pslot[k] = (r + (p1[k] ? 0 : r0)) % (p1[k] ? RR1 : RR2);
+    }
+    /* hand-off values: lane -> (table, value of a chunk of eight steps) */
+    static_assert(NW <= 16, "two hand-off values per loader lane");
+    (void)lw;
+    const int he = lane & 7;
+    int hbase[2];
+    float* hdst[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int hw = (q * 64 + lane) >> 3;
+        hbase[q] = -1;
+        if (hw < NW) {
+            const int tw = g.tab[hw];
+            if (tw >= 0) hbase[q] = ((STEREO ? (int)a.n_self + g.slot * ncand + tw : tw) * (int)a.lcol_stride + 65 + he) * 4;
+        }
+        hdst[q] = lcst + (hw < NW ? hw : 0) * 8 + he;
+    }
+    const bool hok[2] = {(lane >> 3) < NW, ((64 + lane) >> 3) < NW};
+
+    const int nstrips = (ncols - 1 + 63) / 64;
+    for (int strip = 0; strip < nstrips; strip++) {
+        const int cb = b + 1 + 64 * strip;
+        const int last_lane = min(63, ncols - 2 - 64 * strip);
+        const int nchunks = (((nrows - 1) + last_lane + 15) >> 4) * 2;
+        lds_barrier();   /* E: the table waves are done with the rings and their hand-off stores have landed */
+        int ws[kS2NI];
+#pragma unroll
+        for (int k = 0; k < kS2NI; k++) ws[k] = pslot[k];
+        auto piece_load = [&](int k, int j) -> v4f {
+            const int y = min(max(py0[k] + 8 * j, 0), H - 1);
+            return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rE, pv[k] ? pgo[k] + (y * W + cb) * 4 : -1, 0, 0));
+        };
+        auto piece_write = [&](int k, const v4f v) {
+            if (pv[k]) {
+                const int RRk = p1[k] ? RR1 : RR2, RRpk = p1[k] ? RRp1 : RRp2;
+                const int slot = ws[k];
+                ws[k] += 8; ws[k] = ws[k] >= RRk ? ws[k] - RRk : ws[k];
+                float* d = pdst[k] + slot;
+                d[0] = v[0]; d[RRpk] = v[1]; d[2 * RRpk] = v[2]; d[3 * RRpk] = v[3];
+                if (slot < 7) { d += RRk; d[0] = v[0]; d[RRpk] = v[1]; d[2 * RRpk] = v[2]; d[3 * RRpk] = v[3]; }
+            }
+        };
+        auto hand_load = [&](int q, int c) -> float {
+            /* sc0 sc1: served by L2, never by this CU's L1 (the values were stored by the table waves of this workgroup) */
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rLA, hbase[q] >= 0 ? hbase[q] + 32 * c : -1, 0, LFBM5D_S2_HAND_AUX));
+        };
+        /* blocks 0 .. lead of either ring, the hand-off values of chunk 0; then kS2LD blocks / chunks in flight */
+        for (int j = 0; j <= LEADM; j++) {
+            v4f v[kS2NI];
+#pragma unroll
+            for (int k = 0; k < kS2NI; k++) v[k] = piece_load(k, j);
+#pragma unroll
+            for (int k = 0; k < kS2NI; k++) if (j <= (p1[k] ? LEAD1 : LEAD2)) piece_write(k, v[k]);
+        }
+        v4f stg[kS2LD][kS2NI];
+#pragma unroll
+        for (int d = 0; d < kS2LD; d++)
+#pragma unroll
+            for (int k = 0; k < kS2NI; k++) stg[d][k] = piece_load(k, (p1[k] ? LEAD1 : LEAD2) + 1 + d);
+#pragma unroll
+        for (int q = 0; q < 2; q++) { const float h0 = hand_load(q, 0); if (hok[q]) hdst[q][0] = h0; }
+        float hv[kS2LD][2];
+#pragma unroll
+        for (int d = 0; d < kS2LD; d++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) hv[d][q] = hand_load(q, 1 + d);
+        lds_barrier();   /* A */
+#ifdef LFBM5D_PHASE_TIMING
+        long long lk[2] = {0, 0};
+        long long llast = (long long)__builtin_readcyclecounter();
+#endif
+        /* chunk cc: block cc + lead + 1 goes into the ring, the loads of block cc + lead + 1 + kS2LD start */
+        auto chunk = [&](const int d, const int cc) {
+            if (LFBM5D_S2_EXP & 32) { lds_barrier(); return; }   /* experiment: a loader that only keeps the barrier count */
+#pragma unroll
+            for (int k = 0; k < kS2NI; k++) {
+                piece_write(k, stg[d][k]);
+                if (!(LFBM5D_S2_EXP & 4)) stg[d][k] = piece_load(k, cc + (p1[k] ? LEAD1 : LEAD2) + 1 + kS2LD);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (hok[q]) hdst[q][((cc + 1) & 1) * NW * 8] = hv[d][q];
+                hv[d][q] = hand_load(q, cc + 1 + kS2LD);
+            }
+#ifdef LFBM5D_PHASE_TIMING
+            { const long long tn = (long long)__builtin_readcyclecounter(); lk[0] += tn - llast; llast = tn; }
+#endif
+            lds_barrier();
+#ifdef LFBM5D_PHASE_TIMING
+            { const long long tn = (long long)__builtin_readcyclecounter(); lk[1] += tn - llast; llast = tn; }
+#endif
+        };
+        static_assert(kS2LD == 2, "the chunk count is even");
+        for (int c = 0; c < nchunks; c += 2) { chunk(0, c); chunk(1, c + 1); }
+#ifdef LFBM5D_PHASE_TIMING
+        if (lane == 0 && a.dbg && STEREO) { atomicAdd(&a.dbg[5], (unsigned long long)lk[0]); atomicAdd(&a.dbg[11], (unsigned long long)lk[1]); }
+#endif
+    }
+    lds_barrier();   /* the table waves' last E */
+}
+
+/* ---- a table wave ---- */
+template <int K, bool STEREO, int NW>
+__device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g, float* lds, const int w, const int r0) {
+    typedef S2Geom<K> G;
+    constexpr int CW1 = G::CW1, RR1 = G::RR1, RRp1 = G::RRp1;
+    const int lane = threadIdx.x & 63;
     const int W = a.W, H = a.H;
     const int half = STEREO ? (int)a.nDisp : (int)a.nSim;
     const int b = STEREO ? (int)a.nDisp : (int)a.nHW;
@@ -87,23 +247,16 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
     const int di = tb / Ns, dj = tb % Ns;
     const int dioff = STEREO ? di - half : di, djoff = dj - half;       /* second image: row / column offset */
     const int r2lo = g.r2lo, c2lo = g.c2lo;
-    const int CW2 = G::cw2(g.ch), LEAD2 = G::lead2(g.rh), RR2 = G::rr2(g.rh), RRp2 = RR2 + 13;
-    /* row phase of ring 2: (djoff - c2lo) + (dioff - r2lo) + r0 = 0 (mod 4), the same for every table of the workgroup */
-    int r0;
-    {
-        const int t0 = g.tab[0], di0 = t0 / Ns, dj0 = t0 % Ns;
-        r0 = (4 - (((dj0 - half) - c2lo + (STEREO ? di0 - half : di0) - r2lo) & 3)) & 3;
-    }
+    const int CW2 = G::cw2(g.ch), RR2 = G::rr2(g.rh), RRp2 = RR2 + 13;
     float* ring1 = lds;
     float* ring2 = lds + CW1 * RRp1;
-    short* rs = reinterpret_cast<short*>(ring2 + CW2 * RRp2);   /* self search: reference-grid row slot of every image row (+ 64 of padding) */
+    const float* lcst = ring2 + CW2 * RRp2;
+    const short* rs = reinterpret_cast<const short*>(lcst + 2 * NW * 8);   /* self search: reference-grid row slot of every image row (+ 64 of padding) */
 
     const unsigned pl1 = a.pst, pl2 = STEREO ? a.st_of_slot[g.slot] : a.pst;
     const float* img1 = a.est + (size_t)pl1 * WH;
     const float* img2 = a.est + (size_t)pl2 * WH;
     const int dk = dioff * W + djoff;
-    /* one resource over all planes for the ring loads (a thread loads for either image), one per image for the pre-pass */
-    const __amdgpu_buffer_rsrc_t rE = __builtin_amdgcn_make_buffer_rsrc((void*)(a.est - kLeadBytes / 4), 0, (int)(a.est_planes * WH * 4 + kLeadBytes + 1024), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)img1, 0, (int)(WH * 4 + 1024), kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(img2 + dk), 0, (int)(WH * 4 + 1024), kRsrcFlags);
     /* outputs: waves without a table of their own (the last workgroup of a class) run along with stores that go nowhere */
@@ -112,7 +265,7 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
     const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void*)lcolT, 0, live ? (int)(a.lcol_stride * 4) : 0, kRsrcFlags);
     const size_t tstride = STEREO ? stereo_table_stride2(a.W, a.H, a.k, a.nDisp) : 0;
     float* table = STEREO ? a.tables + (size_t)(g.slot * ncand + tb) * tstride : nullptr;
-    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (STEREO && live) ? (int)(tstride * 4) : 0, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (STEREO && live && !(LFBM5D_S2_EXP & 1)) ? (int)(tstride * 4) : 0, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (!STEREO && live) ? (int)a.scores_bytes : 0, kRsrcFlags);
     const int SRq = (int)stereo_table_srq(a.H, a.k, a.nDisp);
     const int nstrips = (ncols - 1 + 63) / 64;      /* strips of 64 columns, starting at column 1 of the table */
@@ -194,21 +347,6 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
             emit0(i, mine, i < nrows);
         }
     }
-    if (!STEREO)
-        for (int i = tid; i < H + 64; i += blockDim.x) rs[i] = (short)a.rslot[i];
-    __syncthreads();
-
-    /* ---- ring loads: thread -> (image, row of the block, group of four columns) ---- */
-    const int n1 = 2 * CW1, n2 = 2 * CW2;                 /* 16-byte pieces of a block of eight rows */
-    const bool ld1 = tid < n1, ld2 = !ld1 && tid - n1 < n2;
-    const bool loader = ld1 || ld2;
-    const int item = ld1 ? tid : tid - n1;
-    const int lr = item & 7, lquad = item >> 3;
-    const int l_RR = ld1 ? RR1 : RR2, l_RRp = ld1 ? RRp1 : RRp2, l_lead = ld1 ? LEAD1 : LEAD2;
-    const int l_y0 = (ld1 ? b : b + r2lo) + lr;                          /* image row of the item in block 0 */
-    const int l_plane = (int)((ld1 ? pl1 : pl2) * WH) * 4 + kLeadBytes;
-    float* const l_dst = (ld1 ? ring1 : ring2) + 4 * lquad * l_RRp;
-    const int l_r0 = ld1 ? 0 : r0;
 
     float row0_left = corner;   /* S[b][cb-1] */
     for (int strip = 0; strip < nstrips; strip++) {
@@ -221,31 +359,11 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
          * columns through the operands at x + K - 1 of the last strip, rows in the ramp-down chunks */
         const int cm1 = (STEREO || x + K - 1 < W - b) ? -1 : 0;
 
-        /* the hand-off column of the previous strip (first strip: the first column) must have landed */
+        /* E: the hand-off column of the previous strip (first strip: the first column) has landed; the loader wave may
+         * refill the rings */
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-        const int l_x = cb - 1 + (ld1 ? 0 : c2lo) + 4 * lquad;
-        auto ring_load = [&](int j) -> v4f {
-            const int y = min(max(l_y0 + 8 * j, 0), H - 1);
-            return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rE, loader ? l_plane + (y * W + l_x) * 4 : -1, 0, 0));
-        };
-        int wslot = (lr + l_r0) % l_RR;   /* row slot of this thread's piece in the next block to write */
-        auto ring_write = [&](const v4f v) {
-            if (loader) {
-                const int slot = wslot;
-                wslot += 8; wslot = wslot >= l_RR ? wslot - l_RR : wslot;
-                float* d = l_dst + slot;
-                d[0] = v[0]; d[l_RRp] = v[1]; d[2 * l_RRp] = v[2]; d[3 * l_RRp] = v[3];
-                if (slot < 7) { d += l_RR; d[0] = v[0]; d[l_RRp] = v[1]; d[2 * l_RRp] = v[2]; d[3 * l_RRp] = v[3]; }
-            }
-        };
-        v4f stg[2];
-        {
-            for (int j = 0; j <= l_lead; j++) ring_write(ring_load(j));
-            stg[0] = ring_load(l_lead + 1);
-            stg[1] = ring_load(l_lead + 2);
-        }
         lds_barrier();
+        lds_barrier();   /* A: rows 0 .. K + 7 of the strip are in the rings, the hand-off values of chunk 0 staged */
 
         /* squared difference at ring row rho (relative to the band's first row), ring-1 column c */
         auto Draw = [&](int rho, int c) -> float {
@@ -289,6 +407,27 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
             const int ry2 = di > 0 ? s2_grid_index(b + di, gR, lastR, gN, gP) : -1;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, S0), rS, (ry2 >= 0 && base_bwd >= 0) ? ry2 * row_bytes + base_bwd : -1, 0, 0);
         }
+        /* Self search on the regular grid: a lane's column is a grid column or not for the whole strip, and the lanes on grid
+         * columns share lane mod p, hence also the steps on which their row 1 + t - lane is a grid row: ONE store step in p,
+         * the same lanes every time, the row slot one further each time.  That holds when every grid column of the strip
+         * and the forced last row lie on the pattern nHW + i p (else: per-step table look-ups, the general form below). */
+        bool fast = false;
+        int nfF = 0x40000000, nfB = 0x40000000, offF = -1, offB = -1, incF = 0, incB = 0;
+        unsigned boundF = 0, boundB = 0;
+        if (!STEREO) {
+            const bool offpat = (base_fwd >= 0 && (x - gN) % gP != 0) || (base_bwd >= 0 && (x + djs - gN) % gP != 0);
+            fast = !__builtin_amdgcn_ballot_w64(offpat) && (lastR - gN) % gP == 0;
+            if (fast) {
+                const int tF0 = ((-(2 + 64 * strip)) % gP + gP) % gP;              /* rows 1 + t - lane of the forward lanes: grid rows */
+                const int tB0 = ((-(2 + 64 * strip + djs + di)) % gP + gP) % gP;   /* rows 1 + t - lane + di of the mirrored lanes */
+                nfF = tF0; nfB = di > 0 ? tB0 : 0x40000000;
+                if (base_fwd >= 0) { offF = ((1 + tF0 - lane) / gP) * row_bytes + base_fwd; incF = row_bytes; }
+                if (base_bwd >= 0) { offB = ((1 + tB0 - lane + di) / gP) * row_bytes + base_bwd; incB = row_bytes; }
+                /* a lane stores while its row is in the table and (plus di) not past the last grid row */
+                boundF = (unsigned)max(min(nrows - 2, lastR - b - 1), -1);
+                boundB = (unsigned)max(min(nrows - 2, lastR - b - 1 - di), -1);
+            }
+        }
 
         /* ---- the remaining rows.  Lane l works on table row 1 + t - l at step t: active for t in [l, nrows-2+l].
          * Operands of the band's upper edge (rows t - l): the lower edge's of K steps ago, from a register FIFO. ---- */
@@ -311,16 +450,17 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
         /* outputs: running byte offsets.  Table: [strip][step / 4 + 1][lane][4]; hand-off: the strip's last lane, rows 1 + t - 63 */
         int voffT = ((strip * SRq + 1) * 64 + lane) * 16;
         int voffL = lane == 63 ? (64 + 1 - 63) * 4 : 0x70000000;
-        /* hand-off column values of steps 0..15 (rows 1..16 of the column left of the strip) */
-        v4f lcr[2][2];
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-                lcr[c][h] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rL, 0, (65 + 8 * c + 4 * h) * 4, 0));
-        int jw = 0;   /* chunk counter of the loader */
+        const float* const lcw = lcst + w * 8;
 
-        /* FL 0: steady -- every lane active on every step, every row in the band; FL 1: edge (ramp-up, ramp-down, short tables) */
+        /* chain flavours: steady -- every lane active on every step, every row in the band; edge (ramp-up, ramp-down, short
+         * tables).  Store flavours of the self search: pattern (above) or look-ups */
+#ifdef LFBM5D_PHASE_TIMING
+        long long tk[4] = {0, 0, 0, 0};
+        long long tlast = (long long)__builtin_readcyclecounter();
+#define S2_MARK(i) do { const long long tn = (long long)__builtin_readcyclecounter(); tk[i] += tn - tlast; tlast = tn; } while (0)
+#else
+#define S2_MARK(i) do {} while (0)
+#endif
         auto body16 = [&](auto fl_tag, const int t0) {
             constexpr bool EDGE = decltype(fl_tag)::value;
             /* per-lane step numbers relative to this group of sixteen (compared with small constants below) */
@@ -329,13 +469,7 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 const int tc = t0 + 8 * ch;
-                /* rows for the next chunk go into the ring, the loads for the one after the next start */
-                ring_write(stg[ch]);
-                stg[ch] = ring_load(jw + l_lead + 3);
-                jw++;
-                const v4f lc[2] = {lcr[ch][0], lcr[ch][1]};
-                lcr[ch][0] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rL, 0, (65 + tc + 16) * 4, 0));
-                lcr[ch][1] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rL, 0, (65 + tc + 20) * 4, 0));
+                const v4f lc[2] = {*reinterpret_cast<const v4f*>(lcw + ch * NW * 8), *reinterpret_cast<const v4f*>(lcw + ch * NW * 8 + 4)};
                 const float* pA = colA + slot1;
                 const float* pB = colB + slot2;
 #pragma unroll
@@ -378,54 +512,108 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
                     if (STEREO) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, out), rT, voffT, 0, 0);
                         voffT += 1024;
+                    } else if (fast) {
+#pragma unroll
+                        for (int s = 0; s < 4; s++) {
+                            const int u = 8 * ch + 4 * gq + s;
+                            const float ov = out[s];   /* (a bit_cast of the vector element itself picks element 0) */
+                            if (u == nfF) {
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ov), rS, (unsigned)(u - rel_start) <= boundF ? offF : -1, 0, 0);
+                                offF += incF; nfF += gP;
+                            }
+                            if (u == nfB) {
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ov), rS, (unsigned)(u - rel_start) <= boundB ? offB : -1, 0, 0);
+                                offB += incB; nfB += gP;
+                            }
+                        }
                     } else {
 #pragma unroll
                         for (int s = 0; s < 4; s++) {
-                            const int t = tg + s;
-                            const bool act = (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2);
-                            const int y = min(max(b + 1 + t - lane, 0), H - 1);
-                            const int r1 = rs[y], r2 = rs[y + di];                  /* -1: not a grid row */
-                            const int v1 = (act && (r1 | base_fwd) >= 0) ? r1 * row_bytes + base_fwd : -1;
-                            const int v2 = (act && (r2 | base_bwd) >= 0) ? r2 * row_bytes + base_bwd : -1;
-                            /* a store no lane takes part in is skipped (on the regular grid three steps in four) */
-                            const float ov = out[s];   /* (a bit_cast of the vector element itself picks element 0) */
-                            if (__builtin_amdgcn_ballot_w64(v1 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ov), rS, v1, 0, 0);
-                            if (__builtin_amdgcn_ballot_w64(v2 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ov), rS, v2, 0, 0);
+                            const float ov = out[s];
+                            {
+                                const int t = tg + s;
+                                const bool act = (unsigned)(t - lane_eff) <= (unsigned)(nrows - 2);
+                                const int y = min(max(b + 1 + t - lane, 0), H - 1);
+                                const int r1 = rs[y], r2 = rs[y + di];                  /* -1: not a grid row */
+                                const int v1 = (act && (r1 | base_fwd) >= 0) ? r1 * row_bytes + base_fwd : -1;
+                                const int v2 = (act && (r2 | base_bwd) >= 0) ? r2 * row_bytes + base_bwd : -1;
+                                /* a store no lane takes part in is skipped (on the regular grid three steps in four) */
+                                if (__builtin_amdgcn_ballot_w64(v1 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ov), rS, v1, 0, 0);
+                                if (__builtin_amdgcn_ballot_w64(v2 != -1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(ov), rS, v2, 0, 0);
+                            }
                         }
                     }
                     /* hand-off column for the next strip: rows 1 + t - 63 of this strip's last column */
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, out), rL, voffL, 0, 0);
+                    if (!(LFBM5D_S2_EXP & 2)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, out), rL, voffL, 0, 0);
                     voffL += 16;
                 }
                 slot1 += 8; slot1 = min(slot1, slot1 - (unsigned)RR1);
                 slot2 += 8; slot2 = min(slot2, slot2 - (unsigned)RR2);
+                S2_MARK(EDGE ? 1 : 0);
                 lds_barrier();
+                S2_MARK(2);
             }
+            if (!STEREO) { nfF -= 16; nfB -= 16; }
         };
 
         const int nsteps = (nrows - 1) + last_lane;
         const int tS1 = (min(nrows - 1, band_rows - K) / 16) * 16;   /* steady chunks end before lane 0 stops / the band ends */
-        {
+        auto run = [&]() {
             int t0 = 0;
             for (; t0 < nsteps && t0 < 64; t0 += 16) body16(std::true_type{}, t0);
             for (; t0 < tS1; t0 += 16) body16(std::false_type{}, t0);
             for (; t0 < nsteps; t0 += 16) body16(std::true_type{}, t0);
-        }
+        };
+        S2_MARK(3);   /* strip prologue: barriers E / A, first row, FIFO */
+        run();
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
+#ifdef LFBM5D_PHASE_TIMING
+        if (lane == 0 && a.dbg && live) {
+            const int base = STEREO ? 0 : 6;
+            for (int i = 0; i < 4; i++) atomicAdd(&a.dbg[base + i], (unsigned long long)tk[i]);
+            atomicAdd(&a.dbg[base + 4], 1ull);
+        }
+#endif
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();   /* the loader wave's last E */
+}
+
+template <int K, bool STEREO, int NW, int NL>
+__device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, float* lds) {
+    typedef S2Geom<K> G;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   /* wave-uniform: everything derived from the wave's table stays scalar */
+    const int half = STEREO ? (int)a.nDisp : (int)a.nSim;
+    const int Ns = 2 * half + 1;
+    /* row phase of ring 2: (djoff - c2lo) + (dioff - r2lo) + r0 = 0 (mod 4), the same for every table of the workgroup */
+    int r0;
+    {
+        const int t0 = g.tab[0], di0 = t0 / Ns, dj0 = t0 % Ns;
+        r0 = (4 - (((dj0 - half) - g.c2lo + (STEREO ? di0 - half : di0) - g.r2lo) & 3)) & 3;
+    }
+    if (!STEREO) {
+        float* ring2 = lds + G::CW1 * G::RRp1;
+        short* rs = reinterpret_cast<short*>(ring2 + G::cw2(g.ch) * (G::rr2(g.rh) + 13) + 2 * NW * 8);
+        for (int i = tid; i < (int)a.H + 64; i += blockDim.x) rs[i] = (short)a.rslot[i];
+    }
+    if (w >= NW) scan2_loader<K, STEREO, NW, NL>(a, g, lds, r0, w - NW);
+    else scan2_table<K, STEREO, NW>(a, g, lds, w, r0);
 }
 
 template <int K>
-__global__ __launch_bounds__(512) void k_bm_scan2(ScanArgs a) {
+__global__ __launch_bounds__((kS2NW + kS2NL) * 64) void k_bm_scan2(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds2[];
     const Scan2Wg& g = a.wgs[blockIdx.x];
+    if ((LFBM5D_S2_EXP & 8) && g.slot < 0) return;     /* experiments: disparity tables only / self tables only */
+    if ((LFBM5D_S2_EXP & 16) && g.slot >= 0) return;
 #ifdef LFBM5D_SCAN2_ONLY_STEREO
-    scan2_body<K, true>(a, g, lds2);
+    scan2_body<K, true, kS2NW, kS2NL>(a, g, lds2);
 #elif defined(LFBM5D_SCAN2_ONLY_SELF)
-    scan2_body<K, false>(a, g, lds2);
+    scan2_body<K, false, kS2NW, kS2NL>(a, g, lds2);
 #else
-    if (g.slot >= 0) scan2_body<K, true>(a, g, lds2);
-    else scan2_body<K, false>(a, g, lds2);
+    if (g.slot >= 0) scan2_body<K, true, kS2NW, kS2NL>(a, g, lds2);
+    else scan2_body<K, false, kS2NW, kS2NL>(a, g, lds2);
 #endif
 }
 
@@ -486,7 +674,7 @@ __global__ __launch_bounds__(256) void k_stereo_argmin2(Argmin2Args a) {
 template <int K> size_t scan2_lds_bytes(const ScanArgs& a, int rh_max, int ch_max) {
     typedef S2Geom<K> G;
     const int RRp2 = G::rr2(rh_max) + 13;
-    return (size_t)(G::CW1 * G::RRp1 + G::cw2(ch_max) * RRp2) * sizeof(float) + (a.n_self ? (size_t)(a.H + 64) * sizeof(short) : 0) + 16;
+    return (size_t)(G::CW1 * G::RRp1 + G::cw2(ch_max) * RRp2 + 2 * kS2NW * 8) * sizeof(float) + (a.n_self ? (size_t)(a.H + 64) * sizeof(short) : 0) + 16;
 }
 
 } /* namespace */
@@ -508,27 +696,27 @@ bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes)
     wgs.clear();
     int rh_max = 0, ch_max = 0;
     auto add = [&](int slot, const std::vector<int>& tabs, int r2lo, int c2lo, int rh, int ch) {
-        for (size_t i = 0; i < tabs.size(); i += 8) {
+        for (size_t i = 0; i < tabs.size(); i += kS2NW) {
             Scan2Wg g;
             std::memset(&g, 0, sizeof(g));
-            for (int w = 0; w < 8; w++) g.tab[w] = i + w < tabs.size() ? (short)tabs[i + w] : (short)-1;
+            for (int w = 0; w < 16; w++) g.tab[w] = (w < kS2NW && i + w < tabs.size()) ? (short)tabs[i + w] : (short)-1;
             g.slot = (short)slot; g.r2lo = (short)r2lo; g.c2lo = (short)c2lo; g.rh = (short)rh; g.ch = (short)ch;
             wgs.push_back(g);
         }
         rh_max = std::max(rh_max, rh); ch_max = std::max(ch_max, ch);
     };
     if (a.n_self) {
-        /* self search: di in [0, nSim], dj in [0, 2 nSim]; tiles of 4 x 8 displacements, one workgroup per class of a tile
-         * (eight tables): the second ring then spans 3 more rows and 7 more columns than the first */
+        /* self search: di in [0, nSim], dj in [0, 2 nSim]; tiles of 4 x kS2NW displacements, one workgroup per class of a
+         * tile (kS2NW tables): the second ring then spans 3 more rows and kS2NW - 1 more columns than the first */
         const int nSim = (int)a.nSim, Ns = 2 * nSim + 1;
         for (int d0 = 0; d0 <= nSim; d0 += 4)
-            for (int j0 = 0; j0 < Ns; j0 += 8)
+            for (int j0 = 0; j0 < Ns; j0 += kS2NW)
                 for (int cls = 0; cls < 4; cls++) {
                     std::vector<int> tabs;
                     for (int di = d0; di < std::min(d0 + 4, nSim + 1); di++)
-                        for (int dj = j0; dj < std::min(j0 + 8, Ns); dj++)
+                        for (int dj = j0; dj < std::min(j0 + kS2NW, Ns); dj++)
                             if (((di + dj) & 3) == cls) tabs.push_back(di * Ns + dj);
-                    if (!tabs.empty()) add(-1, tabs, d0, j0 - nSim, 3, 7);
+                    if (!tabs.empty()) add(-1, tabs, d0, j0 - nSim, 3, kS2NW - 1);
                 }
     }
     if (a.n_stereo) {
@@ -544,9 +732,9 @@ bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes)
     }
     size_t lds = a.k == 8 ? scan2_lds_bytes<8>(a, rh_max, ch_max) : scan2_lds_bytes<16>(a, rh_max, ch_max);
     if (lds_bytes) *lds_bytes = lds;
-    /* one 16-byte piece per thread and chunk; the rings within the CU's LDS */
+    /* at most kS2NI 16-byte pieces per loader lane and chunk; the rings within the CU's LDS */
     const int n1 = 2 * (64 + (int)a.k), n2 = 2 * ((64 + (int)a.k + ch_max + 3) & ~3);
-    if (n1 + n2 > 512 || lds > 160 * 1024) return false;
+    if (n1 + n2 > 64 * kS2NI || lds > 160 * 1024) return false;
     return !wgs.empty();
 }
 
@@ -564,8 +752,8 @@ hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds) {
         if (e != hipSuccess) return e;
         prepared = true;
     }
-    if (a.k == 8) hipLaunchKernelGGL((k_bm_scan2<8>), dim3(a.n_wgs), dim3(512), lds, s, a);
-    else if (a.k == 16) hipLaunchKernelGGL((k_bm_scan2<16>), dim3(a.n_wgs), dim3(512), lds, s, a);
+    if (a.k == 8) hipLaunchKernelGGL((k_bm_scan2<8>), dim3(a.n_wgs), dim3((kS2NW + kS2NL) * 64), lds, s, a);
+    else if (a.k == 16) hipLaunchKernelGGL((k_bm_scan2<16>), dim3(a.n_wgs), dim3((kS2NW + kS2NL) * 64), lds, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -8,6 +8,7 @@ name=$1; extra=$2
 out=../variants; mkdir -p $out/obj_$name
 F="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-result $extra"
 hipcc $F -ffp-contract=off -c lfbm5d_bm.hip -o $out/obj_$name/bm.o &
+hipcc $F -ffp-contract=off -c lfbm5d_scan2.hip -o $out/obj_$name/scan2.o &
 hipcc $F -c lfbm5d_kernels.hip -o $out/obj_$name/kernels.o &
 hipcc $F -c lfbm5d_api.hip -o $out/obj_$name/api.o &
 wait

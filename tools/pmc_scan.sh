@@ -12,7 +12,7 @@ for f in glob.glob("gpurun_out/pmcs/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
         key=None
-        for k in ("k_bm_scan<16","k_bm_scan<8","k_group_dct8w","k_group_id","k_aggregate<false","k_aggregate<true","k_stereo_argmin","k_self_select"):
+        for k in ("k_bm_scan<16","k_bm_scan<8","k_bm_scan2<16","k_bm_scan2<8","k_stereo_argmin2","k_group_dct8w","k_group_id","k_aggregate<false","k_aggregate<true","k_stereo_argmin","k_self_select"):
             if k in n: key=k
         if key:
             acc[key][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[key].add(r["Dispatch_Id"])
