@@ -24,13 +24,20 @@ basic = 0.5 * noisy + 0.5 * torch.roll(noisy, 1, 1)
 num = torch.zeros_like(noisy); den = torch.zeros_like(noisy)
 mask = np.ones(9, np.uint32); proc = np.zeros(9, np.uint32)
 ctx = L.Context(0)
-NSTRIP = (Wb - 2 * nDisp - (k - 1) + 63) // 64
 NT = 8 * (2 * nDisp + 1) ** 2
 NR, NC = Hb - 2 * nDisp - (k - 1), Wb - 2 * nDisp - (k - 1)
-SR = NR + 63                   # rows of a strip in the skewed layout: entry [strip][q][l] = table row q - l, column 64 strip + l
-TS = NSTRIP * 64 * SR
-qq, ll = np.arange(SR)[:, None], np.arange(64)[None, :]
-VALID = np.stack([((qq - ll) >= 0) & ((qq - ll) < NR) & (64 * sp + ll < NC) for sp in range(NSTRIP)])   # [strip][q][l]
+ii, cc = np.meshgrid(np.arange(NR), np.arange(NC), indexing="ij")
+# round 2's kernel (LFBM5D_SCAN_V1=1): [strip][row + lane][64]
+SR1 = NR + 63
+TS1 = ((NC + 63) // 64) * 64 * SR1
+IDX1 = ((cc // 64) * SR1 + ii + cc % 64) * 64 + cc % 64
+# second generation: [strip][Q / 4][lane][Q % 4], Q = row + lane + 3, strips from column 1; column 0 behind the strips
+SRq = ((NR - 1 + 63 + 15) // 16) * 4 + 1
+NS2 = (NC - 1 + 63) // 64
+TS2 = NS2 * SRq * 256 + SRq * 4
+c1 = np.maximum(cc - 1, 0)
+Q = ii + c1 % 64 + 3
+IDX2 = np.where(cc == 0, NS2 * SRq * 256 + ii, (((c1 // 64) * SRq + Q // 4) * 64 + c1 % 64) * 4 + Q % 4)
 
 
 def one():
@@ -39,7 +46,8 @@ def one():
     torch.cuda.synchronize()
     refs, idx, cnt, best, shape = ctx.last_bm(pk[0], 9, Wb * Hb)
     valid = np.arange(pk[0])[None, :] < cnt[:, None]
-    tab = ctx.last_tables(NT * TS).reshape(NT, NSTRIP, SR, 64).copy()
+    ts, ix = (TS1, IDX1) if ctx.last_scan_version() == 1 else (TS2, IDX2)
+    tab = ctx.last_tables(NT * ts).reshape(NT, ts)[:, ix.ravel()].reshape(NT, NR, NC).copy()   # un-skewed: [table][row][column]
     return np.where(valid, idx, 0), cnt.copy(), best.reshape(9, Hb, Wb).copy(), shape.reshape(9, Hb, Wb).copy(), tab
 
 
@@ -74,18 +82,18 @@ for mode in ("quiet", "busy"):
             bad_best += 1
             for (sl, r, c) in d[:12]:
                 diffs.append((it, int(sl), int(r), int(c), int(a[sl, r, c]) - int(b[sl, r, c])))
-        # raw tables, the entries that hold table values (the corners of the skew and the columns past the band do not)
+        # raw tables
         ta, tb = o[4], ref[4]
-        neq = (ta.view(np.uint32) != tb.view(np.uint32)) & VALID[None]
+        neq = ta.view(np.uint32) != tb.view(np.uint32)
         td = np.argwhere(neq)
         if len(td):
             bad_tab += 1
-            for (tbl, sp, r, c) in td[:16]:
-                ctxv = [float(v) for v in ta[tbl, sp, r, max(c - 1, 0):c + 3]]
-                refv = [float(v) for v in tb[tbl, sp, r, max(c - 1, 0):c + 3]]
+            for (tbl, r, c) in td[:16]:
+                ctxv = [float(v) for v in ta[tbl, r, max(c - 1, 0):c + 3]]
+                refv = [float(v) for v in tb[tbl, r, max(c - 1, 0):c + 3]]
                 # where else in the reference table does the wrong value occur?
-                hit = np.argwhere(ref[4][tbl].view(np.uint32) == ta[tbl, sp, r, c].view(np.uint32))[:3].tolist()
-                tdiffs.append({"pass": it, "table": int(tbl), "strip": int(sp), "row": int(r - c), "col": int(64 * sp + c), "got": ctxv, "exp": refv, "got_found_at(strip,q,lane)": hit, "n": int(len(td))})
+                hit = np.argwhere(ref[4][tbl].view(np.uint32) == ta[tbl, r, c].view(np.uint32))[:3].tolist()
+                tdiffs.append({"pass": it, "table": int(tbl), "row": int(r), "col": int(c), "got": ctxv, "exp": refv, "got_found_at(row,col)": hit, "n": int(len(td))})
     if mode == "busy":
         stop = True
         for t in ths: t.join()

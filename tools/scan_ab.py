@@ -2,7 +2,7 @@
 """Distance tables of the two generations of the block-matching scan, entry for entry: one core pass with round 2's
 kernel (LFBM5D_SCAN_V1=1), the same pass with the ring-sharing kernel, raw disparity tables (un-skewed from either
 layout), self-search scores and the selections compared bit for bit.
-usage: python tools/scan_ab.py [H] [W] [step] [sigma]   -> one JSON line; exit code 1 on any difference"""
+usage: python tools/scan_ab.py [H] [W] [step] [sigma] [p] [nDisp] [nSim]   -> one JSON line; exit code 1 on any difference"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,7 +15,10 @@ step = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 sigma = float(sys.argv[4]) if len(sys.argv) > 4 else 25.0
 lf = synth.make_lf(3, 3, H, W).reshape(9, 3, H, W).astype(np.float32)
 lf += sigma * np.random.default_rng(1).standard_normal(lf.shape).astype(np.float32)
-pk = (16, 18, 6, 8, 4, "dct", "sadct", "haar") if step == 2 else (8, 18, 6, 16, 4, "id", "sadct", "haar")
+pstep = int(sys.argv[5]) if len(sys.argv) > 5 else 4          # reference-grid step p
+nDisp_ = int(sys.argv[6]) if len(sys.argv) > 6 else 6
+nSim_ = int(sys.argv[7]) if len(sys.argv) > 7 else 18
+pk = (16, nSim_, nDisp_, 8, pstep, "dct", "sadct", "haar") if step == 2 else (8, nSim_, nDisp_, 16, pstep, "id", "sadct", "haar")
 P = core.make_params(sigma, 2.7, *pk)
 N, nSim, nDisp, k = pk[0], pk[1], pk[2], pk[3]
 nHW = nSim + nDisp
