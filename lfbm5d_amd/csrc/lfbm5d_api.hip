@@ -69,7 +69,7 @@ struct lfbm5d_ctx {
     DevBuf t_noisy, t_basic, t_tnum, t_tden, und_num, und_den;   /* tile mode: one tile of the window, the tiles' interiors */
     DevBuf scan_wgs, scan_lcol;            /* second-generation scan: workgroup list, hand-off columns */
     std::vector<Scan2Wg> scan_plan; unsigned scan_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t scan_lds = 0;
-    int last_scan_version = 0;
+    int last_scan_version = 0; unsigned scan_nwg_slot = 0;
     DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gshape, counters, tb, small, t_num, t_den, d_mask;
     /* step-level buffers */
     DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
@@ -354,7 +354,6 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* the scan addresses the score table through a buffer resource with 32-bit offsets */
     if (N > 1 && (size_t)R * NsS * NsS * sizeof(float) > 0x7fffffffull) return fail(c, "unsupported: candidate score table of 2 GiB or more (reference patches x (2 nSim + 1)^2 x 4 B)");
     if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
-    HIPCK(c, c->tables.reserve((size_t)std::max(1u, n_slots) * NsD * NsD * std::max(stereo_table_stride(Wb, Hb, k, P->nDisp), stereo_table_stride2(Wb, Hb, k, P->nDisp)) * sizeof(float)));
     HIPCK(c, c->self_idx.reserve((size_t)R * Nst * sizeof(unsigned)));
     HIPCK(c, c->self_cnt.reserve((size_t)R * sizeof(unsigned)));
     HIPCK(c, c->best.reserve(A * plane * sizeof(unsigned)));
@@ -406,11 +405,15 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
     const int scan_version = bm_scan_version(sa);
     c->last_scan_version = scan_version;
-    if (scan_version == 2) {
+    if (scan_version == 1) {
+        HIPCK(c, c->tables.reserve(std::max<size_t>(1, scan_tables_floats(sa, 1, n_slots, 0)) * sizeof(float)));
+        sa.tables = c->tables.as<float>();
+    }
+    if (scan_version >= 2) {
         /* ring-sharing workgroups of eight tables (lfbm5d_scan2.hip): the list depends on the search geometry only */
         const unsigned skey[8] = {sa.n_self, sa.n_stereo, sa.nSim, sa.nDisp, sa.k, Hb, Wb, 1u};
         if (std::memcmp(skey, c->scan_key, sizeof(skey)) != 0) {
-            if (!scan2_plan(sa, c->scan_plan, &c->scan_lds)) return fail(c, "scan plan");
+            if (!scan2_plan(sa, c->scan_plan, &c->scan_lds, &c->scan_nwg_slot)) return fail(c, "scan plan");
             HIPCK(c, c->scan_wgs.reserve(c->scan_plan.size() * sizeof(Scan2Wg)));
             HIPCK(c, hipMemcpyAsync(c->scan_wgs.p, c->scan_plan.data(), c->scan_plan.size() * sizeof(Scan2Wg), hipMemcpyHostToDevice, s));
             HIPCK(c, hipStreamSynchronize(s));
@@ -420,7 +423,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         sa.lcol_stride = scan2_lcol_stride(sa);
         HIPCK(c, c->scan_lcol.reserve((size_t)(sa.n_self + sa.n_stereo) * sa.lcol_stride * sizeof(float)));
         sa.lcol = c->scan_lcol.as<float>();
-        HIPCK(c, launch_bm_scan2(s, sa, c->scan_lds));
+        sa.nwg_slot = c->scan_nwg_slot;
+        HIPCK(c, c->tables.reserve(std::max<size_t>(1, scan_tables_floats(sa, scan_version, n_slots, sa.nwg_slot)) * sizeof(float)));
+        sa.tables = c->tables.as<float>();
+        HIPCK(c, launch_bm_scan2(s, sa, c->scan_lds, scan_version == 3));
     } else
         HIPCK(c, launch_bm_scan(s, sa));
     if (N > 1)
@@ -428,7 +434,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
                                     c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
     else
         HIPCK(c, launch_self_trivial(s, c->refs.as<unsigned>(), R, c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
-    if (n_slots && scan_version == 2)
+    if (n_slots && scan_version == 3)
+        HIPCK(c, launch_stereo_argmin3(s, c->tables.as<float>(), slots, n_slots, sa.nwg_slot, Wb, Hb, k, P->nDisp, thr,
+                                       c->best.as<unsigned>(), c->shape.as<unsigned char>()));
+    else if (n_slots && scan_version == 2)
         HIPCK(c, launch_stereo_argmin2(s, c->tables.as<float>(), slots, n_slots, Wb, Hb, k, P->nDisp, thr,
                                        c->best.as<unsigned>(), c->shape.as<unsigned char>()));
     else if (n_slots)

@@ -119,6 +119,25 @@ __host__ __device__ inline size_t stereo_table_stride2(unsigned W, unsigned H, u
     return (size_t)((ncols - 1 + 63) / 64) * stereo_table_srq(H, k, nDisp) * 256 + stereo_table_srq(H, k, nDisp) * 4;
 }
 
+/* Second-generation scan, combined form (the default): the distance tables of the disparity search never reach memory.  A
+ * workgroup reduces its (up to eleven) tables to one (value, scan order) pair per position -- 8 bytes -- laid out
+ * [slot][workgroup of the slot][strip][chunk of eight steps][lane * 8 + step in chunk], where lane l of strip s is table column
+ * 1 + 64 s + l and step t = 8 chunk + step-in-chunk is table row 1 + t - l (entries whose row falls outside the table hold
+ * garbage).  Column 0 and the row-0 entry of every strip's first column are kept per table in an edge array
+ * [rows][strips] behind the pairs. */
+__host__ __device__ inline unsigned stereo_part_chunks(unsigned H, unsigned k, unsigned nDisp) {
+    const unsigned nrows = H - 2 * nDisp - (k - 1);
+    return ((nrows - 1 + 63 + 15) / 16) * 2;
+}
+__host__ __device__ inline size_t stereo_part_stride(unsigned W, unsigned H, unsigned k, unsigned nDisp) {   /* pairs per workgroup */
+    const unsigned ncols = W - 2 * nDisp - (k - 1);
+    return (size_t)((ncols - 1 + 63) / 64) * stereo_part_chunks(H, k, nDisp) * 512;
+}
+__host__ __device__ inline size_t stereo_edge_stride(unsigned W, unsigned H, unsigned k, unsigned nDisp) {   /* floats per table */
+    const unsigned ncols = W - 2 * nDisp - (k - 1), nrows = H - 2 * nDisp - (k - 1);
+    return ((size_t)nrows + (ncols - 1 + 63) / 64 + 3) & ~(size_t)3;
+}
+
 /* One workgroup of the second-generation scan: up to ten displacement tables of one image pair whose (di + dj) mod 4
  * agree (16-byte alignment of the transposed ring reads), and the extent of their displacements (size of the second ring). */
 struct Scan2Wg {
@@ -126,7 +145,8 @@ struct Scan2Wg {
     short slot;                 /* disparity search: table slot (index into st_of_slot); self search: -1 */
     short r2lo, c2lo;           /* smallest row / column offset of the second image's reads against the first's */
     short rh, ch;               /* ... and how many more rows / columns the largest needs */
-    short pad[3];
+    short wgj;                  /* disparity search: index of the workgroup among those of its slot */
+    short pad[2];
 };
 
 struct ScanArgs {
@@ -152,6 +172,7 @@ struct ScanArgs {
     unsigned n_wgs;
     float* lcol;                /* [n_self + n_stereo][lcol_stride] hand-off columns between the strips of a table */
     unsigned lcol_stride;
+    unsigned nwg_slot;          /* workgroups per slot of the disparity search (combined form) */
 };
 
 hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, int forward);
@@ -195,10 +216,14 @@ hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, i
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a);
 /* second generation (lfbm5d_scan2.hip): which kernel a configuration gets (1 or 2), the workgroup list and LDS size of a
  * launch, the hand-off row length, the launch itself and the arg-min over its table layout */
-int bm_scan_version(const ScanArgs& a);
-bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes);
+int bm_scan_version(const ScanArgs& a);   /* 1: round 2's kernel; 2: second generation with full tables (LFBM5D_SCAN_FULL_TABLES=1); 3: combined form */
+bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes, unsigned* nwg_slot = nullptr);
+size_t scan_tables_floats(const ScanArgs& a, int version, unsigned n_slots, unsigned nwg_slot);   /* size of the `tables` buffer */
 unsigned scan2_lcol_stride(const ScanArgs& a);
-hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds_bytes);
+hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds_bytes, bool combined);
+hipError_t launch_stereo_argmin3(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots, unsigned nwg_slot,
+                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
+                                 unsigned* best, unsigned char* shape);
 hipError_t launch_stereo_argmin2(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,
                                  unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
                                  unsigned* best, unsigned char* shape);

@@ -228,8 +228,15 @@ __device__ __forceinline__ void scan2_loader(const ScanArgs& a, const Scan2Wg& g
     lds_barrier();   /* the table waves' last E */
 }
 
-/* ---- a table wave ---- */
-template <int K, bool STEREO, int NW>
+/* ---- a table wave ----
+ * COMB (disparity search): the table values do not leave the workgroup.  The table waves hand the eight values of a chunk
+ * to an exchange area in LDS, and during the next chunk every wave takes a share of the chunk's 512 positions and keeps,
+ * per position, the smallest value of the workgroup's tables and its displacement (ties: the earlier in the reference's
+ * scan order, core:3581-3593 -- the tables of a workgroup are sorted by it): one 8-byte (value, order) pair per position
+ * and workgroup goes to memory instead of one value per position and table, and the arg-min kernel reduces over the
+ * workgroups of a SAI (lfbm5d_kernels.h, stereo_part_*).  Column 0 and the row-0 entry of every strip's first column never
+ * pass through the chunk loop: they go to a small per-table edge array. */
+template <int K, bool STEREO, int NW, bool COMB>
 __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g, float* lds, const int w, const int r0) {
     typedef S2Geom<K> G;
     constexpr int CW1 = G::CW1, RR1 = G::RR1, RRp1 = G::RRp1;
@@ -252,6 +259,7 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
     float* ring2 = lds + CW1 * RRp1;
     const float* lcst = ring2 + CW2 * RRp2;
     const short* rs = reinterpret_cast<const short*>(lcst + 2 * NW * 8);   /* self search: reference-grid row slot of every image row (+ 64 of padding) */
+    float* const xch = const_cast<float*>(lcst) + 2 * NW * 8;              /* COMB: [2][NW][512] values of the current / previous chunk */
 
     const unsigned pl1 = a.pst, pl2 = STEREO ? a.st_of_slot[g.slot] : a.pst;
     const float* img1 = a.est + (size_t)pl1 * WH;
@@ -263,9 +271,24 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
     const int tglob = STEREO ? (int)a.n_self + g.slot * ncand + tb : tb;
     float* lcolT = a.lcol + (size_t)tglob * a.lcol_stride;
     const __amdgpu_buffer_rsrc_t rL = __builtin_amdgcn_make_buffer_rsrc((void*)lcolT, 0, live ? (int)(a.lcol_stride * 4) : 0, kRsrcFlags);
-    const size_t tstride = STEREO ? stereo_table_stride2(a.W, a.H, a.k, a.nDisp) : 0;
-    float* table = STEREO ? a.tables + (size_t)(g.slot * ncand + tb) * tstride : nullptr;
-    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (STEREO && live && !(LFBM5D_S2_EXP & 1)) ? (int)(tstride * 4) : 0, kRsrcFlags);
+    const size_t tstride = (STEREO && !COMB) ? stereo_table_stride2(a.W, a.H, a.k, a.nDisp) : 0;
+    float* table = (STEREO && !COMB) ? a.tables + (size_t)(g.slot * ncand + tb) * tstride : nullptr;
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void*)table, 0, (STEREO && !COMB && live && !(LFBM5D_S2_EXP & 1)) ? (int)(tstride * 4) : 0, kRsrcFlags);
+    /* COMB: the workgroup's (value, order) pairs [strip][chunk][512] and this table's edge array [rows][strips] */
+    const unsigned NCH = stereo_part_chunks(a.H, a.k, a.nDisp);
+    const size_t pstride = COMB ? stereo_part_stride(a.W, a.H, a.k, a.nDisp) : 0;
+    const size_t estride = COMB ? stereo_edge_stride(a.W, a.H, a.k, a.nDisp) : 0;
+    const unsigned n_slots = STEREO ? a.n_stereo / (unsigned)ncand : 0;
+    float* part = COMB ? a.tables + ((size_t)g.slot * a.nwg_slot + g.wgj) * pstride * 2 : nullptr;
+    float* edge = COMB ? a.tables + (size_t)n_slots * a.nwg_slot * pstride * 2 + (size_t)(g.slot * ncand + tb) * estride : nullptr;
+    const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (COMB && !(LFBM5D_S2_EXP & 1)) ? (int)(pstride * 8) : 0, kRsrcFlags);
+    const __amdgpu_buffer_rsrc_t rEd = __builtin_amdgcn_make_buffer_rsrc((void*)edge, 0, (COMB && live) ? (int)(estride * 4) : 0, kRsrcFlags);
+    /* COMB: the live tables of the workgroup (packed from wave 0) and their scan order dj * Ns + di */
+    int nlive = 0, ordw[NW];
+    if (COMB) {
+#pragma unroll
+        for (int q = 0; q < NW; q++) { const int tq = g.tab[q]; nlive += tq >= 0 ? 1 : 0; ordw[q] = tq >= 0 ? (tq % Ns) * Ns + tq / Ns : 0; }
+    }
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (!STEREO && live) ? (int)a.scores_bytes : 0, kRsrcFlags);
     const int SRq = (int)stereo_table_srq(a.H, a.k, a.nDisp);
     const int nstrips = (ncols - 1 + 63) / 64;      /* strips of 64 columns, starting at column 1 of the table */
@@ -296,7 +319,9 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
          * go straight to their place (disparity search: a column area behind the strips; self search: `scores`) */
         auto emit0 = [&](int i, float v, bool on) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rL, on ? (64 + i) * 4 : -1, 0, 0);
-            if (STEREO) {
+            if (STEREO && COMB) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rEd, on ? i * 4 : -1, 0, 0);
+            } else if (STEREO) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rT, on ? (col0_off + i) * 4 : -1, 0, 0);
             } else {
                 const int cxa = s2_grid_index(b, gC, lastC, gN, gP);
@@ -398,7 +423,9 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
         const int base_fwd = (col_ok && cx >= 0) ? (cx * ncand + ord_fwd) * 4 : -1;
         const int base_bwd = (col_ok && cx2 >= 0 && di > 0) ? (cx2 * ncand + ord_bwd) * 4 : -1;
         /* row 0 of the table */
-        if (STEREO) {
+        if (STEREO && COMB) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, S0), rEd, lane == 0 ? (nrows + strip) * 4 : -1, 0, 0);
+        } else if (STEREO) {
             /* lanes 1.. : through the main loop (a lane's "result" of the step before its first is its row-0 value) */
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, S0), rT, lane == 0 ? (strip * SRq * 256 + 3) * 4 : -1, 0, 0);
         } else {
@@ -451,6 +478,27 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
         int voffT = ((strip * SRq + 1) * 64 + lane) * 16;
         int voffL = lane == 63 ? (64 + 1 - 63) * 4 : 0x70000000;
         const float* const lcw = lcst + w * 8;
+        /* COMB: this wave's share of a chunk's positions p = lane-of-the-table * 8 + step-in-chunk */
+        constexpr int kShare = (512 + NW - 1) / NW;
+        const int rp = w * kShare + lane;
+        const bool rok = lane < kShare && rp < 512;
+        auto reduce_chunk = [&](const int cprev) {
+            const float* src = xch + (cprev & 1) * NW * 512 + (rok ? rp : 0);
+            float best = src[0];
+            int bo = ordw[0];
+#pragma unroll
+            for (int q = 1; q < NW; q++) {
+                if (q < nlive) {
+                    const float v = src[q * 512];
+                    const bool lt = v < best;
+                    best = lt ? v : best;
+                    bo = lt ? ordw[q] : bo;
+                }
+            }
+            typedef int v2i __attribute__((ext_vector_type(2)));
+            const v2i pr = {__float_as_int(best), bo};
+            __builtin_amdgcn_raw_buffer_store_b64(pr, rP, rok ? (int)(((strip * NCH + cprev) * 512 + rp) * 8) : -1, 0, 0);
+        };
 
         /* chain flavours: steady -- every lane active on every step, every row in the band; edge (ramp-up, ramp-down, short
          * tables).  Store flavours of the self search: pattern (above) or look-ups */
@@ -470,6 +518,7 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
             for (int ch = 0; ch < 2; ch++) {
                 const int tc = t0 + 8 * ch;
                 const v4f lc[2] = {*reinterpret_cast<const v4f*>(lcw + ch * NW * 8), *reinterpret_cast<const v4f*>(lcw + ch * NW * 8 + 4)};
+                if (COMB && tc > 0) reduce_chunk((tc >> 3) - 1);
                 const float* pA = colA + slot1;
                 const float* pB = colB + slot2;
 #pragma unroll
@@ -509,7 +558,9 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
                         curS = S;
                         left_prev = left;
                     }
-                    if (STEREO) {
+                    if (STEREO && COMB) {
+                        *reinterpret_cast<v4f*>(xch + (ch * NW + w) * 512 + lane * 8 + 4 * gq) = out;
+                    } else if (STEREO) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, out), rT, voffT, 0, 0);
                         voffT += 1024;
                     } else if (fast) {
@@ -566,6 +617,7 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
         };
         S2_MARK(3);   /* strip prologue: barriers E / A, first row, FIFO */
         run();
+        if (COMB && nsteps > 0) reduce_chunk(((nsteps + 15) >> 4) * 2 - 1);   /* the last chunk's values (the barrier behind it has been passed) */
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
 #ifdef LFBM5D_PHASE_TIMING
         if (lane == 0 && a.dbg && live) {
@@ -579,7 +631,7 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
     lds_barrier();   /* the loader wave's last E */
 }
 
-template <int K, bool STEREO, int NW, int NL>
+template <int K, bool STEREO, int NW, int NL, bool COMB>
 __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, float* lds) {
     typedef S2Geom<K> G;
     const int tid = threadIdx.x;
@@ -598,22 +650,22 @@ __device__ __forceinline__ void scan2_body(const ScanArgs& a, const Scan2Wg& g, 
         for (int i = tid; i < (int)a.H + 64; i += blockDim.x) rs[i] = (short)a.rslot[i];
     }
     if (w >= NW) scan2_loader<K, STEREO, NW, NL>(a, g, lds, r0, w - NW);
-    else scan2_table<K, STEREO, NW>(a, g, lds, w, r0);
+    else scan2_table<K, STEREO, NW, COMB>(a, g, lds, w, r0);
 }
 
-template <int K>
+template <int K, bool COMB>
 __global__ __launch_bounds__((kS2NW + kS2NL) * 64) void k_bm_scan2(ScanArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds2[];
     const Scan2Wg& g = a.wgs[blockIdx.x];
     if ((LFBM5D_S2_EXP & 8) && g.slot < 0) return;     /* experiments: disparity tables only / self tables only */
     if ((LFBM5D_S2_EXP & 16) && g.slot >= 0) return;
 #ifdef LFBM5D_SCAN2_ONLY_STEREO
-    scan2_body<K, true, kS2NW, kS2NL>(a, g, lds2);
+    scan2_body<K, true, kS2NW, kS2NL, COMB>(a, g, lds2);
 #elif defined(LFBM5D_SCAN2_ONLY_SELF)
-    scan2_body<K, false, kS2NW, kS2NL>(a, g, lds2);
+    scan2_body<K, false, kS2NW, kS2NL, false>(a, g, lds2);
 #else
-    if (g.slot >= 0) scan2_body<K, true, kS2NW, kS2NL>(a, g, lds2);
-    else scan2_body<K, false, kS2NW, kS2NL>(a, g, lds2);
+    if (g.slot >= 0) scan2_body<K, true, kS2NW, kS2NL, COMB>(a, g, lds2);
+    else scan2_body<K, false, kS2NW, kS2NL, false>(a, g, lds2);
 #endif
 }
 
@@ -674,7 +726,8 @@ __global__ __launch_bounds__(256) void k_stereo_argmin2(Argmin2Args a) {
 template <int K> size_t scan2_lds_bytes(const ScanArgs& a, int rh_max, int ch_max) {
     typedef S2Geom<K> G;
     const int RRp2 = G::rr2(rh_max) + 13;
-    return (size_t)(G::CW1 * G::RRp1 + G::cw2(ch_max) * RRp2 + 2 * kS2NW * 8) * sizeof(float) + (a.n_self ? (size_t)(a.H + 64) * sizeof(short) : 0) + 16;
+    const size_t tail = std::max<size_t>(a.n_self ? (size_t)(a.H + 64) * sizeof(short) : 0, a.n_stereo ? (size_t)2 * kS2NW * 512 * sizeof(float) : 0);
+    return (size_t)(G::CW1 * G::RRp1 + G::cw2(ch_max) * RRp2 + 2 * kS2NW * 8) * sizeof(float) + tail + 16;
 }
 
 } /* namespace */
@@ -688,23 +741,33 @@ int bm_scan_version(const ScanArgs& a) {
     if (a.n_self && a.refmap) return 1;
     std::vector<Scan2Wg> wgs; size_t lds = 0;
     if (!scan2_plan(a, wgs, &lds)) return 1;
-    return 2;
+    if (const char* e = std::getenv("LFBM5D_SCAN_FULL_TABLES")) if (e[0] && e[0] != '0') return 2;
+    return 3;
+}
+
+size_t scan_tables_floats(const ScanArgs& a, int version, unsigned n_slots, unsigned nwg_slot) {
+    const size_t ncand = (size_t)(2 * a.nDisp + 1) * (2 * a.nDisp + 1);
+    if (version == 1) return (size_t)n_slots * ncand * stereo_table_stride(a.W, a.H, a.k, a.nDisp);
+    if (version == 2) return (size_t)n_slots * ncand * stereo_table_stride2(a.W, a.H, a.k, a.nDisp);
+    return (size_t)n_slots * nwg_slot * stereo_part_stride(a.W, a.H, a.k, a.nDisp) * 2 + (size_t)n_slots * ncand * stereo_edge_stride(a.W, a.H, a.k, a.nDisp);
 }
 
 /* Workgroups of a launch: up to eight tables of one image pair and one class (di + dj) mod 4. */
-bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes) {
+bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes, unsigned* nwg_slot) {
     wgs.clear();
     int rh_max = 0, ch_max = 0;
+    int wgj = 0;
     auto add = [&](int slot, const std::vector<int>& tabs, int r2lo, int c2lo, int rh, int ch) {
         for (size_t i = 0; i < tabs.size(); i += kS2NW) {
             Scan2Wg g;
             std::memset(&g, 0, sizeof(g));
             for (int w = 0; w < 16; w++) g.tab[w] = (w < kS2NW && i + w < tabs.size()) ? (short)tabs[i + w] : (short)-1;
-            g.slot = (short)slot; g.r2lo = (short)r2lo; g.c2lo = (short)c2lo; g.rh = (short)rh; g.ch = (short)ch;
+            g.slot = (short)slot; g.r2lo = (short)r2lo; g.c2lo = (short)c2lo; g.rh = (short)rh; g.ch = (short)ch; g.wgj = (short)wgj++;
             wgs.push_back(g);
         }
         rh_max = std::max(rh_max, rh); ch_max = std::max(ch_max, ch);
     };
+    if (nwg_slot) *nwg_slot = 0;
     if (a.n_self) {
         /* self search: di in [0, nSim], dj in [0, 2 nSim]; tiles of 4 x kS2NW displacements, one workgroup per class of a
          * tile (kS2NW tables): the second ring then spans 3 more rows and kS2NW - 1 more columns than the first */
@@ -722,13 +785,20 @@ bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes)
     if (a.n_stereo) {
         const int nD = (int)a.nDisp, Ns = 2 * nD + 1, ncand = Ns * Ns;
         const int n_slots = (int)a.n_stereo / ncand;
-        for (int slot = 0; slot < n_slots; slot++)
+        for (int slot = 0; slot < n_slots; slot++) {
+            wgj = 0;
             for (int cls = 0; cls < 4; cls++) {
+                /* in the reference's scan order dj * Ns + di (core:3581-3593): the combined form resolves ties inside a
+                 * workgroup by position in this list */
                 std::vector<int> tabs;
-                for (int ddk = 0; ddk < ncand; ddk++)
-                    if ((((ddk / Ns) + (ddk % Ns)) & 3) == cls) tabs.push_back(ddk);
+                for (int ord = 0; ord < ncand; ord++) {
+                    const int dj = ord / Ns, di = ord % Ns;
+                    if (((di + dj) & 3) == cls) tabs.push_back(di * Ns + dj);
+                }
                 if (!tabs.empty()) add(slot, tabs, -nD, -nD, 2 * nD, 2 * nD);
             }
+            if (nwg_slot) *nwg_slot = (unsigned)wgj;
+        }
     }
     size_t lds = a.k == 8 ? scan2_lds_bytes<8>(a, rh_max, ch_max) : scan2_lds_bytes<16>(a, rh_max, ch_max);
     if (lds_bytes) *lds_bytes = lds;
@@ -743,18 +813,87 @@ unsigned scan2_lcol_stride(const ScanArgs& a) {
     return ((std::max(rows_self, rows_st) + 64 + 160 + 63) / 64) * 64;
 }
 
-hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds) {
+hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds, bool combined) {
     if (!a.n_wgs) return hipSuccess;
     static bool prepared = false;
     if (!prepared) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bm_scan2<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bm_scan2<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        const void* fns[] = {reinterpret_cast<const void*>(&k_bm_scan2<8, false>), reinterpret_cast<const void*>(&k_bm_scan2<16, false>),
+                             reinterpret_cast<const void*>(&k_bm_scan2<8, true>), reinterpret_cast<const void*>(&k_bm_scan2<16, true>)};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         prepared = true;
     }
-    if (a.k == 8) hipLaunchKernelGGL((k_bm_scan2<8>), dim3(a.n_wgs), dim3((kS2NW + kS2NL) * 64), lds, s, a);
-    else if (a.k == 16) hipLaunchKernelGGL((k_bm_scan2<16>), dim3(a.n_wgs), dim3((kS2NW + kS2NL) * 64), lds, s, a);
+    const dim3 blk((kS2NW + kS2NL) * 64);
+    if (a.k == 8 && combined) hipLaunchKernelGGL((k_bm_scan2<8, true>), dim3(a.n_wgs), blk, lds, s, a);
+    else if (a.k == 8) hipLaunchKernelGGL((k_bm_scan2<8, false>), dim3(a.n_wgs), blk, lds, s, a);
+    else if (a.k == 16 && combined) hipLaunchKernelGGL((k_bm_scan2<16, true>), dim3(a.n_wgs), blk, lds, s, a);
+    else if (a.k == 16) hipLaunchKernelGGL((k_bm_scan2<16, false>), dim3(a.n_wgs), blk, lds, s, a);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+/* arg-min of the combined form: over the (value, order) pairs of a slot's workgroups, position by position; the edge
+ * positions (column 0, row 0 of every strip's first column) over the per-table edge arrays.  Ties: the smaller scan order
+ * (core:3581-3608). */
+struct Argmin3Args { const float* tables; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp, n_slots, nwg_slot; float thr; unsigned* best; unsigned char* shape; };
+__global__ __launch_bounds__(256) void k_stereo_argmin3(Argmin3Args a) {
+    const int W = a.W, H = a.H, nDisp = a.nDisp;
+    const int span_c = W - 2 * nDisp - a.k + 1, span_r = H - 2 * nDisp - a.k + 1;
+    const int nstrips = (span_c - 1 + 63) / 64;
+    const int NCH = (int)stereo_part_chunks(H, a.k, nDisp);
+    const size_t pstride = stereo_part_stride(W, H, a.k, nDisp), estride = stereo_edge_stride(W, H, a.k, nDisp);
+    const int Ns = 2 * nDisp + 1, ncand = Ns * Ns;
+    const unsigned slot = blockIdx.y, st = a.st_of_slot[slot];
+    const size_t WH = (size_t)W * H;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_main = nstrips * NCH * 512, n_edge = span_r + nstrips;
+    if (i >= n_main + n_edge) return;
+    int row, col;
+    float bv; int bo;
+    if (i < n_main) {
+        const int p = i & 511, c = (i >> 9) % NCH, strip = (i >> 9) / NCH;
+        const int l = p >> 3, t = 8 * c + (p & 7);
+        row = 1 + t - l; col = 1 + 64 * strip + l;
+        if (row < 0 || row >= span_r || col >= span_c || (row == 0 && l == 0)) return;
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const f2* src = reinterpret_cast<const f2*>(a.tables) + (size_t)slot * a.nwg_slot * pstride + i;
+        f2 v = src[0];
+        bv = v.x; bo = __float_as_int(v.y);
+        for (int j = 1; j < a.nwg_slot; j++) {
+            v = src[(size_t)j * pstride];
+            const int o = __float_as_int(v.y);
+            if (v.x < bv || (v.x == bv && o < bo)) { bv = v.x; bo = o; }
+        }
+    } else {
+        const int e = i - n_main;
+        if (e < span_r) { row = e; col = 0; } else { row = 0; col = 1 + 64 * (e - span_r); }
+        if (col >= span_c) return;
+        const float* ed = a.tables + (size_t)a.n_slots * a.nwg_slot * pstride * 2 + (size_t)slot * ncand * estride + e;
+        bv = ed[0]; bo = 0;   /* table index ddk = 0 <-> di = dj = 0 <-> order 0 */
+        for (int ddk = 1; ddk < ncand; ddk++) {
+            const float v = ed[(size_t)ddk * estride];
+            const int o = (ddk % Ns) * Ns + ddk / Ns;
+            if (v < bv || (v == bv && o < bo)) { bv = v; bo = o; }
+        }
+    }
+    const int pos = (nDisp + row) * W + nDisp + col;
+    const int dj = bo / Ns, di = bo % Ns;
+    a.best[(size_t)st * WH + pos] = (unsigned)(pos + (di - nDisp) * W + (dj - nDisp));
+    a.shape[(size_t)st * WH + pos] = bv < a.thr ? 1 : 0;
+}
+
+hipError_t launch_stereo_argmin3(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots, unsigned nwg_slot,
+                                 unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,
+                                 unsigned* best, unsigned char* shape) {
+    Argmin3Args a;
+    a.tables = tables; a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.n_slots = (int)n_slots; a.nwg_slot = (int)nwg_slot; a.thr = thr; a.best = best; a.shape = shape;
+    for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
+    const unsigned span_c = W - 2 * nDisp - k + 1, span_r = H - 2 * nDisp - k + 1;
+    const unsigned nstrips = (span_c - 1 + 63) / 64;
+    const unsigned n = nstrips * stereo_part_chunks(H, k, nDisp) * 512 + span_r + nstrips;
+    hipLaunchKernelGGL(k_stereo_argmin3, dim3((n + 255) / 256, n_slots), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -25,7 +25,7 @@ CASES = {
 @pytest.mark.parametrize("name", list(CASES))
 def test_scan_generations_agree_bit_for_bit(name):
     env = dict(os.environ)
-    env.pop("LFBM5D_SCAN_V1", None)
+    env.pop("LFBM5D_SCAN_V1", None); env.pop("LFBM5D_SCAN_FULL_TABLES", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_ab.py")] + CASES[name], capture_output=True, text=True, env=env, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert line, r.stderr[-2000:]
@@ -34,4 +34,9 @@ def test_scan_generations_agree_bit_for_bit(name):
     for k in ("tables_differ", "scores_differ", "self_idx_differ", "self_cnt_differ", "best_differ", "shape_differ"):
         assert d[k] == 0, (k, d)
     assert d["num_equal"] and d["den_equal"], d
+    # ... and the default, combined form (tables reduced inside the workgroup): same selections, same sums
+    assert d["combined_version"] == 3, d
+    for k in ("best_differ", "shape_differ", "self_idx_differ", "self_cnt_differ", "scores_differ"):
+        assert d["combined"][k] == 0, (k, d["combined"])
+    assert d["combined"]["num_equal"] and d["combined"]["den_equal"], d["combined"]
     assert r.returncode == 0

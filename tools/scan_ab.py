@@ -45,26 +45,31 @@ Q = ii + c1 % 64 + 3
 idx2 = np.where(cc == 0, NS2 * SRq * 256 + ii, (((c1 // 64) * SRq + Q // 4) * 64 + c1 % 64) * 4 + Q % 4)
 
 
-def one(v1):
-    if v1: os.environ["LFBM5D_SCAN_V1"] = "1"
-    else: os.environ.pop("LFBM5D_SCAN_V1", None)
+def one(mode):
+    os.environ.pop("LFBM5D_SCAN_V1", None); os.environ.pop("LFBM5D_SCAN_FULL_TABLES", None)
+    if mode == "v1": os.environ["LFBM5D_SCAN_V1"] = "1"
+    if mode == "full": os.environ["LFBM5D_SCAN_FULL_TABLES"] = "1"
     num.zero_(); den.zero_(); torch.cuda.synchronize()
     ctx.core_pass(step, P, 3, 3, Wb, Hb, 3, noisy, basic if step == 2 else None, num, den, mask, proc, 4, 4)
     torch.cuda.synchronize()
     ver = ctx.last_scan_version()
     refs, idx, cnt, best, shape = ctx.last_bm(N, 9, Wb * Hb)
     valid = np.arange(N)[None, :] < cnt[:, None]
-    ts, ix = (TS1, idx1) if ver == 1 else (TS2, idx2)
-    tab = ctx.last_tables(NT * ts).reshape(NT, ts)[:, ix.ravel()].reshape(NT, NR, NC).copy()
+    if ver == 3:   # combined form: the tables never reach memory
+        tab = None
+    else:
+        ts, ix = (TS1, idx1) if ver == 1 else (TS2, idx2)
+        tab = ctx.last_tables(NT * ts).reshape(NT, ts)[:, ix.ravel()].reshape(NT, NR, NC).copy()
     sc = ctx.last_scores(len(refs) * (2 * nSim + 1) ** 2).copy()
     global a_refs
     a_refs = refs.copy()
     return ver, np.where(valid, idx, 0), cnt.copy(), best.copy(), shape.copy(), tab, sc, num.cpu().numpy().copy(), den.cpu().numpy().copy()
 
 
-a = one(True)
-b = one(False)
-out = {"Hb": Hb, "Wb": Wb, "step": step, "versions": [a[0], b[0]]}
+a = one("v1")
+b = one("full")
+cmb = one("comb")
+out = {"Hb": Hb, "Wb": Wb, "step": step, "versions": [a[0], b[0]], "combined_version": cmb[0]}
 tneq = a[5].view(np.uint32) != b[5].view(np.uint32)
 out["tables_differ"] = int(tneq.sum())
 if tneq.any():
@@ -143,6 +148,16 @@ ba = np.delete(a[3].reshape(9, Hb, Wb)[:, ys, xs], 4, axis=0); bb = np.delete(b[
 sa = np.delete(a[4].reshape(9, Hb, Wb)[:, ys, xs], 4, axis=0); sb = np.delete(b[4].reshape(9, Hb, Wb)[:, ys, xs], 4, axis=0)
 out["best_differ"] = int((ba != bb).sum()); out["shape_differ"] = int((sa != sb).sum())
 out["num_equal"] = bool(np.array_equal(a[7], b[7])); out["den_equal"] = bool(np.array_equal(a[8], b[8]))
+# the combined form (the default): selections and sums against round 2's kernel
+bc = np.delete(cmb[3].reshape(9, Hb, Wb)[:, ys, xs], 4, axis=0); sc_ = np.delete(cmb[4].reshape(9, Hb, Wb)[:, ys, xs], 4, axis=0)
+out["combined"] = {"best_differ": int((ba != bc).sum()), "shape_differ": int((sa != sc_).sum()), "self_idx_differ": int((a[1] != cmb[1]).sum()),
+                   "self_cnt_differ": int((a[2] != cmb[2]).sum()), "scores_differ": int((a[6].view(np.uint32) != cmb[6].view(np.uint32)).sum()),
+                   "num_equal": bool(np.array_equal(a[7], cmb[7])), "den_equal": bool(np.array_equal(a[8], cmb[8]))}
+if out["combined"]["best_differ"]:
+    w = np.argwhere(ba != bc)
+    out["combined"]["first_best_diffs(slot,row,col)"] = w[:12].tolist()
+    out["combined"]["rows_min_max"] = [int(w[:, 1].min()), int(w[:, 1].max())]; out["combined"]["cols_min_max"] = [int(w[:, 2].min()), int(w[:, 2].max())]
 print(json.dumps(out))
-bad = out["tables_differ"] or out["scores_differ"] or out["self_idx_differ"] or out["best_differ"] or out["shape_differ"] or b[0] != 2
+cbad = any(out["combined"][k] for k in ("best_differ", "shape_differ", "self_idx_differ", "self_cnt_differ", "scores_differ")) or cmb[0] != 3
+bad = out["tables_differ"] or out["scores_differ"] or out["self_idx_differ"] or out["best_differ"] or out["shape_differ"] or b[0] != 2 or cbad
 sys.exit(1 if bad else 0)
