@@ -421,7 +421,9 @@ def main():
                          "frac_physical": (t_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (t_bytes and pair_ms > 0) else None,
                          "traffic_source": (traffic or {}).get("source"),
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pair_ms, "launches": n_all,
-                         "measured_with": ("the timed region (one lane)" if roof is timed else
+                         "measured_with": ((f"the timed region ({lanes_timed} lane{'s' if lanes_timed != 1 else ''}"
+                                            + ("; kernels of different windows overlap, the intervals are not kernel-alone times)" if lanes_timed != 1 else ")"))
+                                           if roof is timed else
                                            f"{roof_steps} extra untimed step with LFBM5D_LANES=1 (kernels alone on the GPU); the timed region ran {lanes_timed} lanes"),
                          "per_step": {"ht": ph, "wiener": pw}},
             # kernel classes alone on the GPU (the one-lane measurement step); with several lanes the HIP-event intervals of
@@ -430,11 +432,13 @@ def main():
                                    "group": (roof["ht"].get("ms_group", 0.0) + roof["wiener"].get("ms_group", 0.0)) / roof_steps,
                                    "aggregate": (roof["ht"].get("ms_aggregate", 0.0) + roof["wiener"].get("ms_aggregate", 0.0)) / roof_steps,
                                    "comm": (roof["ht"].get("ms_comm", 0.0) + roof["wiener"].get("ms_comm", 0.0)) / roof_steps,
-                                   "measured_with": "the timed region" if roof is timed else "the one-lane measurement step (kernels alone on the GPU)"},
+                                   "measured_with": (f"the timed region ({lanes_timed} lanes: overlapped intervals)" if (roof is timed and lanes_timed != 1)
+                                                     else "the timed region (one lane)" if roof is timed else "the one-lane measurement step (kernels alone on the GPU)")},
             "kernel_ms_per_step_overlapped": {"block_matching": tot["ms_bm"] / args.steps, "group": tot["ms_group"] / args.steps,
                                               "aggregate": tot["ms_aggregate"] / args.steps, "comm": tot["ms_comm"] / args.steps,
                                               "note": "HIP-event intervals on each lane's stream during the timed region; intervals of "
                                                       "different windows overlap and add up to more than the step time"},
+            "rccl_ranks_seen": ctx.comm_ranks() if world > 1 else 1,
             "passes_per_step": tot["passes"] / args.steps, "windows_per_step": tot["windows"] / args.steps,
             "lane_windows_per_step": tot["lane_windows"] / args.steps, "messages_per_step": tot["messages"] / args.steps,
             "psnr": {"noisy": psnr_lf(noisy0), "basic": psnr_lf(basic), "denoised": psnr_lf(den)},

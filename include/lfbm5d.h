@@ -100,7 +100,9 @@ void* lfbm5d_stream(lfbm5d_ctx* ctx);
  * mask, see lfbm5d_plan_windows) form a dependency graph -- a window has to wait exactly for the previous window
  * that touched each of its SAIs, because windows interact only through num / den of shared SAIs (the running
  * estimate block matching reads, the sums aggregation adds to).  Ranks own chains of windows (runs of consecutive
- * windows in one row of SAIs), dealt round-robin; what a window needs from a window of another rank travels as one
+ * windows in one row of SAIs); every chain, in plan order, goes to the rank on which it would finish first in unit
+ * window time, ties to the rank that owns most of its predecessors (lfbm5d_plan_graph returns the assignment -- a pure
+ * function of the mask and the rank count); what a window needs from a window of another rank travels as one
  * RCCL send / recv per SAI (num and den of that SAI, xGMI point-to-point); at the end every SAI's estimate is
  * formed on the rank that touched it last and broadcast.  Every window sees exactly the sums the single-GPU order
  * shows it: the result is BIT-IDENTICAL to one GPU for any rank count (lfbm5d_plan_graph / lfbm5d_plan_messages
@@ -117,10 +119,16 @@ void* lfbm5d_stream(lfbm5d_ctx* ctx);
  * (bm5d.cpp:411-708, utilities_LF.cpp:438-515), without its tile-border quality loss. ---- */
 #define LFBM5D_UNIQUE_ID_BYTES 128
 int lfbm5d_comm_unique_id(void* id_out /* LFBM5D_UNIQUE_ID_BYTES */);
+/* (whole steps on several ranks run window lanes and two exchange streams at once: set GPU_MAX_HW_QUEUES >= 8 in the
+ * environment BEFORE the HIP runtime initialises -- ROCm maps streams onto 4 hardware queues by default, and a send that
+ * waits for its peer must not sit in front of a compute stream on the same queue; bench.py does it for itself) */
 int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);
 /* Diagnostics: all-reduce n floats on the context's stream through the context's communicator (or a
  * one-rank communicator created for the call) and verify the sums.  Returns 0 when RCCL works here. */
 int lfbm5d_comm_selftest(lfbm5d_ctx* ctx, unsigned n);
+/* Ranks of the context's RCCL communicator as RCCL itself counts them (ncclCommCount): 0 without a communicator, -1 on
+ * error.  bench.py prints it so that a multi-GPU record shows the ranks that took part. */
+int lfbm5d_comm_ranks(const lfbm5d_ctx* ctx);
 /* Shard without a communicator (tests): this rank only processes its rows; no reduction. */
 int lfbm5d_set_shard(lfbm5d_ctx* ctx, int rank, int world);
 /* The reference's OpenMP tile mode for whole steps (bm5d.cpp:411-708, run_bm5d_* with nb_threads > 1): every window pass

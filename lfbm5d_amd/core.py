@@ -90,6 +90,8 @@ def lib():
     L.lfbm5d_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.lfbm5d_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.lfbm5d_set_tiles.argtypes = [vp, C.c_int]
+    L.lfbm5d_comm_ranks.argtypes = [vp]
+    L.lfbm5d_comm_ranks.restype = C.c_int
     L.lfbm5d_comm_selftest.argtypes = [vp, C.c_uint]
     L.lfbm5d_shard_rows.argtypes = [C.c_uint, C.c_int, C.c_int, up, up]
     L.lfbm5d_shard_rows.restype = None
@@ -239,6 +241,10 @@ class Context:
     def comm_selftest(self, n=1 << 20):
         """All-reduce n floats through RCCL on the context's stream and check the sums."""
         self._ck(self._L.lfbm5d_comm_selftest(self._h, n))
+
+    def comm_ranks(self):
+        """Ranks of the RCCL communicator as RCCL counts them (0: none)."""
+        return int(self._L.lfbm5d_comm_ranks(self._h))
 
     def set_shard(self, rank, world):
         self._ck(self._L.lfbm5d_set_shard(self._h, rank, world))

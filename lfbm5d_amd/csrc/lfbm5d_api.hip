@@ -1407,6 +1407,12 @@ int lfbm5d_last_windows(const lfbm5d_ctx* c, unsigned* out_sai, unsigned cap) {
     return (int)c->last_windows.size();
 }
 
+int lfbm5d_comm_ranks(const lfbm5d_ctx* c) {
+    if (!c || !c->comm) return 0;
+    int n = 0;
+    return ncclCommCount(c->comm, &n) == ncclSuccess ? n : -1;
+}
+
 int lfbm5d_comm_selftest(lfbm5d_ctx* c, unsigned n) {
     if (!c || !n) return 1;
     (void)hipSetDevice(c->device);

@@ -231,3 +231,82 @@ def test_plan_windows_matches_the_reference_rule():
     assert core.plan_windows(5, 5, 1, mask=mask)[0] == 24
     for st in core.plan_windows(5, 5, 1, mask=mask):
         assert mask[st]
+
+
+def _simulate_exchange(aw, ah, world, lanes, single_channel=False, perturb=False):
+    """Replay of what run_step enqueues on every rank (lfbm5d_api.hip, graph form): every rank walks the windows in plan
+    order; a window goes to its lane's stream (FIFO) and waits for the previous toucher of each of its SAIs -- an event of
+    the same rank, or the arrival of that SAI's message; after a window, the messages it feeds are enqueued on the channel's
+    exchange stream of the sender (gated by the window's completion) and of the receiver, in the list's order on both.
+    A send / recv pair completes when both are at the head of their streams (rendezvous).  Returns the number of operations
+    that never complete (0: the issue order cannot deadlock)."""
+    from lfbm5d_amd import core
+    plan = core.plan_windows(aw, ah, 1)
+    ranks, lane, _ = core.plan_graph(aw, ah, world, lanes)
+    msgs = [tuple(int(v) for v in m) for m in core.plan_messages(aw, ah, world)]
+    cover = []
+    for pst in plan:
+        ps, pt = int(pst) // aw, int(pst) % aw
+        s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
+        cover.append(sorted((s0 + s) * aw + (t0 + t) for s in range(3) for t in range(3)))
+    NW = len(plan)
+    prev = [{st: next((p for p in range(w - 1, -1, -1) if st in cover[p]), None) for st in cover[w]} for w in range(NW)]
+    msg_of = {(a, b, st): i for i, (a, b, st, _) in enumerate(msgs)}
+    # streams: ("lane", rank, lane) -> windows; ("ch", rank, channel) -> (message index, role)
+    streams = {}
+    for w in range(NW):
+        streams.setdefault(("lane", int(ranks[w]), int(lane[w])), []).append(("win", w))
+    for i, (a, b, st, ch) in enumerate(msgs):
+        c = 0 if single_channel else ch
+        streams.setdefault(("ch", int(ranks[a]), c), []).append(("send", i))
+        streams.setdefault(("ch", int(ranks[b]), c), []).append(("recv", i))
+    if perturb:   # negative control: one rank enqueues its receives of a channel in reverse order
+        k = next(k for k, q in streams.items() if k[0] == "ch" and sum(1 for op in q if op[0] == "recv") > 1)
+        rec = [op for op in streams[k] if op[0] == "recv"][::-1]
+        streams[k] = [rec.pop(0) if op[0] == "recv" else op for op in streams[k]]
+    head = {k: 0 for k in streams}
+    win_done, msg_done = [False] * NW, [False] * len(msgs)
+
+    def at_head(kind, i):
+        a, b, st, ch = msgs[i]
+        k = ("ch", int(ranks[a] if kind == "send" else ranks[b]), 0 if single_channel else ch)
+        return head[k] < len(streams[k]) and streams[k][head[k]] == (kind, i)
+    progress = True
+    while progress:
+        progress = False
+        for k, q in streams.items():
+            while head[k] < len(q):
+                kind, i = q[head[k]]
+                if kind == "win":
+                    ok = True
+                    for st, p in prev[i].items():
+                        if p is None:
+                            continue
+                        ok = ok and (win_done[p] if ranks[p] == ranks[i] else msg_done[msg_of[(p, i, st)]])
+                    if not ok:
+                        break
+                    win_done[i] = True
+                else:
+                    a = msgs[i][0]
+                    if not (win_done[a] and at_head("send", i) and at_head("recv", i)):
+                        break
+                    msg_done[i] = True
+                    other = ("ch", int(ranks[msgs[i][1]] if kind == "send" else ranks[a]), 0 if single_channel else msgs[i][3])
+                    head[other] += 1
+                head[k] += 1
+                progress = True
+    return win_done.count(False) + msg_done.count(False)
+
+
+def test_exchange_issue_order_cannot_deadlock():
+    """The RCCL exchange of the window graph has not run between real ranks yet (no multi-GPU box): what can be shown on the
+    host is that the order in which every rank enqueues windows, sends and receives admits a complete execution under FIFO
+    streams and rendezvous send / recv -- for every rank count and lane count bench.py can be asked for, with two exchange
+    channels and with the one-channel fallback (second communicator unavailable)."""
+    for (ah, aw) in ((17, 17), (9, 9), (15, 15), (5, 7), (7, 11)):
+        for world in (2, 3, 4, 5, 8):
+            for lanes in (1, 2, 3):
+                for single in (False, True):
+                    stuck = _simulate_exchange(aw, ah, world, lanes, single)
+                    assert stuck == 0, (ah, aw, world, lanes, single, stuck)
+    assert _simulate_exchange(17, 17, 4, 3, False, perturb=True) > 0      # the replay does see a broken order

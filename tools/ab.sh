@@ -1,14 +1,17 @@
 #!/bin/bash
 # Same-box A/B of two builds of the library (the gpurun boxes differ by +-3 %, so absolute numbers of different calls do
-# not compare): builds HEAD's library as variants/lib_base.so and the working tree's as variants/lib_new.so; run
+# not compare): builds HEAD's library as variants/lib_base.so (from a clean export of HEAD, the working tree is not
+# touched) and the working tree's as variants/lib_new.so; run
 #   gpurun -- 'bash tools/ab.sh run [pass|bench]'
 set -e
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
   mkdir -p lfbm5d_amd/variants
   make -s -C lfbm5d_amd/csrc >/dev/null && cp lfbm5d_amd/liblfbm5d_hip.so lfbm5d_amd/variants/lib_new.so
-  git stash -q && make -s -C lfbm5d_amd/csrc >/dev/null && cp lfbm5d_amd/liblfbm5d_hip.so lfbm5d_amd/variants/lib_base.so; git stash pop -q
-  make -s -C lfbm5d_amd/csrc >/dev/null
+  tmp=$(mktemp -d)
+  git archive HEAD lfbm5d_amd/csrc include | tar -x -C "$tmp"
+  make -s -C "$tmp/lfbm5d_amd/csrc" ../liblfbm5d_hip.so >/dev/null && cp "$tmp/lfbm5d_amd/liblfbm5d_hip.so" lfbm5d_amd/variants/lib_base.so
+  rm -rf "$tmp"
   ls -la lfbm5d_amd/variants/
 else
   mode=${2:-pass}
