@@ -239,6 +239,9 @@ size_t lfbm5d_last_tables(lfbm5d_ctx* ctx, float* h_tables, size_t n_floats);
 /* Candidate scores of the self-similarity search of the last pass, [reference patch][(2 nSim+1)^2] in the scan order of
  * core:3407-3420 (entries no table covers keep 2 * threshold): same calling convention. */
 size_t lfbm5d_last_scores(lfbm5d_ctx* ctx, float* h_scores, size_t n_floats);
+/* Aggregation weights of the groups of the last pass, [reference patch][channel] (core:413-421: 1 / (sigma_c^2 * retained
+ * coefficients) in the hard-threshold step): same calling convention.  Lets a test compare survivor counts group by group. */
+size_t lfbm5d_last_weights(lfbm5d_ctx* ctx, float* h_w, size_t n_floats);
 /* Which generation of the table kernel the last pass used: 2 = ring-sharing workgroups (table layout
  * [slot][(2 nDisp+1)^2]{[strip][Q / 4][lane][Q % 4], column 0}, lfbm5d_kernels.h stereo_table_stride2), 1 = one wave per table
  * (12x12 patches, irregular reference lists, LFBM5D_SCAN_V1=1). */

@@ -113,6 +113,8 @@ def lib():
     L.lfbm5d_bm3d_lf_host.argtypes = [vp, bp, bp, fp, up, fp, fp, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     L.lfbm5d_last_tables.argtypes = [vp, vp, C.c_size_t]
     L.lfbm5d_last_tables.restype = C.c_size_t
+    L.lfbm5d_last_weights.argtypes = [vp, vp, C.c_size_t]
+    L.lfbm5d_last_weights.restype = C.c_size_t
     L.lfbm5d_last_scores.argtypes = [vp, vp, C.c_size_t]
     L.lfbm5d_last_scores.restype = C.c_size_t
     L.lfbm5d_last_scan_version.argtypes = [vp]
@@ -353,6 +355,13 @@ class Context:
         out = np.zeros(n, np.float32)
         got = self._L.lfbm5d_last_scores(self._h, out.ctypes.data, n)
         return out[:got]
+
+    def last_weights(self, n_groups, C_):
+        """Aggregation weights of the groups of the last pass, [group][channel]."""
+        out = np.zeros(n_groups * C_, np.float32)
+        got = self._L.lfbm5d_last_weights(self._h, out.ctypes.data, out.size)
+        assert got == out.size
+        return out.reshape(n_groups, C_)
 
     def last_scan_version(self):
         return int(self._L.lfbm5d_last_scan_version(self._h))

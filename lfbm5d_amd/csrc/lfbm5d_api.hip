@@ -1718,6 +1718,17 @@ size_t lfbm5d_last_tables(lfbm5d_ctx* c, float* h_tables, size_t n_floats) {
     return n;
 }
 
+size_t lfbm5d_last_weights(lfbm5d_ctx* c, float* h_w, size_t n_floats) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    const size_t have = c->wgt.cap / sizeof(float);
+    if (!h_w) return have;
+    const size_t n = std::min(have, n_floats);
+    if (n && hipMemcpy(h_w, c->wgt.p, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+}
+
 size_t lfbm5d_last_scores(lfbm5d_ctx* c, float* h_scores, size_t n_floats) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);

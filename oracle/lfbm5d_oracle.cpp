@@ -684,6 +684,8 @@ int bm_stereo(const float* img1, const float* img2, unsigned W, unsigned H, unsi
 /* ------------------------------------------------------------------------------------------ */
 /* One core pass                                                                                */
 /* ------------------------------------------------------------------------------------------ */
+std::vector<float> g_last_weights;   /* aggregation weights of the last pass's groups (orc_last_weights) */
+
 struct GroupOut {
     unsigned nSx = 0;
     bool use_sadct = false;
@@ -935,6 +937,11 @@ int pass_impl(int step, const orc_params* P, unsigned aw, unsigned ah, unsigned 
                             }
                     }
             }
+        }
+        for (unsigned jj = 0; jj < ncols; jj++) {   /* inspection: the groups' aggregation weights, [reference patch][channel] */
+            const size_t slot = row_start[r] + jj;
+            if (g_last_weights.size() < (slot + 1) * C) g_last_weights.resize((slot + 1) * C, 0.0f);
+            for (unsigned c = 0; c < C; c++) g_last_weights[slot * C + c] = outs[jj].w[c];
         }
         for (const GroupOut& go : outs) { n_groups++; n_sadct += go.use_sadct; n_stack += go.nSx; }
     }
@@ -1566,6 +1573,11 @@ void orc_symetrize(const float* img, float* out, unsigned W, unsigned H, unsigne
 void orc_unsymetrize(float* img, const float* sym, unsigned W, unsigned H, unsigned C, unsigned N) { unsymetrize(img, sym, W, H, C, N); }
 int orc_color_transform(float* img, unsigned cs, unsigned W, unsigned H, unsigned C, int forward) { return color_transform(img, cs, W, H, C, forward != 0); }
 int orc_sigma_table(float sigma, unsigned C, unsigned cs, float* out) { return sigma_table(sigma, C, cs, out); }
+unsigned orc_last_weights(float* out, unsigned cap) {
+    const unsigned n = (unsigned)g_last_weights.size();
+    for (unsigned i = 0; i < n && i < cap; i++) out[i] = g_last_weights[i];
+    return n;
+}
 unsigned orc_ind_initialize(unsigned max_size, unsigned N, unsigned step, unsigned* out) {
     std::vector<unsigned> v; ind_init(v, max_size, N, step);
     if (out) std::memcpy(out, v.data(), v.size() * sizeof(unsigned));

@@ -167,6 +167,9 @@ void orc_unsymetrize(float* img, const float* sym, unsigned W, unsigned H, unsig
 int  orc_color_transform(float* img, unsigned color_space, unsigned W, unsigned H, unsigned C,
                          int forward);
 int  orc_sigma_table(float sigma, unsigned C, unsigned color_space, float* out);
+/* aggregation weights of the groups of the last orc_pass, [reference patch][channel] (core:413-421): count returned,
+ * min(count, cap) written.  For tests that compare hard-threshold survivor counts group by group. */
+unsigned orc_last_weights(float* out, unsigned cap);
 unsigned orc_ind_initialize(unsigned max_size, unsigned N, unsigned step, unsigned* out);
 void orc_search_window(int aidx, unsigned asize, unsigned an, int* c_asw, int* min_asw, int* max_asw);
 float orc_denoised_percent(const float* den, const unsigned* mask, unsigned A, unsigned W,

@@ -94,6 +94,8 @@ def lib():
     L.orc_unsymetrize.argtypes = [_f32p, _f32p, C.c_uint, C.c_uint, C.c_uint, C.c_uint]
     L.orc_color_transform.argtypes = [_f32p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int]
     L.orc_sigma_table.argtypes = [C.c_float, C.c_uint, C.c_uint, _f32p]
+    L.orc_last_weights.argtypes = [_f32p, C.c_uint]
+    L.orc_last_weights.restype = C.c_uint
     L.orc_ind_initialize.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_void_p]
     L.orc_ind_initialize.restype = C.c_uint
     L.orc_search_window.argtypes = [C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_int),
@@ -233,3 +235,11 @@ def run_bm3d_lf(sigma, lam, noisy, mask, W, H, Cc, hard, wien, cs="opp"):
     if rc:
         raise RuntimeError("orc_run_bm3d_lf failed")
     return noisy, basic, den, st
+
+
+def last_weights(n_groups, Cc):
+    """Aggregation weights of the groups of the last orc_pass, [group][channel]."""
+    out = np.zeros(n_groups * Cc, np.float32)
+    n = lib().orc_last_weights(out, out.size)
+    assert n >= out.size
+    return out.reshape(n_groups, Cc)
