@@ -23,7 +23,7 @@ def classify(name):
     if "k_aggregate" in name:
         return ("aggregate", "wiener" if ", 8, 8," in name else "ht")
     if "k_bm_scan" in name:
-        return ("scan", "wiener" if "<8>" in name else "ht")
+        return ("scan", "wiener" if ("<8>" in name or "<8," in name) else "ht")
     if "argmin" in name:
         return ("argmin", "both")
     return None
