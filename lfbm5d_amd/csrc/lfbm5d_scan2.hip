@@ -861,10 +861,16 @@ __global__ __launch_bounds__(256) void k_stereo_argmin3(Argmin3Args a) {
         const f2* src = reinterpret_cast<const f2*>(a.tables) + (size_t)slot * a.nwg_slot * pstride + i;
         f2 v = src[0];
         bv = v.x; bo = __float_as_int(v.y);
-        for (int j = 1; j < a.nwg_slot; j++) {
-            v = src[(size_t)j * pstride];
-            const int o = __float_as_int(v.y);
-            if (v.x < bv || (v.x == bv && o < bo)) { bv = v.x; bo = o; }
+        /* eight pairs in flight (a workgroup past the last repeats the last: a no-op for the minimum) */
+        for (int j0 = 1; j0 < a.nwg_slot; j0 += 8) {
+            f2 w8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) w8[u] = src[(size_t)min(j0 + u, a.nwg_slot - 1) * pstride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int o = __float_as_int(w8[u].y);
+                if (w8[u].x < bv || (w8[u].x == bv && o < bo)) { bv = w8[u].x; bo = o; }
+            }
         }
     } else {
         const int e = i - n_main;
