@@ -848,46 +848,61 @@ __global__ __launch_bounds__(256) void k_stereo_argmin3(Argmin3Args a) {
     const unsigned slot = blockIdx.y, st = a.st_of_slot[slot];
     const size_t WH = (size_t)W * H;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_main = nstrips * NCH * 512, n_edge = span_r + nstrips;
-    if (i >= n_main + n_edge) return;
-    int row, col;
-    float bv; int bo;
+    const int n_main = nstrips * NCH * 256, n_edge = span_r + nstrips;      /* main: two consecutive steps of a lane per thread (16-byte loads) */
+    if (i >= n_main + 16 * n_edge) return;
+    auto put = [&](int row, int col, float bv, int bo) {
+        const int pos = (nDisp + row) * W + nDisp + col;
+        const int dj = bo / Ns, di = bo % Ns;
+        a.best[(size_t)st * WH + pos] = (unsigned)(pos + (di - nDisp) * W + (dj - nDisp));
+        a.shape[(size_t)st * WH + pos] = bv < a.thr ? 1 : 0;
+    };
     if (i < n_main) {
-        const int p = i & 511, c = (i >> 9) % NCH, strip = (i >> 9) / NCH;
+        const int p = 2 * (i & 255), c = (i >> 8) % NCH, strip = (i >> 8) / NCH;
         const int l = p >> 3, t = 8 * c + (p & 7);
-        row = 1 + t - l; col = 1 + 64 * strip + l;
-        if (row < 0 || row >= span_r || col >= span_c || (row == 0 && l == 0)) return;
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        const f2* src = reinterpret_cast<const f2*>(a.tables) + (size_t)slot * a.nwg_slot * pstride + i;
-        f2 v = src[0];
-        bv = v.x; bo = __float_as_int(v.y);
-        /* eight pairs in flight (a workgroup past the last repeats the last: a no-op for the minimum) */
-        for (int j0 = 1; j0 < a.nwg_slot; j0 += 8) {
-            f2 w8[8];
+        const int row = 1 + t - l, col = 1 + 64 * strip + l;      /* rows `row` and `row + 1` */
+        if (row + 1 < 0 || row >= span_r || col >= span_c) return;
+        const v4f* src = reinterpret_cast<const v4f*>(a.tables) + ((size_t)slot * a.nwg_slot * pstride >> 1) + i;
+        float bv0 = __builtin_inff(), bv1 = __builtin_inff(); int bo0 = 0x7fffffff, bo1 = 0x7fffffff;
+        /* sixteen loads in flight -- all of them at nDisp = 6 (a workgroup past the last repeats the last: a no-op for the minimum) */
+        for (int j0 = 0; j0 < a.nwg_slot; j0 += 16) {
+            v4f w8[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) w8[u] = src[(size_t)min(j0 + u, a.nwg_slot - 1) * pstride];
+            for (int u = 0; u < 16; u++) w8[u] = src[(size_t)min(j0 + u, a.nwg_slot - 1) * (pstride >> 1)];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int o = __float_as_int(w8[u].y);
-                if (w8[u].x < bv || (w8[u].x == bv && o < bo)) { bv = w8[u].x; bo = o; }
+            for (int u = 0; u < 16; u++) {
+                const int o0 = __float_as_int(w8[u][1]), o1 = __float_as_int(w8[u][3]);
+                if (w8[u][0] < bv0 || (w8[u][0] == bv0 && o0 < bo0)) { bv0 = w8[u][0]; bo0 = o0; }
+                if (w8[u][2] < bv1 || (w8[u][2] == bv1 && o1 < bo1)) { bv1 = w8[u][2]; bo1 = o1; }
             }
         }
+        if (row >= 0 && !(row == 0 && l == 0)) put(row, col, bv0, bo0);
+        if (row + 1 < span_r && row + 1 >= 0 && !(row + 1 == 0 && l == 0)) put(row + 1, col, bv1, bo1);
     } else {
-        const int e = i - n_main;
+        /* edge positions: sixteen lanes per position, each over every sixteenth table, then a 16-lane minimum */
+        const int e = (i - n_main) >> 4, sub = (i - n_main) & 15;
+        int row, col;
         if (e < span_r) { row = e; col = 0; } else { row = 0; col = 1 + 64 * (e - span_r); }
-        if (col >= span_c) return;
-        const float* ed = a.tables + (size_t)a.n_slots * a.nwg_slot * pstride * 2 + (size_t)slot * ncand * estride + e;
-        bv = ed[0]; bo = 0;   /* table index ddk = 0 <-> di = dj = 0 <-> order 0 */
-        for (int ddk = 1; ddk < ncand; ddk++) {
-            const float v = ed[(size_t)ddk * estride];
-            const int o = (ddk % Ns) * Ns + ddk / Ns;
-            if (v < bv || (v == bv && o < bo)) { bv = v; bo = o; }
+        const bool ok = e < n_edge && col < span_c;
+        const float* ed = a.tables + (size_t)a.n_slots * a.nwg_slot * pstride * 2 + (size_t)slot * ncand * estride + (ok ? e : 0);
+        float bv = __builtin_inff(); int bo = 0x7fffffff;
+        for (int d0 = sub; d0 < ncand; d0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = ed[(size_t)min(d0 + 16 * u, ncand - 1) * estride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int ddk = d0 + 16 * u;
+                const int o = (ddk % Ns) * Ns + ddk / Ns;
+                if (ddk < ncand && (v[u] < bv || (v[u] == bv && o < bo))) { bv = v[u]; bo = o; }
+            }
         }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) {
+            const float ov = __shfl_xor(bv, m, 16); const int oo = __shfl_xor(bo, m, 16);
+            if (ov < bv || (ov == bv && oo < bo)) { bv = ov; bo = oo; }
+        }
+        if (ok && sub == 0) put(row, col, bv, bo);
     }
-    const int pos = (nDisp + row) * W + nDisp + col;
-    const int dj = bo / Ns, di = bo % Ns;
-    a.best[(size_t)st * WH + pos] = (unsigned)(pos + (di - nDisp) * W + (dj - nDisp));
-    a.shape[(size_t)st * WH + pos] = bv < a.thr ? 1 : 0;
 }
 
 hipError_t launch_stereo_argmin3(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots, unsigned nwg_slot,
@@ -898,7 +913,7 @@ hipError_t launch_stereo_argmin3(hipStream_t s, const float* tables, const unsig
     for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
     const unsigned span_c = W - 2 * nDisp - k + 1, span_r = H - 2 * nDisp - k + 1;
     const unsigned nstrips = (span_c - 1 + 63) / 64;
-    const unsigned n = nstrips * stereo_part_chunks(H, k, nDisp) * 512 + span_r + nstrips;
+    const unsigned n = nstrips * stereo_part_chunks(H, k, nDisp) * 256 + 16 * (span_r + nstrips);
     hipLaunchKernelGGL(k_stereo_argmin3, dim3((n + 255) / 256, n_slots), dim3(256), 0, s, a);
     return hipGetLastError();
 }
