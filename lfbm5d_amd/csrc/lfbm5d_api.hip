@@ -933,12 +933,13 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
      * index winning ties (bm5d.cpp:187-213).  A window always ends with all of its SAIs processed
      * (bm5d.cpp:283-402), so an unprocessed SAI has never been aggregated into: all candidates tie and
      * the sequence of windows is a pure function of the mask -- plan_windows() (tests check it against the
-     * data-driven selection, which stays available).  Several GPUs split the planned sequence into
-     * one contiguous block of windows per rank, and add the per-rank num/den with one all-reduce per step.
-     * Windows interact through those sums and through the running estimate block matching uses for SAIs
-     * that earlier windows already processed; a rank only sees its own earlier windows there, which costs
-     * about 0.01 / 0.03 / 0.07 dB of final PSNR on 2 / 4 / 8 ranks (the reference's own parallel
-     * mode, spatial tiles, costs 0.5 dB).  LFBM5D_STEP_SHARDING=rows selects the exact alternative. */
+     * data-driven selection, which stays available).  Several GPUs (and the lanes of one GPU) run the planned
+     * sequence as a dependency graph: windows interact only through num / den of the SAIs they share, chains of
+     * windows go to ranks, and what a window needs from another rank's window travels as one send / recv per SAI --
+     * bit-identical to one GPU for any rank count (build_graph below).
+     * LFBM5D_STEP_SHARDING selects the alternatives: "rows" (every core pass sharded by reference-patch rows, exact,
+     * barely scales) and "blocks" (round 1: one contiguous block of windows per rank + one all-reduce per step; a rank's
+     * block matching then only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks). */
     const char* emu_s = std::getenv("LFBM5D_EMULATE_WORLD");
     const int emu = emu_s ? std::atoi(emu_s) : 0;                    /* test hook: play all ranks on this GPU */
     const char* shard_s = std::getenv("LFBM5D_STEP_SHARDING");

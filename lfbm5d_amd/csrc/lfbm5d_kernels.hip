@@ -2328,9 +2328,10 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
  *   2-4 as before (3x3 angular DCT per (n, pq) fibre; Haar + Wiener + inverse Haar per (st, pq) fibre; inverse 3x3)
  *   5a  item = (column j, patch pair): inverse transform of the filtered stack, two patches packed
  *   5b  item = (row i, patch pair): inverse transform along the row, two 32-byte stores
- * With N = 16 every phase divides evenly over 192 threads (1152 / 576 items = 6 / 3 per thread): three wavefronts per
- * workgroup, all lanes busy.  Items are numbered patch-fastest so that the stack accesses of a wavefront are
- * consecutive float2 (no bank conflicts); the global accesses are 32-byte row segments either way.
+ * Workgroups are 512 threads (eight wavefronts, two workgroups per CU at the stack's 74 KiB: 16 waves per CU; 192 threads --
+ * every phase divides evenly -- measured three times slower, odd wave counts leave SIMDs unevenly loaded).
+ * Items are numbered patch-fastest so that the stack accesses of a wavefront are consecutive float2 (no bank conflicts);
+ * the global accesses are 32-byte row segments either way.
  * ------------------------------------------------------------------------------------------ */
 #ifndef LFBM5D_DCT8W2_THREADS
 #define LFBM5D_DCT8W2_THREADS 512
