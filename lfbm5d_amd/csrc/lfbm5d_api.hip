@@ -881,6 +881,20 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         while (ws.rem_w) {
             if (!ws.counted) {   /* choose the next SAI of the window from the zero-weight counts (bm5d.cpp:299-327) and process it */
                 HIPCK(c, hipMemsetAsync(L.d_small, 0, Aw * sizeof(unsigned), ls));
+                if (n_tiles > 1) {
+                    /* tile mode: the reference counts the zeros tile by tile over the tiles sub_divide cuts from the merged
+                     * window, halos included (bm5d.cpp:598-600) -- a zero under two halos counts twice */
+                    lfbm5d_ctx* x = L.x;
+                    const unsigned hmax = std::max(tl_h, tl_hb) + 2 * nHW, wmax = std::max(tl_w, tl_wb) + 2 * nHW;
+                    HIPCK(c, x->t_tden.reserve(Aw * (size_t)C * hmax * wmax * sizeof(float)));
+                    for (unsigned kt = 0; kt < tl_nw * tl_nh; kt++) {
+                        const unsigned i = kt / tl_nw, j = kt % tl_nw;
+                        const unsigned h = (i == tl_nh - 1 ? tl_hb : tl_h) + 2 * nHW, w = (j == tl_nw - 1 ? tl_wb : tl_w) + 2 * nHW;
+                        const size_t timg = (size_t)C * w * h;
+                        HIPCK(c, launch_copy_rect(ls, x->t_tden.as<float>(), timg, w, h, 0, 0, L.w_den, imgb, wb, hb, j * tl_w, i * tl_h, w, h, C, Aw, ws.win_bits));
+                        HIPCK(c, launch_count_zeros(ls, x->t_tden.as<float>(), timg, Aw, L.d_small));
+                    }
+                } else
                 HIPCK(c, launch_count_zeros(ls, L.w_den, imgb, Aw, L.d_small));
                 HIPCK(c, hipMemcpyAsync(h_tmp_w.data(), L.d_small, Aw * sizeof(unsigned), hipMemcpyDeviceToHost, ls));
                 HIPCK(c, hipStreamSynchronize(ls));
@@ -1007,6 +1021,22 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             c->lanes.push_back(x);
         }
         struct RankState { int rank; lfbm5d_ctx* x; float* g_num; float* g_den; std::vector<Lane> lanes; };
+        /* An error return in the middle of the graph (a failed HIP call, an RCCL call that reports an error) would leave
+         * this rank's queued sends / receives waiting for peers that will never get their counterparts -- and the peers
+         * waiting for this rank.  With real ranks the way out is to abort the communicators: RCCL then fails the pending
+         * operations here, the peers see the failure through their own RCCL error paths (or their caller's watchdog --
+         * bench.py has one), and every later call on this context reports that the communicator is gone instead of
+         * hanging.  Disarmed when the graph has run through. */
+        struct AbortCommsOnError {
+            lfbm5d_ctx* c; bool armed;
+            ~AbortCommsOnError() {
+                if (!armed) return;
+                if (c->comm2) { (void)ncclCommAbort(c->comm2); c->comm2 = nullptr; }
+                if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+                (void)hipDeviceSynchronize();
+                c->err += " (multi-GPU step aborted: the RCCL communicators of this context were torn down, call lfbm5d_comm_init again)";
+            }
+        } abort_guard{c, nranks > 1 && !emulate};
         std::vector<RankState> states(emulate ? (size_t)emu : 1);
         hipEvent_t ev_setup = get_event(c);
         HIPCK(c, hipEventRecord(ev_setup, s));   /* colour transform and the zeroed num / den */
@@ -1141,6 +1171,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             HIPCK(c, hipMemcpyAsync(&complete, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
             HIPCK(c, hipStreamSynchronize(s));
         }
+        abort_guard.armed = false;   /* every exchange of the graph has completed; what follows are plain collectives */
         if (complete) {
             for (size_t w = 0; w < NW; w++) { c->last_windows.push_back(G.plan[w]); if (mine[w]) c->stats.windows += 1; }
             graph_done = true;

@@ -1048,6 +1048,29 @@ float denoised_percent(const float* den, const unsigned* mask, unsigned A, unsig
  * whatever a tile aggregated into its halo is DISCARDED, which is what costs the tiled mode about 0.5 dB) and the window's
  * num / den are padded again for the next pass.  w_* are the padded window buffers [Aw][C*hb*wb], updated in place.
  * pct receives the sum of the tiles' LF_denoised_percent (bm5d.cpp:666-668). */
+/* exact zeros of one padded SAI [C][H + 2N][W + 2N], counted tile by tile over the tiles sub_divide would cut (halo of N) */
+long tiled_zero_count(const float* den_b, unsigned W, unsigned H, unsigned C, unsigned N, int nb_tiles) {
+    const unsigned hb = H + 2 * N, wb = W + 2 * N;
+    unsigned w_small = W, h_small = H, nw = 1, nh = 1;
+    for (int n = nb_tiles; n > 1; n /= 2) {
+        if (w_small > h_small) { w_small = (unsigned)std::floor((float)w_small * 0.5f); nw *= 2; }
+        else { h_small = (unsigned)std::floor((float)h_small * 0.5f); nh *= 2; }
+    }
+    const unsigned h_bound = nh > 1 ? H - (nh - 1) * h_small : h_small;
+    const unsigned w_bound = nw > 1 ? W - (nw - 1) * w_small : w_small;
+    long cnt = 0;
+    for (unsigned i = 0; i < nh; i++)
+        for (unsigned j = 0; j < nw; j++) {
+            const unsigned h = (i == nh - 1 ? h_bound : h_small) + 2 * N, w = (j == nw - 1 ? w_bound : w_small) + 2 * N;
+            for (unsigned c = 0; c < C; c++)
+                for (unsigned y = 0; y < h; y++) {
+                    const float* row = den_b + ((size_t)c * hb + i * h_small + y) * wb + j * w_small;
+                    cnt += (long)std::count(row, row + w, 0.0f);
+                }
+        }
+    return cnt;
+}
+
 int tiled_pass(int step, const orc_params* Pw, unsigned asw, unsigned W, unsigned H, unsigned C, unsigned N,
                const std::vector<float>& w_noisy, const std::vector<float>& w_basic, std::vector<float>& w_num,
                std::vector<float>& w_den, const std::vector<unsigned>& mask_w, const std::vector<unsigned>& proc_w,
@@ -1195,7 +1218,10 @@ int run_step(int step, const orc_params* P, float* LF_noisy, const unsigned* mas
                 long best_cnt = -1;
                 for (unsigned i = 0; i < Aw; i++) {
                     if (proc_w[i]) continue;
-                    const long cnt = (long)std::count(w_den.begin() + i * imgb, w_den.begin() + (i + 1) * imgb, 0.0f);
+                    /* untiled: zeros of the padded SAI (bm5d.cpp:327); tile mode: summed over the tiles as sub_divide cuts
+                     * them, halos included -- a zero under two tiles' halos counts twice (bm5d.cpp:598-600) */
+                    const long cnt = g_tiles <= 1 ? (long)std::count(w_den.begin() + i * imgb, w_den.begin() + (i + 1) * imgb, 0.0f)
+                                                  : tiled_zero_count(&w_den[i * imgb], W, H, C, nHW, g_tiles);
                     if (cnt >= best_cnt) { pst_w = i; best_cnt = cnt; }
                 }
                 if (ang_major == ORC_ROWMAJOR) { ps_w = pst_w / asw; pt_w = pst_w - ps_w * asw; }
@@ -1598,7 +1624,11 @@ int orc_last_windows(unsigned* out, unsigned cap) {
     return (int)g_last_windows.size();
 }
 void orc_set_time_limit(double seconds) { g_time_limit = seconds; }
-void orc_set_tiles(int n) { g_tiles = n > 1 ? n : 1; }
+void orc_set_tiles(int n) {   /* floored to a power of two like main.cpp:101-102 does with nb_threads */
+    int t = 1;
+    while (t * 2 <= n) t *= 2;
+    g_tiles = n > 1 ? t : 1;
+}
 int orc_get_threads(void) {
 #ifdef _OPENMP
     return g_threads > 0 ? g_threads : omp_get_max_threads();

@@ -274,7 +274,7 @@ def test_subset_pass_of_the_wiener_step_matches_oracle(ctx, pk, sigma):
         proc[pst] = 1
 
 
-@pytest.mark.parametrize("tiles,grey", [(4, False), (8, False), (4, True)])
+@pytest.mark.parametrize("tiles,grey", [(4, False), (8, False), (4, True), (8, True), (6, True)])   # 6: floored to 4 on both sides (main.cpp:101-102)
 def test_tile_mode_matches_the_oracles_tile_mode(ctx, tiles, grey):
     """lfbm5d_set_tiles: the reference's OpenMP tile mode (bm5d.cpp:411-708; what run_bm5d_* does with nb_threads > 1) --
     tiles with a discarded halo.  Both steps against the oracle in the same mode: same windows and passes, PSNR within
