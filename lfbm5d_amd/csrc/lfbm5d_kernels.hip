@@ -299,6 +299,43 @@ __device__ __forceinline__ void dct9_inv2(v2f* x, TbPtr tb) {
         for (int j = 0; j < 3; j++)
             x[i * 3 + j] = (t[j] + 2.0f * (t[3 + j] * tb->cos3[3 + i] + t[6 + j] * tb->cos3[6 + i])) * tb->coef4inv;
 }
+/* The same 3x3 transforms with the table's symmetries used (cos3 = {1, 1, 1; c, 0, -c; 1/2, -1, 1/2}: the table's
+ * middle entry is cos(pi/2) in double, 6e-17, taken as 0): less than half the operations, results within an ulp or two of
+ * dct9_fwd2 / dct9_inv2.  For the Wiener kernels only -- a hard-threshold decision can flip on an ulp. */
+__device__ __forceinline__ void dct9_fwd2_fast(v2f* x, TbPtr tb) {
+    const float c2 = 2.0f * tb->cos3[3];
+    v2f t[9];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const v2f a = x[s * 3] + x[s * 3 + 2];
+        t[s * 3] = 2.0f * (a + x[s * 3 + 1]);
+        t[s * 3 + 1] = c2 * (x[s * 3] - x[s * 3 + 2]);
+        t[s * 3 + 2] = a - 2.0f * x[s * 3 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const v2f a = t[u] + t[6 + u];
+        x[u] = (a + t[3 + u]) * (2.0f * tb->cn4[u]);
+        x[3 + u] = (t[u] - t[6 + u]) * (c2 * tb->cn4[3 + u]);
+        x[6 + u] = (a - 2.0f * t[3 + u]) * tb->cn4[6 + u];
+    }
+}
+__device__ __forceinline__ void dct9_inv2_fast(v2f* x, TbPtr tb) {
+    const float c2 = 2.0f * tb->cos3[3];
+    v2f t[9];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const v2f X0 = x[s * 3] * tb->cni4[s * 3], X1 = x[s * 3 + 1] * (c2 * tb->cni4[s * 3 + 1]), X2 = x[s * 3 + 2] * tb->cni4[s * 3 + 2];
+        const v2f p = X0 + X2;
+        t[s * 3] = p + X1; t[s * 3 + 1] = X0 - 2.0f * X2; t[s * 3 + 2] = p - X1;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const v2f T0 = t[j] * tb->coef4inv, T1 = t[3 + j] * (c2 * tb->coef4inv), T2 = t[6 + j] * tb->coef4inv;
+        const v2f p = T0 + T2;
+        x[j] = p + T1; x[3 + j] = T0 - 2.0f * T2; x[6 + j] = p - T1;
+    }
+}
 /* Haar over the NS patches of a group held as pairs P[h] = {patch h, patch h + NS/2} (lib_transforms.cpp:403-471
  * / :290-321, same butterflies and scaling, evaluated two at a time).  Forward leaves the coefficients in
  * C[0..NS/2) (a permutation of the reference order -- the shrinkage treats all coefficients alike); the inverse
@@ -1955,6 +1992,18 @@ template <int NS> __device__ __forceinline__ void haar_fwd2(v2f* v) {
     }
 }
 
+template <int NS> __device__ __forceinline__ void haar_inv2(v2f* v) {
+    const float s = 0.70710678118654752f;
+#pragma unroll
+    for (int h = 1; h < NS; h *= 2) {
+        v2f t[NS > 1 ? NS : 1];
+#pragma unroll
+        for (int i = 0; i < h; i++) { t[2 * i] = (v[i] + v[h + i]) * s; t[2 * i + 1] = (v[i] - v[h + i]) * s; }
+#pragma unroll
+        for (int i = 0; i < 2 * h; i++) v[i] = t[i];
+    }
+}
+
 /* a / b for the Wiener coefficient e^2 / (e^2 + sigma^2) (0 <= a < b, both normal or a = 0): reciprocal estimate and
  * one correction step instead of the IEEE division sequence -- within one ulp of the quotient, which is well inside
  * the float tolerance of this stage (the division was a tenth of the kernel's instructions) */
@@ -2586,6 +2635,323 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Wiener step, 8x8 DCT, Haar along the matches, third generation: ONE image in LDS at a time.  k_group_dct8w2 holds the
+ * noisy and the pilot stack side by side (float2, 74 KiB: two workgroups per CU) and the time of a pass follows the
+ * number of INDEPENDENT workgroups on a CU, not the number of waves (one workgroup of 8 or 16 waves per CU: 2.2 / 2.1 ms;
+ * two of 8 waves: 1.4 ms -- a workgroup spends its phases waiting on one kind of unit, a second one in another phase
+ * fills it).  Here the pilot goes through the forward transforms first, its Wiener coefficients e^2 / (e^2 + sigma^2)
+ * stay in REGISTERS of the thread that owns the (st, pq) fibre, the noisy image then takes the same LDS: a float stack
+ * of 36.5 KiB, four workgroups per CU.  The arithmetic per value is that of k_group_dct8w2 (same transforms on packed
+ * pairs -- here two PATCHES per lane where that kernel packs the two images -- same shrinkage).
+ *   P1-P3  pilot:  rows from the window (item = row i of patches 2pp, 2pp + 1), columns in place, 3x3 angular
+ *   P4     Haar of the pilot fibre -> coefficient (or, outside the SADCT shape, the pilot value: quirk 10) in registers
+ *   P5-P7  noisy: as P1-P3
+ *   P8     Haar of the noisy fibre, times the coefficient, inverse Haar, in place
+ *   P9-P11 inverse 3x3 (fibres pq, pq + 32 packed), inverse columns (patch pairs), inverse rows + store
+ * Stack [pq][patch] floats, row stride 146: pairs of patches are 8-byte aligned, and 146 = 18 mod 32 with the lane
+ * numbering of the fibre phases (16 values of pq x 2 neighbours in n or st) touches 32 distinct banks.
+ * ------------------------------------------------------------------------------------------ */
+#ifndef LFBM5D_DCT8W3_THREADS
+#define LFBM5D_DCT8W3_THREADS 256
+#endif
+constexpr int kDct8w3Threads = LFBM5D_DCT8W3_THREADS;
+constexpr int kW3Stride = 146;
+constexpr unsigned kW3Lds = 64 * kW3Stride * sizeof(float);
+constexpr unsigned kW3Empty = 0xf0000000u;   /* byte offset of an absent patch: beyond any window this kernel is launched on */
+
+template <int NS, int TH>
+__device__ __forceinline__ void w3_forward(__amdgpu_buffer_rsrc_t img, unsigned row_bytes, float* S, const unsigned* pos,
+                                           int tid, ShRef sh, bool do_dct4, bool do_sa4, TbPtr tb) {
+    constexpr int A = 9, NP = NS * A, NPh = (NP + 1) / 2, NPf = kW3Stride;
+    constexpr int kIt = (NPh * 8 + TH - 1) / TH;
+    {
+        /* pos[] holds byte offsets into the window (out of range for an empty SAI / never-filled column: the buffer load returns zeros) */
+        v4f ra0[kIt], ra1[kIt], rb0[kIt], rb1[kIt];
+#pragma unroll
+        for (int q = 0; q < kIt; q++) {
+            const int it = tid + q * TH;
+            if (it < NPh * 8) {
+                const int i = it / NPh, pp = it - i * NPh;
+                const int pA = 2 * pp, pB = pA + 1 < NP ? pA + 1 : pA;
+                const int oa = (int)(pos[pA] + (unsigned)i * row_bytes), ob = (int)(pos[pB] + (unsigned)i * row_bytes);
+                ra0[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, oa, 0, 0));
+                ra1[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, oa + 16, 0, 0));
+                rb0[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, ob, 0, 0));
+                rb1[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, ob + 16, 0, 0));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kIt; q++) {
+            const int it = tid + q * TH;
+            if (it < NPh * 8) {
+                const int i = it / NPh, pp = it - i * NPh;
+                v2f x[8];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    x[j] = v2f{ra0[q][j], rb0[q][j]};
+                    x[4 + j] = v2f{ra1[q][j], rb1[q][j]};
+                }
+                dct8_fwd_t(x);
+                float* dst = S + (i * 8) * NPf + 2 * pp;
+#pragma unroll
+                for (int j = 0; j < 8; j++) *reinterpret_cast<v2f*>(dst + j * NPf) = x[j];
+            }
+        }
+    }
+    __syncthreads();
+    for (int it = tid; it < NPh * 8; it += TH) {
+        const int j = it / NPh, pp = it - j * NPh;
+        float* col = S + j * NPf + 2 * pp;
+        v2f x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = *reinterpret_cast<const v2f*>(col + (i * 8) * NPf);
+        dct8_fwd_t(x);
+#pragma unroll
+        for (int i = 0; i < 8; i++) *reinterpret_cast<v2f*>(col + (i * 8) * NPf) = x[i];
+    }
+    __syncthreads();
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < NS * 32; f += TH) {
+            int n, pq;
+            if (NS > 1) { pq = (f & 15) | ((f >> 1) & 16); n = ((f >> 4) & 1) | ((f >> 5) & ~1); }
+            else { n = 0; pq = f; }
+            float* b0 = S + pq * NPf + n * A;
+            float* b1 = b0 + 32 * NPf;
+            v2f x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = v2f{b0[st], b1[st]};
+            if (do_dct4) dct9_fwd2_fast(x, tb);
+            else {   /* rare: shape-adaptive transform on the scalar path */
+                float t9[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) t9[i] = x[i].x;
+                sadct9_fwd(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
+                sadct9_fwd(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) x[i].y = t9[i];
+            }
+#pragma unroll
+            for (int st = 0; st < 9; st++) { b0[st] = x[st].x; b1[st] = x[st].y; }
+        }
+        __syncthreads();
+    }
+}
+
+template <int NS, int TH>
+__device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsigned* pos, float (*red)[TH / 64], int tid,
+                                        unsigned g, int c) {
+    constexpr int A = 9, K2 = 64, NP = NS * A, NPh = (NP + 1) / 2, NPf = kW3Stride;
+    static_assert(TH == 256, "the fibre phases deal st 0..3 / 4..7 to 256 threads");
+    const int N = a.N;
+    const unsigned win_bytes = (unsigned)((size_t)A * a.C * a.Wb * a.Hb * 4);
+    const TbPtr tb = (TbPtr)a.tb;
+    ShRef sh = group_shape(a, g);
+    const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
+    const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    const float sig = a.sigma[c];
+    const float sig2 = sig * sig;
+    const bool useSD = a.useSD != 0;
+
+    w3_forward<NS, TH>(__builtin_amdgcn_make_buffer_rsrc((void*)a.basic, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, do_dct4, do_sa4, tb);
+    /* fibres (st, pq): every thread owns st and st + 4 (st < 4) as a packed pair, the first wave also st = 8 */
+    const int fpq = (tid & 15) | ((tid >> 1) & 48), fst = ((tid >> 4) & 1) | ((tid >> 6) & 2);
+    float* const fbase = S + fpq * NPf + fst;
+    float* const f8base = S + (tid & 63) * NPf + 8;
+    const bool own8 = tid < 64;
+    v2f vv[NS];
+    float v8[NS];
+    {
+        v2f e[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) e[n] = v2f{fbase[n * A], fbase[n * A + 4]};
+        if (NS > 1) haar_fwd2<NS>(e);
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            const v2f value = e[n] * e[n], den = value + sig2;
+            vv[n] = v2f{wiener_div(value.x, den.x), wiener_div(value.y, den.y)};
+        }
+        if (use_sadct) {   /* outside the shape the pilot's own coefficient passes through (quirk 10) */
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                if (!sh.mask_dct[fst]) vv[n].x = e[n].x;
+                if (!sh.mask_dct[fst + 4]) vv[n].y = e[n].y;
+            }
+        }
+    }
+    if (own8) {
+        float e[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) e[n] = f8base[n * A];
+        if (NS > 1) haar_fwd<NS>(e);
+        const bool in8 = !use_sadct || sh.mask_dct[8];
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            const float value = e[n] * e[n];
+            v8[n] = in8 ? wiener_div(value, value + sig2) : e[n];
+        }
+    }
+    __syncthreads();
+    w3_forward<NS, TH>(__builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, do_dct4, do_sa4, tb);
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    {
+        v2f o[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) o[n] = v2f{fbase[n * A], fbase[n * A + 4]};
+        if (NS > 1) haar_fwd2<NS>(o);
+        if (!use_sadct) {
+            v2f w2 = v2f{0.f, 0.f};
+#pragma unroll
+            for (int n = 0; n < NS; n++) { o[n] = o[n] * vv[n]; w2 += vv[n]; }
+            wacc = w2.x + w2.y;
+        } else {
+            const bool ina = sh.mask_dct[fst], inb = sh.mask_dct[fst + 4];
+#pragma unroll
+            for (int n = 0; n < NS; n++) {
+                o[n].x = ina ? o[n].x * vv[n].x : vv[n].x;
+                o[n].y = inb ? o[n].y * vv[n].y : vv[n].y;
+                wacc += (ina ? vv[n].x : 0.f) + (inb ? vv[n].y : 0.f);
+            }
+        }
+        if (NS > 1) haar_inv2<NS>(o);
+#pragma unroll
+        for (int n = 0; n < NS; n++) { fbase[n * A] = o[n].x; fbase[n * A + 4] = o[n].y; }
+        if (useSD) {
+#pragma unroll
+            for (int n = 0; n < NS; n++) { s1 += o[n].x + o[n].y; s2 += o[n].x * o[n].x + o[n].y * o[n].y; }
+        }
+    }
+    if (own8) {
+        float o[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) o[n] = f8base[n * A];
+        if (NS > 1) haar_fwd<NS>(o);
+        if (!use_sadct || sh.mask_dct[8]) {
+#pragma unroll
+            for (int n = 0; n < NS; n++) { o[n] = o[n] * v8[n]; wacc += v8[n]; }
+        } else {
+#pragma unroll
+            for (int n = 0; n < NS; n++) o[n] = v8[n];
+        }
+        if (NS > 1) haar_inv<NS>(o);
+#pragma unroll
+        for (int n = 0; n < NS; n++) f8base[n * A] = o[n];
+        if (useSD) {
+#pragma unroll
+            for (int n = 0; n < NS; n++) { s1 += o[n]; s2 += o[n] * o[n]; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    if (do_dct4 || do_sa4) {
+        for (int f = tid; f < NS * 32; f += TH) {
+            int n, pq;
+            if (NS > 1) { pq = (f & 15) | ((f >> 1) & 16); n = ((f >> 4) & 1) | ((f >> 5) & ~1); }
+            else { n = 0; pq = f; }
+            float* b0 = S + pq * NPf + n * A;
+            float* b1 = b0 + 32 * NPf;
+            v2f x[9];
+#pragma unroll
+            for (int st = 0; st < 9; st++) x[st] = v2f{b0[st], b1[st]};
+            if (do_dct4) dct9_inv2_fast(x, tb);
+            else {
+                float t9[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) t9[i] = x[i].x;
+                sadct9_inv(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
+                sadct9_inv(t9, sh, tb);
+#pragma unroll
+                for (int i = 0; i < 9; i++) x[i].y = t9[i];
+            }
+#pragma unroll
+            for (int st = 0; st < 9; st++) { b0[st] = x[st].x; b1[st] = x[st].y; }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < TH / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(NS * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) {
+            atomicAdd(&a.counters[0], (unsigned long long)NS);
+            if (use_sadct) atomicAdd(&a.counters[1], 1ull);
+        }
+    }
+    for (int it = tid; it < NPh * 8; it += TH) {
+        const int j = it / NPh, pp = it - j * NPh;
+        float* col = S + j * NPf + 2 * pp;
+        v2f x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = *reinterpret_cast<const v2f*>(col + (i * 8) * NPf);
+        dct8_inv_t(x);
+#pragma unroll
+        for (int i = 0; i < 8; i++) *reinterpret_cast<v2f*>(col + (i * 8) * NPf) = x[i];
+    }
+    __syncthreads();
+    /* rows + store: filt[g][n][st][c][64].  Patches (pa, pa + NPh) packed, row-fastest: the eight lanes with the rows of one
+     * patch write its 256 bytes */
+    for (int it = tid; it < NPh * 8; it += TH) {
+        const int pa = it >> 3, i = it & 7;
+        const bool has_b = pa + NPh < NP;
+        const float* ra = S + (i * 8) * NPf + pa;
+        v2f x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = v2f{ra[j * NPf], ra[j * NPf + (NP > NPh ? NPh : 0)]};
+        dct8_inv_t(x);
+        float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
+        oa[0] = make_float4(x[0].x, x[1].x, x[2].x, x[3].x);
+        oa[1] = make_float4(x[4].x, x[5].x, x[6].x, x[7].x);
+        if (has_b) {
+            float4* ob = oa + (size_t)NPh * a.C * (K2 / 4);
+            ob[0] = make_float4(x[0].y, x[1].y, x[2].y, x[3].y);
+            ob[1] = make_float4(x[4].y, x[5].y, x[6].y, x[7].y);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kDct8w3Threads) void k_group_dct8w3(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[3][kDct8w3Threads / 64];
+    __shared__ unsigned pos[kMaxN * kA3];
+    constexpr int TH = kDct8w3Threads;
+    const int tid = threadIdx.x;
+    const unsigned gi = xcd_group_index(a);
+    if (gi >= a.n_groups) return;
+    const unsigned g = a.ref_begin + gi;
+    const int c = blockIdx.y;
+    const int nSx = (int)a.self_cnt[g];
+    const unsigned plane = a.Wb * a.Hb;
+    for (int i = tid; i < nSx * 9; i += TH) {
+        const unsigned p = a.gpos[(size_t)g * a.N * 9 + i];
+        pos[i] = p != 0xffffffffu ? (((unsigned)(i % 9) * a.C + c) * plane + p) * 4u : kW3Empty;
+    }
+    __syncthreads();
+#ifdef LFBM5D_W3_ONLY16
+    w3_body<16, TH>(a, lds, pos, red, tid, g, c); return;
+#endif
+    switch (nSx) {
+        case 1:  w3_body<1, TH>(a, lds, pos, red, tid, g, c); break;
+        case 2:  w3_body<2, TH>(a, lds, pos, red, tid, g, c); break;
+        case 4:  w3_body<4, TH>(a, lds, pos, red, tid, g, c); break;
+        case 8:  w3_body<8, TH>(a, lds, pos, red, tid, g, c); break;
+        default: w3_body<16, TH>(a, lds, pos, red, tid, g, c); break;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Per-SAI BM3D flavour, 8x8 patches (LFBM3Ddenoising's parameters: bm3d.cpp:315-690 with kHard = kWien = 8).
  * A group is nSx <= 32 patches of ONE image, so a whole group fits a WAVEFRONT: four groups per workgroup, no
  * workgroup barrier anywhere.  Lane = patch for the 2-D stages (the 8x8 patch and its transform in registers, the
@@ -3077,6 +3443,9 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         const size_t l8 = (size_t)(a.step == 2 ? 2 : 1) * 64 * ((a.N * 9) | 1) * sizeof(float);
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR") && !getenv("LFBM5D_DCT8W_V1")) {   /* packed noisy/pilot pair, 2-D stages dealt to all threads */
             const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
+#ifndef LFBM5D_NO_DCT8W3
+            if (a.tau5 == 9 && (size_t)9 * a.C * a.Wb * a.Hb * 4 < 0x70000000ull) hipLaunchKernelGGL(k_group_dct8w3, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a); else
+#endif
             if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w2<true>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);
             else             hipLaunchKernelGGL((k_group_dct8w2<false>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);
             return hipGetLastError();
