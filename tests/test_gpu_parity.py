@@ -97,6 +97,10 @@ def test_core_pass_matches_oracle(ctx, case):
 def _check_pass(ctx, case, strict):
     name, step, sigma, pk, crop, useSD = case
     win, Wb, Hb, Cc = window(sigma, pk, crop)
+    _check_window(ctx, name, step, sigma, pk, useSD, win, Wb, Hb, Cc, strict)
+
+
+def _check_window(ctx, name, step, sigma, pk, useSD, win, Wb, Hb, Cc, strict):
     basic = None
     if step == 2:  # a plausible pilot: the oracle's own HT estimate of this window
         n1, d1, _ = Hh.oracle_pass(1, sigma, (pk[0] // 2 or 1,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, Cc)
@@ -964,6 +968,25 @@ def test_bm3d_lf_with_different_search_windows_matches_oracle(ctx, nHard, nWien)
     assert np.abs(h_basic - b_o).max() < 5e-3
     assert np.abs(h_den - d_o).max() < 2e-2 and abs(O.psnr_lf(h_den, clean) - O.psnr_lf(d_o, clean)) < 0.01
     assert O.psnr_lf(h_den, clean) < O.psnr_lf(h_basic, clean)      # the reference's shifted crop: worse than its own first step
+
+
+# ------------------------------------------------------------------------------------------------
+# the headline's window pass at its own size against the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("step,pk", [(1, (8, 18, 6, 16, 4, "id", "sadct", "haar")), (2, (16, 18, 6, 8, 4, "dct", "sadct", "haar"))],
+                         ids=["ht", "wiener"])
+def test_headline_window_pass_matches_oracle_at_full_size(ctx, step, pk):
+    """One 3x3x512x512 centre-window pass of the benchmark's synthetic light field (560^2 padded, 15 625 / 16 129 groups)
+    against the oracle's pass on the same window (OpenMP over reference patches: some tens of seconds of CPU): the
+    block-matching tables identical, survivor counts group by group, `den` and the estimate as in the random sweep.
+    This is the size the dedicated kernels (table scan with eleven waves per workgroup, register-resident HT kernel,
+    one-image-at-a-time Wiener kernel, gather aggregation) are tuned at."""
+    from lfbm5d_amd import synth
+    H = W = 512
+    lf = synth.make_lf(3, 3, H, W).reshape(9, 3, H, W).astype(np.float32)
+    noisy = lf + 25.0 * np.random.default_rng(1).standard_normal(lf.shape).astype(np.float32)
+    win, Wb, Hb = Hh.padded_window(np.ascontiguousarray(noisy.reshape(9, -1)), W, H, 3, pk[1] + pk[2])
+    _check_window(ctx, "headline-" + ("ht" if step == 1 else "wiener"), step, 25.0, pk, 0, win, Wb, Hb, 3, strict=False)
 
 
 # ------------------------------------------------------------------------------------------------

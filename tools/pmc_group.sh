@@ -15,7 +15,7 @@ for f in glob.glob("gpurun_out/pmcg/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n=r["Kernel_Name"]
         key=None
-        for k in ("k_group_dct8w3","k_group_dct8w2","k_group_id","k_aggregate<false","k_aggregate<true"):
+        for k in ("k_group_dct8w3","k_group_dct8w2","k_group_id","k_aggregate2<false","k_aggregate2<true","k_aggregate<false","k_aggregate<true"):
             if k in n: key=k
         if key:
             acc[key][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[key][p].add(r["Dispatch_Id"])
