@@ -619,12 +619,27 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
         if (lane == 0) { out[0] = k_r; out[1] = k_r; self_cnt[ref] = 2; }
         return;
     }
+    /* minimum of a 64-bit key over the wavefront by DPP row shifts / row broadcasts (a `__shfl_xor` butterfly is six dependent
+     * pairs of ds_bpermute: with 2 nSx of these reductions per reference patch that was half the kernel) */
     auto wave_min = [](unsigned long long v) {
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long oth = __shfl_xor(v, o);
+        auto step = [&](auto ctrl, auto rmask, auto bmask, unsigned long long src) {
+            constexpr int C = decltype(ctrl)::value, R = decltype(rmask)::value, B = decltype(bmask)::value;
+            const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)src, C, R, B, false);
+            const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(src >> 32), C, R, B, false);
+            const unsigned long long oth = ((unsigned long long)hi << 32) | lo;   /* lanes the pattern does not write keep their own key */
             v = oth < v ? oth : v;
-        }
-        return v;
+        };
+        using std::integral_constant;
+        const unsigned long long v0 = v;
+        step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}, v0);   /* row_shr:1 */
+        step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}, v0);   /* row_shr:2 */
+        step(integral_constant<int, 0x113>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xf>{}, v0);   /* row_shr:3 */
+        step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xe>{}, v);    /* row_shr:4 */
+        step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{}, integral_constant<int, 0xc>{}, v);    /* row_shr:8 */
+        step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}, integral_constant<int, 0xf>{}, v);    /* row_bcast:15 */
+        step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}, integral_constant<int, 0xf>{}, v);    /* row_bcast:31 */
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+        return ((unsigned long long)hi << 32) | lo;
     };
     if (cnt > 128) {
         /* Prune before selecting: the nSx-th smallest of the 64 per-lane minima bounds the nSx-th smallest key overall
