@@ -3173,6 +3173,8 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     const bool mul_div = !a.irregular && (long long)n_rr * ncols_span < (1 << 20);
     const unsigned div_m = ((1u << 20) + (unsigned)max(ncols_span, 1) - 1) / (unsigned)max(ncols_span, 1);
     const unsigned g_end = a.ref_begin + a.n_groups;
+    /* every patch index (g N + n) A + st below 2^24: full-rate 24-bit multiplies for the per-candidate index arithmetic */
+    const bool small24 = (((unsigned long long)a.n_refs_total << logN) + 1) * A < (1ull << 24);
     const unsigned* apos = a.aggpos + (size_t)st * a.n_refs_total * N;
     /* channel stride inside a filtered patch, bytes; greyscale: all three loads read channel 0 (its weights are 0) */
     const unsigned cstride = C > 1 ? (unsigned)k2 * 4u : 0u;
@@ -3194,7 +3196,7 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
                 const bool on = (unsigned)dy < (unsigned)k && (unsigned)dx < (unsigned)k;
                 /* pixels the patch does not cover read the nearest pixel it does cover -- a pixel of this tile,
                  * so no extra cache line is touched ... */
-                const unsigned o = (unsigned)(min(max(dy, 0), k - 1) * k + min(max(dx, 0), k - 1));
+                const unsigned o = __umul24((unsigned)min(max(dy, 0), k - 1), (unsigned)k) + (unsigned)min(max(dx, 0), k - 1);   /* v_mad_u32_u24: a 32-bit multiply is quarter rate */
                 const float kz = WINDOWED ? kai[o] : 1.0f;
                 if (BIG) {
                     const char* fp = reinterpret_cast<const char*>(a.filt) + ((size_t)ha.y + o) * 4;
@@ -3236,20 +3238,31 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
                 nn[u] = n;
                 if (a.irregular) g[u] = rr;   /* the list is in raster order too (row lists, then columns) */
                 else {
-                    const unsigned q = mul_div ? (rr * div_m) >> 20 : rr / (unsigned)ncols_span;
-                    g[u] = ((unsigned)r_lo + q) * a.n_ref_cols + (unsigned)c_lo + (rr - q * (unsigned)ncols_span);
+                    /* 24-bit multiplies (full rate): rr, q < 2^20 and div_m <= 2^20 under mul_div; grid rows / columns < 2^16 */
+                    unsigned q = __umul24(rr, div_m) >> 20;
+                    if (!mul_div) { asm volatile("" ::: "memory"); q = rr / (unsigned)ncols_span; }   /* kept a branch: the division's 32-bit multiplies are quarter rate */
+                    g[u] = __umul24((unsigned)r_lo + q, a.n_ref_cols) + (unsigned)c_lo + (rr - __umul24(q, (unsigned)ncols_span));
                 }
                 if (g[u] >= a.ref_begin && g[u] < g_end) p[u] = apos[((size_t)g[u] << logN) + n];
             }
         }
         bool hit[kAggPF];
         float w[kAggPF][3];
+        size_t wbase[kAggPF];
+        if (small24) {
+#pragma unroll
+            for (int u = 0; u < kAggPF; u++) wbase[u] = __umul24(g[u], (unsigned)C);
+        } else {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < kAggPF; u++) wbase[u] = (size_t)g[u] * C;
+        }
 #pragma unroll
         for (int u = 0; u < kAggPF; u++) {
             const int py = (int)(p[u] >> 16), px = (int)(p[u] & 0xffffu);
             hit[u] = p[u] != 0xffffffffu && py < ty0 + TH && py + k > ty0 && px < tx0 + TW && px + k > tx0;
 #pragma unroll
-            for (int c = 0; c < 3; c++) w[u][c] = (hit[u] && c < C) ? a.wgt[(size_t)g[u] * C + (a.wchan0 ? 0 : c)] : 0.0f;
+            for (int c = 0; c < 3; c++) w[u][c] = (hit[u] && c < C) ? a.wgt[wbase[u] + (a.wchan0 ? 0 : c)] : 0.0f;
         }
         /* ordered append of the hits of these chunks */
 #pragma unroll
@@ -3257,7 +3270,10 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
             const unsigned long long bal = __ballot(hit[u]);
             if (hit[u]) {
                 const unsigned slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
-                hit_a[slot] = make_uint4(p[u], (((g[u] << logN) + nn[u]) * A + st) * C * k2, __float_as_uint(w[u][0]), __float_as_uint(w[u][1]));
+                unsigned off;
+                if (small24) off = __umul24(__umul24((g[u] << logN) + nn[u], (unsigned)A) + (unsigned)st, (unsigned)(C * k2));
+                else { asm volatile("" ::: "memory"); off = (((g[u] << logN) + nn[u]) * A + st) * C * k2; }
+                hit_a[slot] = make_uint4(p[u], off, __float_as_uint(w[u][0]), __float_as_uint(w[u][1]));
                 hit_w2[slot] = w[u][2];
             }
             nh += __popcll(bal);
