@@ -3460,7 +3460,8 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         if (a.step == 2 && !getenv("LFBM5D_DCT8_SCALAR") && !getenv("LFBM5D_DCT8W_V1")) {   /* packed noisy/pilot pair, 2-D stages dealt to all threads */
             const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
 #ifndef LFBM5D_NO_DCT8W3
-            if (a.tau5 == 9 && (size_t)9 * a.C * a.Wb * a.Hb * 4 < 0x70000000ull) hipLaunchKernelGGL(k_group_dct8w3, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a); else
+            /* LFBM5D_DCT8W_V2: test hook, round 2's two-image kernel (the path of windows of 1.9 GB and more) */
+            if (a.tau5 == 9 && (size_t)9 * a.C * a.Wb * a.Hb * 4 < 0x70000000ull && !getenv("LFBM5D_DCT8W_V2")) hipLaunchKernelGGL(k_group_dct8w3, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a); else
 #endif
             if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w2<true>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);
             else             hipLaunchKernelGGL((k_group_dct8w2<false>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);

@@ -1003,6 +1003,41 @@ DEDICATED = [
 ]
 
 
+def test_wiener_kernel_generations_agree_at_full_window_size(ctx, monkeypatch):
+    """k_group_dct8w3 (one image in LDS at a time, factorised 3x3 DCT) against round 2's k_group_dct8w2 (LFBM5D_DCT8W_V2: still
+    the kernel of very large windows and of the Hadamard / DCT fibres) on one 3x3x512x512 Wiener pass: same matching, same
+    aggregation; no threshold in this step, so the estimates differ by round-off only."""
+    from lfbm5d_amd import core, synth
+    pk = (16, 18, 6, 8, 4, "dct", "sadct", "haar")
+    H = W = 512
+    lf = synth.make_lf(3, 3, H, W).reshape(9, 3, H, W).astype(np.float32)
+    lf += 25.0 * np.random.default_rng(1).standard_normal(lf.shape).astype(np.float32)
+    nHW = pk[1] + pk[2]
+    pad = np.pad(lf, ((0, 0), (0, 0), (nHW, nHW), (nHW, nHW)), mode="symmetric")
+    Hb, Wb = pad.shape[2:]
+    noisy = torch.from_numpy(np.ascontiguousarray(pad).reshape(9, -1)).cuda()
+    basic = 0.5 * noisy + 0.5 * torch.roll(noisy, 1, 1)
+    P = core.make_params(25.0, 2.7, *pk)
+    mask, proc = np.ones(9, np.uint32), np.zeros(9, np.uint32)
+    res = []
+    for old in (False, True):
+        if old:
+            monkeypatch.setenv("LFBM5D_DCT8W_V2", "1")
+        else:
+            monkeypatch.delenv("LFBM5D_DCT8W_V2", raising=False)
+        num = torch.zeros_like(noisy); den = torch.zeros_like(noisy)
+        ctx.reset_stats()
+        ctx.core_pass(2, P, 3, 3, Wb, Hb, 3, noisy, basic, num, den, mask, proc, 4, 4)
+        res.append((num.cpu().numpy(), den.cpu().numpy(), ctx.stats().ms_group))
+    (n3, d3, ms3), (n2, d2, ms2) = res
+    assert ms3 < ms2
+    assert np.array_equal(d3 > 0, d2 > 0)
+    both = d3 > 0
+    np.testing.assert_allclose(d3[both], d2[both], rtol=2e-5)
+    diff = np.abs(n3[both] / d3[both] - n2[both] / d2[both])
+    assert diff.max() < 2e-3 and diff.mean() < 2e-5
+
+
 @pytest.mark.parametrize("case", DEDICATED, ids=[c[0] for c in DEDICATED])
 def test_dedicated_kernels_agree_with_the_generic_kernel_at_full_window_size(ctx, case, monkeypatch):
     """One 3x3x512x512 centre-window pass (560^2 padded, 15 625 / 16 129 groups -- far beyond what the oracle finishes
