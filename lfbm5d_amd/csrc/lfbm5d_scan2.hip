@@ -283,11 +283,11 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
     float* edge = COMB ? a.tables + (size_t)n_slots * a.nwg_slot * pstride * 2 + (size_t)(g.slot * ncand + tb) * estride : nullptr;
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (COMB && !(LFBM5D_S2_EXP & 1)) ? (int)(pstride * 8) : 0, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rEd = __builtin_amdgcn_make_buffer_rsrc((void*)edge, 0, (COMB && live) ? (int)(estride * 4) : 0, kRsrcFlags);
-    /* COMB: the live tables of the workgroup (packed from wave 0) and their scan order dj * Ns + di */
-    int nlive = 0, ordw[NW];
+    /* COMB: the scan order dj * Ns + di of the workgroup's tables (packed from wave 0) */
+    int ordw[NW];
     if (COMB) {
 #pragma unroll
-        for (int q = 0; q < NW; q++) { const int tq = g.tab[q]; nlive += tq >= 0 ? 1 : 0; ordw[q] = tq >= 0 ? (tq % Ns) * Ns + tq / Ns : 0; }
+        for (int q = 0; q < NW; q++) { const int tq = g.tab[q]; ordw[q] = tq >= 0 ? (tq % Ns) * Ns + tq / Ns : 0; }
     }
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (!STEREO && live) ? (int)a.scores_bytes : 0, kRsrcFlags);
     const int SRq = (int)stereo_table_srq(a.H, a.k, a.nDisp);
@@ -484,16 +484,19 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
         const bool rok = lane < kShare && rp < 512;
         auto reduce_chunk = [&](const int cprev) {
             const float* src = xch + (cprev & 1) * NW * 512 + (rok ? rp : 0);
-            float best = src[0];
+            /* all NW rows at once (waves without a table of their own hand over +inf, which never wins the strict comparison, so
+             * their rows need no test -- a test per row is a branch, a wait and an exec-masked move each, right after the
+             * barrier where every wave of the CU does the same) */
+            float v[NW];
+#pragma unroll
+            for (int q = 0; q < NW; q++) v[q] = src[q * 512];
+            float best = v[0];
             int bo = ordw[0];
 #pragma unroll
             for (int q = 1; q < NW; q++) {
-                if (q < nlive) {
-                    const float v = src[q * 512];
-                    const bool lt = v < best;
-                    best = lt ? v : best;
-                    bo = lt ? ordw[q] : bo;
-                }
+                const bool lt = v[q] < best;
+                best = lt ? v[q] : best;
+                bo = lt ? ordw[q] : bo;
             }
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i pr = {__float_as_int(best), bo};
@@ -559,7 +562,8 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
                         left_prev = left;
                     }
                     if (STEREO && COMB) {
-                        *reinterpret_cast<v4f*>(xch + (ch * NW + w) * 512 + lane * 8 + 4 * gq) = out;
+                        /* a wave without a table of its own (it walks the first table again, without its hand-off column) hands +inf to the reduction */
+                        *reinterpret_cast<v4f*>(xch + (ch * NW + w) * 512 + lane * 8 + 4 * gq) = live ? out : v4f{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
                     } else if (STEREO) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, out), rT, voffT, 0, 0);
                         voffT += 1024;
