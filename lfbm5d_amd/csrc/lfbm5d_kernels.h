@@ -147,6 +147,7 @@ struct Scan2Wg {
     short rh, ch;               /* ... and how many more rows / columns the largest needs */
     short wgj;                  /* disparity search: index of the workgroup among those of its slot */
     short pad[2];
+    short ord[16];              /* disparity search: the reference's scan order dj * Ns + di of each table (ties, and the arg-min's displacement) */
 };
 
 struct ScanArgs {

@@ -283,12 +283,8 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
     float* edge = COMB ? a.tables + (size_t)n_slots * a.nwg_slot * pstride * 2 + (size_t)(g.slot * ncand + tb) * estride : nullptr;
     const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (COMB && !(LFBM5D_S2_EXP & 1)) ? (int)(pstride * 8) : 0, kRsrcFlags);
     const __amdgpu_buffer_rsrc_t rEd = __builtin_amdgcn_make_buffer_rsrc((void*)edge, 0, (COMB && live) ? (int)(estride * 4) : 0, kRsrcFlags);
-    /* COMB: the scan order dj * Ns + di of the workgroup's tables (packed from wave 0) */
-    int ordw[NW];
-    if (COMB) {
-#pragma unroll
-        for (int q = 0; q < NW; q++) { const int tq = g.tab[q]; ordw[q] = tq >= 0 ? (tq % Ns) * Ns + tq / Ns : 0; }
-    }
+    /* COMB: the scan order dj * Ns + di of the workgroup's tables (packed from wave 0) comes with the descriptor: scalar loads
+     * (an array computed here ends up in scratch, indexed by a chain of selects) */
     const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc((void*)a.scores, 0, (!STEREO && live) ? (int)a.scores_bytes : 0, kRsrcFlags);
     const int SRq = (int)stereo_table_srq(a.H, a.k, a.nDisp);
     const int nstrips = (ncols - 1 + 63) / 64;      /* strips of 64 columns, starting at column 1 of the table */
@@ -491,12 +487,12 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
 #pragma unroll
             for (int q = 0; q < NW; q++) v[q] = src[q * 512];
             float best = v[0];
-            int bo = ordw[0];
+            int bo = g.ord[0];
 #pragma unroll
             for (int q = 1; q < NW; q++) {
                 const bool lt = v[q] < best;
                 best = lt ? v[q] : best;
-                bo = lt ? ordw[q] : bo;
+                bo = lt ? (int)g.ord[q] : bo;
             }
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i pr = {__float_as_int(best), bo};
@@ -766,6 +762,7 @@ bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes,
             Scan2Wg g;
             std::memset(&g, 0, sizeof(g));
             for (int w = 0; w < 16; w++) g.tab[w] = (w < kS2NW && i + w < tabs.size()) ? (short)tabs[i + w] : (short)-1;
+            if (slot >= 0) { const int Ns = 2 * (int)a.nDisp + 1; for (int w = 0; w < 16; w++) g.ord[w] = g.tab[w] >= 0 ? (short)((g.tab[w] % Ns) * Ns + g.tab[w] / Ns) : (short)0; }
             g.slot = (short)slot; g.r2lo = (short)r2lo; g.c2lo = (short)c2lo; g.rh = (short)rh; g.ch = (short)ch; g.wgj = (short)wgj++;
             wgs.push_back(g);
         }
