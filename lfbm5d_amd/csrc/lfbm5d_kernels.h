@@ -60,6 +60,8 @@ struct GroupArgs {
     float* wgt;                 /* [R][C] aggregation weights */
     unsigned* aggpos;           /* [A][R][N] where each filtered patch is aggregated (0xffffffff: nowhere) */
     unsigned* gpos;             /* [R][N][A] window position of every patch of every group (pre-pass output) */
+    unsigned* gofs;             /* [R][N][A] the same as a byte offset into channel 0 of the patch's SAI (0 for an absent patch), and ...        */
+    unsigned* gok;              /* [R][N] ... bit st set where patch (n, st) is there: what the register-resident HT kernel's scalar loads need */
     void* gshape;               /* [R] kShapeInfoBytes each: SADCT bookkeeping of the group (pre-pass output) */
     unsigned n_refs_total;
     unsigned long long* counters; /* [0] sum nSx, [1] sadct groups */

@@ -1038,15 +1038,26 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
     const int nSx = (int)a.self_cnt[g];
     const unsigned k_r = a.refs[g];
     const bool masked = (a.mask_bits >> st) & 1;
-    unsigned p = 0xffffffffu;
-    if (n < nSx && masked) {
+    auto position = [&](int s_) {   /* window position of patch (n, s_); 0xffffffff: none */
+        if (!(n < nSx && ((a.mask_bits >> s_) & 1))) return 0xffffffffu;
         const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
-        p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
-    }
+        return (s_ == (int)a.pst) ? ind_pst : a.best[(size_t)s_ * plane + ind_pst];
+    };
     /* gather position: patches whose column equals Wb-k read the reference's never-filled table
      * column, i.e. zeros (core:1697, bm3d.cpp:737) on the centre path -- they are still aggregated */
-    const bool zero_patch = a.fill_quirk && p != 0xffffffffu && (p % a.Wb) >= a.Wb - a.k;
+    auto zero_quirk = [&](unsigned q) { return a.fill_quirk && q != 0xffffffffu && (q % a.Wb) >= a.Wb - a.k; };
+    const unsigned p = position(st);
+    const bool zero_patch = zero_quirk(p);
     a.gpos[(size_t)g * NA + i] = zero_patch ? 0xffffffffu : p;
+    if (A == 9) {   /* 3x3 windows: byte offsets and presence bits for the scalar loads of the register-resident HT kernel */
+        const bool there = !zero_patch && p != 0xffffffffu;
+        a.gofs[(size_t)g * NA + i] = there ? (unsigned)(((size_t)st * a.C * plane + p) * 4) : 0u;
+        if (st == 0) {
+            unsigned bits = 0;
+            for (int s_ = 0; s_ < 9; s_++) { const unsigned q = position(s_); if (q != 0xffffffffu && !zero_quirk(q)) bits |= 1u << s_; }
+            a.gok[(size_t)g * N + n] = bits;
+        }
+    }
     const bool in_shape = st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r]);
     /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
      * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
@@ -1305,6 +1316,9 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
     const int voff = (int)(((unsigned)(pq / k) * a.Wb + pq % k) * 4u);
     const int woff = (pq / k) * (k + 1) + pq % k;      /* this pixel inside a work-area patch */
     unsigned okbits[NS];
+    typedef const __attribute__((address_space(4))) unsigned* cuptr_;
+    const cuptr_ ofs = (cuptr_)(a.gofs + (size_t)g * a.N * A), ok = (cuptr_)(a.gok + (size_t)g * a.N);
+    const unsigned cbase = (unsigned)c * plane * 4u;
     if (LDSW) {
 #pragma unroll
         for (int n = 0; n < NS; n++)
@@ -1317,13 +1331,10 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
     } else
 #pragma unroll
     for (int n = 0; n < NS; n++) {
-        okbits[n] = 0;
+        okbits[n] = ok[n];                            /* uniform: scalar loads (pre-pass: k_group_pos) */
 #pragma unroll
         for (int st = 0; st < 9; st++) {
-            const unsigned p = pos[n * A + st];       /* uniform: scalar load */
-            const bool ok = p != 0xffffffffu;
-            okbits[n] |= ok ? 1u << st : 0u;
-            const unsigned so = (((unsigned)st * a.C + c) * plane + (ok ? p : 0u)) * 4u;
+            const unsigned so = ofs[n * A + st] + cbase;   /* absent patches read offset 0 and are zeroed below */
             const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
             if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
         }
