@@ -1076,11 +1076,14 @@ __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     if (a.tau4 != 6) { out->use_sadct = 0; return; }
     ShapeInfo sh;
     const int A = (int)a.A, aw = A == 9 ? 3 : A == 25 ? 5 : 7;
-    int m[kMaxA];
+    int m[kMaxA], full = 0;
     for (int st = 0; st < A; st++) {
         const bool masked = (a.mask_bits >> st) & 1;
         m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
+        full += m[st];
     }
+    /* the usual case, every SAI in the shape: the plain angular DCT, and the group kernels read nothing but the flag */
+    if (full == A) { out->use_sadct = 0; return; }
     build_shape(sh, m, aw);
     for (int q = 0; q < A; q++) {
         out->mask[q] = sh.mask[q]; out->idx[q] = sh.idx[q]; out->mask_col[q] = sh.mask_col[q];
