@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
     const unsigned p = position(st);
     const bool zero_patch = zero_quirk(p);
     a.gpos[(size_t)g * NA + i] = zero_patch ? 0xffffffffu : p;
-    if (A == 9) {   /* 3x3 windows: byte offsets and presence bits for the scalar loads of the register-resident HT kernel */
+    if (A == 9 && a.tau2 == 4 && a.step == 1) {   /* byte offsets and presence bits for the scalar loads of the register-resident HT kernel (launch_group) */
         const bool there = !zero_patch && p != 0xffffffffu;
         a.gofs[(size_t)g * NA + i] = there ? (unsigned)(((size_t)st * a.C * plane + p) * 4) : 0u;
         if (st == 0) {
