@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
     const unsigned p = position(st);
     const bool zero_patch = zero_quirk(p);
     a.gpos[(size_t)g * NA + i] = zero_patch ? 0xffffffffu : p;
-    if (A == 9 && a.tau2 == 4 && a.step == 1) {   /* byte offsets and presence bits for the scalar loads of the register-resident HT kernel (launch_group) */
+    if (A == 9 && a.tau2 == 4 && a.step == 1 && (size_t)A * a.C * plane * 4 < 0x7fffffffull) {   /* byte offsets and presence bits for the scalar loads of the register-resident HT kernel (launch_group) */
         const bool there = !zero_patch && p != 0xffffffffu;
         a.gofs[(size_t)g * NA + i] = there ? (unsigned)(((size_t)st * a.C * plane + p) * 4) : 0u;
         if (st == 0) {
@@ -3437,7 +3437,7 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     const bool generic_only = getenv("LFBM5D_GROUP_GENERIC") != nullptr;
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
     if (generic_only) {}
-    else if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9) {
+    else if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull) {   /* 32-bit byte offsets into the window */
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
         const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
         if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(gx, a.C), dim3(threads), 0, s, a);
