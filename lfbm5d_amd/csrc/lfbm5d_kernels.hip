@@ -1029,40 +1029,40 @@ __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr 
  * self_idx -> best -> patch dependent-load chain out of every group workgroup.
  * ------------------------------------------------------------------------------------------ */
 __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
+    /* one thread per (group, match): the A disparity look-ups of a match are independent loads */
     const int A = a.A, N = a.N, NA = N * A;
     const size_t plane = (size_t)a.Wb * a.Hb;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)a.n_groups * NA) return;
-    const unsigned g = a.ref_begin + (unsigned)(idx / NA);
-    const int i = (int)(idx % NA), n = i / A, st = i % A;
+    if (idx >= (size_t)a.n_groups * N) return;
+    const unsigned g = a.ref_begin + (unsigned)(idx / N);
+    const int n = (int)(idx % N);
     const int nSx = (int)a.self_cnt[g];
     const unsigned k_r = a.refs[g];
-    const bool masked = (a.mask_bits >> st) & 1;
-    auto position = [&](int s_) {   /* window position of patch (n, s_); 0xffffffff: none */
-        if (!(n < nSx && ((a.mask_bits >> s_) & 1))) return 0xffffffffu;
-        const unsigned ind_pst = a.self_idx[(size_t)g * N + n];
-        return (s_ == (int)a.pst) ? ind_pst : a.best[(size_t)s_ * plane + ind_pst];
-    };
-    /* gather position: patches whose column equals Wb-k read the reference's never-filled table
-     * column, i.e. zeros (core:1697, bm3d.cpp:737) on the centre path -- they are still aggregated */
-    auto zero_quirk = [&](unsigned q) { return a.fill_quirk && q != 0xffffffffu && (q % a.Wb) >= a.Wb - a.k; };
-    const unsigned p = position(st);
-    const bool zero_patch = zero_quirk(p);
-    a.gpos[(size_t)g * NA + i] = zero_patch ? 0xffffffffu : p;
-    if (A == 9 && a.tau2 == 4 && a.step == 1 && (size_t)A * a.C * plane * 4 < 0x7fffffffull) {   /* byte offsets and presence bits for the scalar loads of the register-resident HT kernel (launch_group) */
-        const bool there = !zero_patch && p != 0xffffffffu;
-        a.gofs[(size_t)g * NA + i] = there ? (unsigned)(((size_t)st * a.C * plane + p) * 4) : 0u;
-        if (st == 0) {
-            unsigned bits = 0;
-            for (int s_ = 0; s_ < 9; s_++) { const unsigned q = position(s_); if (q != 0xffffffffu && !zero_quirk(q)) bits |= 1u << s_; }
-            a.gok[(size_t)g * N + n] = bits;
+    const unsigned ind_pst = n < nSx ? a.self_idx[(size_t)g * N + n] : 0u;
+    /* byte offsets and presence bits for the scalar loads of the register-resident HT kernel (launch_group) */
+    const bool want_ofs = A == 9 && a.tau2 == 4 && a.step == 1 && (size_t)A * a.C * plane * 4 < 0x7fffffffull;
+    unsigned bits = 0;
+    for (int st = 0; st < A; st++) {
+        const bool masked = (a.mask_bits >> st) & 1;
+        unsigned p = 0xffffffffu;
+        if (n < nSx && masked) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
+        /* gather position: patches whose column equals Wb-k read the reference's never-filled table
+         * column, i.e. zeros (core:1697, bm3d.cpp:737) on the centre path -- they are still aggregated */
+        const bool zero_patch = a.fill_quirk && p != 0xffffffffu && (p % a.Wb) >= a.Wb - a.k;
+        const int i = n * A + st;
+        a.gpos[(size_t)g * NA + i] = zero_patch ? 0xffffffffu : p;
+        if (want_ofs) {
+            const bool there = !zero_patch && p != 0xffffffffu;
+            a.gofs[(size_t)g * NA + i] = there ? (unsigned)(((size_t)st * a.C * plane + p) * 4) : 0u;
+            bits |= there ? 1u << st : 0u;
         }
+        const bool in_shape = st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r]);
+        /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
+         * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
+        /* stored as (row << 16) | column: the aggregation kernel tests each position against many tiles */
+        a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = ((a.tau4 != 6 || in_shape) && p != 0xffffffffu) ? ((p / a.Wb) << 16) | (p % a.Wb) : 0xffffffffu;
     }
-    const bool in_shape = st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r]);
-    /* positions the aggregation kernel will add this group's patches at; 0xffffffff = none
-     * (match slot unused, empty SAI, or SAI outside the SADCT shape, core:503) */
-    /* stored as (row << 16) | column: the aggregation kernel tests each position against many tiles */
-    a.aggpos[((size_t)st * a.n_refs_total + g) * N + n] = ((a.tau4 != 6 || in_shape) && p != 0xffffffffu) ? ((p / a.Wb) << 16) | (p % a.Wb) : 0xffffffffu;
+    if (want_ofs) a.gok[(size_t)g * N + n] = bits;
 }
 __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3431,7 +3431,7 @@ size_t group_scratch_bytes(const GroupArgs& a) {
 }
 hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* geometry pre-pass: patch positions, aggregation positions, angular shapes */
-    hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N * a.A), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_group_shape, grid1d(a.n_groups), dim3(256), 0, s, a);
     /* LFBM5D_GROUP_GENERIC: test hook, every configuration through the generic LDS kernel (the dedicated kernels' cross-check) */
     const bool generic_only = getenv("LFBM5D_GROUP_GENERIC") != nullptr;
