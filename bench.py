@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 3)")
     ap.add_argument("--noise", default="mt19937", choices=["mt19937", "torch"],
                     help="mt19937: the reference's noise stream, seed 1 (default); torch: quick GPU noise for kernel iteration")
-    ap.add_argument("--watchdog-s", type=int, default=1500,
+    ap.add_argument("--watchdog-s", type=int, default=600,
                     help="several GPUs: print an error line and exit if the run has not finished after this many seconds "
                          "(the RCCL exchange of the window graph has never run between real ranks: a hang should not be silent)")
     ap.add_argument("--sharding", default="graph", choices=["graph", "rows", "blocks"],
