@@ -585,6 +585,7 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
     /* keys of the candidates that pass the threshold, compacted in scan order (ballot prefix): the selection
      * rounds below then only walk those */
     int cnt = 0;
+    unsigned long long mine = ~0ull;   /* smallest key this lane has appended (any split of the keys into 64 sets serves the pruning bound) */
     constexpr int kB = 8;    /* 64-candidate chunks whose score loads are in flight together */
     for (int e0 = 0; e0 < ncand; e0 += 64 * kB) {
         float score[kB], test[kB];
@@ -607,7 +608,11 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
             const int e = e0 + u * 64 + lane;
             const bool pass = e < ncand && test[u] < thr;
             const unsigned long long bal = __ballot(pass);
-            if (pass) keys[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned long long)f2ord(score[u]) << 32) | (unsigned)e;
+            if (pass) {
+                const unsigned long long kk = ((unsigned long long)f2ord(score[u]) << 32) | (unsigned)e;
+                keys[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = kk;
+                mine = kk < mine ? kk : mine;
+            }
             cnt += __popcll(bal);
         }
     }
@@ -641,18 +646,30 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
         const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
         return ((unsigned long long)hi << 32) | lo;
     };
+    /* number of lanes whose key is smaller than this lane's (equal keys -- only the sentinels -- by lane number): 64
+     * broadcast-compare steps, no dependent chain (nSx rounds of a wave minimum are nSx x 7 dependent DPP steps) */
+    auto wave_rank = [&](unsigned long long v) {
+        unsigned r = 0;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), j) << 32)
+                                       | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, j);
+            r += (o < v || (o == v && j < lane)) ? 1u : 0u;
+        }
+        return r;
+    };
     if (cnt > 128) {
         /* Prune before selecting: the nSx-th smallest of the 64 per-lane minima bounds the nSx-th smallest key overall
          * (there are nSx distinct keys at or below it), so only keys up to that bound can be selected.  They are
          * compacted in place -- the write index never passes the read index, and a wavefront's reads of a round
          * precede its writes -- and the selection rounds below walk a list of typically a few dozen keys. */
-        unsigned long long mine = ~0ull;
-        for (int e = lane; e < cnt; e += 64) { const unsigned long long kk = keys[e]; mine = kk < mine ? kk : mine; }
-        unsigned long long bound = 0, m = mine;
-        for (unsigned n = 0; n < nSx; n++) {
-            bound = wave_min(m);
-            if (m == bound) m = ~0ull;          /* keys are unique: exactly one lane drops its minimum */
-        }
+        /* the lane whose minimum has nSx - 1 smaller ones holds the bound (fewer than nSx lanes with a key: the bound is the
+         * sentinel and nothing is pruned) */
+        const unsigned rk = wave_rank(mine);
+        const unsigned long long hb = __ballot(rk == nSx - 1);
+        const int src = __ffsll((long long)hb) - 1;
+        const unsigned long long bound = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), src) << 32)
+                                       | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)mine, src);
         int c2 = 0;
         for (int e0 = 0; e0 < cnt; e0 += 64) {
             const int e = e0 + lane;
@@ -664,6 +681,20 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
         }
         cnt = c2;
         __builtin_amdgcn_wave_barrier();
+    }
+    if (cnt <= 64) {
+        /* one key per lane: its rank is its place in the selection (core:3437-3441: partial_sort by distance, ties in scan order) */
+        const unsigned long long kk = lane < cnt ? keys[lane] : ~0ull;
+        const unsigned rk = wave_rank(kk);
+        if (lane < cnt && rk < nSx) {
+            const int e = (int)(kk & 0xffffffffu);
+            const int djp = e / Ns - nSim, r = e % Ns;
+            const int dip = (r <= nSim) ? r : r - 2 * nSim - 1;
+            out[rk] = (unsigned)(k_r + dip * W + djp);
+            if (nSx == 1) out[1] = out[0]; /* duplicate rule core:3443-3444 */
+        }
+        if (lane == 0) self_cnt[ref] = nSx == 1 ? 2 : nSx;
+        return;
     }
     unsigned long long last = 0;
     bool first = true;
