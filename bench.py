@@ -221,6 +221,10 @@ def main():
     ap.add_argument("--watchdog-s", type=int, default=600,
                     help="several GPUs: print an error line and exit if the run has not finished after this many seconds "
                          "(the RCCL exchange of the window graph has never run between real ranks: a hang should not be silent)")
+    ap.add_argument("--job", default="auto", choices=["auto", "fused", "two-calls"],
+                    help="fused: run_bm5d_1st_step + run_bm5d_2nd_step as ONE dependency graph of windows (lfbm5d_denoise_device; bit-identical "
+                         "to the two calls, second-step windows start as soon as their SAIs' basic estimates are final); two-calls: "
+                         "lfbm5d_step1_device then lfbm5d_step2_device; auto: fused")
     ap.add_argument("--sharding", default="graph", choices=["graph", "rows", "blocks"],
                     help="multi-GPU step scheme: graph = windows as a dependency graph, chains of windows per rank, one message per SAI "
                          "between ranks (default; bit-identical to one GPU); rows = row-sharded passes (exact); blocks = round 1's "
@@ -315,12 +319,19 @@ def main():
     FIELDS = ("windows", "passes", "groups", "stack_patches", "algorithmic_bytes", "ms_bm", "ms_group", "ms_aggregate",
               "ms_comm", "launches_group", "launches_aggregate", "lane_windows", "messages")
 
-    def one_step(acc=None):
-        """HT + Wiener; acc: {"ht": {...}, "wiener": {...}} accumulates the library's counters per step kind."""
+    fused = args.job in ("auto", "fused") and args.sharding == "graph"
+
+    def one_step(acc=None, two_calls=False):
+        """HT + Wiener; acc: {"ht": {...}, "wiener": {...}} accumulates the library's counters per step kind (the fused job's
+        counters all land under "ht": its kernels are not attributed to a step)."""
         noisy.copy_(noisy0)
         torch.cuda.synchronize()
-        for kind, call in (("ht", lambda: ctx.step1(P1, noisy, mask, basic, L.ROWMAJOR, aw, ah, 1, W, H, 3)),
-                           ("wiener", lambda: ctx.step2(P2, noisy, mask, basic, den, L.ROWMAJOR, aw, ah, 1, W, H, 3))):
+        if fused and not two_calls:
+            calls = (("ht", lambda: ctx.denoise(P1, P2, noisy, mask, basic, den, L.ROWMAJOR, aw, ah, 1, 1, W, H, 3)),)
+        else:
+            calls = (("ht", lambda: ctx.step1(P1, noisy, mask, basic, L.ROWMAJOR, aw, ah, 1, W, H, 3)),
+                     ("wiener", lambda: ctx.step2(P2, noisy, mask, basic, den, L.ROWMAJOR, aw, ah, 1, W, H, 3)))
+        for kind, call in calls:
             if acc is not None:
                 ctx.reset_stats()
             call()
@@ -350,10 +361,10 @@ def main():
 
     # roofline measurement: the kernel pair alone on the GPU (one lane).  Outside the timed region.
     roof, roof_steps = timed, args.steps
-    if lanes_timed != 1 and world == 1:
+    if (lanes_timed != 1 or fused) and world == 1:
         os.environ["LFBM5D_LANES"] = "1"
         roof, roof_steps = {"ht": {}, "wiener": {}}, 1
-        one_step(roof)
+        one_step(roof, two_calls=True)
         torch.cuda.synchronize()
         os.environ["LFBM5D_LANES"] = str(lanes_timed)
 
@@ -408,9 +419,12 @@ def main():
                        "params_ht": list(map(str, wl["p1"])), "params_wiener": list(map(str, wl["p2"])),
                        "asw": 1, "color_space": "opp", "noise": ("MT19937 seed 1 (utilities.cpp:176-183)" if args.noise == "mt19937" else "torch.randn seed 1"),
                        "window_lanes": lanes_timed,
+                       "job": ("fused: both steps as one dependency graph of windows (lfbm5d_denoise_device), bit-identical to the two calls"
+                               if fused else "two calls: lfbm5d_step1_device, lfbm5d_step2_device"),
                        "parallelism": ("single GPU" if world == 1 else
-                                       f"{world} ranks x chains of angular windows (dependency graph), RCCL send/recv of num/den per shared SAI, "
-                                       f"final broadcast of the estimates; bit-identical to one GPU" if args.sharding == "graph" else
+                                       f"{world} ranks x chains of angular windows (dependency graph" + (" of both steps" if fused else "") + "), RCCL send/recv of num/den per shared SAI"
+                                       + (" and of each SAI's basic estimate to the ranks that read it" if fused else "") +
+                                       ", final broadcast of the estimates; bit-identical to one GPU" if args.sharding == "graph" else
                                        f"{world} x blocks of angular windows + 1 RCCL all-reduce of num/den per step (NOT the reference's result)"
                                        if args.sharding == "blocks" else
                                        f"{world} x reference-patch rows of every pass + RCCL all-reduce per pass")},
@@ -424,7 +438,7 @@ def main():
                          "measured_with": ((f"the timed region ({lanes_timed} lane{'s' if lanes_timed != 1 else ''}"
                                             + ("; kernels of different windows overlap, the intervals are not kernel-alone times)" if lanes_timed != 1 else ")"))
                                            if roof is timed else
-                                           f"{roof_steps} extra untimed step with LFBM5D_LANES=1 (kernels alone on the GPU); the timed region ran {lanes_timed} lanes"),
+                                           f"{roof_steps} extra untimed step with LFBM5D_LANES=1, the two calls one after the other (kernels alone on the GPU); the timed region ran {lanes_timed} lanes" + (", fused job" if fused else "")),
                          "per_step": {"ht": ph, "wiener": pw}},
             # kernel classes alone on the GPU (the one-lane measurement step); with several lanes the HIP-event intervals of
             # different windows overlap and add up to more than the step, so those are reported under their own key

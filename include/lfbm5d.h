@@ -146,16 +146,36 @@ void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, un
 int lfbm5d_plan_windows(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask,
                         unsigned* out_sai, unsigned cap);
 /* The graph form of a step for `world` ranks with `lanes` lanes each (host only, needs no GPU): owner rank, lane and
- * unit-time start slot of every window of lfbm5d_plan_windows' sequence.  Returns the number of windows (-1 on bad
+ * unit-time start slot of every window of lfbm5d_plan_windows' sequence in the simulated execution whose start order
+ * (ties: the earlier window) is the ISSUE ORDER every rank enqueues in.  Returns the number of windows (-1 on bad
  * arguments); writes min(n, cap) entries to each non-NULL array. */
 int lfbm5d_plan_graph(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask, int world, int lanes,
                       unsigned* out_rank, unsigned* out_lane, unsigned* out_start, unsigned cap);
-/* The messages of that graph in the order every rank issues them: out[4 i] = {producer window, consumer window, SAI,
- * channel}; the producer's rank sends num and den of the SAI to the consumer's rank once the producer window is done.
+/* The messages of that graph in the order every rank issues them (by the producer's place in the issue order, then SAI
+ * slot): out[4 i] = {producer window, consumer window, SAI, channel}; the producer's rank sends num and den of the SAI to the
+ * consumer's rank once the producer window is done.
  * Returns the number of messages (-1 on bad arguments); writes min(n, cap) quadruples. */
 int lfbm5d_plan_messages(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask, int world,
                          unsigned* out, unsigned cap);
-/* The windows the last lfbm5d_step* call on this context actually ran (same encoding). */
+/* The graph of a JOB -- one step (n_steps = 1) or run_bm5d_1st_step + run_bm5d_2nd_step back to back (n_steps = 2, what
+ * lfbm5d_denoise_* executes) -- for `world` graph ranks with `lanes` lanes each (host only, needs no GPU).  an[n_steps] =
+ * half size of every step's angular search window; cost[n_steps] = relative cost of a window pass of every step in the
+ * scheduling model (NULL: 10 / 9 for two steps, 1 for one).  In a two-step job a window of the second step waits, per SAI, for
+ * the LAST window of the first step touching that SAI (the SAI's basic estimate is final then), so the second step's wavefront
+ * follows the first's: 128 windows with a critical path of about 28 on a 17x17 light field instead of 2 x 22.
+ *   out_nodes  8 unsigned per window, step 0's windows in plan order, then step 1's:
+ *              {step slot, index in the step's sequence, processed SAI, graph rank, lane, start time (cost units) of the simulated
+ *               execution, position in the ISSUE ORDER every rank walks, chain}
+ *   out_msgs   6 unsigned per message, in issue order: {kind, producer node, consumer node (kind 0) or 0xffffffff, receiving graph
+ *              rank, SAI, channel}; kind 0 = num and den of the SAI from the producer's rank to its next toucher's, kind 1 = the
+ *              basic estimate of the SAI, finalised behind the producer node, to a rank whose second-step windows read it
+ *   out_counts {windows, messages, makespan of the simulated execution in cost units, 1 if every window centre is non-empty}
+ * Returns the number of windows (-1 on bad arguments); writes min(n, cap) entries to each non-NULL array. */
+int lfbm5d_plan_job(unsigned awidth, unsigned aheight, unsigned ang_major, const unsigned* mask, int n_steps, const unsigned* an,
+                    const unsigned* cost, int world, int lanes, unsigned* out_nodes, unsigned node_cap, unsigned* out_msgs,
+                    unsigned msg_cap, unsigned* out_counts);
+/* The windows the last lfbm5d_step* / lfbm5d_denoise_* call on this context actually ran (same encoding; a two-step job: the
+ * first step's windows, then the second's). */
 int lfbm5d_last_windows(const lfbm5d_ctx* ctx, unsigned* out_sai, unsigned cap);
 
 /* ---- outer seam, device-resident: LF buffers already in HBM ----
@@ -175,6 +195,18 @@ int lfbm5d_step2_device(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* d_noisy,
                         unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
                         unsigned W, unsigned H, unsigned C);
 
+/* Both steps as ONE job == run_bm5d_1st_step followed by run_bm5d_2nd_step (main.cpp:195, :242), bit-identical to
+ * lfbm5d_step1_device + lfbm5d_step2_device: the windows of both steps form one dependency graph (lfbm5d_plan_job) and what the
+ * reference does between the two calls (final estimate, inverse and forward colour transform: bm5d.cpp:405, :711-714, :827-830)
+ * happens SAI by SAI as soon as a SAI's basic estimate is final.  On one GPU that closes the gap between the steps; on several
+ * it is what lets all ranks work (the second step's wavefront follows the first's).  P1 / an1 = the hard-thresholding step's
+ * parameters, P2 / an2 = the Wiener step's.  d_noisy in/out, d_basic and d_denoised out, exactly as the two calls leave them.
+ * Light fields outside the graph form (greyscale, an empty SAI at a window centre, tile mode, LFBM5D_STEP_SHARDING,
+ * LFBM5D_DATA_DRIVEN_SCHEDULE, LFBM5D_FUSED=0) run the two calls one after the other. */
+int lfbm5d_denoise_device(lfbm5d_ctx* ctx, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy,
+                          const unsigned* h_mask, float* d_basic, float* d_denoised, unsigned ang_major,
+                          unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H, unsigned C);
+
 /* ---- outer seam, host buffers (what the run_bm5d_* wrappers of the drop-in call): same
  * semantics, the library stages through HBM (PCIe-inclusive). ---- */
 int lfbm5d_step1_host(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* h_noisy,
@@ -184,6 +216,10 @@ int lfbm5d_step2_host(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* h_noisy,
                       const unsigned* h_mask, float* h_basic, float* h_denoised,
                       unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
                       unsigned W, unsigned H, unsigned C);
+
+int lfbm5d_denoise_host(lfbm5d_ctx* ctx, const lfbm5d_params* P1, const lfbm5d_params* P2, float* h_noisy,
+                        const unsigned* h_mask, float* h_basic, float* h_denoised, unsigned ang_major,
+                        unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H, unsigned C);
 
 /* ---- inner seam: one core pass on a mirror-padded angular window, device pointers ----
  * == bm5d_1st_step (step = 1) / bm5d_2nd_step (step = 2) (bm5d_core_processing.h:6-80).
@@ -233,7 +269,7 @@ int lfbm5d_last_bm(lfbm5d_ctx* ctx, unsigned* n_refs, unsigned* h_refs, unsigned
                    unsigned* h_self_cnt, unsigned* h_best, unsigned char* h_shape);
 
 /* Raw disparity distance tables of the last pass (the scratch precompute_BM_stereo's sum_table plays in the
- * reference, core:3513-3574), layout [slot][(2 nDisp+1)^2][strip][table row + lane][64] (skewed: lfbm5d_kernels.h, stereo_table_stride): copies min(n_floats, size) floats and
+ * reference, core:3513-3574), in the layout of the kernel generation that ran (lfbm5d_last_scan_version below): copies min(n_floats, size) floats and
  * returns the count; h_tables == NULL returns the buffer's size in floats.  For the bit-reproducibility tests. */
 size_t lfbm5d_last_tables(lfbm5d_ctx* ctx, float* h_tables, size_t n_floats);
 /* Candidate scores of the self-similarity search of the last pass, [reference patch][(2 nSim+1)^2] in the scan order of
@@ -242,9 +278,15 @@ size_t lfbm5d_last_scores(lfbm5d_ctx* ctx, float* h_scores, size_t n_floats);
 /* Aggregation weights of the groups of the last pass, [reference patch][channel] (core:413-421: 1 / (sigma_c^2 * retained
  * coefficients) in the hard-threshold step): same calling convention.  Lets a test compare survivor counts group by group. */
 size_t lfbm5d_last_weights(lfbm5d_ctx* ctx, float* h_w, size_t n_floats);
-/* Which generation of the table kernel the last pass used: 2 = ring-sharing workgroups (table layout
- * [slot][(2 nDisp+1)^2]{[strip][Q / 4][lane][Q % 4], column 0}, lfbm5d_kernels.h stereo_table_stride2), 1 = one wave per table
- * (12x12 patches, irregular reference lists, LFBM5D_SCAN_V1=1). */
+/* Which generation of the table kernel the last pass used, i.e. what lfbm5d_last_tables returns:
+ *   3 = ring-sharing workgroups, combined form (the default): the disparity tables never reach memory; the buffer holds
+ *       [slot][workgroup of the slot][strip][chunk of 8 steps][lane * 8 + step] pairs of (smallest value of the workgroup's tables,
+ *       its place in the reference's scan order), 8 bytes each, then per table an edge array [rows][strips] (table column 0 and the
+ *       row-0 entry of every strip's first column) -- lfbm5d_kernels.h, stereo_part_stride / stereo_edge_stride;
+ *   2 = ring-sharing workgroups with full tables (LFBM5D_SCAN_FULL_TABLES=1), [slot][(2 nDisp+1)^2]{[strip][Q / 4][lane][Q % 4],
+ *       column 0}, lfbm5d_kernels.h stereo_table_stride2;
+ *   1 = one wave per table (12x12 patches, irregular reference lists, estimates of 2 GiB and more, LFBM5D_SCAN_V1=1), skewed
+ *       layout [slot][(2 nDisp+1)^2][strip][table row + lane][64], stereo_table_stride. */
 int lfbm5d_last_scan_version(const lfbm5d_ctx* ctx);
 
 /* ---- device memory helpers so hosts without a HIP binding (ctypes, cgo, JNI) can stage data ---- */

@@ -99,6 +99,9 @@ def lib():
     L.lfbm5d_last_windows.argtypes = [vp, up, C.c_uint]
     L.lfbm5d_plan_graph.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, C.c_int, C.c_int, up, up, up, C.c_uint]
     L.lfbm5d_plan_messages.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, C.c_int, up, C.c_uint]
+    L.lfbm5d_plan_job.argtypes = [C.c_uint, C.c_uint, C.c_uint, up, C.c_int, up, up, C.c_int, C.c_int, up, C.c_uint, up, C.c_uint, up]
+    L.lfbm5d_denoise_device.argtypes = [vp, C.POINTER(Params), C.POINTER(Params), fp, up, fp, fp] + [C.c_uint] * 8
+    L.lfbm5d_denoise_host.argtypes = [vp, C.POINTER(Params), C.POINTER(Params), fp, up, fp, fp] + [C.c_uint] * 8
     tail = [C.c_uint] * 7
     L.lfbm5d_step1_device.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
     L.lfbm5d_step2_device.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
@@ -165,6 +168,29 @@ def plan_messages(awidth, aheight, world, an=1, ang_major=None, mask=None):
     out = np.zeros((max(n, 1), 4), np.uint32)
     lib().lfbm5d_plan_messages(awidth, aheight, an, ang_major, mp, world, out.ctypes.data_as(C.POINTER(C.c_uint)), n)
     return out[:n]
+
+
+def plan_job(awidth, aheight, world, lanes=1, an=(1, 1), cost=None, ang_major=None, mask=None):
+    """Graph of a job (len(an) = 1: one step; 2: both steps as lfbm5d_denoise_* runs them), host only.  Returns
+    (nodes, msgs, info): nodes[i] = (step slot, window, processed SAI, graph rank, lane, start, issue position, chain) as a
+    uint32 array [n, 8]; msgs[j] = (kind, producer node, consumer node | 0xffffffff, receiving rank, SAI, channel) [m, 6];
+    info = dict(windows, messages, makespan, centre_ok)."""
+    ang_major = ROWMAJOR if ang_major is None else ang_major
+    m = np.ones(awidth * aheight, np.uint32) if mask is None else _u32(mask)
+    p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint))
+    an_a = _u32(list(an))
+    cost_a = _u32(list(cost)) if cost is not None else None
+    cnt = np.zeros(4, np.uint32)
+    n = lib().lfbm5d_plan_job(awidth, aheight, ang_major, p(m), len(an_a), p(an_a), p(cost_a) if cost_a is not None else None,
+                              world, lanes, None, 0, None, 0, p(cnt))
+    if n < 0:
+        raise LfBm5dError("lfbm5d_plan_job: bad arguments")
+    nodes = np.zeros((max(int(cnt[0]), 1), 8), np.uint32)
+    msgs = np.zeros((max(int(cnt[1]), 1), 6), np.uint32)
+    lib().lfbm5d_plan_job(awidth, aheight, ang_major, p(m), len(an_a), p(an_a), p(cost_a) if cost_a is not None else None,
+                          world, lanes, p(nodes), int(cnt[0]), p(msgs), int(cnt[1]), p(cnt))
+    return nodes[:int(cnt[0])], msgs[:int(cnt[1])], {"windows": int(cnt[0]), "messages": int(cnt[1]), "makespan": int(cnt[2]),
+                                                     "centre_ok": bool(cnt[3])}
 
 
 def shard_rows(n_rows, rank, world):
@@ -290,6 +316,18 @@ class Context:
         else:
             self._ck(self._L.lfbm5d_step2_device(self._h, C.byref(P), _dev_ptr(noisy), mp, _dev_ptr(basic),
                                                  _dev_ptr(denoised), *tail))
+
+    def denoise(self, P1, P2, noisy, mask, basic, denoised, ang_major, awidth, aheight, an1, an2, W, H, Cc):
+        """run_bm5d_1st_step + run_bm5d_2nd_step as one job (lfbm5d_denoise_*): bit-identical to step1() followed by step2()."""
+        m = _u32(mask)
+        mp = m.ctypes.data_as(C.POINTER(C.c_uint))
+        tail = (ang_major, awidth, aheight, an1, an2, W, H, Cc)
+        if isinstance(noisy, np.ndarray):
+            self._ck(self._L.lfbm5d_denoise_host(self._h, C.byref(P1), C.byref(P2), noisy.ctypes.data_as(C.c_void_p), mp,
+                                                 basic.ctypes.data_as(C.c_void_p), denoised.ctypes.data_as(C.c_void_p), *tail))
+        else:
+            self._ck(self._L.lfbm5d_denoise_device(self._h, C.byref(P1), C.byref(P2), _dev_ptr(noisy), mp, _dev_ptr(basic),
+                                                   _dev_ptr(denoised), *tail))
 
     # ---- inner seam ----
     def core_pass(self, step, P, aw, ah, Wb, Hb, Cc, noisy, basic, num, den, mask, procSAI, cst, pst):

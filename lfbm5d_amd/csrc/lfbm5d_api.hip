@@ -9,6 +9,7 @@
  */
 #include "../../include/lfbm5d.h"
 #include "lfbm5d_kernels.h"
+#include "lfbm5d_plan.h"
 
 #include <rccl/rccl.h>
 
@@ -45,6 +46,16 @@ struct DevBuf {
 
 struct PassEvents { hipEvent_t e[5]; bool comm; };
 
+struct GeomCache {
+    DevBuf refs, rslot, tb, scan_wgs;
+    std::vector<Scan2Wg> scan_plan; unsigned scan_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t scan_lds = 0;
+    unsigned scan_nwg_slot = 0; int scan_version = 0;
+    std::vector<unsigned> last_refs_host;
+    unsigned grid_key[5] = {0, 0, 0, 0, 0};      /* cached reference grid */
+    unsigned tb_key[3] = {0, 0, 0};
+    unsigned n_ref_rows = 0, n_ref_cols = 0;
+};
+
 } /* namespace */
 
 constexpr size_t kEstLead = 64;   /* floats of slack in front of the estimate planes */
@@ -67,12 +78,15 @@ struct lfbm5d_ctx {
     lfbm5d_stats stats;
     /* per-pass work buffers (grow only) */
     DevBuf t_noisy, t_basic, t_tnum, t_tden, und_num, und_den;   /* tile mode: one tile of the window, the tiles' interiors */
-    DevBuf scan_wgs, scan_lcol;            /* second-generation scan: workgroup list, hand-off columns */
-    std::vector<Scan2Wg> scan_plan; unsigned scan_key[8] = {0, 0, 0, 0, 0, 0, 0, 0}; size_t scan_lds = 0;
-    int last_scan_version = 0; unsigned scan_nwg_slot = 0;
-    DevBuf est, refs, rslot, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gofs, gok, gshape, counters, tb, small, t_num, t_den, d_mask;
-    /* step-level buffers */
-    DevBuf g_num, g_den, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
+    DevBuf scan_lcol;                      /* second-generation scan: hand-off columns */
+    int last_scan_version = 0;
+    /* what a pass derives from its geometry alone (reference grid, transform tables, the table kernel's workgroup list):
+     * cached, one set per step slot so that the windows of both steps of a two-step job can alternate on a lane without
+     * re-uploading (and without the stream synchronisation an upload from a stack object needs) */
+    GeomCache gc[2]; int gslot = 0;
+    DevBuf est, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gofs, gok, gshape, counters, small, t_num, t_den, d_mask;
+    /* step-level buffers (g_num2 / g_den2 / n2: second step of a two-step job; e_basic: an emulated rank's own basic estimate) */
+    DevBuf g_num, g_den, g_num2, g_den2, n2, e_basic, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
     /* window lanes (run_step, pipelined form): extra contexts on the same device, each with its own stream, window
      * buffers and per-pass work buffers; owned by this context */
@@ -83,11 +97,6 @@ struct lfbm5d_ctx {
     std::vector<PassEvents> pending;
     /* last pass (inspection) */
     unsigned last_n_refs = 0, last_N = 0, last_A = 0; size_t last_plane = 0;
-    std::vector<unsigned> last_refs_host;
-    /* cached reference grid */
-    unsigned grid_key[5] = {0, 0, 0, 0, 0};
-    unsigned tb_key[3] = {0, 0, 0};
-    unsigned n_ref_rows = 0, n_ref_cols = 0;
 };
 
 namespace {
@@ -109,7 +118,7 @@ lfbm5d_ctx* new_ctx(int device, std::string& err) {
     c->device = device;
     std::memset(&c->stats, 0, sizeof(c->stats));
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) { err = hipGetErrorString(e); delete c; return nullptr; }
-    if ((e = prepare_group_kernels()) != hipSuccess) { err = std::string("kernel LDS limits: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
+    if ((e = prepare_group_kernels()) != hipSuccess || (e = prepare_scan2_kernels()) != hipSuccess) { err = std::string("kernel LDS limits: ") + hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     if ((e = hipHostMalloc((void**)&c->h_small, 64 * sizeof(unsigned))) != hipSuccess) { err = hipGetErrorString(e); (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     return c;
 }
@@ -263,6 +272,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     const unsigned A = aw * ah, k = P->k, k2 = k * k, N = P->N, nHW = P->nSim + P->nDisp;
     const size_t plane = (size_t)Wb * Hb;
     hipStream_t s = c->stream;
+    GeomCache& gc = c->gc[c->gslot];
     if (Hb < 2 * nHW + k + 1 || Wb < 2 * nHW + k + 1) return fail(c, "window smaller than the search range");
     if (Hb > 65535 || Wb > 65535) return fail(c, "unsupported: window larger than 65535 pixels a side");
 
@@ -282,24 +292,24 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* reference grid (core:149-156); cached while the geometry is unchanged */
     const bool centre = pst == cst;
     const unsigned key[5] = {Wb, Hb, k, nHW, P->p};
-    if (centre && (std::memcmp(key, c->grid_key, sizeof(key)) != 0 || c->last_refs_host.empty())) {
+    if (centre && (std::memcmp(key, gc.grid_key, sizeof(key)) != 0 || gc.last_refs_host.empty())) {
         std::vector<unsigned> rows, cols;
         ind_init(rows, Hb - k + 1, nHW, P->p);
         ind_init(cols, Wb - k + 1, nHW, P->p);
-        c->n_ref_rows = (unsigned)rows.size(); c->n_ref_cols = (unsigned)cols.size();
-        c->last_refs_host.resize(rows.size() * cols.size());
+        gc.n_ref_rows = (unsigned)rows.size(); gc.n_ref_cols = (unsigned)cols.size();
+        gc.last_refs_host.resize(rows.size() * cols.size());
         for (size_t i = 0; i < rows.size(); i++)
-            for (size_t j = 0; j < cols.size(); j++) c->last_refs_host[i * cols.size() + j] = rows[i] * Wb + cols[j];
+            for (size_t j = 0; j < cols.size(); j++) gc.last_refs_host[i * cols.size() + j] = rows[i] * Wb + cols[j];
         std::vector<int> rslot(Hb + 64, -1);   /* 64 slots of padding: the scan reads rslot[y + di] unclamped */
         for (size_t i = 0; i < rows.size(); i++) rslot[rows[i]] = (int)i;
-        HIPCK(c, c->rslot.reserve(rslot.size() * sizeof(int)));
-        HIPCK(c, hipMemcpyAsync(c->rslot.p, rslot.data(), rslot.size() * sizeof(int), hipMemcpyHostToDevice, s));
-        HIPCK(c, c->refs.reserve(c->last_refs_host.size() * sizeof(unsigned)));
-        HIPCK(c, hipMemcpyAsync(c->refs.p, c->last_refs_host.data(), c->last_refs_host.size() * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        HIPCK(c, gc.rslot.reserve(rslot.size() * sizeof(int)));
+        HIPCK(c, hipMemcpyAsync(gc.rslot.p, rslot.data(), rslot.size() * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCK(c, gc.refs.reserve(gc.last_refs_host.size() * sizeof(unsigned)));
+        HIPCK(c, hipMemcpyAsync(gc.refs.p, gc.last_refs_host.data(), gc.last_refs_host.size() * sizeof(unsigned), hipMemcpyHostToDevice, s));
         HIPCK(c, hipStreamSynchronize(s));
-        std::memcpy(c->grid_key, key, sizeof(key));
+        std::memcpy(gc.grid_key, key, sizeof(key));
     }
-    unsigned R = c->n_ref_rows * c->n_ref_cols;
+    unsigned R = gc.n_ref_rows * gc.n_ref_cols;
     std::vector<unsigned> row_start;   /* subset path: first reference of every listed row (+ end) */
     if (!centre) {
         /* Subset path (core:157-158, utilities_LF.cpp:1000-1099): only reference patches whose k x k
@@ -331,15 +341,15 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         for (unsigned i = nHW; i < max_h - nHW; i += P->p) if (scan_row(i)) { last_row = i; any = true; }
         if (!any || last_row < max_h - nHW - 1) scan_row(max_h - nHW - 1);
         row_start.push_back((unsigned)refs.size());
-        c->last_refs_host = refs;
-        std::memset(c->grid_key, 0, sizeof(c->grid_key));   /* the cached regular grid is gone */
+        gc.last_refs_host = refs;
+        std::memset(gc.grid_key, 0, sizeof(gc.grid_key));   /* the cached regular grid is gone */
         R = (unsigned)refs.size();
         if (R == 0) { c->last_n_refs = 0; return 0; }   /* nothing left to denoise (core:160-165) */
-        HIPCK(c, c->refs.reserve(R * sizeof(unsigned)));
-        HIPCK(c, hipMemcpyAsync(c->refs.p, refs.data(), R * sizeof(unsigned), hipMemcpyHostToDevice, s));
+        HIPCK(c, gc.refs.reserve(R * sizeof(unsigned)));
+        HIPCK(c, hipMemcpyAsync(gc.refs.p, refs.data(), R * sizeof(unsigned), hipMemcpyHostToDevice, s));
         HIPCK(c, c->refmap.reserve(plane * sizeof(int)));
         HIPCK(c, launch_fill_i32(s, c->refmap.as<int>(), -1, plane));
-        HIPCK(c, launch_refmap(s, c->refs.as<unsigned>(), R, c->refmap.as<int>()));
+        HIPCK(c, launch_refmap(s, gc.refs.as<unsigned>(), R, c->refmap.as<int>()));
         HIPCK(c, hipStreamSynchronize(s));   /* refs is a stack vector */
     }
 
@@ -365,17 +375,18 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->gofs.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gok.reserve((size_t)R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gshape.reserve((size_t)R * kShapeInfoBytes));
-    HIPCK(c, c->tb.reserve(sizeof(GroupTables)));
-    if (!c->counters.p) {
-        HIPCK(c, c->counters.reserve(16 * sizeof(unsigned long long)));
-        HIPCK(c, hipMemsetAsync(c->counters.p, 0, 16 * sizeof(unsigned long long), s));
+    HIPCK(c, gc.tb.reserve(sizeof(GroupTables)));
+    if (!c->counters.p) {   /* [step slot][16]: sum nSx, shape-adaptive groups, development clocks */
+        HIPCK(c, c->counters.reserve(32 * sizeof(unsigned long long)));
+        HIPCK(c, hipMemsetAsync(c->counters.p, 0, 32 * sizeof(unsigned long long), s));
     }
-    if (c->tb_key[0] != k || c->tb_key[1] != aw || c->tb_key[2] != ah) {   /* constant tables: uploaded when the geometry changes */
+    unsigned long long* const d_counters = c->counters.as<unsigned long long>() + 16 * c->gslot;
+    if (gc.tb_key[0] != k || gc.tb_key[1] != aw || gc.tb_key[2] != ah) {   /* constant tables: uploaded when the geometry changes */
         GroupTables tb;
         build_tables(tb, k, aw, ah);
-        HIPCK(c, hipMemcpyAsync(c->tb.p, &tb, sizeof(tb), hipMemcpyHostToDevice, s));
+        HIPCK(c, hipMemcpyAsync(gc.tb.p, &tb, sizeof(tb), hipMemcpyHostToDevice, s));
         HIPCK(c, hipStreamSynchronize(s)); /* tb is a stack object */
-        c->tb_key[0] = k; c->tb_key[1] = aw; c->tb_key[2] = ah;
+        gc.tb_key[0] = k; gc.tb_key[1] = aw; gc.tb_key[2] = ah;
     }
 
     PassEvents pe; pe.comm = false;
@@ -395,17 +406,24 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* block matching (core:209-236): all distance tables in one launch, then the two selections */
     ScanArgs sa;
     std::memset(&sa, 0, sizeof(sa));
-    sa.dbg = c->counters.as<unsigned long long>() + 4;
+    sa.dbg = d_counters + 4;
     sa.est = est; sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
     sa.nSim = P->nSim; sa.nDisp = P->nDisp; sa.nHW = nHW;
-    sa.n_ref_rows = c->n_ref_rows; sa.n_ref_cols = c->n_ref_cols; sa.p = P->p;
-    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = c->rslot.as<int>(); sa.refmap = centre ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)((size_t)R * NsS * NsS * sizeof(float));
+    sa.n_ref_rows = gc.n_ref_rows; sa.n_ref_cols = gc.n_ref_cols; sa.p = P->p;
+    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = gc.rslot.as<int>(); sa.refmap = centre ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)((size_t)R * NsS * NsS * sizeof(float));
     sa.n_self = N > 1 ? (P->nSim + 1) * NsS : 0;
     sa.n_stereo = n_slots * NsD * NsD;
     for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
     sa.est_planes = A;
     if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
-    const int scan_version = bm_scan_version(sa);
+    /* which generation of the table kernel, and its workgroup list: functions of the search geometry (and of the two
+     * environment switches bm_scan_version reads), cached with it */
+    const char* const env_v1 = std::getenv("LFBM5D_SCAN_V1"); const char* const env_ft = std::getenv("LFBM5D_SCAN_FULL_TABLES");
+    const unsigned skey[8] = {sa.n_self, sa.n_stereo, sa.nSim, sa.nDisp, sa.k, Hb, Wb,
+                              1u | (centre ? 0u : 2u) | ((env_v1 && env_v1[0] && env_v1[0] != '0') ? 4u : 0u) | ((env_ft && env_ft[0] && env_ft[0] != '0') ? 8u : 0u)};
+    const bool scan_changed = std::memcmp(skey, gc.scan_key, sizeof(skey)) != 0;
+    if (scan_changed) gc.scan_version = bm_scan_version(sa);
+    const int scan_version = gc.scan_version;
     c->last_scan_version = scan_version;
     if (scan_version == 1) {
         HIPCK(c, c->tables.reserve(std::max<size_t>(1, scan_tables_floats(sa, 1, n_slots, 0)) * sizeof(float)));
@@ -413,29 +431,28 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     }
     if (scan_version >= 2) {
         /* ring-sharing workgroups of eight tables (lfbm5d_scan2.hip): the list depends on the search geometry only */
-        const unsigned skey[8] = {sa.n_self, sa.n_stereo, sa.nSim, sa.nDisp, sa.k, Hb, Wb, 1u};
-        if (std::memcmp(skey, c->scan_key, sizeof(skey)) != 0) {
-            if (!scan2_plan(sa, c->scan_plan, &c->scan_lds, &c->scan_nwg_slot)) return fail(c, "scan plan");
-            HIPCK(c, c->scan_wgs.reserve(c->scan_plan.size() * sizeof(Scan2Wg)));
-            HIPCK(c, hipMemcpyAsync(c->scan_wgs.p, c->scan_plan.data(), c->scan_plan.size() * sizeof(Scan2Wg), hipMemcpyHostToDevice, s));
+        if (scan_changed) {
+            if (!scan2_plan(sa, gc.scan_plan, &gc.scan_lds, &gc.scan_nwg_slot)) return fail(c, "scan plan");
+            HIPCK(c, gc.scan_wgs.reserve(gc.scan_plan.size() * sizeof(Scan2Wg)));
+            HIPCK(c, hipMemcpyAsync(gc.scan_wgs.p, gc.scan_plan.data(), gc.scan_plan.size() * sizeof(Scan2Wg), hipMemcpyHostToDevice, s));
             HIPCK(c, hipStreamSynchronize(s));
-            std::memcpy(c->scan_key, skey, sizeof(skey));
         }
-        sa.wgs = c->scan_wgs.as<Scan2Wg>(); sa.n_wgs = (unsigned)c->scan_plan.size();
+        sa.wgs = gc.scan_wgs.as<Scan2Wg>(); sa.n_wgs = (unsigned)gc.scan_plan.size();
         sa.lcol_stride = scan2_lcol_stride(sa);
         HIPCK(c, c->scan_lcol.reserve((size_t)(sa.n_self + sa.n_stereo) * sa.lcol_stride * sizeof(float)));
         sa.lcol = c->scan_lcol.as<float>();
-        sa.nwg_slot = c->scan_nwg_slot;
+        sa.nwg_slot = gc.scan_nwg_slot;
         HIPCK(c, c->tables.reserve(std::max<size_t>(1, scan_tables_floats(sa, scan_version, n_slots, sa.nwg_slot)) * sizeof(float)));
         sa.tables = c->tables.as<float>();
-        HIPCK(c, launch_bm_scan2(s, sa, c->scan_lds, scan_version == 3));
+        HIPCK(c, launch_bm_scan2(s, sa, gc.scan_lds, scan_version == 3));
     } else
         HIPCK(c, launch_bm_scan(s, sa));
+    std::memcpy(gc.scan_key, skey, sizeof(skey));
     if (N > 1)
-        HIPCK(c, launch_self_select(s, c->scores.as<float>(), c->refs.as<unsigned>(), R, Wb, P->nSim, N, thr,
+        HIPCK(c, launch_self_select(s, c->scores.as<float>(), gc.refs.as<unsigned>(), R, Wb, P->nSim, N, thr,
                                     c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
     else
-        HIPCK(c, launch_self_trivial(s, c->refs.as<unsigned>(), R, c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
+        HIPCK(c, launch_self_trivial(s, gc.refs.as<unsigned>(), R, c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
     if (n_slots && scan_version == 3)
         HIPCK(c, launch_stereo_argmin3(s, c->tables.as<float>(), slots, n_slots, sa.nwg_slot, Wb, Hb, k, P->nDisp, thr,
                                        c->best.as<unsigned>(), c->shape.as<unsigned char>()));
@@ -450,9 +467,9 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* shard of reference-patch rows owned by this rank */
     unsigned ref_begin, n_groups;
     if (centre) {
-        unsigned rb = 0, re = c->n_ref_rows;
-        lfbm5d_shard_rows(c->n_ref_rows, c->pass_rank, c->pass_world, &rb, &re);
-        ref_begin = rb * c->n_ref_cols; n_groups = (re - rb) * c->n_ref_cols;
+        unsigned rb = 0, re = gc.n_ref_rows;
+        lfbm5d_shard_rows(gc.n_ref_rows, c->pass_rank, c->pass_world, &rb, &re);
+        ref_begin = rb * gc.n_ref_cols; n_groups = (re - rb) * gc.n_ref_cols;
     } else {
         unsigned rb = 0, re = (unsigned)row_start.size() - 1;
         lfbm5d_shard_rows((unsigned)row_start.size() - 1, c->pass_rank, c->pass_world, &rb, &re);
@@ -462,9 +479,9 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     GroupArgs ga;
     std::memset(&ga, 0, sizeof(ga));
     ga.noisy = d_noisy; ga.basic = d_basic; ga.num = d_num; ga.den = d_den;
-    ga.refs = c->refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
-    ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = c->tb.as<GroupTables>();
-    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gofs = c->gofs.as<unsigned>(); ga.gok = c->gok.as<unsigned>(); ga.gshape = c->gshape.p; ga.n_refs_total = R; ga.counters = c->counters.as<unsigned long long>();
+    ga.refs = gc.refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
+    ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = gc.tb.as<GroupTables>();
+    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gofs = c->gofs.as<unsigned>(); ga.gok = c->gok.as<unsigned>(); ga.gshape = c->gshape.p; ga.n_refs_total = R; ga.counters = d_counters;
     ga.ref_begin = ref_begin; ga.n_groups = n_groups;
     ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
     ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;
@@ -483,7 +500,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     std::memset(&aa, 0, sizeof(aa));
     aa.num = d_num; aa.den = d_den; aa.filt = ga.filt; aa.filt_bytes = (unsigned long long)R * Nst * A * C * k2 * sizeof(float); aa.wgt = ga.wgt; aa.aggpos = ga.aggpos; aa.n_refs_total = R; aa.refs = ga.refs;
     aa.self_idx = ga.self_idx; aa.self_cnt = ga.self_cnt; aa.best = ga.best; aa.shape = ga.shape; aa.tb = ga.tb;
-    aa.ref_begin = ref_begin; aa.n_groups = n_groups; aa.n_ref_rows = c->n_ref_rows; aa.n_ref_cols = c->n_ref_cols;
+    aa.ref_begin = ref_begin; aa.n_groups = n_groups; aa.n_ref_rows = gc.n_ref_rows; aa.n_ref_cols = gc.n_ref_cols;
     aa.Wb = Wb; aa.Hb = Hb; aa.C = C; aa.A = A; aa.k = k; aa.N = Nst; aa.pst = pst; aa.p = P->p;
     aa.nHW = nHW; aa.nSim = P->nSim; aa.nDisp = P->nDisp;
     aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D; aa.irregular = centre ? 0u : 1u;
@@ -508,29 +525,21 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     return 0;
 }
 
-/* utilities_LF.cpp:881-901 */
-void search_window(int aidx, unsigned asize, unsigned an, int& cc, int& mn, int& mx) {
-    mn = aidx - (int)an; mx = aidx + (int)an;
-    int shift = mn < 0 ? -mn : 0;
-    mn += shift; mx += shift; cc = (int)an - shift;
-    shift = mx >= (int)asize ? ((int)asize - mx - 1) : 0;
-    mn += shift; mx += shift; cc -= shift;
-}
-
 /* fold the device counters (sum nSx, sadct groups) into the stats; stream must be idle */
-int fold_counters(lfbm5d_ctx* c, const lfbm5d_params* P, unsigned A, unsigned C, int step) {
+int fold_counters(lfbm5d_ctx* c, const lfbm5d_params* P, unsigned A, unsigned C, int step, int slot = 0) {
     unsigned long long h[4] = {0, 0, 0, 0};
     if (!c->counters.p) return 0;
-    HIPCK(c, hipMemcpyAsync(h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long* const d_counters = c->counters.as<unsigned long long>() + 16 * slot;
+    HIPCK(c, hipMemcpyAsync(h, d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    HIPCK(c, hipMemsetAsync(c->counters.p, 0, sizeof(h), c->stream));
+    HIPCK(c, hipMemsetAsync(d_counters, 0, sizeof(h), c->stream));
     c->stats.stack_patches += h[0];
     c->stats.sadct_groups += h[1];
 #ifdef LFBM5D_PHASE_TIMING   /* kernel-internal phase clocks of development builds (tools/build_variant.sh) */
     {
         unsigned long long ph[12];
-        (void)hipMemcpy(ph, c->counters.as<unsigned long long>() + 4, sizeof(ph), hipMemcpyDeviceToHost);
-        (void)hipMemset(c->counters.as<unsigned long long>() + 4, 0, sizeof(ph));
+        (void)hipMemcpy(ph, d_counters + 4, sizeof(ph), hipMemcpyDeviceToHost);
+        (void)hipMemset(d_counters + 4, 0, sizeof(ph));
         std::fprintf(stderr, "[phases step %d]", step);
         for (int i = 0; i < 12; i++) std::fprintf(stderr, " %.3g", (double)ph[i]);
         std::fprintf(stderr, "\n");
@@ -541,155 +550,382 @@ int fold_counters(lfbm5d_ctx* c, const lfbm5d_params* P, unsigned A, unsigned C,
     return 0;
 }
 
-/* bm5d.cpp:165-407 (step 1) / :861-1106 (step 2) on device-resident buffers */
-/* The sequence of windows run_step processes, as the processed SAI of each (see the comment in run_step):
- * first the centre SAI if it is not empty, then always the last unprocessed SAI; every SAI of a
- * window is processed when the window is done (bm5d.cpp:165-402). */
-void plan_windows(const unsigned* h_mask, unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major,
-                  std::vector<unsigned>& plan) {
-    const unsigned asize = awidth * aheight, asw = 2 * an + 1;
-    const unsigned cs = aheight / 2, ct = awidth / 2;
-    const unsigned cst = ang_major == LFBM5D_ROWMAJOR ? cs * awidth + ct : cs + ct * aheight;
-    std::vector<unsigned> proc(asize);
-    for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
-    unsigned remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
-    const unsigned total = remaining;
-    plan.clear();
-    while (remaining) {
-        unsigned pst = 0;
-        if (remaining == total && h_mask[cst]) pst = cst;
-        else for (unsigned st = 0; st < asize; st++) if (!proc[st]) pst = st;
-        const unsigned ps = ang_major == LFBM5D_ROWMAJOR ? pst / awidth : pst % aheight;
-        const unsigned pt = ang_major == LFBM5D_ROWMAJOR ? pst % awidth : pst / aheight;
-        int cs_w, mins, maxs, ct_w, mint, maxt;
-        search_window((int)ps, aheight, an, cs_w, mins, maxs);
-        search_window((int)pt, awidth, an, ct_w, mint, maxt);
-        for (unsigned si = 0; si < asw; si++)
-            for (unsigned ti = 0; ti < asw; ti++) {
-                const unsigned S = si + mins, T = ti + mint;
-                const unsigned st = ang_major == LFBM5D_ROWMAJOR ? S * awidth + T : S + T * aheight;
-                if (h_mask[st]) proc[st] = 1;
-            }
-        plan.push_back(pst);
-        remaining = (unsigned)std::count(proc.begin(), proc.end(), 0u);
-    }
-}
+/* ------------------------------------------------------------------------------------------ */
+/* The window graph: one step, or both steps of a denoise, executed as a dependency graph     */
+/* ------------------------------------------------------------------------------------------ */
+using plan::search_window;
+using plan::plan_windows;
 
-/* The windows of a step as a dependency graph.  Two windows interact only through num / den of
- * the SAIs they share -- the running estimate block matching reads, the sums aggregation adds to -- so a window has to
- * wait exactly for the previous window that touched each of its SAIs; windows that share no SAI commute bit for bit.
- * Ranks own CHAINS of windows (maximal runs of consecutive windows in the same row of SAIs: every window of a chain
- * depends on its predecessor, so a chain is serial anyway), dealt round-robin; a window's inputs that a window of
- * another rank produced travel as one point-to-point message per SAI (num and den of that SAI). */
-struct StepGraph {
-    std::vector<unsigned> plan, ps, pt, tau4, chain;
-    std::vector<int> rank, lane, start;              /* owner rank, lane within the owner, unit-time start slot */
-    std::vector<std::vector<unsigned>> sai;          /* non-empty SAIs (light-field indices) of every window */
-    std::vector<std::vector<int>> prev, next;        /* per window and SAI: previous / next window touching it (-1: none) */
-    std::vector<int> last_touch;                     /* per SAI of the light field: last window touching it (-1: none) */
-    bool centre_ok = true;                           /* every window's centre SAI is non-empty */
-    struct Xfer { unsigned from_w, to_w, sai; int channel; };
-    std::vector<Xfer> xfers;                         /* in issue order: producer window, then SAI slot */
+/* A JOB: run_bm5d_1st_step, run_bm5d_2nd_step, or the two back to back (lfbm5d_denoise_device).  The graph (lfbm5d_plan.h) is
+ * executed on LANES -- a lane = a context of its own: stream, window buffers, per-pass work buffers -- with HIP events for the
+ * dependencies between lanes; on several GPUs every rank runs the chains of windows it owns and what a window needs from a
+ * window of another rank arrives as point-to-point messages (RCCL send / recv over xGMI).  Either way every window sees exactly
+ * the num / den (and, in the second step of a two-step job, the basic estimate) the window-after-window order of the
+ * reference would show it: the result is bit-identical to one lane on one GPU.
+ *
+ * The reference decides after every pass whether the window is complete (coverage count, bm5d.cpp:370-382); for colour light
+ * fields one centre pass always suffices.  The graph form assumes that, copies every window's
+ * count to pinned memory and checks them all at the end (*complete). */
+struct GraphJob {
+    int n_steps = 1;
+    int step[2] = {1, 2};                          /* the reference step every slot runs */
+    const lfbm5d_params* P[2] = {nullptr, nullptr};
+    unsigned an[2] = {1, 1};
+    const float* noisy[2] = {nullptr, nullptr};    /* the (colour-transformed) light field every slot reads */
+    float* d_basic = nullptr;                      /* step 2: the pilot; two-step jobs: written SAI by SAI as the first step's sums become final */
+    float* g_num[2] = {nullptr, nullptr};          /* the light field's sums, zeroed by the caller */
+    float* g_den[2] = {nullptr, nullptr};
+    float* d_out = nullptr;                        /* several ranks: the last slot's estimate, formed per SAI by its owner and exchanged */
+    const unsigned* d_mask = nullptr;
 };
 
-void build_graph(const unsigned* h_mask, unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, unsigned tau_4D,
-                 int world, int n_lanes, int max_windows, StepGraph& G) {
-    const unsigned asize = awidth * aheight, asw = 2 * an + 1, Aw = asw * asw;
-    plan_windows(h_mask, awidth, aheight, an, ang_major, G.plan);
-    if (max_windows > 0 && G.plan.size() > (size_t)max_windows) G.plan.resize((size_t)max_windows);
-    const size_t NW = G.plan.size();
-    G.ps.assign(NW, 0); G.pt.assign(NW, 0); G.tau4.assign(NW, 0); G.chain.assign(NW, 0);
-    G.rank.assign(NW, 0); G.lane.assign(NW, 0); G.start.assign(NW, 0);
-    G.sai.assign(NW, {}); G.prev.assign(NW, {}); G.next.assign(NW, {});
-    G.last_touch.assign(asize, -1);
-    G.centre_ok = true;
-    G.xfers.clear();
-    unsigned t4 = tau_4D;
-    for (size_t w = 0; w < NW; w++) {
-        G.ps[w] = ang_major == LFBM5D_ROWMAJOR ? G.plan[w] / awidth : G.plan[w] % aheight;
-        G.pt[w] = ang_major == LFBM5D_ROWMAJOR ? G.plan[w] % awidth : G.plan[w] / aheight;
-        int cs_w, mins, maxs, ct_w, mint, maxt;
-        search_window((int)G.ps[w], aheight, an, cs_w, mins, maxs);
-        search_window((int)G.pt[w], awidth, an, ct_w, mint, maxt);
-        for (unsigned si = 0; si < asw; si++)
-            for (unsigned ti = 0; ti < asw; ti++) {
-                const unsigned st = ang_major == LFBM5D_ROWMAJOR ? (si + mins) * awidth + (ti + mint) : (si + mins) + (ti + mint) * aheight;
-                if (h_mask[st]) G.sai[w].push_back(st);
-            }
-        if (G.sai[w].size() != Aw && t4 == LFBM5D_DCT) t4 = LFBM5D_SADCT;   /* sticky switch, bm5d.cpp:276-280 */
-        G.tau4[w] = t4;
-        const unsigned cst_lf = ang_major == LFBM5D_ROWMAJOR ? (unsigned)(mins + cs_w) * awidth + (unsigned)(mint + ct_w)
-                                                             : (unsigned)(mins + cs_w) + (unsigned)(mint + ct_w) * aheight;
-        if (!h_mask[cst_lf]) G.centre_ok = false;
-        G.chain[w] = w == 0 ? 0 : (G.ps[w] == G.ps[w - 1] ? G.chain[w - 1] : G.chain[w - 1] + 1);
-        G.prev[w].assign(G.sai[w].size(), -1);
-        G.next[w].assign(G.sai[w].size(), -1);
-        for (size_t i = 0; i < G.sai[w].size(); i++) {
-            const unsigned st = G.sai[w][i];
-            const int p = G.last_touch[st];
-            G.prev[w][i] = p;
-            if (p >= 0) {
-                const size_t j = std::find(G.sai[p].begin(), G.sai[p].end(), st) - G.sai[p].begin();
-                G.next[p][j] = (int)w;
-            }
-            G.last_touch[st] = (int)w;
-        }
+int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsigned* h_mask, unsigned awidth, unsigned aheight,
+              unsigned ang_major, unsigned W, unsigned H, unsigned C, int nranks, bool emulate, int* complete_out) {
+    const unsigned asize = awidth * aheight;
+    const size_t img = (size_t)C * W * H;
+    hipStream_t s = c->stream;
+    const size_t NN = G.nodes.size();
+    const bool two = J.n_steps == 2;
+    *complete_out = 1;
+    /* geometry of every slot */
+    struct Geo { unsigned asw, Aw, nHW, wb, hb; size_t imgb; };
+    Geo geo[2];
+    size_t imgb_max = 0; unsigned Aw_max = 0;
+    for (int sl = 0; sl < J.n_steps; sl++) {
+        Geo& g = geo[sl];
+        g.asw = 2 * J.an[sl] + 1; g.Aw = g.asw * g.asw; g.nHW = J.P[sl]->nSim + J.P[sl]->nDisp;
+        g.wb = W + 2 * g.nHW; g.hb = H + 2 * g.nHW; g.imgb = (size_t)C * g.wb * g.hb;
+        imgb_max = std::max(imgb_max, g.Aw * g.imgb); Aw_max = std::max(Aw_max, g.Aw);
     }
-    /* Owner of every chain: chains in plan order, each to the rank on which it would finish first in unit window time
-     * (one lane per rank in this model); ties go to the rank that already owns most of the chain's predecessors (fewer
-     * messages), then to the lowest rank.  A pure function of the mask and the rank count: every rank computes the same. */
-    {
-        const int Gn = std::max(1, world);
-        std::vector<unsigned> fin(NW, 0), rank_free((size_t)Gn, 0);
-        size_t a = 0;
-        while (a < NW) {
-            size_t b = a;
-            while (b + 1 < NW && G.chain[b + 1] == G.chain[a]) b++;
-            int best_r = 0; unsigned best_f = ~0u; int best_aff = -1;
-            for (int r = 0; r < Gn; r++) {
-                unsigned t = rank_free[(size_t)r]; int aff = 0;
-                for (size_t w = a; w <= b; w++) {
-                    unsigned ready = t;
-                    for (int p : G.prev[w]) if (p >= 0) { if ((size_t)p < a) { ready = std::max(ready, fin[(size_t)p]); if (G.rank[(size_t)p] == r) aff++; } }
-                    t = ready + 1;
+    const bool any_step2 = J.step[0] == 2 || (two && J.step[1] == 2);
+
+    struct Lane { lfbm5d_ctx* x; float* w_noisy; float* w_basic; float* w_num; float* w_den; unsigned* d_small; };
+    struct RankState { int rank; lfbm5d_ctx* x; float* g_num[2]; float* g_den[2]; float* basic; std::vector<Lane> lanes; };
+    auto lane_buffers = [&](lfbm5d_ctx* x, Lane& L) -> int {
+        HIPCK(c, x->w_noisy.reserve(imgb_max * sizeof(float)));
+        if (any_step2) HIPCK(c, x->w_basic.reserve(imgb_max * sizeof(float)));
+        HIPCK(c, x->w_num.reserve(imgb_max * sizeof(float)));
+        HIPCK(c, x->w_den.reserve(imgb_max * sizeof(float)));
+        HIPCK(c, x->small.reserve((asize + 8) * sizeof(unsigned)));
+        L.x = x; L.w_noisy = x->w_noisy.as<float>(); L.w_basic = x->w_basic.as<float>();
+        L.w_num = x->w_num.as<float>(); L.w_den = x->w_den.as<float>(); L.d_small = x->small.as<unsigned>();
+        return 0;
+    };
+    /* lanes the schedule actually uses (a 3x3 light field is one window: no extra lane, no extra buffers) */
+    int lanes_used = 1;
+    for (const plan::Node& nd : G.nodes) lanes_used = std::max(lanes_used, nd.lane + 1);
+    const int lanes_per_rank = emulate ? 1 : lanes_used;
+    const size_t need_ctx = emulate ? (size_t)nranks - 1 : (size_t)lanes_used - 1;
+    while (c->lanes.size() < need_ctx) {
+        std::string e;
+        lfbm5d_ctx* x = new_ctx(c->device, e);
+        if (!x) return fail(c, "lane context: " + e);
+        c->lanes.push_back(x);
+    }
+    /* An error return in the middle of the graph (a failed HIP call, an RCCL call that reports an error) would leave this
+     * rank's queued sends / receives waiting for peers that will never get their counterparts -- and the peers waiting for this
+     * rank.  With real ranks the way out is to abort the communicators: RCCL then fails the pending operations here, the peers
+     * see the failure through their own RCCL error paths (or their caller's watchdog -- bench.py has one), and every later call
+     * on this context reports that the communicator is gone instead of hanging.  Disarmed when the graph has run through. */
+    struct AbortCommsOnError {
+        lfbm5d_ctx* c; bool armed;
+        ~AbortCommsOnError() {
+            if (!armed) return;
+            if (c->comm2) { (void)ncclCommAbort(c->comm2); c->comm2 = nullptr; }
+            if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+            (void)hipDeviceSynchronize();
+            c->err += " (multi-GPU step aborted: the RCCL communicators of this context were torn down, call lfbm5d_comm_init again)";
+        }
+    } abort_guard{c, nranks > 1 && !emulate};
+
+    std::vector<RankState> states(emulate ? (size_t)nranks : 1);
+    /* two-step jobs: SAIs no window of the first step touches (LFBM5D_MAX_WINDOWS) keep the first step's input as their basic
+     * estimate (bm5d.cpp:405 with den == 0), i.e. what the second step reads as noisy */
+    std::vector<unsigned> untouched_all;
+    if (two) for (unsigned st = 0; st < asize; st++) if (h_mask[st] && G.last_touch[0][st] < 0) untouched_all.push_back(st);
+    for (unsigned st : untouched_all)
+        HIPCK(c, hipMemcpyAsync(J.d_basic + (size_t)st * img, J.noisy[1] + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipEvent_t ev_setup = get_event(c);
+    HIPCK(c, hipEventRecord(ev_setup, s));   /* the caller's colour transforms and zeroed sums */
+    for (size_t r = 0; r < states.size(); r++) {
+        RankState& S = states[r];
+        S.rank = emulate ? (int)r : c->rank;
+        S.x = r == 0 ? c : c->lanes[r - 1];
+        for (int sl = 0; sl < 2; sl++) { S.g_num[sl] = J.g_num[sl]; S.g_den[sl] = J.g_den[sl]; }
+        S.basic = J.d_basic;
+        if (r > 0) {   /* an emulated rank keeps light-field sums (and a basic estimate) of its own, like a real one */
+            DevBuf* nb[2] = {&S.x->g_num, &S.x->g_num2}; DevBuf* db[2] = {&S.x->g_den, &S.x->g_den2};
+            for (int sl = 0; sl < J.n_steps; sl++) {
+                HIPCK(c, nb[sl]->reserve(asize * img * sizeof(float)));
+                HIPCK(c, db[sl]->reserve(asize * img * sizeof(float)));
+                S.g_num[sl] = nb[sl]->as<float>(); S.g_den[sl] = db[sl]->as<float>();
+                HIPCK(c, hipMemsetAsync(S.g_num[sl], 0, asize * img * sizeof(float), S.x->stream));
+                HIPCK(c, hipMemsetAsync(S.g_den[sl], 0, asize * img * sizeof(float), S.x->stream));
+            }
+            if (two) {
+                HIPCK(c, S.x->e_basic.reserve(asize * img * sizeof(float)));
+                S.basic = S.x->e_basic.as<float>();
+                HIPCK(c, hipStreamWaitEvent(S.x->stream, ev_setup, 0));
+            }
+        }
+        if (r > 0)
+            for (unsigned st : untouched_all)
+                HIPCK(c, hipMemcpyAsync(S.basic + (size_t)st * img, J.noisy[1] + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, S.x->stream));
+        S.lanes.resize((size_t)lanes_per_rank);
+        for (int l = 0; l < lanes_per_rank; l++) {
+            lfbm5d_ctx* lx = emulate ? S.x : (l == 0 ? c : c->lanes[(size_t)l - 1]);
+            if (lane_buffers(lx, S.lanes[(size_t)l])) return 1;
+            if (lx != c) HIPCK(c, hipStreamWaitEvent(lx->stream, ev_setup, 0));
+        }
+        if (nranks > 1)
+            for (int ch = 0; ch < 2; ch++) {
+                if (!S.x->cs[ch]) HIPCK(c, hipStreamCreateWithFlags(&S.x->cs[ch], hipStreamNonBlocking));
+                HIPCK(c, hipStreamWaitEvent(S.x->cs[ch], ev_setup, 0));
+                if (r > 0) {   /* an emulated rank's own buffers are prepared on its stream */
+                    hipEvent_t e = get_event(c);
+                    HIPCK(c, hipEventRecord(e, S.x->stream));
+                    HIPCK(c, hipStreamWaitEvent(S.x->cs[ch], e, 0));
                 }
-                if (t < best_f || (t == best_f && aff > best_aff)) { best_f = t; best_r = r; best_aff = aff; }
             }
-            unsigned t = rank_free[(size_t)best_r];
-            for (size_t w = a; w <= b; w++) {
-                unsigned ready = t;
-                for (int p : G.prev[w]) if (p >= 0 && (size_t)p < a) ready = std::max(ready, fin[(size_t)p]);
-                t = ready + 1; fin[w] = t; G.rank[w] = best_r;
+    }
+    auto local = [&](int r) -> RankState* { return emulate ? &states[(size_t)r] : (r == c->rank ? &states[0] : nullptr); };
+    if (c->h_counts_cap < NN) {
+        if (c->h_counts) (void)hipHostFree(c->h_counts);
+        c->h_counts = nullptr; c->h_counts_cap = 0;
+        HIPCK(c, hipHostMalloc((void**)&c->h_counts, NN * sizeof(unsigned)));
+        c->h_counts_cap = NN;
+    }
+    std::vector<hipEvent_t> done(NN, nullptr);
+    std::vector<hipEvent_t> arrived(G.xfers.size(), nullptr);   /* per message: it has reached its consumer's rank */
+    /* message of (producer node, SAI slot) / of (SAI, reader rank) */
+    std::vector<std::vector<int>> sum_xfer(NN);
+    for (size_t n = 0; n < NN; n++) sum_xfer[n].assign(G.nodes[n].sai.size(), -1);
+    std::vector<std::vector<int>> basic_xfer(two ? (size_t)nranks : 0);
+    for (auto& v : basic_xfer) v.assign(asize, -1);
+    for (size_t xi = 0; xi < G.xfers.size(); xi++) {
+        const plan::Xfer& X = G.xfers[xi];
+        if (X.kind == 0) {
+            const plan::Node& pn = G.nodes[X.from];
+            sum_xfer[X.from][(size_t)(std::find(pn.sai.begin(), pn.sai.end(), X.sai) - pn.sai.begin())] = (int)xi;
+        } else basic_xfer[(size_t)X.to_rank][X.sai] = (int)xi;
+    }
+    std::vector<unsigned long long> win_bits(NN, 0);
+    std::vector<char> mine(NN, 0);
+    ncclComm_t comms[2] = {c->comm, c->comm2 ? c->comm2 : c->comm};
+    size_t xi = 0, n_msgs = 0;
+    for (unsigned n : G.order) {
+        const plan::Node& nd = G.nodes[n];
+        const int sl = nd.s, r = nd.rank;
+        const Geo& g = geo[sl];
+        RankState* S = local(r);
+        if (S) {
+            const Lane& Lw = S->lanes[(size_t)nd.lane];
+            hipStream_t ls = Lw.x->stream;
+            auto wait_node = [&](int p) -> int {   /* a node of this rank: same lane = stream order */
+                if (G.nodes[(size_t)p].lane != nd.lane) HIPCK(c, hipStreamWaitEvent(ls, done[(size_t)p], 0));
+                return 0;
+            };
+            for (size_t i = 0; i < nd.sai.size(); i++) {
+                const int pw = nd.prev[i];
+                if (pw >= 0) {
+                    if (G.nodes[(size_t)pw].rank == r) { if (wait_node(pw)) return 1; }
+                    else {
+                        const plan::Node& pn = G.nodes[(size_t)pw];
+                        const size_t j = (size_t)(std::find(pn.sai.begin(), pn.sai.end(), nd.sai[i]) - pn.sai.begin());
+                        HIPCK(c, hipStreamWaitEvent(ls, arrived[(size_t)sum_xfer[(size_t)pw][j]], 0));
+                    }
+                }
+                if (two && sl == 1) {   /* the SAI's basic estimate: finalised behind the first step's last window on it */
+                    const int f = G.last_touch[0][nd.sai[i]];
+                    if (f >= 0) {
+                        if (G.nodes[(size_t)f].rank == r) { if (wait_node(f)) return 1; }
+                        else HIPCK(c, hipStreamWaitEvent(ls, arrived[(size_t)basic_xfer[(size_t)r][nd.sai[i]]], 0));
+                    }
+                }
             }
-            rank_free[(size_t)best_r] = t;
-            a = b + 1;
+            /* one angular window around SAI (ps, pt): bm5d.cpp:215-402 -- padding, the centre pass, its coverage count, and
+             * (optimistic completion) the window's sums back into the light field */
+            int cs_w, mins, maxs, ct_w, mint, maxt;
+            search_window((int)nd.ps, aheight, J.an[sl], cs_w, mins, maxs);
+            search_window((int)nd.pt, awidth, J.an[sl], ct_w, mint, maxt);
+            const unsigned cst_w = ang_major == LFBM5D_ROWMAJOR ? (unsigned)cs_w * g.asw + (unsigned)ct_w : (unsigned)cs_w + (unsigned)ct_w * g.asw;
+            std::vector<unsigned> mask_w(g.Aw, 0), proc_w(g.Aw, 0);
+            SaiList wl; wl.n = g.Aw;
+            for (unsigned si = 0; si < g.asw; si++)
+                for (unsigned ti = 0; ti < g.asw; ti++) {
+                    const unsigned Ss = si + (unsigned)mins, T = ti + (unsigned)mint;
+                    const unsigned st = ang_major == LFBM5D_ROWMAJOR ? Ss * awidth + T : Ss + T * aheight;
+                    const unsigned slot = ang_major == LFBM5D_ROWMAJOR ? si * g.asw + ti : si + ti * g.asw;
+                    mask_w[slot] = h_mask[st];
+                    wl.st[slot] = h_mask[st] ? st : 0xffffffffu;
+                    if (h_mask[st]) win_bits[n] |= 1ull << slot;
+                    proc_w[slot] = !h_mask[st];
+                }
+            const bool wien = J.step[sl] == 2;
+            HIPCK(c, launch_symetrize_multi(ls, J.noisy[sl], img, Lw.w_noisy, g.imgb, wl, W, H, C, g.nHW));
+            if (wien) HIPCK(c, launch_symetrize_multi(ls, S->basic, img, Lw.w_basic, g.imgb, wl, W, H, C, g.nHW));
+            HIPCK(c, launch_symetrize_multi(ls, S->g_num[sl], img, Lw.w_num, g.imgb, wl, W, H, C, g.nHW));
+            HIPCK(c, launch_symetrize_multi(ls, S->g_den[sl], img, Lw.w_den, g.imgb, wl, W, H, C, g.nHW));
+            lfbm5d_params Pw = *J.P[sl];
+            Pw.tau_4D = nd.tau4;
+            Lw.x->gslot = sl;
+            const int prc = pass_impl(Lw.x, J.step[sl], &Pw, g.asw, g.asw, g.wb, g.hb, C, Lw.w_noisy, wien ? Lw.w_basic : nullptr, Lw.w_num, Lw.w_den,
+                                      mask_w.data(), proc_w.data(), cst_w, cst_w);
+            Lw.x->gslot = 0;
+            if (prc) { if (Lw.x != c) c->err = Lw.x->err; return 1; }
+            /* coverage count of the pass (LF_denoised_percent, utilities_LF.cpp:967-995) -> pinned memory */
+            HIPCK(c, hipMemsetAsync(Lw.d_small, 0, sizeof(unsigned), ls));
+            HIPCK(c, launch_count_denoised(ls, Lw.w_den, g.imgb, g.Aw, win_bits[n], W, H, C, g.nHW, J.P[sl]->k, Lw.d_small));
+            HIPCK(c, hipMemcpyAsync(c->h_counts + n, Lw.d_small, sizeof(unsigned), hipMemcpyDeviceToHost, ls));
+            HIPCK(c, launch_unsymetrize_multi(ls, S->g_num[sl], img, Lw.w_num, g.imgb, wl, W, H, C, g.nHW));
+            HIPCK(c, launch_unsymetrize_multi(ls, S->g_den[sl], img, Lw.w_den, g.imgb, wl, W, H, C, g.nHW));
+            if (!nd.fin.empty()) {   /* two-step jobs: these SAIs' first-step sums are final -> their basic estimate as the second step reads it */
+                SaiList fl; fl.n = 0;
+                for (unsigned st : nd.fin) fl.st[fl.n++] = st;
+                const bool colour = C == 3 && J.P[0]->color_space != LFBM5D_RGB;
+                HIPCK(c, launch_finalize_multi(ls, S->g_num[0], S->g_den[0], J.noisy[0], S->basic, img, fl, J.P[0]->color_space, W * H, colour ? 1 : 0));
+            }
+            done[n] = get_event(c);
+            HIPCK(c, hipEventRecord(done[n], ls));
+            mine[n] = 1;
+            if (Lw.x != c) { c->lane_windows += 1; c->stats.lane_windows += 1; }
+        }
+        /* the messages this window's result feeds, in the order every rank issues them */
+        for (; xi < G.xfers.size() && G.xfers[xi].from == n; xi++) {
+            const plan::Xfer& X = G.xfers[xi];
+            /* one channel when the second communicator could not be created: two streams on one communicator would break the
+             * common issue order the exchange relies on */
+            const int ra = r, rb = X.to_rank, ch = (emulate || c->comm2) ? X.channel : 0;
+            RankState* Sa = local(ra); RankState* Sb = local(rb);
+            const size_t off = (size_t)X.sai * img;
+            const int xsl = nd.s;
+            if (emulate) {   /* both ends live here: the message is a device copy between the two ranks' buffers */
+                hipStream_t xs = Sb->x->cs[ch];
+                HIPCK(c, hipStreamWaitEvent(xs, done[n], 0));
+                if (X.kind == 0) {
+                    HIPCK(c, hipMemcpyAsync(Sb->g_num[xsl] + off, Sa->g_num[xsl] + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                    HIPCK(c, hipMemcpyAsync(Sb->g_den[xsl] + off, Sa->g_den[xsl] + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                } else
+                    HIPCK(c, hipMemcpyAsync(Sb->basic + off, Sa->basic + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                arrived[xi] = get_event(c);
+                HIPCK(c, hipEventRecord(arrived[xi], xs));
+                n_msgs++;
+            } else if (Sa || Sb) {
+                hipStream_t xs = c->cs[ch];
+                RankState* Sm = Sa ? Sa : Sb;
+                if (Sa) HIPCK(c, hipStreamWaitEvent(xs, done[n], 0));
+                bool ok = ncclGroupStart() == ncclSuccess;
+                if (X.kind == 0) {
+                    if (Sa) ok = ok && ncclSend(Sm->g_num[xsl] + off, img, ncclFloat, rb, comms[ch], xs) == ncclSuccess
+                                    && ncclSend(Sm->g_den[xsl] + off, img, ncclFloat, rb, comms[ch], xs) == ncclSuccess;
+                    else    ok = ok && ncclRecv(Sm->g_num[xsl] + off, img, ncclFloat, ra, comms[ch], xs) == ncclSuccess
+                                    && ncclRecv(Sm->g_den[xsl] + off, img, ncclFloat, ra, comms[ch], xs) == ncclSuccess;
+                } else {
+                    if (Sa) ok = ok && ncclSend(Sm->basic + off, img, ncclFloat, rb, comms[ch], xs) == ncclSuccess;
+                    else    ok = ok && ncclRecv(Sm->basic + off, img, ncclFloat, ra, comms[ch], xs) == ncclSuccess;
+                }
+                ok = ncclGroupEnd() == ncclSuccess && ok;
+                if (!ok) return fail(c, "RCCL send / recv of a window's SAI failed");
+                if (Sb) { arrived[xi] = get_event(c); HIPCK(c, hipEventRecord(arrived[xi], xs)); }
+                n_msgs++;
+            }
         }
     }
-    /* greedy list schedule in unit window time: every window on the lane of its owner that is free first; ties go to
-     * the lane of its latest predecessor (no event needed) */
-    std::vector<unsigned> finish(NW, 0), lane_free((size_t)std::max(1, world) * (size_t)n_lanes, 0);
-    for (size_t w = 0; w < NW; w++) {
-        unsigned ready = 0; int pref = -1;
-        for (int p : G.prev[w]) if (p >= 0 && finish[p] >= ready) { ready = finish[p]; pref = G.rank[p] == G.rank[w] ? G.lane[p] : -1; }
-        int best_l = 0; unsigned best_t = ~0u;
-        for (int l = 0; l < n_lanes; l++) {
-            const unsigned t = std::max(ready, lane_free[(size_t)G.rank[w] * n_lanes + l]);
-            if (t < best_t || (t == best_t && l == pref)) { best_t = t; best_l = l; }
-        }
-        G.lane[w] = best_l; G.start[w] = (int)best_t; finish[w] = best_t + 1;
-        lane_free[(size_t)G.rank[w] * n_lanes + best_l] = best_t + 1;
+    /* drain: every lane, every exchange stream */
+    for (RankState& S : states) {
+        for (Lane& Lq : S.lanes) HIPCK(c, hipStreamSynchronize(Lq.x->stream));
+        for (int ch = 0; ch < 2; ch++) if (S.x->cs[ch]) HIPCK(c, hipStreamSynchronize(S.x->cs[ch]));
     }
-    /* messages, in the order every rank issues them: by producer window, then SAI slot.  Two channels (communicator +
-     * stream) alternate with the producer's chain: a rank receives its inputs from the chain before its own on one
-     * channel and sends its outputs on the other, so a send that is ready early never queues behind a receive that
-     * completes late (plan order is not time order once rows of windows overlap) */
-    for (size_t w = 0; w < NW; w++)
-        for (size_t i = 0; i < G.sai[w].size(); i++) {
-            const int n = G.next[w][i];
-            if (n >= 0 && G.rank[n] != G.rank[w]) G.xfers.push_back({(unsigned)w, (unsigned)n, G.sai[w][i], (int)(G.chain[w] & 1u)});
+    HIPCK(c, hipStreamSynchronize(s));
+    int complete = 1;
+    for (size_t n = 0; n < NN; n++) {
+        if (!mine[n]) continue;
+        const int sl = G.nodes[n].s;
+        const unsigned n_mask = (unsigned)__builtin_popcountll(win_bits[n]);
+        const float pct = (float)c->h_counts[n] * 100.0f / (float)n_mask / (float)(H - J.P[sl]->k + 1) / (float)(W - J.P[sl]->k + 1);
+        if (!(pct >= 100.0f)) complete = 0;
+    }
+    if (std::getenv("LFBM5D_FORCE_REDO") && nranks == 1 && !two) complete = 0;   /* test hook: exercise the sequential redo */
+    /* fold the other lanes' / emulated ranks' counters and event times into this context */
+    auto fold_all = [&](lfbm5d_ctx* x) -> int {
+        drain_events(x);
+        for (int sl = 0; sl < J.n_steps; sl++)
+            if (fold_counters(x, J.P[sl], geo[sl].Aw, C, J.step[sl], sl)) { c->err = x->err; return 1; }
+        return 0;
+    };
+    for (lfbm5d_ctx* x : c->lanes) {
+        if (x->pending.empty() && x->stats.passes == 0) continue;
+        if (fold_all(x)) return 1;
+        c->stats.passes += x->stats.passes; c->stats.groups += x->stats.groups;
+        c->stats.stack_patches += x->stats.stack_patches; c->stats.sadct_groups += x->stats.sadct_groups;
+        c->stats.algorithmic_bytes += x->stats.algorithmic_bytes;
+        c->stats.ms_bm += x->stats.ms_bm; c->stats.ms_group += x->stats.ms_group; c->stats.ms_aggregate += x->stats.ms_aggregate;
+        c->stats.launches_group += x->stats.launches_group; c->stats.launches_aggregate += x->stats.launches_aggregate;
+        std::memset(&x->stats, 0, sizeof(x->stats));
+    }
+    if (two && fold_all(c)) return 1;   /* (single steps: run_step folds slot 0 of this context itself) */
+    if (nranks > 1 && !emulate) {   /* all ranks must agree before the collective below */
+        HIPCK(c, c->small.reserve((asize + 8) * sizeof(unsigned)));
+        int* d_flag = reinterpret_cast<int*>(c->small.as<unsigned>());
+        HIPCK(c, hipMemcpyAsync(d_flag, &complete, sizeof(int), hipMemcpyHostToDevice, s));
+        if (ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(flag) failed");
+        HIPCK(c, hipMemcpyAsync(&complete, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCK(c, hipStreamSynchronize(s));
+    }
+    abort_guard.armed = false;   /* every exchange of the graph has completed; what follows are plain collectives */
+    *complete_out = complete;
+    if (!complete) return 0;
+    for (size_t n = 0; n < NN; n++) if (mine[n]) c->stats.windows += 1;
+    c->stats.messages += n_msgs;
+    if (nranks > 1) {
+        /* Every SAI's final sums live on the rank of the last window that touched it: that rank forms the SAI's estimate
+         * (bm5d.cpp:405 / :1106), then the estimates are exchanged so that every rank ends with the whole result; two-step jobs
+         * do the same with the basic estimates, which live where they were finalised */
+        const int ls = J.n_steps - 1;
+        std::vector<unsigned> own(asize);
+        for (RankState& S : states) {
+            const float* sub = J.step[ls] == 1 ? J.noisy[ls] : S.basic;
+            for (unsigned st = 0; st < asize; st++)
+                own[st] = (h_mask[st] && G.last_touch[ls][st] >= 0 && G.nodes[(size_t)G.last_touch[ls][st]].rank == S.rank) ? 1u : 0u;
+            HIPCK(c, S.x->d_own.reserve(asize * sizeof(unsigned)));
+            HIPCK(c, hipMemcpyAsync(S.x->d_own.p, own.data(), asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
+            HIPCK(c, launch_estimate_lf(s, S.g_num[ls], S.g_den[ls], sub, J.d_out, img, asize, S.x->d_own.as<unsigned>()));
+            HIPCK(c, hipStreamSynchronize(s));   /* own is reused */
+            if (two && emulate && S.x != c)      /* the basic estimates this emulated rank finalised: what the broadcast below moves between real ranks */
+                for (unsigned st = 0; st < asize; st++)
+                    if (h_mask[st] && G.last_touch[0][st] >= 0 && G.nodes[(size_t)G.last_touch[0][st]].rank == S.rank)
+                        HIPCK(c, hipMemcpyAsync(J.d_basic + (size_t)st * img, S.basic + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
+        if (!emulate) {
+            hipEvent_t e0 = get_event(c), e1 = get_event(c);
+            HIPCK(c, hipEventRecord(e0, s));
+            bool ok = ncclGroupStart() == ncclSuccess;
+            for (unsigned st = 0; st < asize && ok; st++) {
+                if (!h_mask[st]) continue;
+                if (G.last_touch[ls][st] >= 0)
+                    ok = ncclBroadcast(J.d_out + (size_t)st * img, J.d_out + (size_t)st * img, img, ncclFloat, G.nodes[(size_t)G.last_touch[ls][st]].rank, c->comm, s) == ncclSuccess;
+                if (ok && two && G.last_touch[0][st] >= 0)
+                    ok = ncclBroadcast(J.d_basic + (size_t)st * img, J.d_basic + (size_t)st * img, img, ncclFloat, G.nodes[(size_t)G.last_touch[0][st]].rank, c->comm, s) == ncclSuccess;
+            }
+            ok = ncclGroupEnd() == ncclSuccess && ok;
+            if (!ok) return fail(c, "ncclBroadcast of the estimates failed");
+            HIPCK(c, hipEventRecord(e1, s));
+            HIPCK(c, hipStreamSynchronize(s));
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->stats.ms_comm += ms;
+        }
+        /* SAIs no window touched (LFBM5D_MAX_WINDOWS) keep the step's input, like the single-rank estimate */
+        for (unsigned st = 0; st < asize; st++) own[st] = (h_mask[st] && G.last_touch[ls][st] < 0) ? 1u : 0u;
+        if (std::count(own.begin(), own.end(), 1u)) {
+            HIPCK(c, hipMemcpyAsync(c->d_own.p, own.data(), asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
+            HIPCK(c, launch_estimate_lf(s, J.g_num[ls], J.g_den[ls], J.step[ls] == 1 ? J.noisy[ls] : J.d_basic, J.d_out, img, asize, c->d_own.as<unsigned>()));
+            HIPCK(c, hipStreamSynchronize(s));
+        }
+    }
+    return 0;
 }
 
+/* bm5d.cpp:165-407 (step 1) / :861-1106 (step 2) on device-resident buffers */
 int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
              float* d_basic, float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight,
              unsigned an, unsigned W, unsigned H, unsigned C) {
@@ -983,24 +1219,17 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     if (by_rows && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
 
     /* ---- Graph form (colour light fields; the default on one GPU and on several): the planned windows as a dependency
-     * graph (StepGraph above) executed on lanes -- a lane = stream + window buffers + per-pass work buffers.  On one
-     * GPU the lanes only let one window's block matching overlap another window's transform and aggregation; on
-     * several GPUs each rank runs the chains of windows it owns and the SAIs a window needs from another rank's window
-     * arrive as point-to-point messages (RCCL send / recv over xGMI).  Either way every window sees exactly the num /
-     * den the window-after-window order would show it: the result is bit-identical to one lane on one GPU.
-     * The reference decides after every pass whether the window is complete (coverage count, bm5d.cpp:370-382); for
-     * colour light fields one centre pass always suffices.  The graph form assumes that,
-     * copies every window's count to pinned memory and checks them all at the end: if a window would have needed
-     * another pass, a single-GPU step is redone in the sequential form (never observed) and a multi-GPU step fails
-     * with a message; greyscale light fields, where further passes are the rule, take the sequential / row-sharded
-     * forms directly. */
+     * graph (lfbm5d_plan.h) executed by run_graph above.  If a window would have needed another pass, a single-GPU step is
+     * redone in the sequential form (never observed) and a multi-GPU step fails with a message; greyscale light fields,
+     * where further passes are the rule, take the sequential / row-sharded forms directly. */
     const int nranks = emu > 1 ? emu : c->world;
     c->lane_windows = 0;
-    StepGraph G;
+    plan::Graph G;
     if (c->tiles > 1 && nranks > 1) return fail(c, "the tile mode runs on one GPU");
     bool graph_mode = planned && !by_rows && !by_blocks && C == 3 && (n_lanes > 1 || nranks > 1) && c->tiles <= 1;
     if (graph_mode) {
-        build_graph(h_mask, awidth, aheight, an, ang_major, tau_4D, nranks, emu > 1 ? 1 : n_lanes, max_windows, G);
+        const plan::StepDesc sd = {an, tau_4D, 1u};
+        plan::build(h_mask, awidth, aheight, ang_major, &sd, 1, nranks, emu > 1 ? 1 : n_lanes, max_windows, G);
         if (!G.centre_ok) graph_mode = false;   /* empty window centre: the first pass is chosen from device data */
     }
     if (!graph_mode && nranks > 1 && !by_rows && !by_blocks)
@@ -1009,211 +1238,14 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     if (graph_mode && c->world > 1 && emu <= 1 && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
     bool graph_done = false;
     if (graph_mode) {
-        const size_t NW = G.plan.size();
-        const bool emulate = emu > 1;
-        /* lanes the schedule actually uses (a 3x3 light field is one window: no extra lane, no extra buffers) */
-        int lanes_used = 1;
-        for (size_t w = 0; w < NW; w++) lanes_used = std::max(lanes_used, G.lane[w] + 1);
-        const int lanes_per_rank = emulate ? 1 : lanes_used;
-        const size_t need_ctx = emulate ? (size_t)emu - 1 : (size_t)lanes_used - 1;
-        while (c->lanes.size() < need_ctx) {
-            std::string e;
-            lfbm5d_ctx* x = new_ctx(c->device, e);
-            if (!x) return fail(c, "lane context: " + e);
-            c->lanes.push_back(x);
-        }
-        struct RankState { int rank; lfbm5d_ctx* x; float* g_num; float* g_den; std::vector<Lane> lanes; };
-        /* An error return in the middle of the graph (a failed HIP call, an RCCL call that reports an error) would leave
-         * this rank's queued sends / receives waiting for peers that will never get their counterparts -- and the peers
-         * waiting for this rank.  With real ranks the way out is to abort the communicators: RCCL then fails the pending
-         * operations here, the peers see the failure through their own RCCL error paths (or their caller's watchdog --
-         * bench.py has one), and every later call on this context reports that the communicator is gone instead of
-         * hanging.  Disarmed when the graph has run through. */
-        struct AbortCommsOnError {
-            lfbm5d_ctx* c; bool armed;
-            ~AbortCommsOnError() {
-                if (!armed) return;
-                if (c->comm2) { (void)ncclCommAbort(c->comm2); c->comm2 = nullptr; }
-                if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
-                (void)hipDeviceSynchronize();
-                c->err += " (multi-GPU step aborted: the RCCL communicators of this context were torn down, call lfbm5d_comm_init again)";
-            }
-        } abort_guard{c, nranks > 1 && !emulate};
-        std::vector<RankState> states(emulate ? (size_t)emu : 1);
-        hipEvent_t ev_setup = get_event(c);
-        HIPCK(c, hipEventRecord(ev_setup, s));   /* colour transform and the zeroed num / den */
-        for (size_t r = 0; r < states.size(); r++) {
-            RankState& S = states[r];
-            S.rank = emulate ? (int)r : c->rank;
-            S.x = r == 0 ? c : c->lanes[r - 1];
-            S.g_num = g_num; S.g_den = g_den;
-            if (r > 0) {   /* an emulated rank keeps light-field sums of its own, like a real one */
-                HIPCK(c, S.x->g_num.reserve(asize * img * sizeof(float)));
-                HIPCK(c, S.x->g_den.reserve(asize * img * sizeof(float)));
-                S.g_num = S.x->g_num.as<float>(); S.g_den = S.x->g_den.as<float>();
-                HIPCK(c, hipMemsetAsync(S.g_num, 0, asize * img * sizeof(float), S.x->stream));
-                HIPCK(c, hipMemsetAsync(S.g_den, 0, asize * img * sizeof(float), S.x->stream));
-            }
-            S.lanes.resize((size_t)lanes_per_rank);
-            for (int l = 0; l < lanes_per_rank; l++) {
-                lfbm5d_ctx* lx = emulate ? S.x : (l == 0 ? c : c->lanes[(size_t)l - 1]);
-                if (lane_buffers(lx, S.lanes[(size_t)l])) return 1;
-                S.lanes[(size_t)l].g_num = S.g_num; S.lanes[(size_t)l].g_den = S.g_den;
-                if (lx != c) HIPCK(c, hipStreamWaitEvent(lx->stream, ev_setup, 0));
-            }
-            if (nranks > 1)
-                for (int ch = 0; ch < 2; ch++) {
-                    if (!S.x->cs[ch]) HIPCK(c, hipStreamCreateWithFlags(&S.x->cs[ch], hipStreamNonBlocking));
-                    HIPCK(c, hipStreamWaitEvent(S.x->cs[ch], ev_setup, 0));
-                }
-        }
-        auto local = [&](int r) -> RankState* { return emulate ? &states[(size_t)r] : (r == c->rank ? &states[0] : nullptr); };
-        if (c->h_counts_cap < NW) {
-            if (c->h_counts) (void)hipHostFree(c->h_counts);
-            c->h_counts = nullptr; c->h_counts_cap = 0;
-            HIPCK(c, hipHostMalloc((void**)&c->h_counts, NW * sizeof(unsigned)));
-            c->h_counts_cap = NW;
-        }
-        std::vector<hipEvent_t> done(NW, nullptr);
-        std::vector<std::vector<hipEvent_t>> arrived(NW);   /* [producer window][SAI slot]: the message reached its consumer's rank */
-        for (size_t w = 0; w < NW; w++) arrived[w].assign(G.sai[w].size(), nullptr);
-        std::vector<WinState> wss(NW);
-        std::vector<char> mine(NW, 0);
-        ncclComm_t comms[2] = {c->comm, c->comm2 ? c->comm2 : c->comm};
-        size_t xi = 0, n_msgs = 0;
-        for (size_t w = 0; w < NW; w++) {
-            const int r = G.rank[w];
-            RankState* S = local(r);
-            if (S) {
-                const Lane& Lw = S->lanes[(size_t)G.lane[w]];
-                hipStream_t ls = Lw.x->stream;
-                for (size_t i = 0; i < G.sai[w].size(); i++) {
-                    const int pw = G.prev[w][i];
-                    if (pw < 0) continue;
-                    if (G.rank[pw] == r) { if (G.lane[pw] != G.lane[w]) HIPCK(c, hipStreamWaitEvent(ls, done[(size_t)pw], 0)); }
-                    else {
-                        const size_t j = (size_t)(std::find(G.sai[(size_t)pw].begin(), G.sai[(size_t)pw].end(), G.sai[w][i]) - G.sai[(size_t)pw].begin());
-                        HIPCK(c, hipStreamWaitEvent(ls, arrived[(size_t)pw][j], 0));
-                    }
-                }
-                WinState& ws = wss[w];
-                ws.h_count_dst = c->h_counts + w;
-                if (win_begin(Lw, G.ps[w], G.pt[w], G.tau4[w], ws)) return 1;
-                /* optimistic completion: the window's sums go back to the light field right away */
-                HIPCK(c, launch_unsymetrize_multi(ls, Lw.g_num, img, Lw.w_num, imgb, ws.sl, W, H, C, nHW));
-                HIPCK(c, launch_unsymetrize_multi(ls, Lw.g_den, img, Lw.w_den, imgb, ws.sl, W, H, C, nHW));
-                done[w] = get_event(c);
-                HIPCK(c, hipEventRecord(done[w], ls));
-                mine[w] = 1;
-                if (Lw.x != c) { c->lane_windows += 1; c->stats.lane_windows += 1; }
-            }
-            /* the messages this window's result feeds, in the order every rank issues them */
-            for (; xi < G.xfers.size() && G.xfers[xi].from_w == w; xi++) {
-                const StepGraph::Xfer& X = G.xfers[xi];
-                /* one channel when the second communicator could not be created: two streams on one communicator would
-                 * break the common issue order the exchange relies on */
-                const int ra = r, rb = G.rank[X.to_w], ch = (emulate || c->comm2) ? X.channel : 0;
-                RankState* Sa = local(ra); RankState* Sb = local(rb);
-                const size_t j = (size_t)(std::find(G.sai[w].begin(), G.sai[w].end(), X.sai) - G.sai[w].begin());
-                const size_t off = (size_t)X.sai * img;
-                if (emulate) {   /* both ends live here: the message is a device copy between the two ranks' sums */
-                    hipStream_t xs = Sb->x->cs[ch];
-                    HIPCK(c, hipStreamWaitEvent(xs, done[w], 0));
-                    HIPCK(c, hipMemcpyAsync(Sb->g_num + off, Sa->g_num + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
-                    HIPCK(c, hipMemcpyAsync(Sb->g_den + off, Sa->g_den + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
-                    arrived[w][j] = get_event(c);
-                    HIPCK(c, hipEventRecord(arrived[w][j], xs));
-                    n_msgs++;
-                } else if (Sa || Sb) {
-                    hipStream_t xs = c->cs[ch];
-                    if (Sa) HIPCK(c, hipStreamWaitEvent(xs, done[w], 0));
-                    bool ok = ncclGroupStart() == ncclSuccess;
-                    if (Sa) ok = ok && ncclSend(g_num + off, img, ncclFloat, rb, comms[ch], xs) == ncclSuccess
-                                    && ncclSend(g_den + off, img, ncclFloat, rb, comms[ch], xs) == ncclSuccess;
-                    else    ok = ok && ncclRecv(g_num + off, img, ncclFloat, ra, comms[ch], xs) == ncclSuccess
-                                    && ncclRecv(g_den + off, img, ncclFloat, ra, comms[ch], xs) == ncclSuccess;
-                    ok = ncclGroupEnd() == ncclSuccess && ok;
-                    if (!ok) return fail(c, "RCCL send / recv of a window's SAI failed");
-                    if (Sb) { arrived[w][j] = get_event(c); HIPCK(c, hipEventRecord(arrived[w][j], xs)); }
-                    n_msgs++;
-                }
-            }
-        }
-        /* drain: every lane, every exchange stream */
-        for (RankState& S : states) {
-            for (Lane& Lq : S.lanes) HIPCK(c, hipStreamSynchronize(Lq.x->stream));
-            for (int ch = 0; ch < 2; ch++) if (S.x->cs[ch]) HIPCK(c, hipStreamSynchronize(S.x->cs[ch]));
-        }
-        HIPCK(c, hipStreamSynchronize(s));
+        GraphJob J;
+        J.n_steps = 1; J.step[0] = step; J.P[0] = P; J.an[0] = an; J.noisy[0] = d_noisy; J.d_basic = d_basic;
+        J.g_num[0] = g_num; J.g_den[0] = g_den; J.d_out = d_out; J.d_mask = d_mask;
         int complete = 1;
-        for (size_t w = 0; w < NW; w++) {
-            if (!mine[w]) continue;
-            const unsigned n_mask = (unsigned)__builtin_popcountll(wss[w].win_bits);
-            const float pct = (float)c->h_counts[w] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
-            if (!(pct >= 100.0f)) complete = 0;
-        }
-        if (std::getenv("LFBM5D_FORCE_REDO") && nranks == 1) complete = 0;   /* test hook: exercise the sequential redo */
-        /* fold the other lanes' / emulated ranks' counters and event times into this context */
-        for (lfbm5d_ctx* x : c->lanes) {
-            if (x->pending.empty() && x->stats.passes == 0) continue;
-            drain_events(x);
-            if (fold_counters(x, P, Aw, C, step)) { c->err = x->err; return 1; }
-            c->stats.passes += x->stats.passes; c->stats.groups += x->stats.groups;
-            c->stats.stack_patches += x->stats.stack_patches; c->stats.sadct_groups += x->stats.sadct_groups;
-            c->stats.algorithmic_bytes += x->stats.algorithmic_bytes;
-            c->stats.ms_bm += x->stats.ms_bm; c->stats.ms_group += x->stats.ms_group; c->stats.ms_aggregate += x->stats.ms_aggregate;
-            c->stats.launches_group += x->stats.launches_group; c->stats.launches_aggregate += x->stats.launches_aggregate;
-            std::memset(&x->stats, 0, sizeof(x->stats));
-        }
-        if (nranks > 1 && !emulate) {   /* all ranks must agree before the collective below */
-            HIPCK(c, c->small.reserve((asize + 8) * sizeof(unsigned)));
-            int* d_flag = reinterpret_cast<int*>(c->small.as<unsigned>());
-            HIPCK(c, hipMemcpyAsync(d_flag, &complete, sizeof(int), hipMemcpyHostToDevice, s));
-            if (ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(flag) failed");
-            HIPCK(c, hipMemcpyAsync(&complete, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-            HIPCK(c, hipStreamSynchronize(s));
-        }
-        abort_guard.armed = false;   /* every exchange of the graph has completed; what follows are plain collectives */
+        if (run_graph(c, J, G, h_mask, awidth, aheight, ang_major, W, H, C, nranks, emu > 1, &complete)) return 1;
         if (complete) {
-            for (size_t w = 0; w < NW; w++) { c->last_windows.push_back(G.plan[w]); if (mine[w]) c->stats.windows += 1; }
+            for (const plan::Node& nd : G.nodes) c->last_windows.push_back(nd.pst);
             graph_done = true;
-            if (nranks > 1) {
-                /* Every SAI's final sums live on the rank of the last window that touched it: that rank forms the SAI's
-                 * estimate (bm5d.cpp:405), then the estimates are broadcast so that every rank ends with the whole result */
-                std::vector<unsigned> own(asize);
-                const float* sub = step == 1 ? d_noisy : d_basic;
-                for (RankState& S : states) {
-                    for (unsigned st = 0; st < asize; st++)
-                        own[st] = (h_mask[st] && G.last_touch[st] >= 0 && G.rank[(size_t)G.last_touch[st]] == S.rank) ? 1u : 0u;
-                    HIPCK(c, S.x->d_own.reserve(asize * sizeof(unsigned)));
-                    HIPCK(c, hipMemcpyAsync(S.x->d_own.p, own.data(), asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
-                    HIPCK(c, launch_estimate_lf(s, S.g_num, S.g_den, sub, d_out, img, asize, S.x->d_own.as<unsigned>()));
-                    HIPCK(c, hipStreamSynchronize(s));   /* own is reused */
-                }
-                if (!emulate) {
-                    hipEvent_t e0 = get_event(c), e1 = get_event(c);
-                    HIPCK(c, hipEventRecord(e0, s));
-                    bool ok = ncclGroupStart() == ncclSuccess;
-                    for (unsigned st = 0; st < asize && ok; st++) {
-                        if (!h_mask[st] || G.last_touch[st] < 0) continue;
-                        ok = ncclBroadcast(d_out + (size_t)st * img, d_out + (size_t)st * img, img, ncclFloat, G.rank[(size_t)G.last_touch[st]], c->comm, s) == ncclSuccess;
-                    }
-                    ok = ncclGroupEnd() == ncclSuccess && ok;
-                    if (!ok) return fail(c, "ncclBroadcast of the estimates failed");
-                    HIPCK(c, hipEventRecord(e1, s));
-                    HIPCK(c, hipStreamSynchronize(s));
-                    float ms = 0.0f;
-                    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->stats.ms_comm += ms;
-                }
-                /* SAIs no window touched (LFBM5D_MAX_WINDOWS) keep the step's input, like the single-rank estimate */
-                for (unsigned st = 0; st < asize; st++) own[st] = (h_mask[st] && G.last_touch[st] < 0) ? 1u : 0u;
-                if (std::count(own.begin(), own.end(), 1u)) {
-                    HIPCK(c, hipMemcpyAsync(c->d_own.p, own.data(), asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
-                    HIPCK(c, launch_estimate_lf(s, g_num, g_den, sub, d_out, img, asize, c->d_own.as<unsigned>()));
-                    HIPCK(c, hipStreamSynchronize(s));
-                }
-            }
-            c->stats.messages += n_msgs;
         } else if (nranks > 1) {
             return fail(c, "a window needed more than its centre pass: set LFBM5D_STEP_SHARDING=rows for this light field");
         } else {
@@ -1315,6 +1347,87 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     return fold_counters(c, P, Aw, C, step);
 }
 
+/* run_bm5d_1st_step followed by run_bm5d_2nd_step (main.cpp:195, :242) as ONE job: the windows of both steps form one
+ * dependency graph (lfbm5d_plan.h) -- a window of the second step starts when the basic estimate of each of its SAIs is final,
+ * not when the whole first step is -- and what the reference does between the two calls (estimate, inverse colour transform,
+ * forward colour transform: bm5d.cpp:405, :711-714, :827-830) happens SAI by SAI.  Bit-identical to the two calls.  Light fields
+ * the graph form does not cover (greyscale, an empty SAI at a window centre, tile mode, the data-driven schedule, the
+ * alternative multi-GPU schemes) take the two calls. */
+int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask, float* d_basic,
+                float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
+                unsigned C) {
+    const unsigned asize = awidth * aheight;
+    const char* emu_s = std::getenv("LFBM5D_EMULATE_WORLD");
+    const int emu = emu_s ? std::atoi(emu_s) : 0;
+    const char* lanes_s = std::getenv("LFBM5D_LANES");
+    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : 3));
+    const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
+    const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
+    const char* fused_s = std::getenv("LFBM5D_FUSED");
+    const int nranks = emu > 1 ? emu : c->world;
+    bool fused = C == 3 && c->tiles <= 1 && !std::getenv("LFBM5D_STEP_SHARDING") && !std::getenv("LFBM5D_DATA_DRIVEN_SCHEDULE") &&
+                 !(fused_s && fused_s[0] == '0') && P1->color_space == P2->color_space &&
+                 2 * an1 + 1 <= std::min(awidth, aheight) && 2 * an2 + 1 <= std::min(awidth, aheight);
+    plan::Graph G;
+    if (fused) {
+        if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return fail(c, "bad ang_major");
+        if (validate(c, 1, P1, 2 * an1 + 1, 2 * an1 + 1, C) || validate(c, 2, P2, 2 * an2 + 1, 2 * an2 + 1, C)) return 1;
+        if (P1->color_space > LFBM5D_RGB) return fail(c, "bad color space");
+        /* relative cost of a window pass of either step (scheduling model only; measured on the README configuration) */
+        const plan::StepDesc sd[2] = {{an1, P1->tau_4D, 10u}, {an2, P2->tau_4D, 9u}};
+        plan::build(h_mask, awidth, aheight, ang_major, sd, 2, nranks, emu > 1 ? 1 : n_lanes, max_windows, G);
+        if (!G.centre_ok || G.nodes.empty()) fused = false;
+    }
+    if (!fused) {
+        if (run_step(c, 1, P1, d_noisy, h_mask, nullptr, d_basic, ang_major, awidth, aheight, an1, W, H, C)) return 1;
+        return run_step(c, 2, P2, d_noisy, h_mask, d_basic, d_out, ang_major, awidth, aheight, an2, W, H, C);
+    }
+    if (c->world > 1 && emu <= 1 && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+    hipStream_t s = c->stream;
+    const size_t img = (size_t)C * W * H;
+    const bool colour = P1->color_space != LFBM5D_RGB;
+    HIPCK(c, c->d_mask.reserve(asize * sizeof(unsigned)));
+    unsigned* d_mask = c->d_mask.as<unsigned>();
+    HIPCK(c, hipMemcpyAsync(d_mask, h_mask, asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
+    GraphJob J;
+    J.n_steps = 2; J.step[0] = 1; J.step[1] = 2; J.P[0] = P1; J.P[1] = P2; J.an[0] = an1; J.an[1] = an2;
+    J.d_basic = d_basic; J.d_out = d_out; J.d_mask = d_mask;
+    /* what the first step reads: forward(noisy) (bm5d.cpp:133); what the second step reads: forward(inverse(that))
+     * (bm5d.cpp:713, :827): both live for the whole job, the second in a buffer of its own */
+    J.noisy[0] = d_noisy; J.noisy[1] = d_noisy;
+    if (colour) {
+        HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P1->color_space, W * H, 1));
+        HIPCK(c, c->n2.reserve(asize * img * sizeof(float)));
+        HIPCK(c, hipMemcpyAsync(c->n2.p, d_noisy, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));   /* (empty SAIs too) */
+        HIPCK(c, launch_color_roundtrip_lf(s, d_noisy, c->n2.as<float>(), img, asize, d_mask, P1->color_space, W * H));
+        J.noisy[1] = c->n2.as<float>();
+    }
+    DevBuf* nb[2] = {&c->g_num, &c->g_num2}; DevBuf* db[2] = {&c->g_den, &c->g_den2};
+    for (int sl = 0; sl < 2; sl++) {
+        HIPCK(c, nb[sl]->reserve(asize * img * sizeof(float)));
+        HIPCK(c, db[sl]->reserve(asize * img * sizeof(float)));
+        HIPCK(c, hipMemsetAsync(nb[sl]->p, 0, asize * img * sizeof(float), s));
+        HIPCK(c, hipMemsetAsync(db[sl]->p, 0, asize * img * sizeof(float), s));
+        J.g_num[sl] = nb[sl]->as<float>(); J.g_den[sl] = db[sl]->as<float>();
+    }
+    c->lane_windows = 0;
+    c->last_windows.clear();
+    int complete = 1;
+    if (run_graph(c, J, G, h_mask, awidth, aheight, ang_major, W, H, C, nranks, emu > 1, &complete)) return 1;
+    if (!complete) return fail(c, "a window needed more than its centre pass: run the two steps one after the other (LFBM5D_FUSED=0)");
+    for (const plan::Node& nd : G.nodes) c->last_windows.push_back(nd.pst);
+    /* final estimate (bm5d.cpp:1106) and the closing inverse colour transforms of both steps' outputs (bm5d.cpp:1414-1418) */
+    if (nranks == 1) HIPCK(c, launch_estimate_lf(s, J.g_num[1], J.g_den[1], d_basic, d_out, img, asize, d_mask));
+    if (colour) {
+        HIPCK(c, launch_color_lf(s, d_out, img, asize, d_mask, P1->color_space, W * H, 0));
+        HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P1->color_space, W * H, 0));
+        HIPCK(c, hipMemcpyAsync(d_noisy, c->n2.p, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P1->color_space, W * H, 0));
+    }
+    HIPCK(c, hipStreamSynchronize(s));
+    return 0;
+}
+
 } /* namespace */
 
 /* ============================================================================================ */
@@ -1355,9 +1468,10 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     if (c->comm2) ncclCommDestroy(c->comm2);
     if (c->comm) ncclCommDestroy(c->comm);
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
-    DevBuf* bufs[] = {&c->est, &c->refs, &c->rslot, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->gshape, &c->counters, &c->tb, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
-                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch, &c->scan_wgs, &c->scan_lcol};
+    for (GeomCache& g : c->gc) { g.refs.release(); g.rslot.release(); g.tb.release(); g.scan_wgs.release(); }
+    DevBuf* bufs[] = {&c->est, &c->g_num2, &c->g_den2, &c->n2, &c->e_basic, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
+                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->gshape, &c->counters, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch, &c->scan_lcol};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->h_small) (void)hipHostFree(c->h_small);
@@ -1413,26 +1527,56 @@ int lfbm5d_plan_graph(unsigned awidth, unsigned aheight, unsigned an, unsigned a
                       unsigned* out_rank, unsigned* out_lane, unsigned* out_start, unsigned cap) {
     if (!mask || !awidth || !aheight || 2 * an + 1 > awidth || 2 * an + 1 > aheight || world < 1 || lanes < 1) return -1;
     if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return -1;
-    StepGraph G;
-    build_graph(mask, awidth, aheight, an, ang_major, LFBM5D_SADCT, world, lanes, 0, G);
-    for (size_t i = 0; i < G.plan.size() && i < cap; i++) {
-        if (out_rank) out_rank[i] = (unsigned)G.rank[i];
-        if (out_lane) out_lane[i] = (unsigned)G.lane[i];
-        if (out_start) out_start[i] = (unsigned)G.start[i];
+    plan::Graph G;
+    const plan::StepDesc sd = {an, LFBM5D_SADCT, 1u};
+    plan::build(mask, awidth, aheight, ang_major, &sd, 1, world, lanes, 0, G);
+    for (size_t i = 0; i < G.nodes.size() && i < cap; i++) {
+        if (out_rank) out_rank[i] = (unsigned)G.nodes[i].rank;
+        if (out_lane) out_lane[i] = (unsigned)G.nodes[i].lane;
+        if (out_start) out_start[i] = G.nodes[i].start;
     }
-    return (int)G.plan.size();
+    return (int)G.nodes.size();
 }
 
 int lfbm5d_plan_messages(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask, int world,
                          unsigned* out, unsigned cap) {
     if (!mask || !awidth || !aheight || 2 * an + 1 > awidth || 2 * an + 1 > aheight || world < 1) return -1;
     if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return -1;
-    StepGraph G;
-    build_graph(mask, awidth, aheight, an, ang_major, LFBM5D_SADCT, world, 1, 0, G);
+    plan::Graph G;
+    const plan::StepDesc sd = {an, LFBM5D_SADCT, 1u};
+    plan::build(mask, awidth, aheight, ang_major, &sd, 1, world, 1, 0, G);
     for (size_t i = 0; i < G.xfers.size() && i < cap && out; i++) {
-        out[4 * i] = G.xfers[i].from_w; out[4 * i + 1] = G.xfers[i].to_w; out[4 * i + 2] = G.xfers[i].sai; out[4 * i + 3] = (unsigned)G.xfers[i].channel;
+        out[4 * i] = G.xfers[i].from; out[4 * i + 1] = (unsigned)G.xfers[i].to_node; out[4 * i + 2] = G.xfers[i].sai; out[4 * i + 3] = (unsigned)G.xfers[i].channel;
     }
     return (int)G.xfers.size();
+}
+
+int lfbm5d_plan_job(unsigned awidth, unsigned aheight, unsigned ang_major, const unsigned* mask, int n_steps, const unsigned* an,
+                    const unsigned* cost, int world, int lanes, unsigned* out_nodes, unsigned node_cap, unsigned* out_msgs, unsigned msg_cap,
+                    unsigned* out_counts) {
+    if (!mask || !awidth || !aheight || !an || world < 1 || lanes < 1 || n_steps < 1 || n_steps > 2) return -1;
+    if (ang_major != LFBM5D_ROWMAJOR && ang_major != LFBM5D_COLMAJOR) return -1;
+    plan::StepDesc sd[2];
+    for (int i = 0; i < n_steps; i++) {
+        if (2 * an[i] + 1 > awidth || 2 * an[i] + 1 > aheight) return -1;
+        sd[i] = {an[i], LFBM5D_SADCT, cost ? cost[i] : (n_steps == 2 ? (i == 0 ? 10u : 9u) : 1u)};
+    }
+    plan::Graph G;
+    plan::build(mask, awidth, aheight, ang_major, sd, n_steps, world, lanes, 0, G);
+    std::vector<unsigned> pos(G.nodes.size(), 0);
+    for (size_t i = 0; i < G.order.size(); i++) pos[G.order[i]] = (unsigned)i;
+    for (size_t i = 0; i < G.nodes.size() && i < node_cap && out_nodes; i++) {
+        const plan::Node& nd = G.nodes[i];
+        unsigned* o = out_nodes + 8 * i;
+        o[0] = (unsigned)nd.s; o[1] = nd.w; o[2] = nd.pst; o[3] = (unsigned)nd.rank; o[4] = (unsigned)nd.lane; o[5] = nd.start; o[6] = pos[i]; o[7] = nd.chain;
+    }
+    for (size_t i = 0; i < G.xfers.size() && i < msg_cap && out_msgs; i++) {
+        const plan::Xfer& X = G.xfers[i];
+        unsigned* o = out_msgs + 6 * i;
+        o[0] = (unsigned)X.kind; o[1] = X.from; o[2] = X.to_node < 0 ? 0xffffffffu : (unsigned)X.to_node; o[3] = (unsigned)X.to_rank; o[4] = X.sai; o[5] = (unsigned)X.channel;
+    }
+    if (out_counts) { out_counts[0] = (unsigned)G.nodes.size(); out_counts[1] = (unsigned)G.xfers.size(); out_counts[2] = G.makespan; out_counts[3] = G.centre_ok ? 1u : 0u; }
+    return (int)G.nodes.size();
 }
 
 int lfbm5d_last_windows(const lfbm5d_ctx* c, unsigned* out_sai, unsigned cap) {
@@ -1586,6 +1730,34 @@ int lfbm5d_step2_device(lfbm5d_ctx* c, const lfbm5d_params* P, float* d_noisy, c
     return run_step(c, 2, P, d_noisy, h_mask, d_basic, d_denoised, ang_major, awidth, aheight, an, W, H, C);
 }
 
+int lfbm5d_denoise_device(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask,
+                          float* d_basic, float* d_denoised, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1,
+                          unsigned an2, unsigned W, unsigned H, unsigned C) {
+    if (!c || !P1 || !P2 || !h_mask) return 1;
+    (void)hipSetDevice(c->device);
+    return run_denoise(c, P1, P2, d_noisy, h_mask, d_basic, d_denoised, ang_major, awidth, aheight, an1, an2, W, H, C);
+}
+
+int lfbm5d_denoise_host(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* h_noisy, const unsigned* h_mask,
+                        float* h_basic, float* h_denoised, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1,
+                        unsigned an2, unsigned W, unsigned H, unsigned C) {
+    if (!c || !P1 || !P2 || !h_mask) return 1;
+    (void)hipSetDevice(c->device);
+    const size_t bytes = (size_t)awidth * aheight * C * W * H * sizeof(float);
+    HIPCK(c, c->h2d_noisy.reserve(bytes));
+    HIPCK(c, c->h2d_basic.reserve(bytes));
+    HIPCK(c, c->h2d_out.reserve(bytes));
+    HIPCK(c, hipMemcpy(c->h2d_noisy.p, h_noisy, bytes, hipMemcpyHostToDevice));
+    HIPCK(c, hipMemsetAsync(c->h2d_basic.p, 0, bytes, c->stream));
+    HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
+    if (run_denoise(c, P1, P2, c->h2d_noisy.as<float>(), h_mask, c->h2d_basic.as<float>(), c->h2d_out.as<float>(), ang_major, awidth, aheight,
+                    an1, an2, W, H, C)) return 1;
+    HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h_basic, c->h2d_basic.p, bytes, hipMemcpyDeviceToHost));
+    HIPCK(c, hipMemcpy(h_denoised, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int lfbm5d_step1_host(lfbm5d_ctx* c, const lfbm5d_params* P, float* h_noisy, const unsigned* h_mask,
                       float* h_basic, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
                       unsigned W, unsigned H, unsigned C) {
@@ -1733,7 +1905,7 @@ int lfbm5d_last_bm(lfbm5d_ctx* c, unsigned* n_refs, unsigned* h_refs, unsigned* 
     const unsigned R = c->last_n_refs;
     if (n_refs) *n_refs = R;
     if (!R) return 0;
-    if (h_refs) std::memcpy(h_refs, c->last_refs_host.data(), R * sizeof(unsigned));
+    if (h_refs) std::memcpy(h_refs, c->gc[c->gslot].last_refs_host.data(), R * sizeof(unsigned));
     if (h_self_idx) HIPCK(c, hipMemcpy(h_self_idx, c->self_idx.p, (size_t)R * c->last_N * sizeof(unsigned), hipMemcpyDeviceToHost));
     if (h_self_cnt) HIPCK(c, hipMemcpy(h_self_cnt, c->self_cnt.p, (size_t)R * sizeof(unsigned), hipMemcpyDeviceToHost));
     if (h_best) HIPCK(c, hipMemcpy(h_best, c->best.p, c->last_A * c->last_plane * sizeof(unsigned), hipMemcpyDeviceToHost));

@@ -182,6 +182,9 @@ hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, i
 /* whole light field [SAI][3][n_px] / [SAI][seg] in one launch; d_mask: device copy of the SAI mask (0 = skip) */
 hipError_t launch_color_lf(hipStream_t s, float* lf, size_t sai_stride, unsigned n_sai, const unsigned* d_mask, unsigned cs,
                            unsigned n_px, int forward);
+/* out = forward(inverse(in)) of every masked SAI (the colour round trip between the two steps); in == out allowed */
+hipError_t launch_color_roundtrip_lf(hipStream_t s, const float* in, float* out, size_t sai_stride, unsigned n_sai, const unsigned* d_mask,
+                                     unsigned cs, unsigned n_px);
 hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t seg,
                               unsigned n_sai, const unsigned* d_mask);
 hipError_t launch_symetrize(hipStream_t s, const float* src, float* dst, unsigned W, unsigned H,
@@ -195,6 +198,10 @@ hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, co
                            float* est, size_t n);
 /* all SAIs of an angular window in one launch: slot i of the window <-> SAI L.st[i] of the light field */
 struct SaiList { unsigned st[kMaxA]; unsigned n; };
+/* two-step jobs: basic[st] = forward(inverse(den ? num / den : sub)) for the light-field SAIs L.st[0 .. L.n) (colour = 0: no
+ * colour round trip); light fields with three channels of n_px pixels */
+hipError_t launch_finalize_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* basic, size_t sai_stride,
+                                 const SaiList& L, unsigned cs, unsigned n_px, int colour);
 hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,
                                   const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride, const float* src, size_t src_stride,
@@ -223,6 +230,7 @@ int bm_scan_version(const ScanArgs& a);   /* 1: round 2's kernel; 2: second gene
 bool scan2_plan(const ScanArgs& a, std::vector<Scan2Wg>& wgs, size_t* lds_bytes, unsigned* nwg_slot = nullptr);
 size_t scan_tables_floats(const ScanArgs& a, int version, unsigned n_slots, unsigned nwg_slot);   /* size of the `tables` buffer */
 unsigned scan2_lcol_stride(const ScanArgs& a);
+hipError_t prepare_scan2_kernels();   /* per device, like prepare_group_kernels: the LDS limit of the table kernel */
 hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds_bytes, bool combined);
 hipError_t launch_stereo_argmin3(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots, unsigned nwg_slot,
                                  unsigned W, unsigned H, unsigned k, unsigned nDisp, float thr,

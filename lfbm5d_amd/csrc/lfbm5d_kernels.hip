@@ -36,16 +36,9 @@ typedef const __attribute__((address_space(4))) float* TbFloats;
 
 /* ============================== elementwise helpers ======================================= */
 
-/* blockIdx.y = SAI of a light field laid out [SAI][3][n]; SAIs whose mask entry is 0 are left alone */
-__global__ void k_color(float* __restrict__ img, size_t sai_stride, const unsigned* __restrict__ mask, unsigned cs, unsigned n, int fwd) {
-    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || (mask && !mask[blockIdx.y])) return;
-    img += blockIdx.y * sai_stride;
-    /* utilities.cpp:482-599, same expressions; contraction off to keep their rounding */
-    float x, y, z;
-    {
+/* colour transform of one pixel: utilities.cpp:482-599, same expressions; contraction off to keep their rounding */
+__device__ __forceinline__ void color_px(unsigned cs, int fwd, const float R, const float G, const float B, float& x, float& y, float& z) {
 #pragma clang fp contract(off)
-    const float R = img[i], G = img[i + n], B = img[i + 2 * n];
     if (cs == 0) { /* YUV */
         if (fwd) { x = 0.299f * R + 0.587f * G + 0.114f * B; y = -0.14713f * R - 0.28886f * G + 0.436f * B; z = 0.615f * R - 0.51498f * G - 0.10001f * B; }
         else     { x = R + 1.13983f * B; y = R - 0.39465f * G - 0.5806f * B; z = R + 2.03211f * G; }
@@ -56,8 +49,30 @@ __global__ void k_color(float* __restrict__ img, size_t sai_stride, const unsign
         if (fwd) { x = 0.333f * R + 0.333f * G + 0.333f * B; y = 0.500f * R + 0.000f * G - 0.500f * B; z = 0.250f * R - 0.500f * G + 0.250f * B; }
         else     { x = 1.0f * R + 1.0f * G + 0.666f * B; y = 1.0f * R + 0.0f * G - 1.333f * B; z = 1.0f * R - 1.0f * G + 0.666f * B; }
     }
-    }
+}
+
+/* blockIdx.y = SAI of a light field laid out [SAI][3][n]; SAIs whose mask entry is 0 are left alone */
+__global__ void k_color(float* __restrict__ img, size_t sai_stride, const unsigned* __restrict__ mask, unsigned cs, unsigned n, int fwd) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (mask && !mask[blockIdx.y])) return;
+    img += blockIdx.y * sai_stride;
+    float x, y, z;
+    color_px(cs, fwd, img[i], img[i + n], img[i + 2 * n], x, y, z);
     img[i] = x; img[i + n] = y; img[i + 2 * n] = z;
+}
+
+/* out = fwd(inv(in)) per pixel: what a light field looks like to the second step after the first step's closing inverse
+ * transform and the second's opening forward transform (bm5d.cpp:711-714, :827-830; the reference's matrices are not
+ * inverses of each other).  in == out is allowed. */
+__global__ void k_color_roundtrip(const float* in, float* out, size_t sai_stride, const unsigned* __restrict__ mask,
+                                  unsigned cs, unsigned n) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (mask && !mask[blockIdx.y])) return;
+    in += blockIdx.y * sai_stride; out += blockIdx.y * sai_stride;
+    float x, y, z, u, v, w;
+    color_px(cs, 0, in[i], in[i + n], in[i + 2 * n], x, y, z);
+    color_px(cs, 1, x, y, z, u, v, w);
+    out[i] = u; out[i + n] = v; out[i + 2 * n] = w;
 }
 
 __device__ __forceinline__ int mirror(int x, int n) { return x < 0 ? -x - 1 : (x >= n ? 2 * n - x - 1 : x); }
@@ -139,6 +154,29 @@ __global__ void k_estimate_lf(const float* __restrict__ num, const float* __rest
     const size_t o = blockIdx.y * seg + i;
     const float d = den[o];
     est[o] = d ? __fdiv_rn(num[o], d) : sub[o];
+}
+
+/* Two-step jobs: the basic estimate of the SAIs whose first-step sums have just become final, as the second step reads it:
+ * compute_LF_estimate (bm5d.cpp:405), inverse colour transform (bm5d.cpp:711), forward colour transform (bm5d.cpp:829) --
+ * the operations run_bm5d_1st_step ends with and run_bm5d_2nd_step begins with, pixel by pixel.  blockIdx.y = entry of L. */
+__global__ void k_finalize_multi(const float* __restrict__ num, const float* __restrict__ den, const float* __restrict__ sub,
+                                 float* __restrict__ basic, size_t sai_stride, SaiList L, unsigned cs, unsigned n, int colour) {
+    const unsigned st = L.st[blockIdx.y];
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = (size_t)st * sai_stride + i;
+    float e[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float d = den[o + (size_t)c * n];
+        e[c] = d ? __fdiv_rn(num[o + (size_t)c * n], d) : sub[o + (size_t)c * n];
+    }
+    if (colour) {
+        float x, y, z;
+        color_px(cs, 0, e[0], e[1], e[2], x, y, z);
+        color_px(cs, 1, x, y, z, e[0], e[1], e[2]);
+    }
+    basic[o] = e[0]; basic[o + n] = e[1]; basic[o + 2 * (size_t)n] = e[2];
 }
 
 __global__ void k_copy_rect(float* __restrict__ dst, size_t dst_stride, int dW, int dH, int dx0, int dy0,
@@ -3312,6 +3350,17 @@ hipError_t launch_color(hipStream_t s, float* img, unsigned cs, unsigned n_px, i
 hipError_t launch_color_lf(hipStream_t s, float* lf, size_t sai_stride, unsigned n_sai, const unsigned* d_mask, unsigned cs,
                            unsigned n_px, int forward) {
     hipLaunchKernelGGL(k_color, dim3(grid1d(n_px).x, n_sai), dim3(256), 0, s, lf, sai_stride, d_mask, cs, n_px, forward);
+    return hipGetLastError();
+}
+hipError_t launch_color_roundtrip_lf(hipStream_t s, const float* in, float* out, size_t sai_stride, unsigned n_sai, const unsigned* d_mask,
+                                     unsigned cs, unsigned n_px) {
+    hipLaunchKernelGGL(k_color_roundtrip, dim3((n_px + 255) / 256, n_sai), dim3(256), 0, s, in, out, sai_stride, d_mask, cs, n_px);
+    return hipGetLastError();
+}
+hipError_t launch_finalize_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* basic, size_t sai_stride,
+                                 const SaiList& L, unsigned cs, unsigned n_px, int colour) {
+    if (!L.n) return hipSuccess;
+    hipLaunchKernelGGL(k_finalize_multi, dim3((n_px + 255) / 256, L.n), dim3(256), 0, s, num, den, sub, basic, sai_stride, L, cs, n_px, colour);
     return hipGetLastError();
 }
 hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t seg,

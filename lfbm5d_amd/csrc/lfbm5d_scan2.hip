@@ -739,6 +739,8 @@ int bm_scan_version(const ScanArgs& a) {
     if (const char* e = std::getenv("LFBM5D_SCAN_V1")) if (e[0] && e[0] != '0') return 1;
     if (a.k != 8 && a.k != 16) return 1;
     if (a.n_self && a.refmap) return 1;
+    /* the loader wave addresses all planes of the estimate through ONE buffer resource with 32-bit offsets */
+    if ((size_t)a.est_planes * a.W * a.H * 4 + kLeadBytes + 1024 > 0x7fffffffull) return 1;
     std::vector<Scan2Wg> wgs; size_t lds = 0;
     if (!scan2_plan(a, wgs, &lds)) return 1;
     if (const char* e = std::getenv("LFBM5D_SCAN_FULL_TABLES")) if (e[0] && e[0] != '0') return 2;
@@ -814,18 +816,20 @@ unsigned scan2_lcol_stride(const ScanArgs& a) {
     return ((std::max(rows_self, rows_st) + 64 + 160 + 63) / 64) * 64;
 }
 
+/* The dynamic-LDS limit is a per-DEVICE function attribute: raised for the current device, by every context creation
+ * (lfbm5d_create after hipSetDevice, and the lane contexts) -- not once per process. */
+hipError_t prepare_scan2_kernels() {
+    const void* fns[] = {reinterpret_cast<const void*>(&k_bm_scan2<8, false>), reinterpret_cast<const void*>(&k_bm_scan2<16, false>),
+                         reinterpret_cast<const void*>(&k_bm_scan2<8, true>), reinterpret_cast<const void*>(&k_bm_scan2<16, true>)};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds, bool combined) {
     if (!a.n_wgs) return hipSuccess;
-    static bool prepared = false;
-    if (!prepared) {
-        const void* fns[] = {reinterpret_cast<const void*>(&k_bm_scan2<8, false>), reinterpret_cast<const void*>(&k_bm_scan2<16, false>),
-                             reinterpret_cast<const void*>(&k_bm_scan2<8, true>), reinterpret_cast<const void*>(&k_bm_scan2<16, true>)};
-        for (const void* f : fns) {
-            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-        }
-        prepared = true;
-    }
     const dim3 blk((kS2NW + kS2NL) * 64);
     if (a.k == 8 && combined) hipLaunchKernelGGL((k_bm_scan2<8, true>), dim3(a.n_wgs), blk, lds, s, a);
     else if (a.k == 8) hipLaunchKernelGGL((k_bm_scan2<8, false>), dim3(a.n_wgs), blk, lds, s, a);

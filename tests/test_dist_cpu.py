@@ -70,17 +70,23 @@ def test_row_sharded_pass_all_reduce_equals_full_pass():
     assert all(ok for _, ok, _ in res), res
 
 
-def _graph_worker(rank, world, port, q):
-    """One rank of the graph form of a step, with the oracle's core pass standing in for the device kernels and gloo
-    send / recv for RCCL's: the rank runs the windows lfbm5d_plan_graph gives it, in plan order, on num / den of its
-    own, and handles the messages of lfbm5d_plan_messages in their issue order."""
+def _window_cover(aw, ah, pst):
+    ps, pt = int(pst) // aw, int(pst) % aw
+    s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
+    return [(s0 + s) * aw + (t0 + t) for s in range(3) for t in range(3)], (ps - s0) * 3 + (pt - t0)
+
+
+def _graph_worker(rank, world, port, q, n_steps):
+    """One rank of the graph form of a job (one step, or both steps as lfbm5d_denoise_* runs them), with the oracle's core
+    pass standing in for the device kernels and gloo send / recv for RCCL's: the rank walks the nodes of lfbm5d_plan_job in
+    ISSUE ORDER, runs the windows it owns on num / den (and a basic estimate) of its own, and handles the messages in their
+    issue order -- sums of a shared SAI between consecutive touchers, basic estimates from the rank that finalised them."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    import ctypes as C
     import helpers as Hh
     from oracle import oracle as O
     from lfbm5d_amd import core
@@ -88,86 +94,117 @@ def _graph_worker(rank, world, port, q):
     # two rows of windows for two ranks, three for three (a chain = a row of windows is the unit dealt to ranks)
     ah, aw = (5, 7) if world == 2 else (7, 11)
     H, W, Cc, sigma = 40, 40, 3, 25.0
-    pk = (4, 5, 2, 8, 4, "id", "sadct", "haar")
-    nHW = pk[1] + pk[2]
+    pks = [(4, 5, 2, 8, 4, "id", "sadct", "haar"), (8, 4, 2, 8, 3, "dct", "sadct", "haar")][:n_steps]
     A = ah * aw
     clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, H, W), sigma)
     mask = np.ones(A, np.uint32)
-    plan = core.plan_windows(aw, ah, 1)                       # host-only entry points of the C-ABI library
-    ranks, _, _ = core.plan_graph(aw, ah, world)
-    msgs = core.plan_messages(aw, ah, world)
-    # what run_bm5d_1st_step does before the windows (bm5d.cpp:133): forward colour transform
-    lf = noisy.copy()
+    nodes, msgs, info = core.plan_job(aw, ah, world, 1, an=(1,) * n_steps)
+    order = np.argsort(nodes[:, 6])
+    assert sorted(nodes[:, 6].tolist()) == list(range(len(nodes)))
+    plan = core.plan_windows(aw, ah, 1)
+    for sl in range(n_steps):
+        assert [int(n[2]) for n in nodes if n[0] == sl] == plan.tolist()
+    # what run_bm5d_1st_step does before the windows (bm5d.cpp:133): forward colour transform; the second step reads the
+    # light field after the first step's closing inverse transform and its own forward transform (bm5d.cpp:713, :827)
+    lf = [noisy.copy()]
     for st in range(A):
-        lib.orc_color_transform(lf[st], O.OPP, W, H, Cc, 1)
-    num, den = np.zeros_like(lf), np.zeros_like(lf)
-    Wb, Hb = W + 2 * nHW, H + 2 * nHW
+        lib.orc_color_transform(lf[0][st], O.OPP, W, H, Cc, 1)
+    if n_steps == 2:
+        lf.append(lf[0].copy())
+        for st in range(A):
+            lib.orc_color_transform(lf[1][st], O.OPP, W, H, Cc, 0)
+            lib.orc_color_transform(lf[1][st], O.OPP, W, H, Cc, 1)
+    num = [np.zeros_like(lf[0]) for _ in range(n_steps)]
+    den = [np.zeros_like(lf[0]) for _ in range(n_steps)]
+    basic = np.zeros_like(lf[0])
+    last = [{}, {}]
+    for i, n in enumerate(nodes):
+        for st in _window_cover(aw, ah, n[2])[0]:
+            last[int(n[0])][st] = i
     mi = 0
     n_sent = n_recv = 0
-    for w, pst in enumerate(plan):
-        if ranks[w] == rank:
-            ps, pt = int(pst) // aw, int(pst) % aw
-            cs_w, mins, maxs, ct_w, mint, maxt = (C.c_int() for _ in range(6))
-            lib.orc_search_window(ps, ah, 1, C.byref(cs_w), C.byref(mins), C.byref(maxs))
-            lib.orc_search_window(pt, aw, 1, C.byref(ct_w), C.byref(mint), C.byref(maxt))
-            idx = [(mins.value + s) * aw + (mint.value + t) for s in range(3) for t in range(3)]
-            wn, wnum, wden = (np.zeros((9, Cc * Wb * Hb), np.float32) for _ in range(3))
-            for i, st in enumerate(idx):
-                lib.orc_symetrize(lf[st], wn[i], W, H, Cc, nHW)
-                lib.orc_symetrize(num[st], wnum[i], W, H, Cc, nHW)
-                lib.orc_symetrize(den[st], wden[i], W, H, Cc, nHW)
-            cst_w = cs_w.value * 3 + ct_w.value
-            Hh.oracle_pass(1, sigma, pk, wn, None, Wb, Hb, Cc, num=wnum, den=wden, cst=cst_w, pst=cst_w)
-            for i, st in enumerate(idx):
-                lib.orc_unsymetrize(num[st], wnum[i], W, H, Cc, nHW)
-                lib.orc_unsymetrize(den[st], wden[i], W, H, Cc, nHW)
-        while mi < len(msgs) and msgs[mi][0] == w:            # the messages this window's result feeds
-            _, to_w, st, _ = (int(v) for v in msgs[mi])
+    for i in order:
+        sl, pst, r = int(nodes[i][0]), int(nodes[i][2]), int(nodes[i][3])
+        if r == rank:
+            pk = pks[sl]
+            nHW = pk[1] + pk[2]
+            Wb, Hb = W + 2 * nHW, H + 2 * nHW
+            idx, cst_w = _window_cover(aw, ah, pst)
+            wn, wb, wnum, wden = (np.zeros((9, Cc * Wb * Hb), np.float32) for _ in range(4))
+            for j, st in enumerate(idx):
+                lib.orc_symetrize(lf[sl][st], wn[j], W, H, Cc, nHW)
+                if sl == 1:
+                    lib.orc_symetrize(basic[st], wb[j], W, H, Cc, nHW)
+                lib.orc_symetrize(num[sl][st], wnum[j], W, H, Cc, nHW)
+                lib.orc_symetrize(den[sl][st], wden[j], W, H, Cc, nHW)
+            Hh.oracle_pass(sl + 1, sigma, pk, wn, wb if sl == 1 else None, Wb, Hb, Cc, num=wnum, den=wden, cst=cst_w, pst=cst_w)
+            for j, st in enumerate(idx):
+                lib.orc_unsymetrize(num[sl][st], wnum[j], W, H, Cc, nHW)
+                lib.orc_unsymetrize(den[sl][st], wden[j], W, H, Cc, nHW)
+            if n_steps == 2 and sl == 0:      # SAIs whose first-step sums are final: estimate, inverse + forward colour transform
+                for st in idx:
+                    if last[0][st] == i:
+                        basic[st] = np.where(den[0][st] != 0, num[0][st] / np.where(den[0][st] != 0, den[0][st], 1), lf[0][st])
+                        lib.orc_color_transform(basic[st], O.OPP, W, H, Cc, 0)
+                        lib.orc_color_transform(basic[st], O.OPP, W, H, Cc, 1)
+        while mi < len(msgs) and msgs[mi][1] == i:            # the messages this window's result feeds
+            kind, _, to_node, to_rank, st, _ = (int(v) for v in msgs[mi])
             mi += 1
-            if ranks[w] == rank:
-                dist.send(torch.from_numpy(num[st]), int(ranks[to_w])); dist.send(torch.from_numpy(den[st]), int(ranks[to_w]))
+            if kind == 0:
+                assert int(nodes[to_node][3]) == to_rank != r and int(nodes[to_node][0]) == sl
+            bufs = [num[sl][st], den[sl][st]] if kind == 0 else [basic[st]]
+            if r == rank:
+                for bf in bufs:
+                    dist.send(torch.from_numpy(bf), to_rank)
                 n_sent += 1
-            elif ranks[to_w] == rank:
-                dist.recv(torch.from_numpy(num[st]), int(ranks[w])); dist.recv(torch.from_numpy(den[st]), int(ranks[w]))
+            elif to_rank == rank:
+                for bf in bufs:
+                    dist.recv(torch.from_numpy(bf), r)
                 n_recv += 1
-    # every SAI's final sums live on the rank of the last window that touched it
-    last = {}
-    for w, pst in enumerate(plan):
-        ps, pt = int(pst) // aw, int(pst) % aw
-        s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
-        for s in range(3):
-            for t in range(3):
-                last[(s0 + s) * aw + (t0 + t)] = w
-    est = np.zeros_like(lf)
+    assert mi == len(msgs)
+    # every SAI's final sums live on the rank of the last window that touched it; basic estimates where they were finalised
+    ls = n_steps - 1
+    est = np.zeros_like(lf[0])
     for st in range(A):
-        if ranks[last[st]] == rank:
-            est[st] = np.where(den[st] != 0, num[st] / np.where(den[st] != 0, den[st], 1), lf[st])
-        t = torch.from_numpy(est[st])
-        dist.broadcast(t, int(ranks[last[st]]))
+        owner = int(nodes[last[ls][st]][3])
+        if owner == rank:
+            sub = lf[0][st] if ls == 0 else basic[st]
+            est[st] = np.where(den[ls][st] != 0, num[ls][st] / np.where(den[ls][st] != 0, den[ls][st], 1), sub)
+        dist.broadcast(torch.from_numpy(est[st]), owner)
         lib.orc_color_transform(est[st], O.OPP, W, H, Cc, 0)
-    # the single-process oracle (data-driven windows, one rank)
-    _, b_o, st1 = O.run_step1(O.make_params(sigma, 2.7, *pk), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
-    q.put((rank, bool(np.array_equal(est, b_o)), float(np.abs(est - b_o).max()), int(sum(1 for r in ranks if r == rank)), n_sent, n_recv,
-           len(msgs), bool(np.array_equal(O.last_windows(), plan))))
+        if n_steps == 2:
+            dist.broadcast(torch.from_numpy(basic[st]), int(nodes[last[0][st]][3]))
+            lib.orc_color_transform(basic[st], O.OPP, W, H, Cc, 0)
+    # the single-process oracle (data-driven windows, one rank): the two reference calls one after the other
+    n_o, b_o, st1 = O.run_step1(O.make_params(sigma, 2.7, *pks[0]), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
+    same_plan = bool(np.array_equal(O.last_windows(), plan))
+    if n_steps == 1:
+        ok = bool(np.array_equal(est, b_o)); err = float(np.abs(est - b_o).max())
+    else:
+        _, b2_o, d_o, _ = O.run_step2(O.make_params(sigma, 2.7, *pks[1]), n_o, b_o, mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
+        ok = bool(np.array_equal(est, d_o) and np.array_equal(basic, b2_o)); err = float(max(np.abs(est - d_o).max(), np.abs(basic - b2_o).max()))
+    q.put((rank, ok, err, int(sum(1 for n in nodes if n[3] == rank)), n_sent, n_recv, len(msgs), same_plan))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_graph_form_with_messages_equals_the_single_rank_step(world):
-    """world_size-2 / -3 gloo run of the step-level multi-GPU scheme (graph form): windows owned per rank, one message per
-    SAI a window needs from another rank's window, estimates formed by the last toucher -- bit-identical to the
-    oracle's single-process step, and every planned message is used exactly once."""
+@pytest.mark.parametrize("world,n_steps", [(2, 1), (3, 1), (2, 2)])
+def test_graph_form_with_messages_equals_the_single_rank_step(world, n_steps):
+    """world_size-2 / -3 gloo run of the multi-GPU scheme (graph form) -- windows owned per rank, one message per SAI a window
+    needs from another rank's window, estimates formed by the last toucher -- for one step and for the TWO-STEP job
+    (lfbm5d_denoise_*: second-step windows start as soon as their SAIs' basic estimates are final, which travel from the rank
+    that finalised them): bit-identical to the oracle's single-process run_step1 (+ run_step2), every planned message used
+    exactly once."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q, n_steps)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join(timeout=60)
     assert all(ok and same_plan for _, ok, _, _, _, _, _, same_plan in res), res
@@ -176,43 +213,87 @@ def test_graph_form_with_messages_equals_the_single_rank_step(world):
 
 
 def test_graph_plan_properties():
-    """Host-side properties of the graph form for 1..8 ranks: every window has an owner, chains stay on one rank, the
-    unit-time schedule respects the dependencies (a window starts after every earlier window it shares an SAI with),
-    and messages connect exactly the consecutive touchers of an SAI that live on different ranks."""
+    """Host-side properties of the graph form for 1..8 ranks, one step and both: every window has an owner, chains stay on one
+    rank, the simulated execution respects the dependencies (a window starts after every earlier window of its step it shares an
+    SAI with; a second-step window after the last first-step window on each of its SAIs), the issue order is the start order,
+    and messages connect exactly the consecutive touchers of an SAI that live on different ranks (+ one basic estimate per SAI
+    and reading rank in two-step jobs)."""
     from lfbm5d_amd import core
     for (ah, aw) in ((17, 17), (9, 9), (15, 15), (5, 7), (3, 3)):
         plan = core.plan_windows(aw, ah, 1)
-        cover = []
-        for pst in plan:
-            ps, pt = int(pst) // aw, int(pst) % aw
-            s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
-            cover.append({(s0 + s) * aw + (t0 + t) for s in range(3) for t in range(3)})
+        cover = [set(_window_cover(aw, ah, pst)[0]) for pst in plan]
+        NW = len(plan)
         for world in (1, 2, 3, 4, 8):
             for lanes in (1, 3):
                 ranks, lane, start = core.plan_graph(aw, ah, world, lanes)
-                assert len(ranks) == len(plan) and ranks.max() < world and lane.max() < lanes
-                for w in range(len(plan)):
+                assert len(ranks) == NW and ranks.max() < world and lane.max() < lanes
+                for w in range(NW):
                     for p in range(w):
                         if cover[w] & cover[p]:
                             assert start[p] < start[w], (ah, aw, world, lanes, p, w)
                     if w and int(plan[w]) // aw == int(plan[w - 1]) // aw:
                         assert ranks[w] == ranks[w - 1]               # a chain (same row of SAIs) stays on one rank
                 # no two windows at once on one lane
-                assert len({(int(ranks[w]), int(lane[w]), int(start[w])) for w in range(len(plan))}) == len(plan)
+                assert len({(int(ranks[w]), int(lane[w]), int(start[w])) for w in range(NW)}) == NW
             msgs = core.plan_messages(aw, ah, world)
-            ranks, _, _ = core.plan_graph(aw, ah, world)
+            ranks, _, start = core.plan_graph(aw, ah, world)
             expect = []
-            for w in range(len(plan)):
+            for w in range(NW):
                 for st in sorted(cover[w]):
-                    nxt = next((n for n in range(w + 1, len(plan)) if st in cover[n]), None)
+                    nxt = next((n for n in range(w + 1, NW) if st in cover[n]), None)
                     if nxt is not None and ranks[nxt] != ranks[w]:
                         expect.append((w, nxt, st))
             assert sorted((int(a), int(b), int(c)) for a, b, c, _ in msgs) == sorted(expect)
-            assert [int(m[0]) for m in msgs] == sorted(int(m[0]) for m in msgs)   # issued by producer window
+            key = [(int(start[int(m[0])]), int(m[0])) for m in msgs]
+            assert key == sorted(key)                                 # issued by producer window, in start (= issue) order
             if world == 1:
                 assert len(msgs) == 0
+            # the two-step job
+            for lanes in (1, 3):
+                nodes, jm, info = core.plan_job(aw, ah, world, lanes, an=(1, 1))
+                assert len(nodes) == 2 * NW and info["centre_ok"]
+                pos = nodes[:, 6].astype(int)
+                assert sorted(pos.tolist()) == list(range(2 * NW))
+                st_ = nodes[:, 5].astype(int)
+                assert all(st_[a] <= st_[b] for a, b in zip(np.argsort(pos)[:-1], np.argsort(pos)[1:]))   # issue order = start order
+                cost = [10 if n[0] == 0 else 9 for n in nodes]
+                last1 = {}
+                for w in range(NW):
+                    for st in cover[w]:
+                        last1[st] = w
+                for i in range(2 * NW):
+                    sl, w = int(nodes[i][0]), int(nodes[i][1])
+                    assert i == sl * NW + w
+                    for p in range(w):
+                        if cover[w] & cover[p]:
+                            assert st_[sl * NW + p] + cost[sl * NW + p] <= st_[i]
+                    if sl == 1:
+                        for st in cover[w]:
+                            assert st_[last1[st]] + 10 <= st_[i]
+                    if w and int(plan[w]) // aw == int(plan[w - 1]) // aw:
+                        assert nodes[i][3] == nodes[i - 1][3]
+                assert len({(int(n[3]), int(n[4]), int(n[5])) for n in nodes}) == 2 * NW
+                if lanes == 1:
+                    rk = nodes[:, 3].astype(int)
+                    expect = []
+                    for sl in range(2):
+                        for w in range(NW):
+                            for st in sorted(cover[w]):
+                                nxt = next((n for n in range(w + 1, NW) if st in cover[n]), None)
+                                if nxt is not None and rk[sl * NW + nxt] != rk[sl * NW + w]:
+                                    expect.append((0, sl * NW + w, sl * NW + nxt, int(rk[sl * NW + nxt]), st))
+                    for st, w in last1.items():
+                        readers = sorted({int(rk[NW + n]) for n in range(NW) if st in cover[n]} - {int(rk[w])})
+                        expect += [(1, w, 0xffffffff, r, st) for r in readers]
+                    assert sorted(tuple(int(v) for v in m[:5]) for m in jm) == sorted(expect)
+                    assert [int(pos[int(m[1])]) for m in jm] == sorted(int(pos[int(m[1])]) for m in jm)
     r17, _, t17 = core.plan_graph(17, 17, 8)
     assert t17.max() + 1 <= 24                                        # critical path of the 17x17 backward raster
+    # the two-step job is what lets eight ranks work: all of them busy, and a simulated makespan below a quarter of the serial time
+    for (a, bound) in ((17, 4.0), (15, 3.5)):
+        nodes, _, info = core.plan_job(a, a, 8, 1, an=(1, 1))
+        assert len(set(nodes[:, 3].tolist())) == 8
+        assert sum(10 if n[0] == 0 else 9 for n in nodes) / info["makespan"] >= bound
 
 
 def test_plan_windows_matches_the_reference_rule():
@@ -233,43 +314,54 @@ def test_plan_windows_matches_the_reference_rule():
         assert mask[st]
 
 
-def _simulate_exchange(aw, ah, world, lanes, single_channel=False, perturb=False):
-    """Replay of what run_step enqueues on every rank (lfbm5d_api.hip, graph form): every rank walks the windows in plan
-    order; a window goes to its lane's stream (FIFO) and waits for the previous toucher of each of its SAIs -- an event of
-    the same rank, or the arrival of that SAI's message; after a window, the messages it feeds are enqueued on the channel's
-    exchange stream of the sender (gated by the window's completion) and of the receiver, in the list's order on both.
-    A send / recv pair completes when both are at the head of their streams (rendezvous).  Returns the number of operations
-    that never complete (0: the issue order cannot deadlock)."""
+def _simulate_exchange(aw, ah, world, lanes, single_channel=False, perturb=False, n_steps=1):
+    """Replay of what run_graph enqueues on every rank (lfbm5d_api.hip): every rank walks the nodes of the job in ISSUE ORDER;
+    a window goes to its lane's stream (FIFO) and waits for the previous toucher of each of its SAIs -- an event of the same
+    rank, or the arrival of that SAI's message -- and, in the second step of a two-step job, for each SAI's basic estimate
+    (finalised behind a window of the same rank, or arrived as a message); after a window, the messages it feeds are enqueued on
+    the channel's exchange stream of the sender (gated by the window's completion) and of the receiver, in the list's order on
+    both.  A send / recv pair completes when both are at the head of their streams (rendezvous).  Returns the number of
+    operations that never complete (0: the issue order cannot deadlock)."""
     from lfbm5d_amd import core
     plan = core.plan_windows(aw, ah, 1)
-    ranks, lane, _ = core.plan_graph(aw, ah, world, lanes)
-    msgs = [tuple(int(v) for v in m) for m in core.plan_messages(aw, ah, world)]
-    cover = []
-    for pst in plan:
-        ps, pt = int(pst) // aw, int(pst) % aw
-        s0, t0 = min(max(ps - 1, 0), ah - 3), min(max(pt - 1, 0), aw - 3)
-        cover.append(sorted((s0 + s) * aw + (t0 + t) for s in range(3) for t in range(3)))
     NW = len(plan)
-    prev = [{st: next((p for p in range(w - 1, -1, -1) if st in cover[p]), None) for st in cover[w]} for w in range(NW)]
-    msg_of = {(a, b, st): i for i, (a, b, st, _) in enumerate(msgs)}
+    nodes, msgs, _ = core.plan_job(aw, ah, world, lanes, an=(1,) * n_steps)
+    msgs = [tuple(int(v) for v in m) for m in msgs]
+    ranks, lane, pos = nodes[:, 3].astype(int), nodes[:, 4].astype(int), nodes[:, 6].astype(int)
+    order = np.argsort(pos)
+    cover = [sorted(_window_cover(aw, ah, pst)[0]) for pst in plan]
+    NN = len(nodes)
+    prev = []
+    for i in range(NN):
+        sl, w = divmod(i, NW)
+        prev.append({st: next((sl * NW + p for p in range(w - 1, -1, -1) if st in cover[p]), None) for st in cover[w]})
+    last1 = {}
+    for w in range(NW):
+        for st in cover[w]:
+            last1[st] = w
+    sum_msg = {(a, b, st): i for i, (k, a, b, r, st, ch) in enumerate(msgs) if k == 0}
+    basic_msg = {(st, r): i for i, (k, a, b, r, st, ch) in enumerate(msgs) if k == 1}
     # streams: ("lane", rank, lane) -> windows; ("ch", rank, channel) -> (message index, role)
     streams = {}
-    for w in range(NW):
-        streams.setdefault(("lane", int(ranks[w]), int(lane[w])), []).append(("win", w))
-    for i, (a, b, st, ch) in enumerate(msgs):
+    for i in order:
+        streams.setdefault(("lane", int(ranks[i]), int(lane[i])), []).append(("win", int(i)))
+    for i, (k, a, b, r, st, ch) in enumerate(msgs):
         c = 0 if single_channel else ch
         streams.setdefault(("ch", int(ranks[a]), c), []).append(("send", i))
-        streams.setdefault(("ch", int(ranks[b]), c), []).append(("recv", i))
+        streams.setdefault(("ch", r, c), []).append(("recv", i))
     if perturb:   # negative control: one rank enqueues its receives of a channel in reverse order
         k = next(k for k, q in streams.items() if k[0] == "ch" and sum(1 for op in q if op[0] == "recv") > 1)
         rec = [op for op in streams[k] if op[0] == "recv"][::-1]
         streams[k] = [rec.pop(0) if op[0] == "recv" else op for op in streams[k]]
     head = {k: 0 for k in streams}
-    win_done, msg_done = [False] * NW, [False] * len(msgs)
+    win_done, msg_done = [False] * NN, [False] * len(msgs)
+
+    def chan(i, kind):
+        k, a, b, r, st, ch = msgs[i]
+        return ("ch", int(ranks[a]) if kind == "send" else r, 0 if single_channel else ch)
 
     def at_head(kind, i):
-        a, b, st, ch = msgs[i]
-        k = ("ch", int(ranks[a] if kind == "send" else ranks[b]), 0 if single_channel else ch)
+        k = chan(i, kind)
         return head[k] < len(streams[k]) and streams[k][head[k]] == (kind, i)
     progress = True
     while progress:
@@ -280,19 +372,20 @@ def _simulate_exchange(aw, ah, world, lanes, single_channel=False, perturb=False
                 if kind == "win":
                     ok = True
                     for st, p in prev[i].items():
-                        if p is None:
-                            continue
-                        ok = ok and (win_done[p] if ranks[p] == ranks[i] else msg_done[msg_of[(p, i, st)]])
+                        if p is not None:
+                            ok = ok and (win_done[p] if ranks[p] == ranks[i] else msg_done[sum_msg[(p, i, st)]])
+                        if n_steps == 2 and i >= NW:
+                            f = last1[st]
+                            ok = ok and (win_done[f] if ranks[f] == ranks[i] else msg_done[basic_msg[(st, int(ranks[i]))]])
                     if not ok:
                         break
                     win_done[i] = True
                 else:
-                    a = msgs[i][0]
+                    a = msgs[i][1]
                     if not (win_done[a] and at_head("send", i) and at_head("recv", i)):
                         break
                     msg_done[i] = True
-                    other = ("ch", int(ranks[msgs[i][1]] if kind == "send" else ranks[a]), 0 if single_channel else msgs[i][3])
-                    head[other] += 1
+                    head[chan(i, "recv" if kind == "send" else "send")] += 1
                 head[k] += 1
                 progress = True
     return win_done.count(False) + msg_done.count(False)
@@ -302,11 +395,13 @@ def test_exchange_issue_order_cannot_deadlock():
     """The RCCL exchange of the window graph has not run between real ranks yet (no multi-GPU box): what can be shown on the
     host is that the order in which every rank enqueues windows, sends and receives admits a complete execution under FIFO
     streams and rendezvous send / recv -- for every rank count and lane count bench.py can be asked for, with two exchange
-    channels and with the one-channel fallback (second communicator unavailable)."""
+    channels and with the one-channel fallback (second communicator unavailable), for single steps and for the two-step job."""
     for (ah, aw) in ((17, 17), (9, 9), (15, 15), (5, 7), (7, 11)):
         for world in (2, 3, 4, 5, 8):
             for lanes in (1, 2, 3):
                 for single in (False, True):
-                    stuck = _simulate_exchange(aw, ah, world, lanes, single)
-                    assert stuck == 0, (ah, aw, world, lanes, single, stuck)
+                    for n_steps in (1, 2):
+                        stuck = _simulate_exchange(aw, ah, world, lanes, single, n_steps=n_steps)
+                        assert stuck == 0, (ah, aw, world, lanes, single, n_steps, stuck)
     assert _simulate_exchange(17, 17, 4, 3, False, perturb=True) > 0      # the replay does see a broken order
+    assert _simulate_exchange(17, 17, 8, 3, False, perturb=True, n_steps=2) > 0

@@ -1,0 +1,170 @@
+"""GPU tests of the two-step job (lfbm5d_denoise_*): run_bm5d_1st_step + run_bm5d_2nd_step as ONE dependency graph of windows
+(lfbm5d_plan.h) -- a second-step window starts when the basic estimate of each of its SAIs is final, and what the reference does
+between the two calls (estimate, inverse and forward colour transform: bm5d.cpp:405, :711-714, :827-830) happens SAI by SAI.
+The bar is bit-identity with the two calls: for one lane, several lanes, and the multi-GPU form with every rank played on this
+GPU (LFBM5D_EMULATE_WORLD: own sums and basic estimate per rank, messages as device copies in the RCCL issue order)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ENV = ("LFBM5D_EMULATE_WORLD", "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_STEP_SHARDING", "LFBM5D_LANES", "LFBM5D_MAX_WINDOWS", "LFBM5D_FUSED")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import lfbm5d_amd as L
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _two_calls(ctx, P1, P2, noisy, mask, aw, ah, an, W, H, major):
+    d_noisy = torch.from_numpy(noisy).cuda()
+    d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+    ctx.step1(P1, d_noisy, mask, d_basic, major, aw, ah, an[0], W, H, 3)
+    w1 = ctx.last_windows()
+    ctx.step2(P2, d_noisy, mask, d_basic, d_den, major, aw, ah, an[1], W, H, 3)
+    return d_noisy.cpu().numpy(), d_basic.cpu().numpy(), d_den.cpu().numpy(), np.concatenate([w1, ctx.last_windows()])
+
+
+def _one_job(ctx, P1, P2, noisy, mask, aw, ah, an, W, H, major):
+    d_noisy = torch.from_numpy(noisy).cuda()
+    d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+    ctx.reset_stats()
+    ctx.denoise(P1, P2, d_noisy, mask, d_basic, d_den, major, aw, ah, an[0], an[1], W, H, 3)
+    return d_noisy.cpu().numpy(), d_basic.cpu().numpy(), d_den.cpu().numpy(), ctx.last_windows(), ctx.stats()
+
+
+CASES = [
+    # name, ah, aw, H, W, an, empty SAIs, colour space, major, HT parameters, Wiener parameters
+    ("7x9", 7, 9, 64, 64, (1, 1), (), "opp", "row", (4, 6, 2, 8, 4, "id", "sadct", "haar"), (8, 6, 2, 8, 4, "dct", "sadct", "haar")),
+    ("7x9-holes-col", 7, 9, 64, 64, (1, 1), (0, 11, 40, 62), "opp", "col", (4, 6, 2, 8, 4, "id", "dct", "haar"), (8, 6, 2, 8, 4, "dct", "dct", "haar")),
+    ("6x7-asw2-then-1", 6, 7, 56, 60, (2, 1), (), "yuv", "row", (2, 5, 2, 8, 4, "dct", "sadct", "haar"), (4, 5, 2, 8, 3, "dct", "sadct", "hw")),
+    ("5x5-rgb-k16", 5, 5, 72, 64, (1, 1), (), "rgb", "row", (4, 6, 2, 16, 4, "bior", "sadct", "haar"), (8, 4, 3, 8, 4, "bior", "sadct", "haar")),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_two_step_job_is_bit_identical_to_the_two_calls(ctx, monkeypatch, case):
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    name, ah, aw, Hs, Ws, an, holes, cs, major, pk1, pk2 = case
+    mj = L.ROWMAJOR if major == "row" else L.COLMAJOR
+    lf = Hh.textured_lf(ah, aw, Hs, Ws)
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    mask[list(holes)] = 0
+    P1 = core.make_params(25.0, 2.7, *pk1, color_space=cs)
+    P2 = core.make_params(25.0, 2.7, *pk2, color_space=cs)
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LFBM5D_LANES", "1")
+    n0, b0, d0, w0 = _two_calls(ctx, P1, P2, noisy, mask, aw, ah, an, Ws, Hs, mj)
+    assert not np.array_equal(n0, noisy) or cs == "rgb"             # the colour round trips do change LF_noisy (quirk 5)
+    # the job on one lane, on three lanes, and the opt-out (the two calls behind the same entry point)
+    for lanes in ("1", "3"):
+        monkeypatch.setenv("LFBM5D_LANES", lanes)
+        n1, b1, d1, w1, s1 = _one_job(ctx, P1, P2, noisy, mask, aw, ah, an, Ws, Hs, mj)
+        assert np.array_equal(w1, w0) and s1.windows == s1.passes == len(w0) and s1.messages == 0
+        assert np.array_equal(n1, n0) and np.array_equal(b1, b0) and np.array_equal(d1, d0), (name, lanes)
+    monkeypatch.setenv("LFBM5D_FUSED", "0")
+    n1, b1, d1, w1, s1 = _one_job(ctx, P1, P2, noisy, mask, aw, ah, an, Ws, Hs, mj)
+    assert np.array_equal(n1, n0) and np.array_equal(b1, b0) and np.array_equal(d1, d0)
+    monkeypatch.delenv("LFBM5D_FUSED")
+    monkeypatch.delenv("LFBM5D_LANES")
+    # several ranks, all played on this GPU
+    for n in (2, 3, 4, 8):
+        monkeypatch.setenv("LFBM5D_EMULATE_WORLD", str(n))
+        nn, bn, dn, wn, sn = _one_job(ctx, P1, P2, noisy, mask, aw, ah, an, Ws, Hs, mj)
+        nodes, msgs, info = core.plan_job(aw, ah, n, 1, an=an, mask=mask, ang_major=mj)
+        assert np.array_equal(wn, w0) and sn.windows == len(w0) and sn.messages == len(msgs) > 0
+        assert len(set(nodes[:, 3].tolist())) > 1                     # several ranks really own windows
+        assert (msgs[:, 0] == 1).sum() > 0                            # ... and basic estimates do travel
+        assert np.array_equal(nn, n0) and np.array_equal(bn, b0) and np.array_equal(dn, d0), (name, n)
+    monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
+    assert O.psnr_lf(d0[mask != 0], clean[mask != 0]) > O.psnr_lf(noisy[mask != 0], clean[mask != 0]) + 5
+
+
+def test_two_step_job_with_a_window_limit(ctx, monkeypatch):
+    """LFBM5D_MAX_WINDOWS bounds both steps' sequences (bench.py's CPU comparison uses it): SAIs the first step never reaches keep
+    the noisy image as their basic estimate, SAIs the second never reaches the basic estimate as the result -- like the two calls."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    ah, aw, Hs, Ws = 7, 9, 64, 64
+    clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, Hs, Ws), 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    P1 = core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "sadct", "haar")
+    P2 = core.make_params(25.0, 2.7, 8, 6, 2, 8, 4, "dct", "sadct", "haar")
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LFBM5D_MAX_WINDOWS", "5")
+    n0, b0, d0, w0 = _two_calls(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+    assert len(w0) == 10
+    for emu in (None, "3"):
+        if emu:
+            monkeypatch.setenv("LFBM5D_EMULATE_WORLD", emu)
+        n1, b1, d1, w1, _ = _one_job(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+        assert np.array_equal(w1, w0) and np.array_equal(n1, n0) and np.array_equal(b1, b0) and np.array_equal(d1, d0), emu
+
+
+def test_greyscale_job_takes_the_two_calls(ctx, monkeypatch):
+    """Greyscale light fields need data-driven further passes per window: lfbm5d_denoise_* runs the two calls."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    ah, aw, Hs, Ws = 3, 5, 48, 48
+    lf = Hh.textured_lf(ah, aw, Hs, Ws)[:, :1]
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    P1 = core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "sadct", "haar")
+    P2 = core.make_params(25.0, 2.7, 8, 6, 2, 8, 4, "dct", "sadct", "haar")
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    d_n = torch.from_numpy(noisy).cuda()
+    d_b, d_d = torch.zeros_like(d_n), torch.zeros_like(d_n)
+    ctx.step1(P1, d_n, mask, d_b, L.ROWMAJOR, aw, ah, 1, Ws, Hs, 1)
+    ctx.step2(P2, d_n, mask, d_b, d_d, L.ROWMAJOR, aw, ah, 1, Ws, Hs, 1)
+    e_n = torch.from_numpy(noisy).cuda()
+    e_b, e_d = torch.zeros_like(e_n), torch.zeros_like(e_n)
+    ctx.denoise(P1, P2, e_n, mask, e_b, e_d, L.ROWMAJOR, aw, ah, 1, 1, Ws, Hs, 1)
+    assert torch.equal(d_b, e_b) and torch.equal(d_d, e_d) and torch.equal(d_n, e_n)
+
+
+def test_headline_job_on_eight_emulated_ranks_is_bit_identical(ctx, monkeypatch):
+    """The headline light field (17x17x512x512, sigma 25) as ONE two-step job on eight ranks played on this GPU: all eight ranks
+    own windows (the single steps' graphs keep five busy), the result is bit-identical to the two calls on one rank."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core, synth
+    ah = aw = 17
+    Hs = Ws = 512
+    A = ah * aw
+    clean = torch.from_numpy(synth.make_lf(ah, aw, Hs, Ws).reshape(A, -1)).cuda().float()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    noisy0 = clean + 25.0 * torch.randn(clean.shape, generator=g, device="cuda")
+    del clean
+    mask = np.ones(A, np.uint32)
+    P1, P2 = core.make_params(25.0, 2.7, *Hh.README_HT), core.make_params(25.0, 2.7, *Hh.README_WIEN)
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    n0 = noisy0.clone()
+    b0, d0 = torch.zeros_like(n0), torch.zeros_like(n0)
+    ctx.step1(P1, n0, mask, b0, L.ROWMAJOR, aw, ah, 1, Ws, Hs, 3)
+    ctx.step2(P2, n0, mask, b0, d0, L.ROWMAJOR, aw, ah, 1, Ws, Hs, 3)
+    for emu in (None, "8"):
+        if emu:
+            monkeypatch.setenv("LFBM5D_EMULATE_WORLD", emu)
+        n1 = noisy0.clone()
+        b1, d1 = torch.zeros_like(n1), torch.zeros_like(n1)
+        ctx.reset_stats()
+        ctx.denoise(P1, P2, n1, mask, b1, d1, L.ROWMAJOR, aw, ah, 1, 1, Ws, Hs, 3)
+        s = ctx.stats()
+        assert s.windows == s.passes == 128
+        assert torch.equal(n0, n1) and torch.equal(b0, b1) and torch.equal(d0, d1), emu
+        del n1, b1, d1
+    nodes, msgs, info = core.plan_job(aw, ah, 8, 1, an=(1, 1))
+    assert len(set(nodes[:, 3].tolist())) == 8 and s.messages == len(msgs) >= 400
