@@ -84,6 +84,7 @@ struct lfbm5d_ctx {
      * cached, one set per step slot so that the windows of both steps of a two-step job can alternate on a lane without
      * re-uploading (and without the stream synchronisation an upload from a stack object needs) */
     GeomCache gc[2]; int gslot = 0;
+    bool est_ready = false;                /* the caller of pass_impl has formed the matching estimate in `est` already (graph form) */
     DevBuf est, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gofs, gok, gshape, counters, small, t_num, t_den, d_mask;
     /* step-level buffers (g_num2 / g_den2 / n2: second step of a two-step job; e_basic: an emulated rank's own basic estimate) */
     DevBuf g_num, g_den, g_num2, g_den2, n2, e_basic, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
@@ -394,7 +395,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
 
     /* current estimate for matching, channel 0 (core:167-170) */
     const float* sub = step == 1 ? d_noisy : d_basic;
-    HIPCK(c, launch_estimate_multi(s, d_num, d_den, sub, est, plane, C, A, mask_bits));
+    if (!c->est_ready) HIPCK(c, launch_estimate_multi(s, d_num, d_den, sub, est, plane, C, A, mask_bits));
+    c->est_ready = false;
     /* multi-GPU: ranks > 0 accumulate their shard into zeroed buffers; the all-reduce restores
      * base + all contributions on every rank */
     if (c->pass_world > 1 && c->pass_rank > 0) {
@@ -762,23 +764,22 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
                     proc_w[slot] = !h_mask[st];
                 }
             const bool wien = J.step[sl] == 2;
-            HIPCK(c, launch_symetrize_multi(ls, J.noisy[sl], img, Lw.w_noisy, g.imgb, wl, W, H, C, g.nHW));
-            if (wien) HIPCK(c, launch_symetrize_multi(ls, S->basic, img, Lw.w_basic, g.imgb, wl, W, H, C, g.nHW));
-            HIPCK(c, launch_symetrize_multi(ls, S->g_num[sl], img, Lw.w_num, g.imgb, wl, W, H, C, g.nHW));
-            HIPCK(c, launch_symetrize_multi(ls, S->g_den[sl], img, Lw.w_den, g.imgb, wl, W, H, C, g.nHW));
+            /* (the estimate buffer as pass_impl lays it out: slack on both sides for the table kernel's row loads) */
+            HIPCK(c, Lw.x->est.reserve((kEstLead + g.Aw * (size_t)g.wb * g.hb + 256) * sizeof(float)));
+            HIPCK(c, launch_window_begin(ls, J.noisy[sl], wien ? S->basic : nullptr, S->g_num[sl], S->g_den[sl], img, Lw.w_noisy, Lw.w_basic, Lw.w_num,
+                                         Lw.w_den, Lw.x->est.as<float>() + kEstLead, g.imgb, wl, W, H, C, g.nHW, Lw.d_small));
             lfbm5d_params Pw = *J.P[sl];
             Pw.tau_4D = nd.tau4;
             Lw.x->gslot = sl;
+            Lw.x->est_ready = true;
             const int prc = pass_impl(Lw.x, J.step[sl], &Pw, g.asw, g.asw, g.wb, g.hb, C, Lw.w_noisy, wien ? Lw.w_basic : nullptr, Lw.w_num, Lw.w_den,
                                       mask_w.data(), proc_w.data(), cst_w, cst_w);
             Lw.x->gslot = 0;
             if (prc) { if (Lw.x != c) c->err = Lw.x->err; return 1; }
-            /* coverage count of the pass (LF_denoised_percent, utilities_LF.cpp:967-995) -> pinned memory */
-            HIPCK(c, hipMemsetAsync(Lw.d_small, 0, sizeof(unsigned), ls));
-            HIPCK(c, launch_count_denoised(ls, Lw.w_den, g.imgb, g.Aw, win_bits[n], W, H, C, g.nHW, J.P[sl]->k, Lw.d_small));
+            /* the window's sums back into the light field, and the coverage count of the pass (LF_denoised_percent,
+             * utilities_LF.cpp:967-995) -> pinned memory */
+            HIPCK(c, launch_window_end(ls, S->g_num[sl], S->g_den[sl], img, Lw.w_num, Lw.w_den, g.imgb, wl, W, H, C, g.nHW, J.P[sl]->k, Lw.d_small));
             HIPCK(c, hipMemcpyAsync(c->h_counts + n, Lw.d_small, sizeof(unsigned), hipMemcpyDeviceToHost, ls));
-            HIPCK(c, launch_unsymetrize_multi(ls, S->g_num[sl], img, Lw.w_num, g.imgb, wl, W, H, C, g.nHW));
-            HIPCK(c, launch_unsymetrize_multi(ls, S->g_den[sl], img, Lw.w_den, g.imgb, wl, W, H, C, g.nHW));
             if (!nd.fin.empty()) {   /* two-step jobs: these SAIs' first-step sums are final -> their basic estimate as the second step reads it */
                 SaiList fl; fl.n = 0;
                 for (unsigned st : nd.fin) fl.st[fl.n++] = st;

@@ -206,6 +206,15 @@ hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_st
                                   const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride, const float* src, size_t src_stride,
                                     const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
+/* The two ends of a window of the graph form, one launch each.  begin: mirror-padded noisy (+ basic, NULL in step 1) + num + den of the
+ * window's SAIs and the channel-0 matching estimate from the padded sums (= launch_symetrize_multi x 3..4 + launch_estimate_multi),
+ * *zero cleared;  end: the window's sums back into the light field and the pass's coverage count added to *count
+ * (= launch_unsymetrize_multi x 2 + launch_count_denoised).  lf_stride / w_stride: floats per SAI of the light field / window. */
+hipError_t launch_window_begin(hipStream_t s, const float* noisy, const float* basic, const float* num, const float* den, size_t lf_stride,
+                               float* w_noisy, float* w_basic, float* w_num, float* w_den, float* est, size_t w_stride, const SaiList& L,
+                               unsigned W, unsigned H, unsigned C, unsigned N, unsigned* zero);
+hipError_t launch_window_end(hipStream_t s, float* num, float* den, size_t lf_stride, const float* w_num, const float* w_den, size_t w_stride,
+                             const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count);
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
                                  size_t plane, unsigned C, unsigned A, unsigned long long mask_bits);
 /* w x h rectangle of every channel of n_slots images: dst image (dW x dH, slots dst_stride apart) at (dx0, dy0) <- src image

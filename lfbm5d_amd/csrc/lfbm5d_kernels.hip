@@ -241,6 +241,76 @@ __global__ void k_count_denoised(const float* __restrict__ den, size_t sai_strid
     if (threadIdx.x == 0 && t) atomicAdd(count, t);
 }
 
+/* ---- the two ends of a window of the graph form (run_graph, lfbm5d_api.hip), one launch each ----
+ * begin: mirror-pad noisy (+ basic) + num + den of every SAI of the window (symetrize, utilities.cpp:215-263, bm5d.cpp:252-265)
+ * and form the matching estimate of channel 0 (compute_LF_estimate, core:167-170) from the padded sums -- what
+ * k_symetrize_multi x 3..4 + k_estimate_multi do, with one index computation per pixel instead of a 64-bit division per
+ * element.  Thread = one padded pixel of one SAI, all channels; blockIdx.z = window slot. */
+struct WinBeginArgs {
+    const float* noisy; const float* basic; const float* num; const float* den;   /* light field [SAI][C][H][W] (basic: NULL in step 1) */
+    float* w_noisy; float* w_basic; float* w_num; float* w_den;                   /* window [slot][C][Hb][Wb] */
+    float* est;                                                                   /* [slot][Hb][Wb] */
+    size_t lf_stride, w_stride;
+    SaiList L;
+    int W, H, C, N;
+    unsigned* zero;                                                               /* the window's coverage counter, cleared here */
+};
+__global__ __launch_bounds__(256) void k_window_begin(WinBeginArgs a) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && threadIdx.y == 0 && a.zero) *a.zero = 0u;
+    const unsigned st = a.L.st[blockIdx.z];
+    if (st == 0xffffffffu) return;
+    const int w = a.W + 2 * a.N, h = a.H + 2 * a.N;
+    const int xx = blockIdx.x * 64 + threadIdx.x, yy = blockIdx.y * 4 + threadIdx.y;
+    if (xx >= w || yy >= h) return;
+    const size_t so = (size_t)st * a.lf_stride + (size_t)mirror(yy - a.N, a.H) * a.W + mirror(xx - a.N, a.W);
+    const size_t d_o = (size_t)blockIdx.z * a.w_stride + (size_t)yy * w + xx;
+    const size_t sp = (size_t)a.W * a.H, dp = (size_t)w * h;
+    float n0 = 0.0f, u0 = 0.0f, d0 = 0.0f, b0 = 0.0f;
+    for (int c = 0; c < a.C; c++) {
+        const float nv = a.noisy[so + c * sp], uv = a.num[so + c * sp], dv = a.den[so + c * sp];
+        a.w_noisy[d_o + c * dp] = nv; a.w_num[d_o + c * dp] = uv; a.w_den[d_o + c * dp] = dv;
+        float bv = 0.0f;
+        if (a.basic) { bv = a.basic[so + c * sp]; a.w_basic[d_o + c * dp] = bv; }
+        if (c == 0) { n0 = nv; u0 = uv; d0 = dv; b0 = bv; }
+    }
+    a.est[(size_t)blockIdx.z * dp + (size_t)yy * w + xx] = d0 ? __fdiv_rn(u0, d0) : (a.basic ? b0 : n0);
+}
+
+/* end: the window's sums back into the light field (unsymetrize, utilities.cpp:265-298, bm5d.cpp:388-396) and the coverage
+ * count of the pass (LF_denoised_percent, utilities_LF.cpp:985-992: (i, j, c) triples with den > 0 over the (H-k+1) x (W-k+1)
+ * patch origins) -- k_unsymetrize_multi x 2 + k_count_denoised.  Thread = one pixel of one SAI, all channels. */
+struct WinEndArgs {
+    float* num; float* den; const float* w_num; const float* w_den;
+    size_t lf_stride, w_stride;
+    SaiList L;
+    int W, H, C, N, k;
+    unsigned* count;
+};
+__global__ __launch_bounds__(256) void k_window_end(WinEndArgs a) {
+    __shared__ unsigned red[4];
+    const unsigned st = a.L.st[blockIdx.z];
+    if (st == 0xffffffffu) return;      /* (uniform per workgroup) */
+    const int w = a.W + 2 * a.N, h = a.H + 2 * a.N;
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    unsigned cnt = 0;
+    if (x < a.W && y < a.H) {
+        const size_t d_o = (size_t)st * a.lf_stride + (size_t)y * a.W + x;
+        const size_t so = (size_t)blockIdx.z * a.w_stride + (size_t)(y + a.N) * w + x + a.N;
+        const size_t dp = (size_t)a.W * a.H, sp = (size_t)w * h;
+        const bool counted = x < a.W - a.k + 1 && y < a.H - a.k + 1;
+        for (int c = 0; c < a.C; c++) {
+            const float dv = a.w_den[so + c * sp];
+            a.num[d_o + c * dp] = a.w_num[so + c * sp];
+            a.den[d_o + c * dp] = dv;
+            cnt += (counted && dv > 0.0f) ? 1u : 0u;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (threadIdx.x == 0) red[threadIdx.y] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0) { const unsigned t = red[0] + red[1] + red[2] + red[3]; if (t) atomicAdd(a.count, t); }
+}
+
 /* ================================== group kernel ========================================== */
 
 constexpr int kThreads = 256;
@@ -3397,6 +3467,23 @@ hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride
                                     const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N) {
     hipLaunchKernelGGL(k_unsymetrize_multi, dim3(grid1d((size_t)W * H * C).x, L.n), dim3(256), 0, s,
                        dst, dst_stride, src, src_stride, L, (int)W, (int)H, (int)C, (int)N);
+    return hipGetLastError();
+}
+hipError_t launch_window_begin(hipStream_t s, const float* noisy, const float* basic, const float* num, const float* den, size_t lf_stride,
+                               float* w_noisy, float* w_basic, float* w_num, float* w_den, float* est, size_t w_stride, const SaiList& L,
+                               unsigned W, unsigned H, unsigned C, unsigned N, unsigned* zero) {
+    WinBeginArgs a;
+    a.noisy = noisy; a.basic = basic; a.num = num; a.den = den; a.w_noisy = w_noisy; a.w_basic = w_basic; a.w_num = w_num; a.w_den = w_den;
+    a.est = est; a.lf_stride = lf_stride; a.w_stride = w_stride; a.L = L; a.W = (int)W; a.H = (int)H; a.C = (int)C; a.N = (int)N; a.zero = zero;
+    hipLaunchKernelGGL(k_window_begin, dim3((W + 2 * N + 63) / 64, (H + 2 * N + 3) / 4, L.n), dim3(64, 4), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_window_end(hipStream_t s, float* num, float* den, size_t lf_stride, const float* w_num, const float* w_den, size_t w_stride,
+                             const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count) {
+    WinEndArgs a;
+    a.num = num; a.den = den; a.w_num = w_num; a.w_den = w_den; a.lf_stride = lf_stride; a.w_stride = w_stride; a.L = L;
+    a.W = (int)W; a.H = (int)H; a.C = (int)C; a.N = (int)N; a.k = (int)k; a.count = count;
+    hipLaunchKernelGGL(k_window_end, dim3((W + 63) / 64, (H + 3) / 4, L.n), dim3(64, 4), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,

@@ -82,9 +82,10 @@ def test_two_step_job_is_bit_identical_to_the_two_calls(ctx, monkeypatch, case):
         monkeypatch.setenv("LFBM5D_EMULATE_WORLD", str(n))
         nn, bn, dn, wn, sn = _one_job(ctx, P1, P2, noisy, mask, aw, ah, an, Ws, Hs, mj)
         nodes, msgs, info = core.plan_job(aw, ah, n, 1, an=an, mask=mask, ang_major=mj)
-        assert np.array_equal(wn, w0) and sn.windows == len(w0) and sn.messages == len(msgs) > 0
-        assert len(set(nodes[:, 3].tolist())) > 1                     # several ranks really own windows
-        assert (msgs[:, 0] == 1).sum() > 0                            # ... and basic estimates do travel
+        assert np.array_equal(wn, w0) and sn.windows == len(w0) and sn.messages == len(msgs)
+        if ah * aw > 25:      # (the five windows of a 5x5 light field all share the centre SAIs: one chain after the other, one rank)
+            assert len(set(nodes[:, 3].tolist())) > 1 and len(msgs) > 0   # several ranks really own windows
+            assert (msgs[:, 0] == 1).sum() > 0                            # ... and basic estimates do travel
         assert np.array_equal(nn, n0) and np.array_equal(bn, b0) and np.array_equal(dn, d0), (name, n)
     monkeypatch.delenv("LFBM5D_EMULATE_WORLD")
     assert O.psnr_lf(d0[mask != 0], clean[mask != 0]) > O.psnr_lf(noisy[mask != 0], clean[mask != 0]) + 5
