@@ -13,7 +13,7 @@ the JSON line.
 
 Prints ONE JSON line on rank 0.
   value      whole-job throughput of the timed region (default execution: the step's windows as a dependency
-             graph on LFBM5D_LANES = 3 streams, bit-identical to the window-after-window order)
+             graph on LFBM5D_LANES = 2 streams, bit-identical to the window-after-window order)
   roofline   the transform + aggregate kernel pair (k_group* + k_aggregate; the SURVEY 8d algorithmic bytes
              cover exactly that pair), durations from HIP events on the library's stream.  With lanes the
              kernels of different windows overlap on the GPU, so the pair is timed in one extra, untimed step
@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-check", action="store_true",
                     help="also run the centre window of each step through the oracle and the C-ABI and report the differences (+20 s)")
-    ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 3)")
+    ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 2)")
     ap.add_argument("--noise", default="mt19937", choices=["mt19937", "torch"],
                     help="mt19937: the reference's noise stream, seed 1 (default); torch: quick GPU noise for kernel iteration")
     ap.add_argument("--watchdog-s", type=int, default=600,
@@ -246,7 +246,7 @@ def main():
         os.environ.pop("LFBM5D_STEP_SHARDING", None)
     if args.lanes > 0:
         os.environ["LFBM5D_LANES"] = str(args.lanes)
-    lanes_timed = int(os.environ.get("LFBM5D_LANES", "3"))
+    lanes_timed = int(os.environ.get("LFBM5D_LANES", "2"))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -58,6 +58,10 @@ struct GeomCache {
 
 } /* namespace */
 
+/* window lanes of the graph form when LFBM5D_LANES does not say (same-box sweep at the headline workload, round 4: one lane 194,
+ * two 220, three 211, four 210, five / six 215 SAI-MP/s -- the table kernel fills the register files of the CUs it runs on, so
+ * a third window mostly queues) */
+constexpr int kDefaultLanes = 2;
 constexpr size_t kEstLead = 64;   /* floats of slack in front of the estimate planes */
 
 struct lfbm5d_ctx {
@@ -608,7 +612,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         if (any_step2) HIPCK(c, x->w_basic.reserve(imgb_max * sizeof(float)));
         HIPCK(c, x->w_num.reserve(imgb_max * sizeof(float)));
         HIPCK(c, x->w_den.reserve(imgb_max * sizeof(float)));
-        HIPCK(c, x->small.reserve((asize + 8) * sizeof(unsigned)));
+        HIPCK(c, x->small.reserve((asize + 8 + kWinCounters) * sizeof(unsigned)));
         L.x = x; L.w_noisy = x->w_noisy.as<float>(); L.w_basic = x->w_basic.as<float>();
         L.w_num = x->w_num.as<float>(); L.w_den = x->w_den.as<float>(); L.d_small = x->small.as<unsigned>();
         return 0;
@@ -691,11 +695,11 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             }
     }
     auto local = [&](int r) -> RankState* { return emulate ? &states[(size_t)r] : (r == c->rank ? &states[0] : nullptr); };
-    if (c->h_counts_cap < NN) {
+    if (c->h_counts_cap < NN * kWinCounters) {
         if (c->h_counts) (void)hipHostFree(c->h_counts);
         c->h_counts = nullptr; c->h_counts_cap = 0;
-        HIPCK(c, hipHostMalloc((void**)&c->h_counts, NN * sizeof(unsigned)));
-        c->h_counts_cap = NN;
+        HIPCK(c, hipHostMalloc((void**)&c->h_counts, NN * kWinCounters * sizeof(unsigned)));
+        c->h_counts_cap = NN * kWinCounters;
     }
     std::vector<hipEvent_t> done(NN, nullptr);
     std::vector<hipEvent_t> arrived(G.xfers.size(), nullptr);   /* per message: it has reached its consumer's rank */
@@ -779,7 +783,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             /* the window's sums back into the light field, and the coverage count of the pass (LF_denoised_percent,
              * utilities_LF.cpp:967-995) -> pinned memory */
             HIPCK(c, launch_window_end(ls, S->g_num[sl], S->g_den[sl], img, Lw.w_num, Lw.w_den, g.imgb, wl, W, H, C, g.nHW, J.P[sl]->k, Lw.d_small));
-            HIPCK(c, hipMemcpyAsync(c->h_counts + n, Lw.d_small, sizeof(unsigned), hipMemcpyDeviceToHost, ls));
+            HIPCK(c, hipMemcpyAsync(c->h_counts + (size_t)n * kWinCounters, Lw.d_small, kWinCounters * sizeof(unsigned), hipMemcpyDeviceToHost, ls));
             if (!nd.fin.empty()) {   /* two-step jobs: these SAIs' first-step sums are final -> their basic estimate as the second step reads it */
                 SaiList fl; fl.n = 0;
                 for (unsigned st : nd.fin) fl.st[fl.n++] = st;
@@ -843,7 +847,9 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         if (!mine[n]) continue;
         const int sl = G.nodes[n].s;
         const unsigned n_mask = (unsigned)__builtin_popcountll(win_bits[n]);
-        const float pct = (float)c->h_counts[n] * 100.0f / (float)n_mask / (float)(H - J.P[sl]->k + 1) / (float)(W - J.P[sl]->k + 1);
+        unsigned covered = 0;
+        for (unsigned q = 0; q < kWinCounters; q++) covered += c->h_counts[n * kWinCounters + q];
+        const float pct = (float)covered * 100.0f / (float)n_mask / (float)(H - J.P[sl]->k + 1) / (float)(W - J.P[sl]->k + 1);
         if (!(pct >= 100.0f)) complete = 0;
     }
     if (std::getenv("LFBM5D_FORCE_REDO") && nranks == 1 && !two) complete = 0;   /* test hook: exercise the sequential redo */
@@ -1208,7 +1214,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
     const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
     const char* lanes_s = std::getenv("LFBM5D_LANES");
-    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : 3));
+    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : kDefaultLanes));
     /* LFBM5D_DATA_DRIVEN_SCHEDULE: select every window from the zero-weight counts like the reference does (one
      * device round trip per window); the default takes the same sequence from plan_windows() */
     const bool planned = (c->world > 1 && !by_rows) || emu > 1 || std::getenv("LFBM5D_DATA_DRIVEN_SCHEDULE") == nullptr;   /* several ranks always plan */
@@ -1361,7 +1367,7 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
     const char* emu_s = std::getenv("LFBM5D_EMULATE_WORLD");
     const int emu = emu_s ? std::atoi(emu_s) : 0;
     const char* lanes_s = std::getenv("LFBM5D_LANES");
-    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : 3));
+    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : kDefaultLanes));
     const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
     const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
     const char* fused_s = std::getenv("LFBM5D_FUSED");

@@ -208,8 +208,10 @@ hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride
                                     const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 /* The two ends of a window of the graph form, one launch each.  begin: mirror-padded noisy (+ basic, NULL in step 1) + num + den of the
  * window's SAIs and the channel-0 matching estimate from the padded sums (= launch_symetrize_multi x 3..4 + launch_estimate_multi),
- * *zero cleared;  end: the window's sums back into the light field and the pass's coverage count added to *count
- * (= launch_unsymetrize_multi x 2 + launch_count_denoised).  lf_stride / w_stride: floats per SAI of the light field / window. */
+ * zero[0 .. kWinCounters) cleared;  end: the window's sums back into the light field and the pass's coverage count added to
+ * count[0 .. kWinCounters) -- partial counters, the count is their sum -- (= launch_unsymetrize_multi x 2 + launch_count_denoised).
+ * lf_stride / w_stride: floats per SAI of the light field / window. */
+constexpr unsigned kWinCounters = 32;
 hipError_t launch_window_begin(hipStream_t s, const float* noisy, const float* basic, const float* num, const float* den, size_t lf_stride,
                                float* w_noisy, float* w_basic, float* w_num, float* w_den, float* est, size_t w_stride, const SaiList& L,
                                unsigned W, unsigned H, unsigned C, unsigned N, unsigned* zero);

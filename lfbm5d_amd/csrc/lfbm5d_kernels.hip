@@ -253,10 +253,10 @@ struct WinBeginArgs {
     size_t lf_stride, w_stride;
     SaiList L;
     int W, H, C, N;
-    unsigned* zero;                                                               /* the window's coverage counter, cleared here */
+    unsigned* zero;                                                               /* the window's partial coverage counters (kWinEndCounters of them), cleared here */
 };
 __global__ __launch_bounds__(256) void k_window_begin(WinBeginArgs a) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && threadIdx.y == 0 && a.zero) *a.zero = 0u;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.y == 0 && threadIdx.x < kWinCounters && a.zero) a.zero[threadIdx.x] = 0u;
     const unsigned st = a.L.st[blockIdx.z];
     if (st == 0xffffffffu) return;
     const int w = a.W + 2 * a.N, h = a.H + 2 * a.N;
@@ -286,29 +286,38 @@ struct WinEndArgs {
     int W, H, C, N, k;
     unsigned* count;
 };
+constexpr int kWinEndRows = 32;     /* rows of a SAI per workgroup (8 rounds of 4) */
+static_assert(kWinCounters == 32, "k_window_end");
+constexpr int kWinEndCounters = 32; /* partial coverage counters: atomics to ONE address serialise (a hundred million a second) */
 __global__ __launch_bounds__(256) void k_window_end(WinEndArgs a) {
     __shared__ unsigned red[4];
     const unsigned st = a.L.st[blockIdx.z];
     if (st == 0xffffffffu) return;      /* (uniform per workgroup) */
     const int w = a.W + 2 * a.N, h = a.H + 2 * a.N;
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const size_t dp = (size_t)a.W * a.H, sp = (size_t)w * h;
     unsigned cnt = 0;
-    if (x < a.W && y < a.H) {
-        const size_t d_o = (size_t)st * a.lf_stride + (size_t)y * a.W + x;
-        const size_t so = (size_t)blockIdx.z * a.w_stride + (size_t)(y + a.N) * w + x + a.N;
-        const size_t dp = (size_t)a.W * a.H, sp = (size_t)w * h;
-        const bool counted = x < a.W - a.k + 1 && y < a.H - a.k + 1;
-        for (int c = 0; c < a.C; c++) {
-            const float dv = a.w_den[so + c * sp];
-            a.num[d_o + c * dp] = a.w_num[so + c * sp];
-            a.den[d_o + c * dp] = dv;
-            cnt += (counted && dv > 0.0f) ? 1u : 0u;
+    if (x < a.W)
+        for (int r = 0; r < kWinEndRows; r += 4) {
+            const int y = blockIdx.y * kWinEndRows + r + threadIdx.y;
+            if (y >= a.H) break;
+            const size_t d_o = (size_t)st * a.lf_stride + (size_t)y * a.W + x;
+            const size_t so = (size_t)blockIdx.z * a.w_stride + (size_t)(y + a.N) * w + x + a.N;
+            const bool counted = x < a.W - a.k + 1 && y < a.H - a.k + 1;
+            for (int c = 0; c < a.C; c++) {
+                const float dv = a.w_den[so + c * sp];
+                a.num[d_o + c * dp] = a.w_num[so + c * sp];
+                a.den[d_o + c * dp] = dv;
+                cnt += (counted && dv > 0.0f) ? 1u : 0u;
+            }
         }
-    }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     if (threadIdx.x == 0) red[threadIdx.y] = cnt;
     __syncthreads();
-    if (threadIdx.x == 0 && threadIdx.y == 0) { const unsigned t = red[0] + red[1] + red[2] + red[3]; if (t) atomicAdd(a.count, t); }
+    if (threadIdx.x == 0 && threadIdx.y == 0) {
+        const unsigned t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(a.count + (blockIdx.x + blockIdx.y * 5 + blockIdx.z * 11) % kWinEndCounters, t);
+    }
 }
 
 /* ================================== group kernel ========================================== */
@@ -3483,7 +3492,7 @@ hipError_t launch_window_end(hipStream_t s, float* num, float* den, size_t lf_st
     WinEndArgs a;
     a.num = num; a.den = den; a.w_num = w_num; a.w_den = w_den; a.lf_stride = lf_stride; a.w_stride = w_stride; a.L = L;
     a.W = (int)W; a.H = (int)H; a.C = (int)C; a.N = (int)N; a.k = (int)k; a.count = count;
-    hipLaunchKernelGGL(k_window_end, dim3((W + 63) / 64, (H + 3) / 4, L.n), dim3(64, 4), 0, s, a);
+    hipLaunchKernelGGL(k_window_end, dim3((W + 63) / 64, (H + kWinEndRows - 1) / kWinEndRows, L.n), dim3(64, 4), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,

@@ -807,7 +807,7 @@ def test_full_size_properties(ctx, monkeypatch, name):
     mask = np.ones(A, np.uint32)
     plan = core.plan_windows(aw, ah, 1, L.ROWMAJOR)
     outs = []
-    for lanes in ("3", "1"):
+    for lanes in ("2", "1"):
         monkeypatch.setenv("LFBM5D_LANES", lanes)
         noisy = noisy0.clone()
         basic, den = torch.zeros_like(noisy), torch.zeros_like(noisy)
@@ -820,7 +820,7 @@ def test_full_size_properties(ctx, monkeypatch, name):
         outs.append((b1, den.clone()))
         s = ctx.stats()
         assert s.windows == s.passes == 2 * len(plan)            # one centre pass per window (quirk 1)
-        assert (s.lane_windows > 0) == (lanes == "3")
+        assert (s.lane_windows > 0) == (lanes == "2")
         del noisy, basic, den
 
     def psnr(x):
