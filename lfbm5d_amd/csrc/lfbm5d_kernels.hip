@@ -3254,8 +3254,8 @@ constexpr int kAggFlush = 64;   /* hits that make a consume phase worth starting
  * kAggPF chunks per scan round and kAggU hits per load round trade latency hiding against registers and LDS
  * (occupancy): the k = 8 pass has few hits per candidate and wants occupancy, the k = 16 pass deeper rounds.
  * BIG: filt is 4 GiB or more (windows far beyond 560 x 560): 64-bit gather addresses instead of a buffer resource. */
-template <bool WINDOWED, int TW, int TH, int kAggPF, int kAggU, bool BIG>
-__global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
+template <bool WINDOWED, int TW, int TH, int kAggPF, int kAggU, bool BIG, bool VEC4>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW == 8 && !BIG) ? 8 : 1))) void k_aggregate(AggArgs a) {
     constexpr int kAggCap = kAggFlush + kAggPF * 64 + kAggU;   /* + padding of the last round */
     __shared__ uint4 hit_a[kAggCap];       /* (py << 16) | px, offset of the patch in filt, weights of channels 0 and 1 */
     __shared__ float hit_w2[kAggCap];      /* weight of channel 2 */
@@ -3358,6 +3358,75 @@ __global__ __launch_bounds__(64) void k_aggregate(AggArgs a) {
     };
 
     __builtin_amdgcn_wave_barrier();
+    if (VEC4) {
+        /* N a multiple of four (round 4): a lane takes FOUR consecutive candidates -- matches n0 .. n0 + 3 of ONE reference patch -- with
+         * one 16-byte load of their aggregation positions; the group index, the weights and the patch offset are per lane instead of per
+         * candidate, the tile test is two unsigned range checks per candidate.  Hits are appended in candidate order (lane-major: an
+         * exclusive prefix of the lanes' hit counts from three ballots) -- the list the consume phase walks is the same as before, entry
+         * for entry.  A super-chunk of 256 candidates can hold more hits than the list has room for: lanes are then taken in
+         * runs that fit, with a consume phase in between. */
+        constexpr unsigned cap_hits = (unsigned)(kAggCap - kAggU);
+        const unsigned lo_y = (unsigned)(ty0 - k + 1), lo_x = (unsigned)(tx0 - k + 1);          /* (wrap around for tiles at the border: the */
+        const unsigned span_y = (unsigned)(TH + k - 1), span_x = (unsigned)(TW + k - 1);        /*  unsigned test below still means lo <= v < lo + span) */
+        const unsigned pstep = (unsigned)(A * C * k2);                                          /* filt offset from match n to n + 1 */
+        /* the candidates c0 + 4 lane .. + 3 of the lanes [l0, l1): test, and append the hits if the list has room (else: false, nothing
+         * appended).  Nothing computed here is alive across a consume phase -- that is what keeps the kernel at its wave count. */
+        auto try_append = [&](const int c0, const unsigned l0, const unsigned l1) -> bool {
+            const int e = c0 + lane * 4;
+            unsigned g = 0, n0 = 0;
+            uint4 p4 = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if (e < n_cand && (unsigned)lane >= l0 && (unsigned)lane < l1) {
+                n0 = (unsigned)e & (unsigned)(N - 1);
+                const unsigned rr = (unsigned)e >> logN;
+                if (a.irregular) g = rr;
+                else {
+                    unsigned q = __umul24(rr, div_m) >> 20;
+                    if (!mul_div) { asm volatile("" ::: "memory"); q = rr / (unsigned)ncols_span; }
+                    g = __umul24((unsigned)r_lo + q, a.n_ref_cols) + (unsigned)c_lo + (rr - __umul24(q, (unsigned)ncols_span));
+                }
+                if (g >= a.ref_begin && g < g_end) p4 = *reinterpret_cast<const uint4*>(apos + ((size_t)g << logN) + n0);
+            }
+            const unsigned pj[4] = {p4.x, p4.y, p4.z, p4.w};
+            unsigned m4 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {   /* an absent patch (0xffffffff) is at row / column 65535: outside every tile's range */
+                const bool h = ((pj[j] >> 16) - lo_y) < span_y && ((pj[j] & 0xffffu) - lo_x) < span_x;
+                m4 |= h ? (1u << j) : 0u;
+            }
+            const unsigned cnt = (unsigned)__popc(m4);
+            /* exclusive prefix of cnt (0 .. 4) over the lanes below this one */
+            const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+            auto below = [&](unsigned long long b) { return __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u)); };
+            const unsigned total = (unsigned)__popcll(b0) + 2u * (unsigned)__popcll(b1) + 4u * (unsigned)__popcll(b2);
+            if (nh + total > cap_hits) return false;
+            if (m4) {
+                unsigned slot = nh + below(b0) + 2u * below(b1) + 4u * below(b2);
+                size_t wbase; unsigned off;
+                if (small24) { wbase = __umul24(g, (unsigned)C); off = __umul24(__umul24((g << logN) + n0, (unsigned)A) + (unsigned)st, (unsigned)(C * k2)); }
+                else { asm volatile("" ::: "memory"); wbase = (size_t)g * C; off = (((g << logN) + n0) * A + st) * C * k2; }
+                float w[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) w[c] = c < C ? a.wgt[wbase + (a.wchan0 ? 0 : c)] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (m4 & (1u << j)) {
+                        hit_a[slot] = make_uint4(pj[j], off, __float_as_uint(w[0]), __float_as_uint(w[1]));
+                        hit_w2[slot] = w[2];
+                        slot++;
+                    }
+                    off += pstep;
+                }
+            }
+            nh += total;
+            __builtin_amdgcn_wave_barrier();
+            return true;
+        };
+        for (int c0 = 0; c0 < n_cand; c0 += 256) {
+            if (!try_append(c0, 0u, 64u))                     /* more hits than the list has room for: sixteen lanes (<= 64 hits) at a time */
+                for (unsigned l0 = 0; l0 < 64; l0 += 16) { consume(); (void)try_append(c0, l0, l0 + 16); }
+            if (nh >= kAggFlush) consume();
+        }
+    } else
     for (int c0 = 0; c0 < n_cand; c0 += 64 * kAggPF) {
         unsigned g[kAggPF], p[kAggPF], nn[kAggPF];
 #pragma unroll
@@ -3662,9 +3731,17 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
     const unsigned tiles = ((a.Wb + tw - 1) / tw) * ((a.Hb + th - 1) / th) * a.A;
     const dim3 grid(((tiles + 7) / 8) * 8), block(64);
     const bool big = a.filt_bytes > 0xfffff000ull || getenv("LFBM5D_AGG_64BIT") != nullptr;   /* env: exercise the 64-bit path in tests */
+    /* four candidates per lane and 16-byte position loads when a reference patch's N matches come in fours (LFBM5D_AGG_SCALAR_SCAN: the
+     * one-candidate-per-lane scan of rounds 1-3, for A/B runs; N = 1, 2 always take it) */
+    /* Measured at the headline window (same box, rounds of tools/pass_time.py; instruction counts: tools/pmc_agg_ab.sh): VALU instructions
+     * -14 % (k = 8) / -11 % (k = 16), scalar -51 % / -43 %, time 0.648 against 0.658 ms (k = 8), 0.973 against 0.964 (k = 16) -- the
+     * kernel's time is its consume phase, not the scan -- so only the 8 x 8 tiles take it. */
+    const bool vec4 = a.N % 4 == 0 && !wide && getenv("LFBM5D_AGG_SCALAR_SCAN") == nullptr;
 #define LFBM5D_AGG(W_, TW_, TH_, PF_, U_) \
-    do { if (big) hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, true>), grid, block, 0, s, a); \
-         else     hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, false>), grid, block, 0, s, a); } while (0)
+    do { if (big && vec4) hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, true, true>), grid, block, 0, s, a); \
+         else if (big)    hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, true, false>), grid, block, 0, s, a); \
+         else if (vec4)   hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, false, true>), grid, block, 0, s, a); \
+         else             hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, false, false>), grid, block, 0, s, a); } while (0)
     if (a.k == 12)      LFBM5D_AGG(true, 16, 4, 3, 12);
     else if (a.k == 8)  LFBM5D_AGG(true, 8, 8, 2, 6);
     else if (wide)      LFBM5D_AGG(false, 16, 4, 3, 12);

@@ -973,20 +973,30 @@ def test_bm3d_lf_with_different_search_windows_matches_oracle(ctx, nHard, nWien)
 # ------------------------------------------------------------------------------------------------
 # the headline's window pass at its own size against the oracle
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("step,pk", [(1, (8, 18, 6, 16, 4, "id", "sadct", "haar")), (2, (16, 18, 6, 8, 4, "dct", "sadct", "haar"))],
-                         ids=["ht", "wiener"])
-def test_headline_window_pass_matches_oracle_at_full_size(ctx, step, pk):
-    """One 3x3x512x512 centre-window pass of the benchmark's synthetic light field (560^2 padded, 15 625 / 16 129 groups)
-    against the oracle's pass on the same window (OpenMP over reference patches: some tens of seconds of CPU): the
-    block-matching tables identical, survivor counts group by group, `den` and the estimate as in the random sweep.
-    This is the size the dedicated kernels (table scan with eleven waves per workgroup, register-resident HT kernel,
-    one-image-at-a-time Wiener kernel, gather aggregation) are tuned at."""
+FULL_WINDOWS = [
+    # name, step, parameters, H, W, sigma
+    ("ht", 1, Hh.README_HT, 512, 512, 25.0),                 # headline: k_bm_scan2<16>, k_group_id_haar, k_aggregate<16x4>
+    ("wiener", 2, Hh.README_WIEN, 512, 512, 25.0),           # headline: k_bm_scan2<8>, k_group_dct8w3, k_aggregate<8x8>
+    ("config3-ht-bior", 1, Hh.C4_HT, 512, 512, 10.0),        # BASELINE configs[3]: k_group_bior16_haar
+    ("config4-ht-n1", 1, Hh.C5_HT, 434, 625, 50.0),          # BASELINE configs[4]: 49 tables per SAI, no self search, three groups per workgroup
+    ("config4-wiener-n8", 2, Hh.C5_WIEN, 434, 625, 50.0),    # BASELINE configs[4]: p = 3 grid, N = 8 Wiener stacks, 667 x 476 window
+]
+
+
+@pytest.mark.parametrize("case", FULL_WINDOWS, ids=[c[0] for c in FULL_WINDOWS])
+def test_headline_window_pass_matches_oracle_at_full_size(ctx, case):
+    """One 3x3 centre-window pass of the benchmark's synthetic light field at the window sizes of the headline and of BASELINE
+    configurations [3] and [4] (560^2 / 667 x 476 padded; 15 625 ... 29 601 groups) against the oracle's pass on the same window
+    (OpenMP over reference patches: some tens of seconds of CPU): the block-matching tables identical, survivor counts group
+    by group, `den` and the estimate as in the random sweep.  These are the sizes the dedicated kernels (table scan with
+    eleven waves per workgroup, register-resident HT kernel, the 16x16 wavelet kernel, its three-groups-per-workgroup N = 1
+    form, the one-image-at-a-time Wiener kernel, gather aggregation) are tuned at."""
     from lfbm5d_amd import synth
-    H = W = 512
+    name, step, pk, H, W, sigma = case
     lf = synth.make_lf(3, 3, H, W).reshape(9, 3, H, W).astype(np.float32)
-    noisy = lf + 25.0 * np.random.default_rng(1).standard_normal(lf.shape).astype(np.float32)
+    noisy = lf + sigma * np.random.default_rng(1).standard_normal(lf.shape).astype(np.float32)
     win, Wb, Hb = Hh.padded_window(np.ascontiguousarray(noisy.reshape(9, -1)), W, H, 3, pk[1] + pk[2])
-    _check_window(ctx, "headline-" + ("ht" if step == 1 else "wiener"), step, 25.0, pk, 0, win, Wb, Hb, 3, strict=False)
+    _check_window(ctx, "full-" + name, step, sigma, pk, 0, win, Wb, Hb, 3, strict=False)
 
 
 # ------------------------------------------------------------------------------------------------
