@@ -1,9 +1,9 @@
 # Round profile collection (run on the GPU box):  gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r02_a'
-# 1) headline bench line incl. CPU baseline (default execution: three window lanes),
+# 1) headline bench line incl. CPU baseline (default execution: the fused two-step job on two window lanes),
 # 2) rocprofv3 kernel trace + stats of `bench.py --lanes 1` (kernels alone on the GPU: the durations the roofline uses)
 #    and of the default command (lanes overlap kernels of different windows),
 # 3) FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, counters only) on the headline workload.
-tag=${1:-r03_x}
+tag=${1:-r04_x}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/$tag; rm -rf $out; mkdir -p $out
 python3 bench.py --gpus 1 --steps 2 --warmup 1 > $out/bench.log 2>&1; tail -1 $out/bench.log > $out/bench.json
