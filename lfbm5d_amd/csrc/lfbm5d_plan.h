@@ -10,9 +10,9 @@
  * first step that touches that SAI -- the SAI's basic estimate is final then (bm5d.cpp:405) -- so the second step's
  * wavefront follows the first's instead of waiting for the whole first step.
  *
- * Partition: graph ranks own CHAINS of windows (runs of consecutive windows in one row of SAIs: serial anyway); a graph
- * rank is a TEAM of `team` GPUs that split every window of the rank between them (lfbm5d_api.hip).  Whatever a window
- * needs from a window of another graph rank travels as messages: num and den of a shared SAI between consecutive
+ * Partition: every window has an owner rank (chosen along a simulated execution: a window follows the rank of its chain --
+ * the windows of its row of SAIs -- while that rank is free).  Whatever a window needs from a window of another rank
+ * travels as messages: num and den of a shared SAI between consecutive
  * touchers, the basic estimate of a SAI from the rank that finalised it to the ranks whose second-step windows read it.
  * Every rank walks the nodes in the same ISSUE ORDER -- the start order of a simulated execution, a topological order of
  * the whole graph -- and enqueues its windows, sends and receives in that order on FIFO streams, which is what makes the
@@ -170,17 +170,15 @@ inline void build(const unsigned* h_mask, unsigned awidth, unsigned aheight, uns
             if (f >= 0) G.nodes[(size_t)f].fin.push_back(st);
         }
 
-    /* Owner of every chain, decided along a simulated execution with one server per rank: again and again the window that
-     * can start first (ties: the lower index); a chain gets its owner when its first window is picked -- the rank on which that
-     * window starts first, ranks without an unfinished chain first, then the rank that owns most of the window's predecessors
-     * (fewer messages), then the lowest rank.  A pure function of the mask, the steps and the rank count: every rank computes
-     * the same. */
+    /* Owner of every window, decided along a simulated execution with one server per rank: again and again the window that can
+     * start first (ties: the lower index) goes to the rank on which it starts first; among equally early ranks to the one that
+     * owns most of the window's predecessors -- one point per SAI whose sums, or basic estimate, would not have to travel -- then
+     * to the lowest rank.  A window therefore follows its chain (the run of windows in its row of SAIs, each of which shares a
+     * column of SAIs with the one before) while that rank is free and moves when it is not; round 4 measured this against
+     * whole chains per rank (rounds 2-3): 4.76 against 4.19 of the serial time on a 17x17 light field at eight ranks, the
+     * critical path of the two-step graph, with fewer cross-rank edges (lfbm5d_plan_job, tools/scale_model.py).  A pure function
+     * of the mask, the steps and the rank count: every rank computes the same. */
     {
-        unsigned n_chains = 0;
-        for (const Node& nd : G.nodes) n_chains = std::max(n_chains, nd.chain + 1);
-        std::vector<int> crank(n_chains, -1), active((size_t)Gn, 0);
-        std::vector<unsigned> last_of(n_chains, 0);
-        for (size_t n = 0; n < NN; n++) last_of[G.nodes[n].chain] = (unsigned)n;
         std::vector<unsigned> fin(NN, 0), rank_free((size_t)Gn, 0);
         std::vector<char> done(NN, 0);
         for (size_t it = 0; it < NN; it++) {
@@ -191,25 +189,19 @@ inline void build(const unsigned* h_mask, unsigned awidth, unsigned aheight, uns
                 unsigned ready = 0; bool ok = true;
                 for (int p : nd.deps) { if (!done[(size_t)p]) { ok = false; break; } ready = std::max(ready, fin[(size_t)p]); }
                 if (!ok) continue;
-                int r = crank[nd.chain]; unsigned t;
-                if (r >= 0) t = std::max(ready, rank_free[(size_t)r]);
-                else {
-                    unsigned best_key = ~0u; int best_aff = -1; t = 0;
-                    for (int q = 0; q < Gn; q++) {
-                        const unsigned tq = std::max(ready, rank_free[(size_t)q]);
-                        const unsigned key = tq + (active[(size_t)q] ? 0x40000000u : 0u);
-                        int aff = 0;
-                        for (int p : nd.prev) if (p >= 0 && G.nodes[(size_t)p].rank == q) aff++;
-                        if (nd.s == 1) for (unsigned st : nd.sai) { const int f = G.last_touch[0][st]; if (f >= 0 && G.nodes[(size_t)f].rank == q) aff++; }
-                        if (key < best_key || (key == best_key && aff > best_aff)) { best_key = key; best_aff = aff; r = q; t = tq; }
-                    }
+                int r = 0; unsigned t = ~0u; int best_aff = -1;
+                for (int q = 0; q < Gn; q++) {
+                    const unsigned tq = std::max(ready, rank_free[(size_t)q]);
+                    if (tq > t) continue;
+                    int aff = 0;
+                    for (int p : nd.prev) if (p >= 0 && G.nodes[(size_t)p].rank == q) aff++;
+                    if (nd.s == 1) for (unsigned st : nd.sai) { const int f = G.last_touch[0][st]; if (f >= 0 && G.nodes[(size_t)f].rank == q) aff++; }
+                    if (tq < t || aff > best_aff) { t = tq; best_aff = aff; r = q; }
                 }
                 if (t < pick_t) { pick = n; pick_t = t; pick_r = r; }
             }
             Node& nd = G.nodes[pick];
-            if (crank[nd.chain] < 0) { crank[nd.chain] = pick_r; active[(size_t)pick_r]++; }
             nd.rank = pick_r; fin[pick] = pick_t + nd.cost; rank_free[(size_t)pick_r] = fin[pick]; done[pick] = 1;
-            if (last_of[nd.chain] == pick) active[(size_t)pick_r]--;
         }
     }
     /* Simulated execution, the lanes of a rank as parallel servers: again and again the node that can start first (its

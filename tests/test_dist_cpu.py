@@ -91,7 +91,7 @@ def _graph_worker(rank, world, port, q, n_steps):
     from oracle import oracle as O
     from lfbm5d_amd import core
     lib = O.lib()
-    # two rows of windows for two ranks, three for three (a chain = a row of windows is the unit dealt to ranks)
+    # two rows of windows for two ranks, three for three
     ah, aw = (5, 7) if world == 2 else (7, 11)
     H, W, Cc, sigma = 40, 40, 3, 25.0
     pks = [(4, 5, 2, 8, 4, "id", "sadct", "haar"), (8, 4, 2, 8, 3, "dct", "sadct", "haar")][:n_steps]
@@ -208,13 +208,12 @@ def test_graph_form_with_messages_equals_the_single_rank_step(world, n_steps):
     for p in procs:
         p.join(timeout=60)
     assert all(ok and same_plan for _, ok, _, _, _, _, _, same_plan in res), res
-    assert all(n_win > 0 for _, _, _, n_win, *_ in res)                    # every rank owns windows
+    assert sum(1 for _, _, _, n_win, *_ in res if n_win > 0) >= 2          # several ranks own windows (a rank the plan does not need only relays nothing)
     assert sum(r[4] for r in res) == sum(r[5] for r in res) == res[0][6] > 0   # every message sent once, received once
 
 
 def test_graph_plan_properties():
-    """Host-side properties of the graph form for 1..8 ranks, one step and both: every window has an owner, chains stay on one
-    rank, the simulated execution respects the dependencies (a window starts after every earlier window of its step it shares an
+    """Host-side properties of the graph form for 1..8 ranks, one step and both: every window has an owner, the simulated execution respects the dependencies (a window starts after every earlier window of its step it shares an
     SAI with; a second-step window after the last first-step window on each of its SAIs), the issue order is the start order,
     and messages connect exactly the consecutive touchers of an SAI that live on different ranks (+ one basic estimate per SAI
     and reading rank in two-step jobs)."""
@@ -231,8 +230,6 @@ def test_graph_plan_properties():
                     for p in range(w):
                         if cover[w] & cover[p]:
                             assert start[p] < start[w], (ah, aw, world, lanes, p, w)
-                    if w and int(plan[w]) // aw == int(plan[w - 1]) // aw:
-                        assert ranks[w] == ranks[w - 1]               # a chain (same row of SAIs) stays on one rank
                 # no two windows at once on one lane
                 assert len({(int(ranks[w]), int(lane[w]), int(start[w])) for w in range(NW)}) == NW
             msgs = core.plan_messages(aw, ah, world)
@@ -270,8 +267,6 @@ def test_graph_plan_properties():
                     if sl == 1:
                         for st in cover[w]:
                             assert st_[last1[st]] + 10 <= st_[i]
-                    if w and int(plan[w]) // aw == int(plan[w - 1]) // aw:
-                        assert nodes[i][3] == nodes[i - 1][3]
                 assert len({(int(n[3]), int(n[4]), int(n[5])) for n in nodes}) == 2 * NW
                 if lanes == 1:
                     rk = nodes[:, 3].astype(int)
@@ -290,9 +285,9 @@ def test_graph_plan_properties():
     r17, _, t17 = core.plan_graph(17, 17, 8)
     assert t17.max() + 1 <= 24                                        # critical path of the 17x17 backward raster
     # the two-step job is what lets eight ranks work: all of them busy, and a simulated makespan below a quarter of the serial time
-    for (a, bound) in ((17, 4.0), (15, 3.5)):
+    for (a, bound, busy) in ((17, 4.5, 8), (15, 3.5, 7)):
         nodes, _, info = core.plan_job(a, a, 8, 1, an=(1, 1))
-        assert len(set(nodes[:, 3].tolist())) == 8
+        assert len(set(nodes[:, 3].tolist())) >= busy
         assert sum(10 if n[0] == 0 else 9 for n in nodes) / info["makespan"] >= bound
 
 
