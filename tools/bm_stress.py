@@ -46,8 +46,16 @@ def one():
     torch.cuda.synchronize()
     refs, idx, cnt, best, shape = ctx.last_bm(pk[0], 9, Wb * Hb)
     valid = np.arange(pk[0])[None, :] < cnt[:, None]
-    ts, ix = (TS1, IDX1) if ctx.last_scan_version() == 1 else (TS2, IDX2)
-    tab = ctx.last_tables(NT * ts).reshape(NT, ts)[:, ix.ravel()].reshape(NT, NR, NC).copy()   # un-skewed: [table][row][column]
+    ver = ctx.last_scan_version()
+    if ver == 3:
+        # combined form (the default): the disparity tables never reach memory -- `tables` holds (value, order) pairs per workgroup
+        # and per-table edge arrays (include/lfbm5d.h, lfbm5d_last_scan_version).  The raw-table diff needs the full tables:
+        # LFBM5D_SCAN_FULL_TABLES=1 (same kernel, table stores instead of the in-workgroup reduction); without it only the
+        # arg-mins and selections are compared (pair entries whose row lies outside the table are never written).
+        tab = np.zeros((1, 1, 1), np.float32)
+    else:
+        ts, ix = (TS1, IDX1) if ver == 1 else (TS2, IDX2)
+        tab = ctx.last_tables(NT * ts).reshape(NT, ts)[:, ix.ravel()].reshape(NT, NR, NC).copy()   # un-skewed: [table][row][column]
     return np.where(valid, idx, 0), cnt.copy(), best.reshape(9, Hb, Wb).copy(), shape.reshape(9, Hb, Wb).copy(), tab
 
 
