@@ -878,6 +878,12 @@ __device__ __forceinline__ void bior_inv_level(float* Tp, int r, TbPtr tb) {
         bior_inv_level<K, N1 * 2>(Tp, r, tb);
     }
 }
+/* Floats per patch of the 16x16 kernels' work area [patch][16][17]: 16 * 17 = 272 = 16 (mod 32) put every other patch of a wave on the
+ * same banks -- two-way conflicts in every pass of the 16x16 level, 62 % of the LDS-active cycles in conflicts
+ * (profiles/r04_a_sq_counters.txt).  280 = 8 (mod 32): the four patches of a half-wave (eight lanes each) start 0 / 8 / 16 / 24 banks
+ * apart, and rows 17 r + c as well as columns r + 17 c of eight lanes then fall on 32 distinct banks; two workgroups of 72 patches
+ * still fit a CU (2 x 80 640 B). */
+constexpr int kT16Patch = 16 * 17 + 8;
 /* The same levels for the 16x16 kernel below, two rows (then two columns) per thread as packed pairs: a level of
  * side N1 takes N1/2 threads per patch, rows r and r + N1/2 travel as one v2f (one ds_read2 / ds_write2 per
  * element: the partner sits N1/2 rows, or N1/2 floats, away), every tap is one packed multiply or add.  Same
@@ -927,7 +933,7 @@ __device__ __forceinline__ void bior16_pass2(float* Tp, int r, TbPtr tb) {
 /* one level of all NP patches of the work area [patch][16][17]; all 256 threads call it */
 template <int N1, bool FWD>
 __device__ __forceinline__ void bior16_level_all(float* work, int NP, int tid, TbPtr tb) {
-    constexpr int TPP = N1 / 2, PPI = kThreads / TPP, PSZ = 16 * 17;   /* threads per patch (one wavefront holds them all) */
+    constexpr int TPP = N1 / 2, PPI = kThreads / TPP, PSZ = kT16Patch;   /* threads per patch (one wavefront holds them all) */
     const int slot = tid / TPP, r = tid % TPP;
     for (int p0 = 0; p0 < NP; p0 += PPI) {
         const int patch = p0 + slot;
@@ -1444,7 +1450,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
         for (int n = 0; n < NS; n++)
 #pragma unroll
             for (int st = 0; st < 9; st++) {
-                const float x = work[(n * A + st) * k * (k + 1) + woff];
+                const float x = work[(n * A + st) * kT16Patch + woff];
                 if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
                 okbits[n] = 0x1ffu;
             }
@@ -1541,7 +1547,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
 #pragma unroll
         for (int st = 0; st < 9; st++) {
             const float r = n < NH ? V[n][st].x : V[n - NH][st].y;
-            if (LDSW) work[(n * A + st) * k * (k + 1) + woff] = r;
+            if (LDSW) work[(n * A + st) * kT16Patch + woff] = r;
             else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
         }
 }
@@ -1693,7 +1699,7 @@ template <bool HAAR, bool BIOR, bool MULTI>
 __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     extern __shared__ float lds[];
     __shared__ float red[MULTI ? kT16Groups : 1][3][4];
-    constexpr int K = 16, RS = K + 1, PSZ = K * RS, A = 9;
+    constexpr int K = 16, RS = K + 1, PSZ = kT16Patch, A = 9;
     const int tid = threadIdx.x;
     const unsigned g = a.ref_begin + blockIdx.x * (MULTI ? kT16Groups : 1);     /* first group of the workgroup */
     const int ngr = MULTI ? (int)min((unsigned)kT16Groups, a.ref_begin + a.n_groups - g) : 1;
@@ -3659,11 +3665,11 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         return hipGetLastError();
     }
     else if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
-        const size_t lb = (size_t)a.N * 9 * 16 * 17 * sizeof(float);
+        const size_t lb = (size_t)a.N * 9 * kT16Patch * sizeof(float);
         const dim3 grid(a.n_groups, a.C), block(256);
         if (a.N == 1 && a.tau5 != 5) {   /* nine patches per group: a few groups share a workgroup (Haar / Hadamard of one patch: identity) */
             const dim3 grid8((a.n_groups + kT16Groups - 1) / kT16Groups, a.C);
-            const size_t l1 = (size_t)kT16Groups * 9 * 16 * 17 * sizeof(float);
+            const size_t l1 = (size_t)kT16Groups * 9 * kT16Patch * sizeof(float);
             if (a.tau2 == 7) hipLaunchKernelGGL(k_group_bior16_n1, grid8, block, l1, s, a);
             else             hipLaunchKernelGGL(k_group_dct16_n1, grid8, block, l1, s, a);
             return hipGetLastError();
