@@ -476,6 +476,11 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
         const float* const lcw = lcst + w * 8;
         /* COMB: this wave's share of a chunk's positions p = lane-of-the-table * 8 + step-in-chunk */
         constexpr int kShare = (512 + NW - 1) / NW;
+        /* the scan orders of the workgroup's tables, lane q of a register holding table q's: the reduction tracks the INDEX of the winning
+         * table (selects of inline constants) and fetches its order with one ds_bpermute.  Written as `bo = lt ? g.ord[q] : bo`, hipcc
+         * turns the selects of loads into ONE vector load at a selected address -- a global (or, from a local copy, scratch) load and an
+         * s_waitcnt vmcnt(0), which also waits for the wave's stores, per chunk and in front of the chunk barrier. */
+        const int ordv = (int)g.ord[lane & 15];
         const int rp = w * kShare + lane;
         const bool rok = lane < kShare && rp < 512;
         auto reduce_chunk = [&](const int cprev) {
@@ -487,13 +492,14 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
 #pragma unroll
             for (int q = 0; q < NW; q++) v[q] = src[q * 512];
             float best = v[0];
-            int bo = g.ord[0];
+            int bq = 0;
 #pragma unroll
             for (int q = 1; q < NW; q++) {
                 const bool lt = v[q] < best;
                 best = lt ? v[q] : best;
-                bo = lt ? (int)g.ord[q] : bo;
+                bq = lt ? q : bq;
             }
+            const int bo = __builtin_amdgcn_ds_bpermute(bq << 2, ordv);
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i pr = {__float_as_int(best), bo};
             __builtin_amdgcn_raw_buffer_store_b64(pr, rP, rok ? (int)(((strip * NCH + cprev) * 512 + rp) * 8) : -1, 0, 0);
