@@ -260,6 +260,14 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
     const float* lcst = ring2 + CW2 * RRp2;
     const short* rs = reinterpret_cast<const short*>(lcst + 2 * NW * 8);   /* self search: reference-grid row slot of every image row (+ 64 of padding) */
     float* const xch = const_cast<float*>(lcst) + 2 * NW * 8;              /* COMB: [2][NW][512] values of the current / previous chunk */
+    if (STEREO && COMB && !live) {   /* its rows of the exchange area: +inf once, never written again (eight selects per chunk for every wave otherwise) */
+        const v4f inf4 = {__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            *reinterpret_cast<v4f*>(xch + (ch * NW + w) * 512 + lane * 8) = inf4;
+            *reinterpret_cast<v4f*>(xch + (ch * NW + w) * 512 + lane * 8 + 4) = inf4;
+        }
+    }
 
     const unsigned pl1 = a.pst, pl2 = STEREO ? a.st_of_slot[g.slot] : a.pst;
     const float* img1 = a.est + (size_t)pl1 * WH;
@@ -491,14 +499,15 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
             float v[NW];
 #pragma unroll
             for (int q = 0; q < NW; q++) v[q] = src[q * 512];
+            /* smallest value (three-operand minima), then the FIRST table that holds it: the same (value, table) as the sequential
+             * `if (v[q] < best)` scan -- ties to the earlier table -- with a dependent chain of 5 + NW instead of 2 NW instructions */
             float best = v[0];
-            int bq = 0;
 #pragma unroll
-            for (int q = 1; q < NW; q++) {
-                const bool lt = v[q] < best;
-                best = lt ? v[q] : best;
-                bq = lt ? q : bq;
-            }
+            for (int q = 1; q + 1 < NW; q += 2) best = __builtin_fminf(__builtin_fminf(best, v[q]), v[q + 1]);
+            if ((NW & 1) == 0) best = __builtin_fminf(best, v[NW - 1]);
+            int bq = NW - 1;
+#pragma unroll
+            for (int q = NW - 2; q >= 0; q--) bq = v[q] == best ? q : bq;
             const int bo = __builtin_amdgcn_ds_bpermute(bq << 2, ordv);
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i pr = {__float_as_int(best), bo};
@@ -564,8 +573,8 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
                         left_prev = left;
                     }
                     if (STEREO && COMB) {
-                        /* a wave without a table of its own (it walks the first table again, without its hand-off column) hands +inf to the reduction */
-                        *reinterpret_cast<v4f*>(xch + (ch * NW + w) * 512 + lane * 8 + 4 * gq) = live ? out : v4f{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+                        /* (a wave without a table of its own walks the first table again, without its hand-off column, and hands +inf to the reduction) */
+                        if (live) *reinterpret_cast<v4f*>(xch + (ch * NW + w) * 512 + lane * 8 + 4 * gq) = out;   /* (uniform: its rows hold +inf from the start otherwise) */
                     } else if (STEREO) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, out), rT, voffT, 0, 0);
                         voffT += 1024;
