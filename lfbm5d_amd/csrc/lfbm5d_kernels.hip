@@ -3342,9 +3342,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
                     val[u][2] = *reinterpret_cast<const float*>(fp + 2 * cstride);
                 } else {
                     const int vo = (int)((ha.y + o) * 4u);
+#if defined(LFBM5D_AGG_EXP) && LFBM5D_AGG_EXP == 1     /* timing experiment (results garbage): one gather per hit instead of three */
+                    val[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_filt, vo, 0, 0));
+                    val[u][1] = val[u][0]; val[u][2] = val[u][0];
+#elif defined(LFBM5D_AGG_EXP) && LFBM5D_AGG_EXP == 2   /* timing experiment: one 12-byte gather per hit (as if the channels were interleaved) */
+                    { typedef float v3f __attribute__((ext_vector_type(3)));
+                      const v3f t3 = __builtin_bit_cast(v3f, __builtin_amdgcn_raw_buffer_load_b96(rs_filt, (int)(ha.y * 4u + o * 12u), 0, 0));
+                      val[u][0] = t3[0]; val[u][1] = t3[1]; val[u][2] = t3[2]; }
+#else
                     val[u][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_filt, vo, 0, 0));
                     val[u][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_filt, vo, (int)cstride, 0));
                     val[u][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_filt, vo, (int)(2 * cstride), 0));
+#endif
                 }
                 kw[u][0] = on ? kz * __uint_as_float(ha.z) : 0.0f;   /* ... and add it with weight zero */
                 kw[u][1] = on ? kz * __uint_as_float(ha.w) : 0.0f;
