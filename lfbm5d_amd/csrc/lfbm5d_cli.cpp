@@ -351,13 +351,24 @@ int main(int argc, char** argv) {
         cout << endl << "Average PSNR:" << endl << "- Noisy light field: " << ap_n << endl;
         write_psnr(results, "noisy", mask, ang_major, aw, ah, ps, ap_n, sp, rm, ar, sr);
     }
-    cout << endl << " ---> Running LFBM5D filter <--- " << endl << endl << "Step 1 running..." << endl;
+    /* LFBM5D_ONE_JOB=1 (not in the reference): both steps as one job (run_bm5d, run_bm5d.h) -- same files and PSNRs, one time for both */
+    const char* one_job_s = getenv("LFBM5D_ONE_JOB");
+    const bool one_job = one_job_s && *one_job_s && *one_job_s != '0';
+    cout << endl << " ---> Running LFBM5D filter <--- " << endl << endl << (one_job ? "Steps 1 and 2 running as one job..." : "Step 1 running...") << endl;
     const double tb = now_s();
     double t1 = now_s();
+    double job = 0.0;
+    if (one_job) {
+        if (run_bm5d(sigma, lambda, LF_noisy, mask, LF_basic, LF_den, ang_major, aw, ah, anH, anW, W, H, C, N[0], nSim[0], nDisp[0], k[0], p[0],
+                     sd[0] != 0, t2[0], t4[0], t5[0], N[1], nSim[1], nDisp[1], k[1], p[1], sd[1] != 0, t2[1], t4[1], t5[1], cs, nb_threads) != EXIT_SUCCESS)
+            return EXIT_FAILURE;
+        job = now_s() - t1;
+    } else
     if (run_bm5d_1st_step(sigma, lambda, LF_noisy, mask, LF_basic, ang_major, aw, ah, anH, W, H, C, N[0], nSim[0], nDisp[0], k[0], p[0],
                           sd[0] != 0, t2[0], t4[0], t5[0], cs, nb_threads) != EXIT_SUCCESS) return EXIT_FAILURE;
-    const double step1 = now_s() - t1;
-    cout << endl << "Step 1 done in " << step1 << " secs." << endl << endl;
+    const double step1 = one_job ? job : now_s() - t1;
+    if (one_job) cout << endl << "Steps 1 and 2 done in " << job << " secs." << endl << endl;
+    else cout << endl << "Step 1 done in " << step1 << " secs." << endl << endl;
     if (gt) {
         psnr_LF(LF, LF_basic, mask, ps, ap_b, sp, rm, ar, sr);
         cout << endl << "Average PSNR:" << endl << "- Noisy light field: " << ap_n << endl << "- Basic light field: " << ap_b << endl;
@@ -366,12 +377,12 @@ int main(int argc, char** argv) {
     }
     cout << endl << "Save basic light field..." << endl;
     if (save_LF(d_basic, name, sep, LF_basic, ang_major, aw, ah, s0, t0, W, H, C) != EXIT_SUCCESS) return EXIT_FAILURE;
-    cout << endl << endl << "Step 2 running..." << endl;
+    if (!one_job) cout << endl << endl << "Step 2 running..." << endl;
     t1 = now_s();
-    if (run_bm5d_2nd_step(sigma, LF_noisy, mask, LF_basic, LF_den, ang_major, aw, ah, anW, W, H, C, N[1], nSim[1], nDisp[1], k[1], p[1],
+    if (!one_job && run_bm5d_2nd_step(sigma, LF_noisy, mask, LF_basic, LF_den, ang_major, aw, ah, anW, W, H, C, N[1], nSim[1], nDisp[1], k[1], p[1],
                           sd[1] != 0, t2[1], t4[1], t5[1], cs, nb_threads) != EXIT_SUCCESS) return EXIT_FAILURE;
-    const double step2 = now_s() - t1;
-    cout << endl << "Step 2 done in " << step2 << " secs." << endl << endl;
+    const double step2 = one_job ? 0.0 : now_s() - t1;
+    if (!one_job) cout << endl << "Step 2 done in " << step2 << " secs." << endl << endl;
     if (gt) {
         float ap_d;
         psnr_LF(LF, LF_den, mask, ps, ap_d, sp, rm, ar, sr);

@@ -121,6 +121,42 @@ int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_no
     return EXIT_SUCCESS;
 }
 
+/* main.cpp:195 + :242 as one job (lfbm5d_denoise_host): same buffers on return as the two calls.  The tile mode (LFBM5D_TILED) has no
+ * graph form: the library then runs the two steps one after the other behind the same entry point. */
+int run_bm5d(const float sigma, const float lambdaHard5D, std::vector<std::vector<float> >& LF_noisy, std::vector<unsigned>& LF_SAI_mask,
+             std::vector<std::vector<float> >& LF_basic, std::vector<std::vector<float> >& LF_denoised, const unsigned ang_major,
+             const unsigned awidth, const unsigned aheight, const unsigned anHard, const unsigned anWien, const unsigned width,
+             const unsigned height, const unsigned chnls, const unsigned NHard, const unsigned nSimHard, const unsigned nDispHard,
+             const unsigned kHard, const unsigned pHard, const bool useSDHard, const unsigned tau_2D_hard, unsigned tau_4D_hard,
+             const unsigned tau_5D_hard, const unsigned NWien, const unsigned nSimWien, const unsigned nDispWien, const unsigned kWien,
+             const unsigned pWien, const bool useSDWien, const unsigned tau_2D_wien, unsigned tau_4D_wien, const unsigned tau_5D_wien,
+             const unsigned color_space, const unsigned nb_threads) {
+    const unsigned asize = awidth * aheight;
+    if (LF_noisy.size() != asize || LF_SAI_mask.size() != asize) {
+        std::cout << "run_bm5d: light field and mask must hold awidth*aheight SAIs" << std::endl;
+        return EXIT_FAILURE;
+    }
+    lfbm5d_ctx* ctx = context();
+    if (!ctx) return EXIT_FAILURE;
+    lfbm5d_set_tiles(ctx, tiles_for(nb_threads));
+    if (LF_basic.size() != asize) LF_basic.resize(asize);
+    if (LF_denoised.size() != asize) LF_denoised.resize(asize);
+    const size_t img = (size_t)width * height * chnls;
+    std::vector<float> noisy, basic(asize * img, 0.0f), den(asize * img, 0.0f);
+    flatten(LF_noisy, LF_SAI_mask, img, noisy);
+    const lfbm5d_params P1 = make(sigma, lambdaHard5D, NHard, nSimHard, nDispHard, kHard, pHard, useSDHard, tau_2D_hard, tau_4D_hard, tau_5D_hard, color_space);
+    const lfbm5d_params P2 = make(sigma, 0.0f, NWien, nSimWien, nDispWien, kWien, pWien, useSDWien, tau_2D_wien, tau_4D_wien, tau_5D_wien, color_space);
+    if (lfbm5d_denoise_host(ctx, &P1, &P2, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), ang_major, awidth, aheight,
+                            anHard, anWien, width, height, chnls) != 0) {
+        std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
+        return EXIT_FAILURE;
+    }
+    unflatten(LF_noisy, LF_SAI_mask, img, noisy);
+    unflatten(LF_basic, LF_SAI_mask, img, basic);
+    unflatten(LF_denoised, LF_SAI_mask, img, den);
+    return EXIT_SUCCESS;
+}
+
 /* run_bm3d_LF (src/bm3d_LF.h:10-35, bm3d_LF.cpp:75-125): BM3D on every SAI of the mask */
 #include "run_bm3d_lf.h"
 int run_bm3d_LF(const float sigma, std::vector<std::vector<float> >& LF_noisy, std::vector<unsigned>& LF_SAI_mask,

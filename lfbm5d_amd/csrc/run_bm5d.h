@@ -67,4 +67,30 @@ int run_bm5d_2nd_step(
 ,   const unsigned nb_threads
 );
 
+//! Both steps as ONE job -- not in the reference (whose main.cpp:195, :242 calls the two functions above one after the other; BASELINE.json
+//! names it "run_bm5d()"): == run_bm5d_1st_step(...) followed by run_bm5d_2nd_step(...) with the same arguments, bit for bit, but
+//! the windows of both steps run as one dependency graph on the GPU(s) (lfbm5d_denoise_host, include/lfbm5d.h).
+int run_bm5d(
+    const float sigma
+,   const float lambdaHard5D
+,   std::vector<std::vector<float> > &LF_noisy
+,   std::vector<unsigned> &LF_SAI_mask
+,   std::vector<std::vector<float> > &LF_basic
+,   std::vector<std::vector<float> > &LF_denoised
+,   const unsigned ang_major
+,   const unsigned awidth
+,   const unsigned aheight
+,   const unsigned anHard
+,   const unsigned anWien
+,   const unsigned width
+,   const unsigned height
+,   const unsigned chnls
+,   const unsigned NHard, const unsigned nSimHard, const unsigned nDispHard, const unsigned kHard, const unsigned pHard
+,   const bool useSDHard, const unsigned tau_2D_hard, unsigned tau_4D_hard, const unsigned tau_5D_hard
+,   const unsigned NWien, const unsigned nSimWien, const unsigned nDispWien, const unsigned kWien, const unsigned pWien
+,   const bool useSDWien, const unsigned tau_2D_wien, unsigned tau_4D_wien, const unsigned tau_5D_wien
+,   const unsigned color_space
+,   const unsigned nb_threads
+);
+
 #endif

@@ -62,6 +62,35 @@ def test_readme_command_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_readme_command_as_one_job_writes_the_same_files(tmp_path):
+    """LFBM5D_ONE_JOB=1: the CLI calls run_bm5d() (both steps as one dependency graph of windows, lfbm5d_denoise_host) instead of
+    run_bm5d_1st_step + run_bm5d_2nd_step: the basic and denoised PNGs and the PSNR report are the same, byte for byte."""
+    outs = {}
+    for mode in ("two", "one"):
+        tmp = os.path.join(str(tmp_path), mode)
+        os.makedirs(tmp)
+        src, lf = write_source_lf(tmp)
+        for d in ("noisy", "basic", "denoised", "diff"):
+            os.makedirs(os.path.join(tmp, d))
+        res = os.path.join(tmp, "measures.txt")
+        args = [CLI, src, "SAI", "_", "3", "3", "1", "1", "1", "1", "row", "25", "2.7", f"{tmp}/noisy", f"{tmp}/basic",
+                f"{tmp}/denoised", f"{tmp}/diff", "8", "18", "6", "16", "4", "id", "sadct", "haar", "0", "16", "18", "6", "8", "4",
+                "dct", "sadct", "haar", "0", "opp", "0", res]
+        env = dict(os.environ, LFBM5D_SEED="1")
+        if mode == "one":
+            env["LFBM5D_ONE_JOB"] = "1"
+        out = subprocess.run(args, capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout[-2000:]
+        assert ("Steps 1 and 2 done in" in out.stdout) == (mode == "one")
+        txt = open(res).read()
+        outs[mode] = ({k: txt.split(f"-> Average PSNR {k} = ")[1].split()[0] for k in ("noisy", "basic", "denoised")},
+                      {f"{d}/SAI_0{s}_0{t}.png": open(f"{tmp}/{d}/SAI_0{s}_0{t}.png", "rb").read()
+                       for d in ("basic", "denoised") for s in (1, 2, 3) for t in (1, 2, 3)})
+    assert outs["one"][0] == outs["two"][0]
+    assert outs["one"][1] == outs["two"][1]
+
+
+@pytest.mark.gpu
 def test_readme_command_in_tile_mode_matches_the_oracles_tile_mode(tmp_path):
     """nbThreads = 8 with LFBM5D_TILED=1: the drop-in reproduces the reference's OpenMP tile mode (bm5d.cpp:411-708) --
     PSNR report within 0.01 dB of the oracle's tiled run on the same noise, half a dB below the untiled numbers."""
