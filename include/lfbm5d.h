@@ -96,30 +96,31 @@ void lfbm5d_get_stats(const lfbm5d_ctx* ctx, lfbm5d_stats* out);
 void* lfbm5d_stream(lfbm5d_ctx* ctx);
 
 /* ---- multi-GPU: one process per GPU, every rank holds the whole (read-only) light field.
- * Whole steps (lfbm5d_step*): the windows of the reference's schedule (bm5d.cpp:165-407; a pure function of the SAI
- * mask, see lfbm5d_plan_windows) form a dependency graph -- a window has to wait exactly for the previous window
- * that touched each of its SAIs, because windows interact only through num / den of shared SAIs (the running
- * estimate block matching reads, the sums aggregation adds to).  Ranks own chains of windows (runs of consecutive
- * windows in one row of SAIs); every chain, in plan order, goes to the rank on which it would finish first in unit
- * window time, ties to the rank that owns most of its predecessors (lfbm5d_plan_graph returns the assignment -- a pure
- * function of the mask and the rank count); what a window needs from a window of another rank travels as one
- * RCCL send / recv per SAI (num and den of that SAI, xGMI point-to-point); at the end every SAI's estimate is
- * formed on the rank that touched it last and broadcast.  Every window sees exactly the sums the single-GPU order
- * shows it: the result is BIT-IDENTICAL to one GPU for any rank count (lfbm5d_plan_graph / lfbm5d_plan_messages
- * expose the assignment and the message list).  The reference's backward raster leaves a wavefront -- a row of
- * windows may run two windows behind the row before it -- so the speed-up is bounded by the graph's critical path
- * (22 of 64 window slots on a 17x17 light field), not by the rank count.  Environment LFBM5D_STEP_SHARDING selects
- * the alternatives: "rows" = single-GPU window order with every core pass row-sharded as below (exact, two
- * all-reduces per pass; also what greyscale light fields need); "blocks" = round 1's contiguous blocks of windows
- * per rank + ONE all-reduce per step, which scales with the rank count but is NOT the reference's result (a rank's
- * block matching only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks).
+ * Whole steps (lfbm5d_step*) and the two-step job (lfbm5d_denoise_*): the windows of the reference's schedule
+ * (bm5d.cpp:165-407; a pure function of the SAI mask, see lfbm5d_plan_windows) form a dependency graph -- a window has to
+ * wait exactly for the previous window of its step that touched each of its SAIs, because windows interact only through
+ * num / den of shared SAIs (the running estimate block matching reads, the sums aggregation adds to); in the two-step job a
+ * window of the second step also waits for the last first-step window on each of its SAIs, behind which that SAI's basic
+ * estimate is final.  Every window has an owner rank, chosen along a simulated execution (a window follows the rank of the
+ * windows of its row of SAIs while that rank is free; lfbm5d_plan_graph / lfbm5d_plan_job return the assignment -- a pure
+ * function of the mask, the steps and the rank count); what a window needs from a window of another rank travels as one
+ * RCCL send / recv per SAI (num and den of that SAI, or its basic estimate; xGMI point-to-point); at the end every SAI's
+ * outputs are formed on the rank that holds them and broadcast.  Every window sees exactly the sums the single-GPU order shows
+ * it: the result is BIT-IDENTICAL to one GPU for any rank count (lfbm5d_plan_job exposes owners, issue order and the
+ * message list).  The reference's backward raster leaves a wavefront -- a row of windows may run two windows behind the row
+ * before it -- so the speed-up is bounded by the graph's critical path: 22 of 64 window slots for ONE step of a 17x17 light
+ * field (2.9x however many ranks), 27 of 128 window times for the two-step job (4.75x at eight ranks): use lfbm5d_denoise_*.
+ * Environment LFBM5D_STEP_SHARDING selects the alternatives: "rows" = single-GPU window order with every core pass
+ * row-sharded as below (exact, two all-reduces per pass; also what greyscale light fields need); "blocks" = round 1's
+ * contiguous blocks of windows per rank + ONE all-reduce per step, which scales with the rank count but is NOT the
+ * reference's result (a rank's block matching only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks).
  * Single core passes (lfbm5d_pass_device): the reference patches are sharded by rows over the ranks and
  * the window's num/den all-reduced.
  * Replaces the reference's only parallelism, the OpenMP tile loop + undivide_LF merge
  * (bm5d.cpp:411-708, utilities_LF.cpp:438-515), without its tile-border quality loss. ---- */
 #define LFBM5D_UNIQUE_ID_BYTES 128
 int lfbm5d_comm_unique_id(void* id_out /* LFBM5D_UNIQUE_ID_BYTES */);
-/* (whole steps on several ranks run window lanes and two exchange streams at once: set GPU_MAX_HW_QUEUES >= 8 in the
+/* (whole steps / jobs on several ranks run window lanes and two exchange streams at once: set GPU_MAX_HW_QUEUES >= 8 in the
  * environment BEFORE the HIP runtime initialises -- ROCm maps streams onto 4 hardware queues by default, and a send that
  * waits for its peer must not sit in front of a compute stream on the same queue; bench.py does it for itself) */
 int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);

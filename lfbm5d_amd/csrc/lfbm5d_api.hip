@@ -564,7 +564,7 @@ using plan::plan_windows;
 
 /* A JOB: run_bm5d_1st_step, run_bm5d_2nd_step, or the two back to back (lfbm5d_denoise_device).  The graph (lfbm5d_plan.h) is
  * executed on LANES -- a lane = a context of its own: stream, window buffers, per-pass work buffers -- with HIP events for the
- * dependencies between lanes; on several GPUs every rank runs the chains of windows it owns and what a window needs from a
+ * dependencies between lanes; on several GPUs every rank runs the windows it owns and what a window needs from a
  * window of another rank arrives as point-to-point messages (RCCL send / recv over xGMI).  Either way every window sees exactly
  * the num / den (and, in the second step of a two-step job, the basic estimate) the window-after-window order of the
  * reference would show it: the result is bit-identical to one lane on one GPU.
@@ -1195,7 +1195,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
      * data-driven selection, which stays available).  Several GPUs (and the lanes of one GPU) run the planned
      * sequence as a dependency graph: windows interact only through num / den of the SAIs they share, chains of
      * windows go to ranks, and what a window needs from another rank's window travels as one send / recv per SAI --
-     * bit-identical to one GPU for any rank count (build_graph below).
+     * bit-identical to one GPU for any rank count (lfbm5d_plan.h).
      * LFBM5D_STEP_SHARDING selects the alternatives: "rows" (every core pass sharded by reference-patch rows, exact,
      * barely scales) and "blocks" (round 1: one contiguous block of windows per rank + one all-reduce per step; a rank's
      * block matching then only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks). */
