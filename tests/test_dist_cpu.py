@@ -188,7 +188,7 @@ def _graph_worker(rank, world, port, q, n_steps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_steps", [(2, 1), (3, 1), (2, 2)])
+@pytest.mark.parametrize("world,n_steps", [(2, 1), (3, 1), (2, 2), (3, 2)])
 def test_graph_form_with_messages_equals_the_single_rank_step(world, n_steps):
     """world_size-2 / -3 gloo run of the multi-GPU scheme (graph form) -- windows owned per rank, one message per SAI a window
     needs from another rank's window, estimates formed by the last toucher -- for one step and for the TWO-STEP job
