@@ -113,6 +113,30 @@ def test_two_step_job_with_a_window_limit(ctx, monkeypatch):
         assert np.array_equal(w1, w0) and np.array_equal(n1, n0) and np.array_equal(b1, b0) and np.array_equal(d1, d0), emu
 
 
+def test_job_with_empty_sais_in_the_middle_of_windows(ctx, monkeypatch):
+    """Empty SAIs at the geometric centre of a raster window and inside the first (centre) window: every window is still built
+    around a non-empty processed SAI (the plan only picks those), tau_4D switches to the shape-adaptive transform for good at
+    the first such window of either step (bm5d.cpp:276-280) -- the job equals the two calls."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    ah, aw, Hs, Ws = 7, 9, 56, 56
+    clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, Hs, Ws), 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    mask[[52, 22]] = 0                                                # (5, 7): middle of the first raster window; (2, 4): in the centre window
+    P1 = core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "dct", "haar")
+    P2 = core.make_params(25.0, 2.7, 8, 6, 2, 8, 4, "dct", "dct", "haar")
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LFBM5D_LANES", "1")
+    n0, b0, d0, w0 = _two_calls(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+    monkeypatch.delenv("LFBM5D_LANES")
+    for emu in (None, "4"):
+        if emu:
+            monkeypatch.setenv("LFBM5D_EMULATE_WORLD", emu)
+        n1, b1, d1, w1, _ = _one_job(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+        assert np.array_equal(w1, w0) and np.array_equal(n1, n0) and np.array_equal(b1, b0) and np.array_equal(d1, d0), emu
+
+
 def test_greyscale_job_takes_the_two_calls(ctx, monkeypatch):
     """Greyscale light fields need data-driven further passes per window: lfbm5d_denoise_* runs the two calls."""
     import lfbm5d_amd as L
