@@ -193,3 +193,18 @@ def test_headline_job_on_eight_emulated_ranks_is_bit_identical(ctx, monkeypatch)
         del n1, b1, d1
     nodes, msgs, info = core.plan_job(aw, ah, 8, 1, an=(1, 1))
     assert len(set(nodes[:, 3].tolist())) == 8 and s.messages == len(msgs) >= 400
+
+
+def test_seeded_sweep_of_job_configurations():
+    """tools/fuzz_denoise.py: random angular / image sizes, search windows per step, empty SAIs, colour spaces, orders, parameter
+    sets, lanes, emulated ranks and window limits -- the job equals the two calls in every case (80 cases of seeds 1 and 2 were
+    run when the tool was written; this keeps a dozen in the suite)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("LFBM5D_") or k == "LFBM5D_HIP_LIB"}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_denoise.py"), "12", "3", "11"], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "12 of 12 cases identical" in r.stdout
