@@ -546,6 +546,88 @@ __device__ __noinline__ void sadct9_inv(float* v, ShRef sh, TbPtr tb) {
     }
     for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask[i];
 }
+/* The same two transforms for callers that cannot afford a call: inline, the vector in LDS (dynamic indices), the length-n
+ * transforms unrolled to three with the terms past n left out -- the same products added in the same order.  (Around a call the
+ * 72 live values of the 16x16 kernels' register stage have to sit in the sparse callee-saved registers: 124 VGPRs become 168 and
+ * 80 spills for every group, shape-adaptive or not.) */
+__device__ __forceinline__ void r10_small3(const float (&x)[3], float (&y)[3], int n, TbPtr tb) {
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 3; j++) if (j < n && u < n) a += x[j] * tb->cos1[n][u * n + j];
+        y[u] = 2.0f * a;
+    }
+}
+__device__ __forceinline__ void r01_small3(const float (&x)[3], float (&y)[3], int n, TbPtr tb) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        float a = 0.0f;
+#pragma unroll
+        for (int u = 1; u < 3; u++) if (u < n && j < n) a += x[u] * tb->cos1[n][u * n + j];
+        y[j] = x[0] + 2.0f * a;
+    }
+}
+__device__ __forceinline__ void sadct9_fwd_lds(float* v, ShRef sh, TbPtr tb) {
+    float x[3], y[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int n = sh.row_n[s];
+        if (n == 1) v[s * 3] = v[s * 3 + sh.idx[s * 3]];
+        else if (n > 1) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) x[t] = t < n ? v[s * 3 + sh.idx[s * 3 + t]] : 0.0f;
+            r10_small3(x, y, n, tb);
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (t < n) v[s * 3 + t] = y[t] * tb->cn1[n][t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int n = sh.col_n[t];
+        if (n == 1) v[t] = v[sh.idx_col[t] * 3 + t];
+        else if (n > 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 3; s2++) x[s2] = s2 < n ? v[sh.idx_col[s2 * 3 + t] * 3 + t] : 0.0f;
+            r10_small3(x, y, n, tb);
+#pragma unroll
+            for (int s2 = 0; s2 < 3; s2++) if (s2 < n) v[s2 * 3 + t] = y[s2] * tb->cn1[n][s2];
+        }
+    }
+    const float coef = 0.5f * 0.70710678118654752f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask_dct[i] * coef;
+}
+__device__ __forceinline__ void sadct9_inv_lds(float* v, ShRef sh, TbPtr tb) {
+    float x[3], y[3];
+    const float coef = 2.0f * 1.41421356237309505f;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int n = sh.col_n[t];
+        if (n == 1) v[sh.idx_col[t] * 3 + t] = v[t] * coef;
+        else if (n > 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 3; s2++) x[s2] = s2 < n ? v[s2 * 3 + t] * tb->cni1[n][s2] * coef : 0.0f;
+            r01_small3(x, y, n, tb);
+#pragma unroll
+            for (int s2 = 0; s2 < 3; s2++) if (s2 < n) v[sh.idx_col[s2 * 3 + t] * 3 + t] = y[s2] * tb->c1inv[n];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int n = sh.row_n[s];
+        if (n == 1) v[s * 3 + sh.idx[s * 3]] = v[s * 3];
+        else if (n > 1) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) x[t] = t < n ? v[s * 3 + t] * tb->cni1[n][t] : 0.0f;
+            r01_small3(x, y, n, tb);
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (t < n) v[s * 3 + sh.idx[s * 3 + t]] = y[t] * tb->c1inv[n];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask[i];
+}
 
 /* General aw x aw angular window (aswSize 2: 5x5): the same transforms with run-time sizes, generic kernel only.
  * dct_4d_process / dct_4d_inverse (core:1862-1954) and sadct_4d_process / _inverse (core:1969-2264) on one vector. */
@@ -1426,58 +1508,13 @@ __global__ __launch_bounds__(kThreads) void k_group_big(GroupArgs a, float* scra
  * through buffer resources with the per-patch part of the address in a scalar register (the patch
  * positions are uniform), so none of the 2 * NS * 9 memory operations needs address VGPRs; the
  * 3x3 angular DCTs run on pairs of patches (n, n + 1) with packed fp32 arithmetic. */
-template <int NS, bool HAAR, bool LDSW = false>   /* LDSW: values come from / go back to an LDS work area [patch][k][k+1] (2-D transformed patches) */
-__device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
-                                              ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2, float* work = nullptr) {
-    const int k = a.k, k2 = k * k, A = 9;
-    const unsigned plane = a.Wb * a.Hb;
-    const TbPtr tb = (TbPtr)a.tb;
-    const unsigned kRsrcFlags = 0x00020000u;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)((size_t)a.A * a.C * plane * 4), kRsrcFlags);
-    float* const out = a.filt + (size_t)g * a.N * A * a.C * k2;
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((size_t)a.N * A * a.C * k2 * 4), kRsrcFlags);
-    /* the pixel's NS * 9 values as pairs of patches: V[h][st] = {patch h, patch h + NS/2} (NS = 1: .y unused) */
+/* the angular transform, the 5th-dimension transform with the hard threshold and their inverses on one pixel's NS * 9 values
+ * V[h][st] = {patch h, patch h + NS/2} (the register stage shared by the tau_2D = id kernel and the 16x16 kernels) */
+template <int NS, bool HAAR, bool SA_LDS = false>   /* SA_LDS: the shape-adaptive transform inline on sa_lds, nine floats of LDS of this thread's */
+__device__ __forceinline__ void group_id_compute(const GroupArgs& a, int c, ShRef sh, bool use_sadct, v2f (&V)[NS > 1 ? NS / 2 : 1][9],
+                                                 float& wacc, float& s1, float& s2, float* sa_lds = nullptr) {
     constexpr int NH = NS > 1 ? NS / 2 : 1;
-    v2f V[NH][9];
-    const int voff = (int)(((unsigned)(pq / k) * a.Wb + pq % k) * 4u);
-    const int woff = (pq / k) * (k + 1) + pq % k;      /* this pixel inside a work-area patch */
-    unsigned okbits[NS];
-    typedef const __attribute__((address_space(4))) unsigned* cuptr_;
-    const cuptr_ ofs = (cuptr_)(a.gofs + (size_t)g * a.N * A), ok = (cuptr_)(a.gok + (size_t)g * a.N);
-    const unsigned cbase = (unsigned)c * plane * 4u;
-    if (LDSW) {
-#pragma unroll
-        for (int n = 0; n < NS; n++)
-#pragma unroll
-            for (int st = 0; st < 9; st++) {
-                const float x = work[(n * A + st) * kT16Patch + woff];
-                if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
-                okbits[n] = 0x1ffu;
-            }
-    } else
-#pragma unroll
-    for (int n = 0; n < NS; n++) {
-        okbits[n] = ok[n];                            /* uniform: scalar loads (pre-pass: k_group_pos) */
-#pragma unroll
-        for (int st = 0; st < 9; st++) {
-            const unsigned so = ofs[n * A + st] + cbase;   /* absent patches read offset 0 and are zeroed below */
-            const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
-            if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
-        }
-    }
-    if (NS == 1) {
-#pragma unroll
-        for (int st = 0; st < 9; st++) V[0][st].y = 0.0f;
-    }
-#pragma unroll
-    for (int n = 0; n < NS; n++)
-        if (okbits[n] != 0x1ffu) {   /* uniform, rare: patches of empty SAIs / never-filled table column read as zeros */
-#pragma unroll
-            for (int st = 0; st < 9; st++) {
-                if (n < NH) V[n][st].x = ((okbits[n] >> st) & 1) ? V[n][st].x : 0.0f;
-                else V[n - NH][st].y = ((okbits[n] >> st) & 1) ? V[n - NH][st].y : 0.0f;
-            }
-        }
+    const TbPtr tb = (TbPtr)a.tb;
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
     auto sadct_pairs = [&](bool fwd) {   /* rare: shape-adaptive transform on the scalar path, staged through t9 */
@@ -1485,12 +1522,20 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
         for (int h = 0; h < NH; h++)
 #pragma unroll
             for (int half = 0; half < (NS > 1 ? 2 : 1); half++) {
-                float t9[9];
+                if (SA_LDS) {
 #pragma unroll
-                for (int i = 0; i < 9; i++) t9[i] = half ? V[h][i].y : V[h][i].x;
-                if (fwd) sadct9_fwd(t9, sh, tb); else sadct9_inv(t9, sh, tb);
+                    for (int i = 0; i < 9; i++) sa_lds[i] = half ? V[h][i].y : V[h][i].x;
+                    if (fwd) sadct9_fwd_lds(sa_lds, sh, tb); else sadct9_inv_lds(sa_lds, sh, tb);
 #pragma unroll
-                for (int i = 0; i < 9; i++) { if (half) V[h][i].y = t9[i]; else V[h][i].x = t9[i]; }
+                    for (int i = 0; i < 9; i++) { if (half) V[h][i].y = sa_lds[i]; else V[h][i].x = sa_lds[i]; }
+                } else {
+                    float t9[9];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) t9[i] = half ? V[h][i].y : V[h][i].x;
+                    if (fwd) sadct9_fwd(t9, sh, tb); else sadct9_inv(t9, sh, tb);
+#pragma unroll
+                    for (int i = 0; i < 9; i++) { if (half) V[h][i].y = t9[i]; else V[h][i].x = t9[i]; }
+                }
             }
     };
     if (do_dct4) {
@@ -1541,6 +1586,60 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
 #pragma unroll
         for (int h = 0; h < NH; h++) dct9_inv2(V[h], tb);
     } else if (do_sa4) sadct_pairs(false);
+}
+
+template <int NS, bool HAAR, bool LDSW = false>   /* LDSW: values come from / go back to an LDS work area [patch][k][k+1] (2-D transformed patches) */
+__device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
+                                              ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2, float* work = nullptr) {
+    const int k = a.k, k2 = k * k, A = 9;
+    const unsigned plane = a.Wb * a.Hb;
+    const unsigned kRsrcFlags = 0x00020000u;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)((size_t)a.A * a.C * plane * 4), kRsrcFlags);
+    float* const out = a.filt + (size_t)g * a.N * A * a.C * k2;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((size_t)a.N * A * a.C * k2 * 4), kRsrcFlags);
+    /* the pixel's NS * 9 values as pairs of patches: V[h][st] = {patch h, patch h + NS/2} (NS = 1: .y unused) */
+    constexpr int NH = NS > 1 ? NS / 2 : 1;
+    v2f V[NH][9];
+    const int voff = (int)(((unsigned)(pq / k) * a.Wb + pq % k) * 4u);
+    const int woff = (pq / k) * (k + 1) + pq % k;      /* this pixel inside a work-area patch */
+    unsigned okbits[NS];
+    typedef const __attribute__((address_space(4))) unsigned* cuptr_;
+    const cuptr_ ofs = (cuptr_)(a.gofs + (size_t)g * a.N * A), ok = (cuptr_)(a.gok + (size_t)g * a.N);
+    const unsigned cbase = (unsigned)c * plane * 4u;
+    if (LDSW) {
+#pragma unroll
+        for (int n = 0; n < NS; n++)
+#pragma unroll
+            for (int st = 0; st < 9; st++) {
+                const float x = work[(n * A + st) * kT16Patch + woff];
+                if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
+                okbits[n] = 0x1ffu;
+            }
+    } else
+#pragma unroll
+    for (int n = 0; n < NS; n++) {
+        okbits[n] = ok[n];                            /* uniform: scalar loads (pre-pass: k_group_pos) */
+#pragma unroll
+        for (int st = 0; st < 9; st++) {
+            const unsigned so = ofs[n * A + st] + cbase;   /* absent patches read offset 0 and are zeroed below */
+            const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
+            if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
+        }
+    }
+    if (NS == 1) {
+#pragma unroll
+        for (int st = 0; st < 9; st++) V[0][st].y = 0.0f;
+    }
+#pragma unroll
+    for (int n = 0; n < NS; n++)
+        if (okbits[n] != 0x1ffu) {   /* uniform, rare: patches of empty SAIs / never-filled table column read as zeros */
+#pragma unroll
+            for (int st = 0; st < 9; st++) {
+                if (n < NH) V[n][st].x = ((okbits[n] >> st) & 1) ? V[n][st].x : 0.0f;
+                else V[n - NH][st].y = ((okbits[n] >> st) & 1) ? V[n - NH][st].y : 0.0f;
+            }
+        }
+    group_id_compute<NS, HAAR>(a, c, sh, use_sadct, V, wacc, s1, s2);
     const int vout = pq * 4;
 #pragma unroll
     for (int n = 0; n < NS; n++)
@@ -1695,7 +1794,8 @@ __device__ __forceinline__ void dct16_inv(float* X) {
 #define LFBM5D_T16_GROUPS 3
 #endif
 constexpr int kT16Groups = LFBM5D_T16_GROUPS;
-template <bool HAAR, bool BIOR, bool MULTI>
+constexpr int kT16Split = 32, kT16Half = 72 - kT16Split;   /* full groups (N = 8): patches per round of the two-round form */
+template <bool HAAR, bool BIOR, bool MULTI, bool SPLIT = false>
 __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     extern __shared__ float lds[];
     __shared__ float red[MULTI ? kT16Groups : 1][3][4];
@@ -1729,64 +1829,118 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
         ok = p != 0xffffffffu;            /* empty SAI / never-filled table column: zeros */
         return a.noisy + ((size_t)(patch % A) * a.C + c) * plane + (ok ? p : 0u);
     };
-    if (BIOR) {
-        constexpr int TPP = 8, PPI = kThreads / TPP;   /* rows r and r + 8 per thread */
-        const int slot = tid / TPP, r = tid % TPP;
-        for (int p0 = 0; p0 < NP; p0 += PPI) {
-            const int patch = p0 + slot;
-            if (patch < NP) {
-                bool ok;
-                const float* src = patch_src(patch, ok);
-                v2f v[K], o[K];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f4u lo = *reinterpret_cast<const f4u*>(src + (size_t)r * a.Wb + 4 * q);
-                    const f4u hi = *reinterpret_cast<const f4u*>(src + (size_t)(r + 8) * a.Wb + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) v[4 * q + e] = ok ? v2f{lo.v[e], hi.v[e]} : v2f{0.0f, 0.0f};
+    /* patches base .. base + np - 1 of the group -> work area slots 0 .. np - 1 */
+    auto fwd2d = [&](const int base, const int np) {
+        if (BIOR) {
+            constexpr int TPP = 8, PPI = kThreads / TPP;   /* rows r and r + 8 per thread */
+            const int slot = tid / TPP, r = tid % TPP;
+            for (int p0 = 0; p0 < np; p0 += PPI) {
+                const int patch = p0 + slot;
+                if (patch < np) {
+                    bool ok;
+                    const float* src = patch_src(base + patch, ok);
+                    v2f v[K], o[K];
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const f4u lo = *reinterpret_cast<const f4u*>(src + (size_t)r * a.Wb + 4 * q);
+                        const f4u hi = *reinterpret_cast<const f4u*>(src + (size_t)(r + 8) * a.Wb + 4 * q);
+    #pragma unroll
+                        for (int e = 0; e < 4; e++) v[4 * q + e] = ok ? v2f{lo.v[e], hi.v[e]} : v2f{0.0f, 0.0f};
+                    }
+                    bior_taps2<K, true>(v, o, tb);
+                    float* Tp = work + patch * PSZ;
+    #pragma unroll
+                    for (int cc = 0; cc < K; cc++) { Tp[r * RS + cc] = o[cc].x; Tp[(r + 8) * RS + cc] = o[cc].y; }
+                    __builtin_amdgcn_wave_barrier();
+                    bior16_pass2<K, true, false>(Tp, r, tb);
                 }
-                bior_taps2<K, true>(v, o, tb);
-                float* Tp = work + patch * PSZ;
-#pragma unroll
-                for (int cc = 0; cc < K; cc++) { Tp[r * RS + cc] = o[cc].x; Tp[(r + 8) * RS + cc] = o[cc].y; }
-                __builtin_amdgcn_wave_barrier();
-                bior16_pass2<K, true, false>(Tp, r, tb);
+            }
+            __syncthreads();
+            bior16_level_all<8, true>(work, np, tid, tb);
+            bior16_level_all<4, true>(work, np, tid, tb);
+            bior16_level_all<2, true>(work, np, tid, tb);
+        } else {
+            const int slot = tid / K, r = tid % K;         /* DCT: 16 threads per patch, thread = row, then column */
+            for (int p0 = 0; p0 < np; p0 += kThreads / K) {
+                const int patch = p0 + slot;
+                if (patch < np) {
+                    bool ok;
+                    const float* src = patch_src(base + patch, ok);
+                    float x[K];
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const f4u t4 = *reinterpret_cast<const f4u*>(src + (size_t)r * a.Wb + 4 * q);
+    #pragma unroll
+                        for (int e = 0; e < 4; e++) x[4 * q + e] = ok ? t4.v[e] : 0.0f;
+                    }
+                    dct16_fwd(x);
+                    float* Tp = work + patch * PSZ;
+    #pragma unroll
+                    for (int cc = 0; cc < K; cc++) Tp[r * RS + cc] = x[cc];
+                    __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                    for (int i = 0; i < K; i++) x[i] = Tp[i * RS + r];
+                    dct16_fwd(x);
+    #pragma unroll
+                    for (int i = 0; i < K; i++) Tp[i * RS + r] = x[i];
+                }
+            }
+            __syncthreads();
+        }
+    };
+    /* inverse 2-D transform; its last pass (the rows of the 16x16 level) stores the filtered patches: filt[g][n][st][c][256] */
+    float* const out = a.filt + (size_t)g * N * A * a.C * K * K;
+    auto inv2d = [&](const int base, const int np) {
+        if (BIOR) {
+            bior16_level_all<2, false>(work, np, tid, tb);
+            bior16_level_all<4, false>(work, np, tid, tb);
+            bior16_level_all<8, false>(work, np, tid, tb);
+            constexpr int TPP = 8, PPI = kThreads / TPP;
+            const int slot = tid / TPP, r = tid % TPP;
+            for (int p0 = 0; p0 < np; p0 += PPI) {
+                const int patch = p0 + slot;
+                if (patch < np) {
+                    float* Tp = work + patch * PSZ;
+                    bior16_pass2<K, false, false>(Tp, r, tb);
+                    __builtin_amdgcn_wave_barrier();
+                    v2f v[K], o[K];
+    #pragma unroll
+                    for (int cc = 0; cc < K; cc++) v[cc] = v2f{Tp[r * RS + cc], Tp[(r + 8) * RS + cc]};
+                    bior_taps2<K, false>(v, o, tb);
+                    float4* dst = reinterpret_cast<float4*>(out + ((size_t)(base + patch) * a.C + c) * K * K);
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        dst[r * 4 + q] = make_float4(o[4 * q].x, o[4 * q + 1].x, o[4 * q + 2].x, o[4 * q + 3].x);
+                        dst[(r + 8) * 4 + q] = make_float4(o[4 * q].y, o[4 * q + 1].y, o[4 * q + 2].y, o[4 * q + 3].y);
+                    }
+                }
+            }
+        } else {
+            const int slot = tid / K, r = tid % K;
+            for (int p0 = 0; p0 < np; p0 += kThreads / K) {
+                const int patch = p0 + slot;
+                if (patch < np) {
+                    float* Tp = work + patch * PSZ;
+                    float x[K];
+    #pragma unroll
+                    for (int i = 0; i < K; i++) x[i] = Tp[i * RS + r];
+                    dct16_inv(x);
+    #pragma unroll
+                    for (int i = 0; i < K; i++) Tp[i * RS + r] = x[i];
+                    __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                    for (int cc = 0; cc < K; cc++) x[cc] = Tp[r * RS + cc];
+                    dct16_inv(x);
+                    float4* dst = reinterpret_cast<float4*>(out + ((size_t)(base + patch) * a.C + c) * K * K);
+    #pragma unroll
+                    for (int q = 0; q < 4; q++) dst[r * 4 + q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+                }
             }
         }
-        __syncthreads();
-        bior16_level_all<8, true>(work, NP, tid, tb);
-        bior16_level_all<4, true>(work, NP, tid, tb);
-        bior16_level_all<2, true>(work, NP, tid, tb);
-    } else {
-        const int slot = tid / K, r = tid % K;         /* DCT: 16 threads per patch, thread = row, then column */
-        for (int p0 = 0; p0 < NP; p0 += kThreads / K) {
-            const int patch = p0 + slot;
-            if (patch < NP) {
-                bool ok;
-                const float* src = patch_src(patch, ok);
-                float x[K];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f4u t4 = *reinterpret_cast<const f4u*>(src + (size_t)r * a.Wb + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; e++) x[4 * q + e] = ok ? t4.v[e] : 0.0f;
-                }
-                dct16_fwd(x);
-                float* Tp = work + patch * PSZ;
-#pragma unroll
-                for (int cc = 0; cc < K; cc++) Tp[r * RS + cc] = x[cc];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < K; i++) x[i] = Tp[i * RS + r];
-                dct16_fwd(x);
-#pragma unroll
-                for (int i = 0; i < K; i++) Tp[i * RS + r] = x[i];
-            }
-        }
-        __syncthreads();
-    }
-    T16_MARK();
+    };
     float wacc[MULTI ? kT16Groups : 1], s1[MULTI ? kT16Groups : 1], s2[MULTI ? kT16Groups : 1];
+    const bool split = SPLIT && !MULTI;
+    if (!split) { fwd2d(0, NP); T16_MARK(); }
     if (MULTI) {
 #pragma unroll
         for (int gi = 0; gi < kT16Groups; gi++) {
@@ -1797,6 +1951,57 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
                                              work + gi * A * PSZ);
             }
         }
+    } else if (SPLIT) {
+        /* Round 4: a work area of kT16Half patches instead of the whole group's (three workgroups per CU instead of two).  A thread
+         * collects its pixel's coefficients in registers from the forward transforms -- one round of them for groups of up to four
+         * matches, two for the full group --, runs the register stage of the tau_2D = id kernel on them, and the results go back
+         * through the same area for the inverse transforms.  Between the two the area is free: the shape-adaptive transform of the
+         * rare groups that need it runs inline on nine floats of it per thread (as a call it costs every group 44 VGPRs). */
+        wacc[0] = 0.0f; s1[0] = 0.0f; s2[0] = 0.0f;
+        const int woff = (tid / K) * RS + tid % K;
+        auto rounds = [&](auto ns_tag) {
+            constexpr int NS = decltype(ns_tag)::value, NH = NS > 1 ? NS / 2 : 1, NPc = NS * A;
+            constexpr int P0 = NPc <= kT16Half ? NPc : kT16Split;   /* patches of the first round */
+            static_assert(NPc - P0 <= kT16Half && P0 <= kT16Half, "two rounds hold the group");
+            v2f V[NH][9];
+            auto put = [&](const int pch, const float x) { if (pch / 9 < NH) V[pch / 9][pch % 9].x = x; else V[pch / 9 - NH][pch % 9].y = x; };
+            auto get = [&](const int pch) { return pch / 9 < NH ? V[pch / 9][pch % 9].x : V[pch / 9 - NH][pch % 9].y; };
+            if (NS == 1) {
+#pragma unroll
+                for (int st = 0; st < 9; st++) V[0][st].y = 0.0f;
+            }
+            fwd2d(0, P0);
+#pragma unroll
+            for (int pch = 0; pch < P0; pch++) put(pch, work[pch * PSZ + woff]);
+            __syncthreads();
+            if (P0 < NPc) {
+                fwd2d(P0, NPc - P0);
+#pragma unroll
+                for (int pch = P0; pch < NPc; pch++) put(pch, work[(pch - P0) * PSZ + woff]);
+                __syncthreads();
+            }
+            T16_MARK();
+            group_id_compute<NS, HAAR, true>(a, c, sh, use_sadct, V, wacc[0], s1[0], s2[0], work + tid * 9);
+            __syncthreads();
+            T16_MARK();
+            if (P0 < NPc) {
+#pragma unroll
+                for (int pch = P0; pch < NPc; pch++) work[(pch - P0) * PSZ + woff] = get(pch);
+                __syncthreads();
+                inv2d(P0, NPc - P0);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int pch = 0; pch < P0; pch++) work[pch * PSZ + woff] = get(pch);
+            __syncthreads();
+            inv2d(0, P0);
+        };
+        switch (nSx) {
+            case 1:  rounds(std::integral_constant<int, 1>{}); break;
+            case 2:  rounds(std::integral_constant<int, 2>{}); break;
+            case 4:  rounds(std::integral_constant<int, 4>{}); break;
+            default: rounds(std::integral_constant<int, 8>{}); break;
+        }
     } else {
         wacc[0] = 0.0f; s1[0] = 0.0f; s2[0] = 0.0f;
         switch (nSx) {
@@ -1806,56 +2011,7 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
             default: group_id_body<8, HAAR, true>(a, g, c, tid, pos, sh, use_sadct, wacc[0], s1[0], s2[0], work); break;
         }
     }
-    __syncthreads();
-    T16_MARK();
-    /* inverse 2-D transform; its last pass (the rows of the 16x16 level) stores the filtered patches: filt[g][n][st][c][256] */
-    float* const out = a.filt + (size_t)g * N * A * a.C * K * K;
-    if (BIOR) {
-        bior16_level_all<2, false>(work, NP, tid, tb);
-        bior16_level_all<4, false>(work, NP, tid, tb);
-        bior16_level_all<8, false>(work, NP, tid, tb);
-        constexpr int TPP = 8, PPI = kThreads / TPP;
-        const int slot = tid / TPP, r = tid % TPP;
-        for (int p0 = 0; p0 < NP; p0 += PPI) {
-            const int patch = p0 + slot;
-            if (patch < NP) {
-                float* Tp = work + patch * PSZ;
-                bior16_pass2<K, false, false>(Tp, r, tb);
-                __builtin_amdgcn_wave_barrier();
-                v2f v[K], o[K];
-#pragma unroll
-                for (int cc = 0; cc < K; cc++) v[cc] = v2f{Tp[r * RS + cc], Tp[(r + 8) * RS + cc]};
-                bior_taps2<K, false>(v, o, tb);
-                float4* dst = reinterpret_cast<float4*>(out + ((size_t)patch * a.C + c) * K * K);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    dst[r * 4 + q] = make_float4(o[4 * q].x, o[4 * q + 1].x, o[4 * q + 2].x, o[4 * q + 3].x);
-                    dst[(r + 8) * 4 + q] = make_float4(o[4 * q].y, o[4 * q + 1].y, o[4 * q + 2].y, o[4 * q + 3].y);
-                }
-            }
-        }
-    } else {
-        const int slot = tid / K, r = tid % K;
-        for (int p0 = 0; p0 < NP; p0 += kThreads / K) {
-            const int patch = p0 + slot;
-            if (patch < NP) {
-                float* Tp = work + patch * PSZ;
-                float x[K];
-#pragma unroll
-                for (int i = 0; i < K; i++) x[i] = Tp[i * RS + r];
-                dct16_inv(x);
-#pragma unroll
-                for (int i = 0; i < K; i++) Tp[i * RS + r] = x[i];
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int cc = 0; cc < K; cc++) x[cc] = Tp[r * RS + cc];
-                dct16_inv(x);
-                float4* dst = reinterpret_cast<float4*>(out + ((size_t)patch * a.C + c) * K * K);
-#pragma unroll
-                for (int q = 0; q < 4; q++) dst[r * 4 + q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-            }
-        }
-    }
+    if (!split) { __syncthreads(); T16_MARK(); inv2d(0, NP); }
     T16_MARK();
 #ifdef LFBM5D_PHASE_TIMING
     T16_MARK();
@@ -1887,9 +2043,17 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
         }
     }
 }
+#ifndef LFBM5D_T16_NOSPLIT
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true, false, true>(a); }
+#else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true, false>(a); }
+#endif
 __global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_t16_kernel<false, true, false>(a); }
+#ifndef LFBM5D_T16_NOSPLIT
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false, false, true>(a); }
+#else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false, false>(a); }
+#endif
 __global__ __launch_bounds__(256) void k_group_dct16_any(GroupArgs a) { group_t16_kernel<false, false, false>(a); }
 /* N = 1: kT16Groups groups per workgroup (the 5th-dimension transform is the identity, HAAR or not) */
 __global__ __launch_bounds__(256) void k_group_bior16_n1(GroupArgs a) { group_t16_kernel<true, true, true>(a); }
@@ -3684,10 +3848,18 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
             return hipGetLastError();
         }
         if (a.tau2 == 7) {
+#ifndef LFBM5D_T16_NOSPLIT   /* two rounds through a work area of 40 patches: groups of fewer than eight matches fit it whole (N <= 4: 36 patches) */
+            if (a.tau5 == 9) hipLaunchKernelGGL(k_group_bior16_haar, grid, block, std::min(lb, (size_t)kT16Half * kT16Patch * sizeof(float)), s, a);
+#else
             if (a.tau5 == 9) hipLaunchKernelGGL(k_group_bior16_haar, grid, block, lb, s, a);
+#endif
             else             hipLaunchKernelGGL(k_group_bior16_any, grid, block, lb, s, a);
         } else {
+#ifndef LFBM5D_T16_NOSPLIT
+            if (a.tau5 == 9) hipLaunchKernelGGL(k_group_dct16_haar, grid, block, std::min(lb, (size_t)kT16Half * kT16Patch * sizeof(float)), s, a);
+#else
             if (a.tau5 == 9) hipLaunchKernelGGL(k_group_dct16_haar, grid, block, lb, s, a);
+#endif
             else             hipLaunchKernelGGL(k_group_dct16_any, grid, block, lb, s, a);
         }
         return hipGetLastError();

@@ -213,6 +213,29 @@ def test_empty_sai_switches_to_sadct_like_the_reference(ctx):
     assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 2e-3
 
 
+@pytest.mark.parametrize("pk", [(8, 8, 3, 16, 4, "bior", "sadct", "haar"), (4, 6, 2, 16, 4, "bior", "sadct", "haar"),
+                                (2, 6, 2, 16, 4, "bior", "sadct", "haar"), (8, 8, 3, 16, 4, "dct", "sadct", "haar"),
+                                (8, 8, 3, 16, 4, "bior", "sadct", "hw")],
+                         ids=["bior-n8", "bior-n4", "bior-n2", "dct-n8", "bior-n8-hadamard"])
+def test_empty_sai_with_16x16_transform_kernels(ctx, pk):
+    """The shape-adaptive angular transform inside the 16x16 kernels (k_group_bior16_haar since round 4: inline on LDS scratch between
+    the two rounds of 2-D transforms; the others: the call form): an empty SAI makes every group shape-adaptive."""
+    win, Wb, Hb, Cc = window(10.0, pk, 96)
+    mask = np.ones(9, np.uint32)
+    mask[5] = 0
+    win[5] = 0
+    proc = (1 - mask).astype(np.uint32)
+    num_o, den_o, st = Hh.oracle_pass(1, 10.0, pk, win, None, Wb, Hb, Cc, mask=mask, proc=proc)
+    ctx.reset_stats()
+    num_g, den_g = gpu_pass(ctx, 1, 10.0, pk, win, None, Wb, Hb, Cc, mask=mask, proc=proc)
+    s = ctx.stats()
+    assert st.sadct_groups == st.groups and (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
+    assert not den_g[5].any() and not num_g[5].any()
+    assert np.array_equal(den_o != 0, den_g != 0)
+    np.testing.assert_allclose(den_g, den_o, rtol=2e-5)
+    assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 2e-2
+
+
 def test_row_shards_sum_to_full_pass(ctx):
     pk = (8, 6, 2, 8, 3, "dct", "sadct", "haar")
     win, Wb, Hb, Cc = window(25.0, pk, 64)
