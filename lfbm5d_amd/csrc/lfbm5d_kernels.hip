@@ -1794,7 +1794,13 @@ __device__ __forceinline__ void dct16_inv(float* X) {
 #define LFBM5D_T16_GROUPS 3
 #endif
 constexpr int kT16Groups = LFBM5D_T16_GROUPS;
-constexpr int kT16Split = 32, kT16Half = 72 - kT16Split;   /* full groups (N = 8): patches per round of the two-round form */
+#ifndef LFBM5D_T16_ROUND
+#define LFBM5D_T16_ROUND 40
+#endif
+#ifndef LFBM5D_T16_WAVES
+#define LFBM5D_T16_WAVES 3
+#endif
+constexpr int kT16Half = LFBM5D_T16_ROUND;   /* patches per round of 2-D transforms: the work area of the Haar kernels (40: two rounds for a full group of 72, three workgroups per CU) */
 template <bool HAAR, bool BIOR, bool MULTI, bool SPLIT = false>
 __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     extern __shared__ float lds[];
@@ -1960,9 +1966,7 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
         wacc[0] = 0.0f; s1[0] = 0.0f; s2[0] = 0.0f;
         const int woff = (tid / K) * RS + tid % K;
         auto rounds = [&](auto ns_tag) {
-            constexpr int NS = decltype(ns_tag)::value, NH = NS > 1 ? NS / 2 : 1, NPc = NS * A;
-            constexpr int P0 = NPc <= kT16Half ? NPc : kT16Split;   /* patches of the first round */
-            static_assert(NPc - P0 <= kT16Half && P0 <= kT16Half, "two rounds hold the group");
+            constexpr int NS = decltype(ns_tag)::value, NH = NS > 1 ? NS / 2 : 1, NPc = NS * A, PR = kT16Half, NR = (NPc + PR - 1) / PR, F0 = NPc - (NR - 1) * PR;
             v2f V[NH][9];
             auto put = [&](const int pch, const float x) { if (pch / 9 < NH) V[pch / 9][pch % 9].x = x; else V[pch / 9 - NH][pch % 9].y = x; };
             auto get = [&](const int pch) { return pch / 9 < NH ? V[pch / 9][pch % 9].x : V[pch / 9 - NH][pch % 9].y; };
@@ -1970,31 +1974,27 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
 #pragma unroll
                 for (int st = 0; st < 9; st++) V[0][st].y = 0.0f;
             }
-            fwd2d(0, P0);
 #pragma unroll
-            for (int pch = 0; pch < P0; pch++) put(pch, work[pch * PSZ + woff]);
-            __syncthreads();
-            if (P0 < NPc) {
-                fwd2d(P0, NPc - P0);
+            for (int r = 0; r < NR; r++) {   /* the first round is the short one: fewest coefficients in registers while the transforms of the others run */
+                const int b0 = r == 0 ? 0 : F0 + (r - 1) * PR, cnt = r == 0 ? F0 : PR;
+                fwd2d(b0, cnt);
 #pragma unroll
-                for (int pch = P0; pch < NPc; pch++) put(pch, work[(pch - P0) * PSZ + woff]);
+                for (int q = 0; q < PR; q++) if (q < cnt) put(b0 + q, work[q * PSZ + woff]);
                 __syncthreads();
             }
             T16_MARK();
             group_id_compute<NS, HAAR, true>(a, c, sh, use_sadct, V, wacc[0], s1[0], s2[0], work + tid * 9);
             __syncthreads();
             T16_MARK();
-            if (P0 < NPc) {
 #pragma unroll
-                for (int pch = P0; pch < NPc; pch++) work[(pch - P0) * PSZ + woff] = get(pch);
+            for (int r = NR - 1; r >= 0; r--) {
+                const int b0 = r == 0 ? 0 : F0 + (r - 1) * PR, cnt = r == 0 ? F0 : PR;
+#pragma unroll
+                for (int q = 0; q < PR; q++) if (q < cnt) work[q * PSZ + woff] = get(b0 + q);
                 __syncthreads();
-                inv2d(P0, NPc - P0);
-                __syncthreads();
+                inv2d(b0, cnt);
+                if (r > 0) __syncthreads();
             }
-#pragma unroll
-            for (int pch = 0; pch < P0; pch++) work[pch * PSZ + woff] = get(pch);
-            __syncthreads();
-            inv2d(0, P0);
         };
         switch (nSx) {
             case 1:  rounds(std::integral_constant<int, 1>{}); break;
@@ -2044,13 +2044,13 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     }
 }
 #ifndef LFBM5D_T16_NOSPLIT
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true, false, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LFBM5D_T16_WAVES, LFBM5D_T16_WAVES))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true, false, true>(a); }
 #else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_bior16_haar(GroupArgs a) { group_t16_kernel<true, true, false>(a); }
 #endif
 __global__ __launch_bounds__(256) void k_group_bior16_any(GroupArgs a) { group_t16_kernel<false, true, false>(a); }
 #ifndef LFBM5D_T16_NOSPLIT
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false, false, true>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LFBM5D_T16_WAVES, LFBM5D_T16_WAVES))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false, false, true>(a); }
 #else
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_group_dct16_haar(GroupArgs a) { group_t16_kernel<true, false, false>(a); }
 #endif
