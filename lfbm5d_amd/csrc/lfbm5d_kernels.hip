@@ -568,6 +568,90 @@ __device__ __forceinline__ void r01_small3(const float (&x)[3], float (&y)[3], i
         y[j] = x[0] + 2.0f * a;
     }
 }
+/* ... and in REGISTERS: a group's shape is uniform, so every index of the transform is a scalar -- the gathers become two selects on
+ * scalar conditions, the scatters three conditional moves per destination, the loops over the run lengths predicated code; no
+ * dynamic indexing, no call, no scratch.  Same products in the same order as sadct9_fwd / sadct9_inv.  (A window with an empty SAI
+ * makes every group shape-adaptive, bm5d.cpp:276-280: with the call form such a 560^2 pass took 13.6 instead of 0.94 ms in the
+ * HT group kernel and 9.3 instead of 1.1 ms in the Wiener one.) */
+__device__ __forceinline__ float pick3(float a, float b, float c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
+__device__ __forceinline__ void sadct9_fwd_sel(float (&v)[9], ShRef sh, TbPtr tb) {
+    float x[3], y[3];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int n = sh.row_n[s];
+#pragma unroll
+        for (int t = 0; t < 3; t++) x[t] = pick3(v[s * 3], v[s * 3 + 1], v[s * 3 + 2], sh.idx[s * 3 + t]);
+        if (n == 1) v[s * 3] = x[0];
+        else if (n > 1) {
+            r10_small3(x, y, n, tb);
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (t < n) v[s * 3 + t] = y[t] * tb->cn1[n][t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int n = sh.col_n[t];
+#pragma unroll
+        for (int s2 = 0; s2 < 3; s2++) x[s2] = pick3(v[t], v[3 + t], v[6 + t], sh.idx_col[s2 * 3 + t]);
+        if (n == 1) v[t] = x[0];
+        else if (n > 1) {
+            r10_small3(x, y, n, tb);
+#pragma unroll
+            for (int s2 = 0; s2 < 3; s2++) if (s2 < n) v[s2 * 3 + t] = y[s2] * tb->cn1[n][s2];
+        }
+    }
+    const float coef = 0.5f * 0.70710678118654752f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask_dct[i] * coef;
+}
+__device__ __forceinline__ void sadct9_inv_sel(float (&v)[9], ShRef sh, TbPtr tb) {
+    float x[3], y[3];
+    const float coef = 2.0f * 1.41421356237309505f;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int n = sh.col_n[t];
+        if (n == 1) { y[0] = v[t] * coef; y[1] = 0.0f; y[2] = 0.0f; }
+        else if (n > 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < 3; s2++) x[s2] = s2 < n ? v[s2 * 3 + t] * tb->cni1[n][s2] * coef : 0.0f;
+            r01_small3(x, y, n, tb);
+#pragma unroll
+            for (int s2 = 0; s2 < 3; s2++) y[s2] *= tb->c1inv[n];
+        }
+        if (n >= 1) {   /* v[idx_col[s2][t]][t] = y[s2] for s2 < n: the destinations are distinct rows */
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                float w = v[r * 3 + t];
+#pragma unroll
+                for (int s2 = 0; s2 < 3; s2++) w = (s2 < n && sh.idx_col[s2 * 3 + t] == r) ? y[s2] : w;
+                v[r * 3 + t] = w;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const int n = sh.row_n[s];
+        if (n == 1) { y[0] = v[s * 3]; y[1] = 0.0f; y[2] = 0.0f; }
+        else if (n > 1) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) x[t] = t < n ? v[s * 3 + t] * tb->cni1[n][t] : 0.0f;
+            r01_small3(x, y, n, tb);
+#pragma unroll
+            for (int t = 0; t < 3; t++) y[t] *= tb->c1inv[n];
+        }
+        if (n >= 1) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                float w = v[s * 3 + q];
+#pragma unroll
+                for (int t = 0; t < 3; t++) w = (t < n && sh.idx[s * 3 + t] == q) ? y[t] : w;
+                v[s * 3 + q] = w;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) v[i] *= (float)sh.mask[i];
+}
 __device__ __forceinline__ void sadct9_fwd_lds(float* v, ShRef sh, TbPtr tb) {
     float x[3], y[3];
 #pragma unroll
@@ -1510,7 +1594,10 @@ __global__ __launch_bounds__(kThreads) void k_group_big(GroupArgs a, float* scra
  * 3x3 angular DCTs run on pairs of patches (n, n + 1) with packed fp32 arithmetic. */
 /* the angular transform, the 5th-dimension transform with the hard threshold and their inverses on one pixel's NS * 9 values
  * V[h][st] = {patch h, patch h + NS/2} (the register stage shared by the tau_2D = id kernel and the 16x16 kernels) */
-template <int NS, bool HAAR, bool SA_LDS = false>   /* SA_LDS: the shape-adaptive transform inline on sa_lds, nine floats of LDS of this thread's */
+/* SA_MODE: how the (rare) shape-adaptive transform is reached -- 0: calls (scratch vector; keeps its code out of the caller's
+ * register allocation), 1: inline on sa_lds, nine floats of LDS of this thread's, 2: inline in registers (the *_sa kernels, which
+ * the host launches for windows with an empty SAI, where EVERY group is shape-adaptive) */
+template <int NS, bool HAAR, int SA_MODE = 0>
 __device__ __forceinline__ void group_id_compute(const GroupArgs& a, int c, ShRef sh, bool use_sadct, v2f (&V)[NS > 1 ? NS / 2 : 1][9],
                                                  float& wacc, float& s1, float& s2, float* sa_lds = nullptr) {
     constexpr int NH = NS > 1 ? NS / 2 : 1;
@@ -1522,7 +1609,7 @@ __device__ __forceinline__ void group_id_compute(const GroupArgs& a, int c, ShRe
         for (int h = 0; h < NH; h++)
 #pragma unroll
             for (int half = 0; half < (NS > 1 ? 2 : 1); half++) {
-                if (SA_LDS) {
+                if (SA_MODE == 1) {
 #pragma unroll
                     for (int i = 0; i < 9; i++) sa_lds[i] = half ? V[h][i].y : V[h][i].x;
                     if (fwd) sadct9_fwd_lds(sa_lds, sh, tb); else sadct9_inv_lds(sa_lds, sh, tb);
@@ -1532,7 +1619,8 @@ __device__ __forceinline__ void group_id_compute(const GroupArgs& a, int c, ShRe
                     float t9[9];
 #pragma unroll
                     for (int i = 0; i < 9; i++) t9[i] = half ? V[h][i].y : V[h][i].x;
-                    if (fwd) sadct9_fwd(t9, sh, tb); else sadct9_inv(t9, sh, tb);
+                    if (SA_MODE == 2) { if (fwd) sadct9_fwd_sel(t9, sh, tb); else sadct9_inv_sel(t9, sh, tb); }
+                    else if (fwd) sadct9_fwd(t9, sh, tb); else sadct9_inv(t9, sh, tb);
 #pragma unroll
                     for (int i = 0; i < 9; i++) { if (half) V[h][i].y = t9[i]; else V[h][i].x = t9[i]; }
                 }
@@ -1588,7 +1676,7 @@ __device__ __forceinline__ void group_id_compute(const GroupArgs& a, int c, ShRe
     } else if (do_sa4) sadct_pairs(false);
 }
 
-template <int NS, bool HAAR, bool LDSW = false>   /* LDSW: values come from / go back to an LDS work area [patch][k][k+1] (2-D transformed patches) */
+template <int NS, bool HAAR, bool LDSW = false, int SA_MODE = 0>   /* LDSW: values come from / go back to an LDS work area [patch][k][k+1] (2-D transformed patches) */
 __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
                                               ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2, float* work = nullptr) {
     const int k = a.k, k2 = k * k, A = 9;
@@ -1639,7 +1727,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
                 else V[n - NH][st].y = ((okbits[n] >> st) & 1) ? V[n - NH][st].y : 0.0f;
             }
         }
-    group_id_compute<NS, HAAR>(a, c, sh, use_sadct, V, wacc, s1, s2);
+    group_id_compute<NS, HAAR, SA_MODE>(a, c, sh, use_sadct, V, wacc, s1, s2);
     const int vout = pq * 4;
 #pragma unroll
     for (int n = 0; n < NS; n++)
@@ -1651,7 +1739,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
         }
 }
 
-template <bool HAAR>
+template <bool HAAR, bool SA = false>
 __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
     __shared__ float red[3][4];
     const int tid = threadIdx.x;
@@ -1669,10 +1757,10 @@ __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (tid < (int)(a.k * a.k)) {
         switch (nSx) {
-            case 1:  group_id_body<1, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            case 2:  group_id_body<2, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            case 4:  group_id_body<4, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            default: group_id_body<8, HAAR>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 1:  group_id_body<1, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 2:  group_id_body<2, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 4:  group_id_body<4, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            default: group_id_body<8, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
         }
     }
     for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
@@ -1702,6 +1790,9 @@ __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
  * the Hadamard / DCT fibre transforms need more registers and keep two */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar(GroupArgs a) { group_id_kernel<true>(a); }
 __global__ __launch_bounds__(256) void k_group_id_any(GroupArgs a) { group_id_kernel<false>(a); }
+/* the same kernels for windows with an empty SAI (every group shape-adaptive): the transform inline, in registers */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar_sa(GroupArgs a) { group_id_kernel<true, true>(a); }
+__global__ __launch_bounds__(256) void k_group_id_any_sa(GroupArgs a) { group_id_kernel<false, true>(a); }
 
 __device__ __forceinline__ void dct8_fwd(float* x) {
     const float a0 = 0.35355339059327376f;   /* 1/sqrt(8) */
@@ -1983,7 +2074,7 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
                 __syncthreads();
             }
             T16_MARK();
-            group_id_compute<NS, HAAR, true>(a, c, sh, use_sadct, V, wacc[0], s1[0], s2[0], work + tid * 9);
+            group_id_compute<NS, HAAR, 1>(a, c, sh, use_sadct, V, wacc[0], s1[0], s2[0], work + tid * 9);
             __syncthreads();
             T16_MARK();
 #pragma unroll
@@ -2960,7 +3051,7 @@ constexpr int kW3Stride = 146;
 constexpr unsigned kW3Lds = 64 * kW3Stride * sizeof(float);
 constexpr unsigned kW3Empty = 0xf0000000u;   /* byte offset of an absent patch: beyond any window this kernel is launched on */
 
-template <int NS, int TH>
+template <int NS, int TH, bool SA>
 __device__ __forceinline__ void w3_forward(__amdgpu_buffer_rsrc_t img, unsigned row_bytes, float* S, const unsigned* pos,
                                            int tid, ShRef sh, bool do_dct4, bool do_sa4, TbPtr tb) {
     constexpr int A = 9, NP = NS * A, NPh = (NP + 1) / 2, NPf = kW3Stride;
@@ -3026,10 +3117,10 @@ __device__ __forceinline__ void w3_forward(__amdgpu_buffer_rsrc_t img, unsigned 
                 float t9[9];
 #pragma unroll
                 for (int i = 0; i < 9; i++) t9[i] = x[i].x;
-                sadct9_fwd(t9, sh, tb);
+                if (SA) sadct9_fwd_sel(t9, sh, tb); else sadct9_fwd(t9, sh, tb);
 #pragma unroll
                 for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
-                sadct9_fwd(t9, sh, tb);
+                if (SA) sadct9_fwd_sel(t9, sh, tb); else sadct9_fwd(t9, sh, tb);
 #pragma unroll
                 for (int i = 0; i < 9; i++) x[i].y = t9[i];
             }
@@ -3040,7 +3131,7 @@ __device__ __forceinline__ void w3_forward(__amdgpu_buffer_rsrc_t img, unsigned 
     }
 }
 
-template <int NS, int TH>
+template <int NS, int TH, bool SA>
 __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsigned* pos, float (*red)[TH / 64], int tid,
                                         unsigned g, int c) {
     constexpr int A = 9, K2 = 64, NP = NS * A, NPh = (NP + 1) / 2, NPf = kW3Stride;
@@ -3056,7 +3147,7 @@ __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsi
     const float sig2 = sig * sig;
     const bool useSD = a.useSD != 0;
 
-    w3_forward<NS, TH>(__builtin_amdgcn_make_buffer_rsrc((void*)a.basic, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, do_dct4, do_sa4, tb);
+    w3_forward<NS, TH, SA>(__builtin_amdgcn_make_buffer_rsrc((void*)a.basic, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, do_dct4, do_sa4, tb);
     /* fibres (st, pq): every thread owns st and st + 4 (st < 4) as a packed pair, the first wave also st = 8 */
     const int fpq = (tid & 15) | ((tid >> 1) & 48), fst = ((tid >> 4) & 1) | ((tid >> 6) & 2);
     float* const fbase = S + fpq * NPf + fst;
@@ -3095,7 +3186,7 @@ __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsi
         }
     }
     __syncthreads();
-    w3_forward<NS, TH>(__builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, do_dct4, do_sa4, tb);
+    w3_forward<NS, TH, SA>(__builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, do_dct4, do_sa4, tb);
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     {
         v2f o[NS];
@@ -3162,10 +3253,10 @@ __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsi
                 float t9[9];
 #pragma unroll
                 for (int i = 0; i < 9; i++) t9[i] = x[i].x;
-                sadct9_inv(t9, sh, tb);
+                if (SA) sadct9_inv_sel(t9, sh, tb); else sadct9_inv(t9, sh, tb);
 #pragma unroll
                 for (int i = 0; i < 9; i++) { x[i].x = t9[i]; t9[i] = x[i].y; }
-                sadct9_inv(t9, sh, tb);
+                if (SA) sadct9_inv_sel(t9, sh, tb); else sadct9_inv(t9, sh, tb);
 #pragma unroll
                 for (int i = 0; i < 9; i++) x[i].y = t9[i];
             }
@@ -3223,7 +3314,11 @@ __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsi
     }
 }
 
-__global__ __launch_bounds__(kDct8w3Threads) void k_group_dct8w3(GroupArgs a) {
+#ifndef LFBM5D_W3SA_WAVES
+#define LFBM5D_W3SA_WAVES 4   /* 128 VGPRs (a few spills): four workgroups per CU beat 129 without */
+#endif
+template <bool SA>   /* SA: for windows with an empty SAI (every group shape-adaptive): the transform inline, in registers */
+__global__ __launch_bounds__(kDct8w3Threads) __attribute__((amdgpu_waves_per_eu(SA ? LFBM5D_W3SA_WAVES : 1))) void k_group_dct8w3(GroupArgs a) {
     extern __shared__ float lds[];
     __shared__ float red[3][kDct8w3Threads / 64];
     __shared__ unsigned pos[kMaxN * kA3];
@@ -3241,14 +3336,14 @@ __global__ __launch_bounds__(kDct8w3Threads) void k_group_dct8w3(GroupArgs a) {
     }
     __syncthreads();
 #ifdef LFBM5D_W3_ONLY16
-    w3_body<16, TH>(a, lds, pos, red, tid, g, c); return;
+    w3_body<16, TH, SA>(a, lds, pos, red, tid, g, c); return;
 #endif
     switch (nSx) {
-        case 1:  w3_body<1, TH>(a, lds, pos, red, tid, g, c); break;
-        case 2:  w3_body<2, TH>(a, lds, pos, red, tid, g, c); break;
-        case 4:  w3_body<4, TH>(a, lds, pos, red, tid, g, c); break;
-        case 8:  w3_body<8, TH>(a, lds, pos, red, tid, g, c); break;
-        default: w3_body<16, TH>(a, lds, pos, red, tid, g, c); break;
+        case 1:  w3_body<1, TH, SA>(a, lds, pos, red, tid, g, c); break;
+        case 2:  w3_body<2, TH, SA>(a, lds, pos, red, tid, g, c); break;
+        case 4:  w3_body<4, TH, SA>(a, lds, pos, red, tid, g, c); break;
+        case 8:  w3_body<8, TH, SA>(a, lds, pos, red, tid, g, c); break;
+        default: w3_body<16, TH, SA>(a, lds, pos, red, tid, g, c); break;
     }
 }
 
@@ -3826,6 +3921,9 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* geometry pre-pass: patch positions, aggregation positions, angular shapes */
     hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_group_shape, grid1d(a.n_groups), dim3(256), 0, s, a);
+    /* a window with an empty SAI: tau_4D is the shape-adaptive transform (bm5d.cpp:276-280) and every group uses it */
+    const unsigned long long full = a.A >= 64 ? ~0ull : (1ull << a.A) - 1ull;
+    const bool all_sa = a.tau4 == 6 && (a.mask_bits & full) != full && getenv("LFBM5D_NO_SA_KERNELS") == nullptr;
     /* LFBM5D_GROUP_GENERIC: test hook, every configuration through the generic LDS kernel (the dedicated kernels' cross-check) */
     const bool generic_only = getenv("LFBM5D_GROUP_GENERIC") != nullptr;
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
@@ -3833,8 +3931,12 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     else if (a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1 && a.A == 9 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull) {   /* 32-bit byte offsets into the window */
         const unsigned threads = ((a.k * a.k + 63) / 64) * 64;
         const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
-        if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(gx, a.C), dim3(threads), 0, s, a);
-        else             hipLaunchKernelGGL(k_group_id_any, dim3(gx, a.C), dim3(threads), 0, s, a);
+        if (all_sa) {
+            if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar_sa, dim3(gx, a.C), dim3(threads), 0, s, a);
+            else             hipLaunchKernelGGL(k_group_id_any_sa, dim3(gx, a.C), dim3(threads), 0, s, a);
+        }
+        else if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(gx, a.C), dim3(threads), 0, s, a);
+        else                  hipLaunchKernelGGL(k_group_id_any, dim3(gx, a.C), dim3(threads), 0, s, a);
         return hipGetLastError();
     }
     else if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */
@@ -3876,7 +3978,7 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
             const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
 #ifndef LFBM5D_NO_DCT8W3
             /* LFBM5D_DCT8W_V2: test hook, round 2's two-image kernel (the path of windows of 1.9 GB and more) */
-            if (a.tau5 == 9 && (size_t)9 * a.C * a.Wb * a.Hb * 4 < 0x70000000ull && !getenv("LFBM5D_DCT8W_V2")) hipLaunchKernelGGL(k_group_dct8w3, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a); else
+            if (a.tau5 == 9 && (size_t)9 * a.C * a.Wb * a.Hb * 4 < 0x70000000ull && !getenv("LFBM5D_DCT8W_V2")) { if (all_sa) hipLaunchKernelGGL(k_group_dct8w3<true>, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a); else hipLaunchKernelGGL(k_group_dct8w3<false>, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a); } else
 #endif
             if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w2<true>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);
             else             hipLaunchKernelGGL((k_group_dct8w2<false>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);

@@ -196,7 +196,7 @@ def test_pass_accumulates_into_existing_buffers_and_skips_processed_sais(ctx):
     np.testing.assert_allclose(num_g, num_o, rtol=2e-5, atol=1e-2)
 
 
-def test_empty_sai_switches_to_sadct_like_the_reference(ctx):
+def test_empty_sai_switches_to_sadct_like_the_reference(ctx, monkeypatch):
     """bm5d.cpp:276-280: an empty SAI in the window forces SADCT; its slot stays untouched."""
     pk_dct = (4, 6, 2, 8, 3, "id", "dct", "haar")
     pk_sa = (4, 6, 2, 8, 3, "id", "sadct", "haar")
@@ -211,6 +211,10 @@ def test_empty_sai_switches_to_sadct_like_the_reference(ctx):
     assert not den_g[2].any() and not num_g[2].any()
     np.testing.assert_allclose(den_g, den_o, rtol=2e-5)
     assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 2e-3
+    # the kernels of such windows (k_group_id_haar_sa: the transform inline, in registers) against the call form of the others
+    monkeypatch.setenv("LFBM5D_NO_SA_KERNELS", "1")
+    num_c, den_c = gpu_pass(ctx, 1, 25.0, pk_sa, win, None, Wb, Hb, Cc, mask=mask, proc=proc)
+    assert np.array_equal(den_c, den_g) and np.array_equal(num_c, num_g)   # same products in the same order: same thresholds, same bits
 
 
 @pytest.mark.parametrize("pk", [(8, 8, 3, 16, 4, "bior", "sadct", "haar"), (4, 6, 2, 16, 4, "bior", "sadct", "haar"),
@@ -234,6 +238,38 @@ def test_empty_sai_with_16x16_transform_kernels(ctx, pk):
     assert np.array_equal(den_o != 0, den_g != 0)
     np.testing.assert_allclose(den_g, den_o, rtol=2e-5)
     assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 2e-2
+
+
+@pytest.mark.parametrize("pk", [(16, 6, 2, 8, 3, "dct", "sadct", "haar"), (8, 6, 2, 8, 3, "dct", "sadct", "haar"), (4, 6, 2, 8, 3, "dct", "sadct", "hw")],
+                         ids=["n16-haar", "n8-haar", "n4-hadamard"])
+def test_empty_sai_wiener_window_matches_oracle(ctx, pk, monkeypatch):
+    """A Wiener window with an empty SAI: every group takes the shape-adaptive angular transform -- since round 4 in kernels of
+    their own (k_group_dct8w3<true>: the transform inline, in registers; the call form made such a pass 8x slower).  Both forms
+    against the oracle, and against each other."""
+    win, Wb, Hb, Cc = window(25.0, pk, 64)
+    mask = np.ones(9, np.uint32)
+    mask[6] = 0
+    win[6] = 0
+    proc = (1 - mask).astype(np.uint32)
+    n1, d1, _ = Hh.oracle_pass(1, 25.0, (4,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, Cc, mask=mask, proc=proc)
+    basic = np.ascontiguousarray(Hh.estimate(n1, d1, win).astype(np.float32))
+    num_o, den_o, st = Hh.oracle_pass(2, 25.0, pk, win, basic, Wb, Hb, Cc, mask=mask, proc=proc)
+    assert st.sadct_groups == st.groups
+    res = []
+    for call_form in (False, True):
+        if call_form:
+            monkeypatch.setenv("LFBM5D_NO_SA_KERNELS", "1")
+        ctx.reset_stats()
+        num_g, den_g = gpu_pass(ctx, 2, 25.0, pk, win, basic, Wb, Hb, Cc, mask=mask, proc=proc)
+        s = ctx.stats()
+        assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
+        assert not den_g[6].any() and not num_g[6].any()
+        np.testing.assert_allclose(den_g, den_o, rtol=2e-4)
+        assert np.abs(Hh.estimate(num_o, den_o, win) - Hh.estimate(num_g, den_g, win)).max() < 2e-2
+        res.append((num_g, den_g))
+    monkeypatch.delenv("LFBM5D_NO_SA_KERNELS")
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=2e-5)
+    assert np.abs(Hh.estimate(res[0][0], res[0][1], win) - Hh.estimate(res[1][0], res[1][1], win)).max() < 2e-3
 
 
 def test_row_shards_sum_to_full_pass(ctx):

@@ -39,6 +39,8 @@ def main():
         den = torch.zeros_like(noisy)
         mask = np.ones(9, np.uint32)
         proc = np.zeros(9, np.uint32)
+        for e in [int(x) for x in os.environ.get("PASS_TIME_EMPTY", "").split(",") if x]:   # empty SAIs: every group shape-adaptive (bm5d.cpp:276-280)
+            mask[e] = 0; proc[e] = 1; noisy[e] = 0
         for it in range(reps + 1):
             if it == 1:
                 torch.cuda.synchronize()
