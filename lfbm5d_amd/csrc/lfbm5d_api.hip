@@ -52,6 +52,7 @@ struct GeomCache {
     unsigned scan_nwg_slot = 0; int scan_version = 0;
     std::vector<unsigned> last_refs_host;
     unsigned grid_key[5] = {0, 0, 0, 0, 0};      /* cached reference grid */
+    unsigned rslot_key[5] = {0, 0, 0, 0, 0};     /* geometry rslot / n_ref_rows / n_ref_cols were built for (survives a subset pass, which replaces refs) */
     unsigned tb_key[3] = {0, 0, 0};
     unsigned n_ref_rows = 0, n_ref_cols = 0;
 };
@@ -313,8 +314,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         HIPCK(c, hipMemcpyAsync(gc.refs.p, gc.last_refs_host.data(), gc.last_refs_host.size() * sizeof(unsigned), hipMemcpyHostToDevice, s));
         HIPCK(c, hipStreamSynchronize(s));
         std::memcpy(gc.grid_key, key, sizeof(key));
+        std::memcpy(gc.rslot_key, key, sizeof(key));
     }
     unsigned R = gc.n_ref_rows * gc.n_ref_cols;
+    const unsigned R_full = R;
     std::vector<unsigned> row_start;   /* subset path: first reference of every listed row (+ end) */
     if (!centre) {
         /* Subset path (core:157-158, utilities_LF.cpp:1000-1099): only reference patches whose k x k
@@ -367,8 +370,14 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->est.reserve((kEstLead + A * plane + 256) * sizeof(float)));
     float* const est = c->est.as<float>() + kEstLead;
     /* the scan addresses the score table through a buffer resource with 32-bit offsets */
-    if (N > 1 && (size_t)R * NsS * NsS * sizeof(float) > 0x7fffffffull) return fail(c, "unsupported: candidate score table of 2 GiB or more (reference patches x (2 nSim + 1)^2 x 4 B)");
-    if (N > 1) HIPCK(c, c->scores.reserve((size_t)R * NsS * NsS * sizeof(float)));
+    /* Subset passes (round 4): their list is part of the regular grid (rows / columns of ind_initialize), so the table kernel runs
+     * on the full grid exactly as in a centre pass -- the second-generation kernel, whose score stores follow the grid's pattern --
+     * and the selection takes a reference's scores from its place in that grid.  (Before: round 2's kernel with a position map,
+     * 2.4 instead of 0.8 ms per pass, five passes per window on a greyscale light field.) */
+    const bool full_scan = !centre && N > 1 && std::memcmp(key, gc.rslot_key, sizeof(key)) == 0 && std::getenv("LFBM5D_SUBSET_SCAN_V1") == nullptr;
+    const unsigned R_sc = full_scan ? R_full : R;   /* rows of the score table */
+    if (N > 1 && (size_t)R_sc * NsS * NsS * sizeof(float) > 0x7fffffffull) return fail(c, "unsupported: candidate score table of 2 GiB or more (reference patches x (2 nSim + 1)^2 x 4 B)");
+    if (N > 1) HIPCK(c, c->scores.reserve((size_t)R_sc * NsS * NsS * sizeof(float)));
     HIPCK(c, c->self_idx.reserve((size_t)R * Nst * sizeof(unsigned)));
     HIPCK(c, c->self_cnt.reserve((size_t)R * sizeof(unsigned)));
     HIPCK(c, c->best.reserve(A * plane * sizeof(unsigned)));
@@ -416,17 +425,17 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     sa.est = est; sa.W = Wb; sa.H = Hb; sa.k = k; sa.pst = pst;
     sa.nSim = P->nSim; sa.nDisp = P->nDisp; sa.nHW = nHW;
     sa.n_ref_rows = gc.n_ref_rows; sa.n_ref_cols = gc.n_ref_cols; sa.p = P->p;
-    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = gc.rslot.as<int>(); sa.refmap = centre ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)((size_t)R * NsS * NsS * sizeof(float));
+    sa.scores = c->scores.as<float>(); sa.tables = c->tables.as<float>(); sa.rslot = gc.rslot.as<int>(); sa.refmap = (centre || full_scan) ? nullptr : c->refmap.as<int>(); sa.scores_bytes = (unsigned)((size_t)R_sc * NsS * NsS * sizeof(float));
     sa.n_self = N > 1 ? (P->nSim + 1) * NsS : 0;
     sa.n_stereo = n_slots * NsD * NsD;
     for (unsigned i = 0; i < n_slots; i++) sa.st_of_slot[i] = slots[i];
     sa.est_planes = A;
-    if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R * NsS * NsS));
+    if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R_sc * NsS * NsS));
     /* which generation of the table kernel, and its workgroup list: functions of the search geometry (and of the two
      * environment switches bm_scan_version reads), cached with it */
     const char* const env_v1 = std::getenv("LFBM5D_SCAN_V1"); const char* const env_ft = std::getenv("LFBM5D_SCAN_FULL_TABLES");
     const unsigned skey[8] = {sa.n_self, sa.n_stereo, sa.nSim, sa.nDisp, sa.k, Hb, Wb,
-                              1u | (centre ? 0u : 2u) | ((env_v1 && env_v1[0] && env_v1[0] != '0') ? 4u : 0u) | ((env_ft && env_ft[0] && env_ft[0] != '0') ? 8u : 0u)};
+                              1u | ((centre || full_scan) ? 0u : 2u) | ((env_v1 && env_v1[0] && env_v1[0] != '0') ? 4u : 0u) | ((env_ft && env_ft[0] && env_ft[0] != '0') ? 8u : 0u)};
     const bool scan_changed = std::memcmp(skey, gc.scan_key, sizeof(skey)) != 0;
     if (scan_changed) gc.scan_version = bm_scan_version(sa);
     const int scan_version = gc.scan_version;
@@ -456,7 +465,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     std::memcpy(gc.scan_key, skey, sizeof(skey));
     if (N > 1)
         HIPCK(c, launch_self_select(s, c->scores.as<float>(), gc.refs.as<unsigned>(), R, Wb, P->nSim, N, thr,
-                                    c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
+                                    c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>(),
+                                    full_scan ? gc.n_ref_cols : 0u, nHW, P->p, Hb - k - nHW, Wb - k - nHW));
     else
         HIPCK(c, launch_self_trivial(s, gc.refs.as<unsigned>(), R, c->self_idx.as<unsigned>(), c->self_cnt.as<unsigned>()));
     if (n_slots && scan_version == 3)

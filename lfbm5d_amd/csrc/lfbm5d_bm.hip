@@ -572,7 +572,8 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
                                                      const unsigned* __restrict__ refs, unsigned n_refs,
                                                      int W, int nSim, int N, float thr,
                                                      unsigned* __restrict__ self_idx,
-                                                     unsigned* __restrict__ self_cnt) {
+                                                     unsigned* __restrict__ self_cnt,
+                                                     int grid_cols, int nHW, int p, int last_r, int last_c) {
     extern __shared__ unsigned long long keys[];
     const int lane = threadIdx.x;
     const unsigned ref = blockIdx.x;
@@ -580,8 +581,15 @@ __global__ __launch_bounds__(64) void k_self_select(const float* __restrict__ sc
     const int Ns = 2 * nSim + 1, ncand = Ns * Ns;
     /* e / Ns by multiplication: exact for e < 2^20 / Ns, i.e. for every candidate index (Ns <= 127) */
     const unsigned div_m = ((1u << 20) + (unsigned)Ns - 1) / (unsigned)Ns;
-    const float* sc = scores + (size_t)ref * ncand;
     const int k_r = (int)refs[ref];
+    size_t row = ref;
+    if (grid_cols) {   /* the score table is the regular grid's: this reference's row in it */
+        const int y = k_r / W, x = k_r - y * W;
+        const int gi = y == last_r ? (last_r - nHW + p - 1) / p : (y - nHW) / p;   /* the forced last index sits behind the stepped ones */
+        const int gj = x == last_c ? (last_c - nHW + p - 1) / p : (x - nHW) / p;
+        row = (size_t)gi * grid_cols + gj;
+    }
+    const float* sc = scores + row * ncand;
     /* keys of the candidates that pass the threshold, compacted in scan order (ballot prefix): the selection
      * rounds below then only walk those */
     int cnt = 0;
@@ -815,10 +823,11 @@ hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
 
 hipError_t launch_self_select(hipStream_t s, const float* scores, const unsigned* refs, unsigned n_refs,
                               unsigned W, unsigned nSim, unsigned N, float thr, unsigned* self_idx,
-                              unsigned* self_cnt) {
+                              unsigned* self_cnt, unsigned grid_cols, unsigned nHW, unsigned p, unsigned last_r, unsigned last_c) {
     const unsigned Ns = 2 * nSim + 1;
     hipLaunchKernelGGL(k_self_select, dim3(n_refs), dim3(64), (size_t)Ns * Ns * sizeof(unsigned long long), s,
-                       scores, refs, n_refs, (int)W, (int)nSim, (int)N, thr, self_idx, self_cnt);
+                       scores, refs, n_refs, (int)W, (int)nSim, (int)N, thr, self_idx, self_cnt,
+                       (int)grid_cols, (int)nHW, (int)p, (int)last_r, (int)last_c);
     return hipGetLastError();
 }
 

@@ -251,7 +251,11 @@ hipError_t launch_stereo_argmin2(hipStream_t s, const float* tables, const unsig
                                  unsigned* best, unsigned char* shape);
 hipError_t launch_self_select(hipStream_t s, const float* scores, const unsigned* refs, unsigned n_refs,
                               unsigned W, unsigned nSim, unsigned N, float thr, unsigned* self_idx,
-                              unsigned* self_cnt);
+                              unsigned* self_cnt,
+                              /* grid_cols != 0: `scores` has a row per reference patch of the REGULAR grid (rows / columns nHW + i p,
+                               * the last one forced to last_r / last_c) and `refs` lists some of them: a reference's scores are
+                               * taken from its place in that grid */
+                              unsigned grid_cols = 0, unsigned nHW = 0, unsigned p = 1, unsigned last_r = 0, unsigned last_c = 0);
 hipError_t launch_self_trivial(hipStream_t s, const unsigned* refs, unsigned n_refs, unsigned* self_idx,
                                unsigned* self_cnt);
 hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsigned* st_of_slot, unsigned n_slots,

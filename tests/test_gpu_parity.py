@@ -444,6 +444,34 @@ def test_greyscale_multi_window_steps(ctx):
     assert abs(O.psnr_lf(d_den.cpu().numpy(), clean) - O.psnr_lf(d_o, clean)) < bar
 
 
+def test_subset_passes_on_the_full_grid_scan_equal_the_position_map_form(ctx, monkeypatch):
+    """Round 4: the subset passes of a greyscale light field run the second-generation table kernel on the full regular grid and
+    take a reference's scores from its place in it (before: round 2's kernel with a position map, LFBM5D_SUBSET_SCAN_V1=1).  Same
+    tables, same selections: both steps bit-identical, pass for pass."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    lf = np.ascontiguousarray(Hh.textured_lf(5, 5, 72, 64)[:, :1])
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(25, np.uint32)
+    mask[3] = 0
+    P1 = core.make_params(25.0, 2.7, 4, 5, 2, 8, 4, "dct", "sadct", "haar", color_space="rgb")
+    P2 = core.make_params(25.0, 2.7, 8, 5, 2, 8, 3, "dct", "sadct", "haar", color_space="rgb")
+    res = []
+    for v1 in (False, True):
+        if v1:
+            monkeypatch.setenv("LFBM5D_SUBSET_SCAN_V1", "1")
+        d_noisy = torch.from_numpy(noisy).cuda()
+        d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+        ctx.reset_stats()
+        ctx.step1(P1, d_noisy, mask, d_basic, L.ROWMAJOR, 5, 5, 1, 64, 72, 1)
+        ctx.step2(P2, d_noisy, mask, d_basic, d_den, L.ROWMAJOR, 5, 5, 1, 64, 72, 1)
+        s = ctx.stats()
+        res.append((d_basic.cpu().numpy(), d_den.cpu().numpy(), int(s.passes), int(s.groups)))
+    assert res[0][2] == res[1][2] > 10 and res[0][3] == res[1][3]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert O.psnr_lf(res[0][1][mask != 0], clean[mask != 0]) > O.psnr_lf(noisy[mask != 0], clean[mask != 0]) + 5
+
+
 E2E = {
     "readme": (25.0, Hh.README_HT, Hh.README_WIEN),
     "config4": (10.0, Hh.C4_HT, Hh.README_WIEN),
