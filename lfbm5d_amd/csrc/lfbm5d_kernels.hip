@@ -1892,7 +1892,7 @@ constexpr int kT16Groups = LFBM5D_T16_GROUPS;
 #define LFBM5D_T16_WAVES 3
 #endif
 constexpr int kT16Half = LFBM5D_T16_ROUND;   /* patches per round of 2-D transforms: the work area of the Haar kernels (40: two rounds for a full group of 72, three workgroups per CU) */
-template <bool HAAR, bool BIOR, bool MULTI, bool SPLIT = false>
+template <bool HAAR, bool BIOR, bool MULTI, bool SPLIT = false, bool SA = false>   /* SA: windows with an empty SAI -- the shape-adaptive transform inline, in registers (N = 1 form) */
 __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     extern __shared__ float lds[];
     __shared__ float red[MULTI ? kT16Groups : 1][3][4];
@@ -2044,8 +2044,8 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
             wacc[gi] = 0.0f; s1[gi] = 0.0f; s2[gi] = 0.0f;
             if (gi < ngr) {
                 ShRef shg = group_shape(a, g + gi);
-                group_id_body<1, HAAR, true>(a, g + gi, c, tid, pos + gi * A, shg, a.tau4 == 6 && shg.use_sadct, wacc[gi], s1[gi], s2[gi],
-                                             work + gi * A * PSZ);
+                group_id_body<1, HAAR, true, SA ? 2 : 0>(a, g + gi, c, tid, pos + gi * A, shg, a.tau4 == 6 && shg.use_sadct, wacc[gi], s1[gi], s2[gi],
+                                                         work + gi * A * PSZ);
             }
         }
     } else if (SPLIT) {
@@ -2149,6 +2149,8 @@ __global__ __launch_bounds__(256) void k_group_dct16_any(GroupArgs a) { group_t1
 /* N = 1: kT16Groups groups per workgroup (the 5th-dimension transform is the identity, HAAR or not) */
 __global__ __launch_bounds__(256) void k_group_bior16_n1(GroupArgs a) { group_t16_kernel<true, true, true>(a); }
 __global__ __launch_bounds__(256) void k_group_dct16_n1(GroupArgs a) { group_t16_kernel<true, false, true>(a); }
+__global__ __launch_bounds__(256) void k_group_bior16_n1_sa(GroupArgs a) { group_t16_kernel<true, true, true, false, true>(a); }
+__global__ __launch_bounds__(256) void k_group_dct16_n1_sa(GroupArgs a) { group_t16_kernel<true, false, true, false, true>(a); }
 
 /* ------------------------------------------------------------------------------------------
  * 8x8 2-D DCT variant (the README Wiener configuration: k = 8, tau_2D = dct).  The 2-D transform
@@ -3885,6 +3887,7 @@ hipError_t prepare_group_kernels() {
         reinterpret_cast<const void*>(&k_group_bior16_haar), reinterpret_cast<const void*>(&k_group_bior16_any),
         reinterpret_cast<const void*>(&k_group_dct16_haar), reinterpret_cast<const void*>(&k_group_dct16_any),
         reinterpret_cast<const void*>(&k_group_bior16_n1), reinterpret_cast<const void*>(&k_group_dct16_n1),
+        reinterpret_cast<const void*>(&k_group_bior16_n1_sa), reinterpret_cast<const void*>(&k_group_dct16_n1_sa),
         reinterpret_cast<const void*>(&k_group_bm3d8<2, true>), reinterpret_cast<const void*>(&k_group_bm3d8<2, false>)};
     for (const void* f : fns) {
         const bool generic = f == reinterpret_cast<const void*>(&k_group<1>) || f == reinterpret_cast<const void*>(&k_group<2>);
@@ -3945,8 +3948,12 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         if (a.N == 1 && a.tau5 != 5) {   /* nine patches per group: a few groups share a workgroup (Haar / Hadamard of one patch: identity) */
             const dim3 grid8((a.n_groups + kT16Groups - 1) / kT16Groups, a.C);
             const size_t l1 = (size_t)kT16Groups * 9 * kT16Patch * sizeof(float);
-            if (a.tau2 == 7) hipLaunchKernelGGL(k_group_bior16_n1, grid8, block, l1, s, a);
-            else             hipLaunchKernelGGL(k_group_dct16_n1, grid8, block, l1, s, a);
+            if (all_sa) {
+                if (a.tau2 == 7) hipLaunchKernelGGL(k_group_bior16_n1_sa, grid8, block, l1, s, a);
+                else             hipLaunchKernelGGL(k_group_dct16_n1_sa, grid8, block, l1, s, a);
+            }
+            else if (a.tau2 == 7) hipLaunchKernelGGL(k_group_bior16_n1, grid8, block, l1, s, a);
+            else                  hipLaunchKernelGGL(k_group_dct16_n1, grid8, block, l1, s, a);
             return hipGetLastError();
         }
         if (a.tau2 == 7) {

@@ -219,8 +219,9 @@ def test_empty_sai_switches_to_sadct_like_the_reference(ctx, monkeypatch):
 
 @pytest.mark.parametrize("pk", [(8, 8, 3, 16, 4, "bior", "sadct", "haar"), (4, 6, 2, 16, 4, "bior", "sadct", "haar"),
                                 (2, 6, 2, 16, 4, "bior", "sadct", "haar"), (8, 8, 3, 16, 4, "dct", "sadct", "haar"),
-                                (8, 8, 3, 16, 4, "bior", "sadct", "hw")],
-                         ids=["bior-n8", "bior-n4", "bior-n2", "dct-n8", "bior-n8-hadamard"])
+                                (8, 8, 3, 16, 4, "bior", "sadct", "hw"), (1, 6, 2, 16, 3, "bior", "sadct", "haar"),
+                                (1, 6, 2, 16, 3, "dct", "sadct", "haar")],
+                         ids=["bior-n8", "bior-n4", "bior-n2", "dct-n8", "bior-n8-hadamard", "bior-n1", "dct-n1"])
 def test_empty_sai_with_16x16_transform_kernels(ctx, pk):
     """The shape-adaptive angular transform inside the 16x16 kernels (k_group_bior16_haar since round 4: inline on LDS scratch between
     the two rounds of 2-D transforms; the others: the call form): an empty SAI makes every group shape-adaptive."""
