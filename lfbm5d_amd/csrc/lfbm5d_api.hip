@@ -1848,31 +1848,59 @@ int run_bm3d_lf(lfbm5d_ctx* c, const lfbm5d_bm3d_params* Hd, const lfbm5d_bm3d_p
      * as 0 / 0: no result to reproduce */
     if (Wn->nHW > Hd->nHW) return fail(c, "unsupported: BM3D with nWien > nHard (the reference's own result is undefined there: 0 / 0 in the cropped border)");
     if (Hd->color_space != Wn->color_space || Hd->sigma != Wn->sigma) return fail(c, "BM3D: both steps share sigma and colour space");
-    hipStream_t s = c->stream;
     const unsigned nP = Hd->nHW, Wb = W + 2 * nP, Hb = H + 2 * nP;
     const size_t img = (size_t)C * W * H, imgb = (size_t)C * Wb * Hb;
-    HIPCK(c, c->w_noisy.reserve(imgb * sizeof(float)));
-    HIPCK(c, c->w_basic.reserve(imgb * sizeof(float)));
-    HIPCK(c, c->t_num.reserve(imgb * sizeof(float)));
-    float* const wn = c->w_noisy.as<float>(); float* const wb = c->w_basic.as<float>(); float* const wo = c->t_num.as<float>();
+    /* The SAIs are independent images (bm3d_LF.cpp:106-121 is a plain loop): they are dealt to lanes -- contexts with a stream and
+     * work buffers of their own -- so that the kernels of several SAIs are in flight together.  One SAI's launches are small (a
+     * 512 x 512 image: 99 workgroups of the table kernel, whose duration is one table walk however few they are).
+     * LFBM5D_BM3D_LANES (default 3: 64 -> 105 SAI-MP/s on 512 x 512 SAIs; 1: the sequential form); results do not depend on it. */
+    const char* lanes_s = std::getenv("LFBM5D_BM3D_LANES");
+    unsigned n_sai = 0;
+    for (unsigned st = 0; st < asize; st++) n_sai += h_mask[st] ? 1u : 0u;
+    const unsigned n_l = std::max(1u, std::min({8u, (unsigned)(lanes_s ? std::max(1, std::atoi(lanes_s)) : 3), std::max(1u, n_sai)}));
+    while (c->lanes.size() + 1 < n_l) {
+        std::string e;
+        lfbm5d_ctx* x = new_ctx(c->device, e);
+        if (!x) return fail(c, "lane context: " + e);
+        c->lanes.push_back(x);
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));   /* the caller's stream has produced d_noisy */
+    unsigned turn = 0;
     for (unsigned st = 0; st < asize; st++) {
         if (!h_mask[st]) continue;
+        lfbm5d_ctx* const x = turn % n_l == 0 ? c : c->lanes[turn % n_l - 1];
+        turn++;
+        hipStream_t s = x->stream;
+        HIPCK(c, x->w_noisy.reserve(imgb * sizeof(float)));
+        HIPCK(c, x->w_basic.reserve(imgb * sizeof(float)));
+        HIPCK(c, x->t_num.reserve(imgb * sizeof(float)));
+        float* const wn = x->w_noisy.as<float>(); float* const wb = x->w_basic.as<float>(); float* const wo = x->t_num.as<float>();
         float* noisy = d_noisy + st * img; float* basic = d_basic + st * img; float* deno = d_denoised + st * img;
         if (C == 3) HIPCK(c, launch_color(s, noisy, Hd->color_space, W * H, 1));
         HIPCK(c, launch_symetrize(s, noisy, wn, W, H, C, nP));
-        if (bm3d_step(c, 1, Hd, Wb, Hb, C, wn, nullptr, wo)) return 1;
+        if (bm3d_step(x, 1, Hd, Wb, Hb, C, wn, nullptr, wo)) { if (x != c) c->err = x->err; return 1; }
         HIPCK(c, launch_unsymetrize(s, basic, wo, W, H, C, nP));
         HIPCK(c, launch_symetrize(s, basic, wb, W, H, C, nP));
-        if (bm3d_step(c, 2, Wn, Wb, Hb, C, wn, wb, wo)) return 1;
+        if (bm3d_step(x, 2, Wn, Wb, Hb, C, wn, wb, wo)) { if (x != c) c->err = x->err; return 1; }
         HIPCK(c, launch_crop(s, deno, wo, W, H, C, nP, Wn->nHW));
         if (C == 3) {
             HIPCK(c, launch_color(s, deno, Hd->color_space, W * H, 0));
             HIPCK(c, launch_color(s, noisy, Hd->color_space, W * H, 0));
             HIPCK(c, launch_color(s, basic, Hd->color_space, W * H, 0));
         }
-        if (c->pending.size() >= 64) {   /* bound the event pool on large light fields */
-            if (bm3d_fold(c, Hd, C, 1)) return 1;
+        if (x->pending.size() >= 64) {   /* bound the event pool on large light fields */
+            if (bm3d_fold(x, Hd, C, 1)) { if (x != c) c->err = x->err; return 1; }
         }
+    }
+    /* drain the lanes, fold their counters and event times into this context */
+    for (unsigned l = 1; l < n_l; l++) {
+        lfbm5d_ctx* const x = c->lanes[l - 1];
+        if (bm3d_fold(x, Wn, C, 2)) { c->err = x->err; return 1; }
+        c->stats.passes += x->stats.passes; c->stats.groups += x->stats.groups; c->stats.stack_patches += x->stats.stack_patches;
+        c->stats.sadct_groups += x->stats.sadct_groups; c->stats.algorithmic_bytes += x->stats.algorithmic_bytes;
+        c->stats.ms_bm += x->stats.ms_bm; c->stats.ms_group += x->stats.ms_group; c->stats.ms_aggregate += x->stats.ms_aggregate;
+        c->stats.launches_group += x->stats.launches_group; c->stats.launches_aggregate += x->stats.launches_aggregate;
+        std::memset(&x->stats, 0, sizeof(x->stats));
     }
     return bm3d_fold(c, Wn, C, 2);
 }

@@ -1058,6 +1058,29 @@ def test_bm3d_lf_with_different_search_windows_matches_oracle(ctx, nHard, nWien)
     assert O.psnr_lf(h_den, clean) < O.psnr_lf(h_basic, clean)      # the reference's shifted crop: worse than its own first step
 
 
+def test_bm3d_lf_lanes_do_not_change_the_result(ctx, monkeypatch):
+    """LFBM3D's SAIs are independent images: run_bm3d_lf deals them to lanes (streams + work buffers of their own, round 4:
+    64 -> 105 SAI-MP/s on 512 x 512 SAIs); one, three or five lanes, with an empty SAI in between: the same bytes."""
+    from lfbm5d_amd import core
+    lf = Hh.source_lf(crop=64)[[0, 2, 4, 5, 6, 7, 8]]
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(7, np.uint32)
+    mask[3] = 0
+    hard, wien = core.make_bm3d_params(25.0, 2.7, 8, 8, 8, 3, "bior"), core.make_bm3d_params(25.0, 2.7, 16, 8, 8, 3, "dct")
+    res = []
+    for lanes in ("1", "3", "5"):
+        monkeypatch.setenv("LFBM5D_BM3D_LANES", lanes)
+        h_noisy, h_basic, h_den = noisy.copy(), np.zeros_like(noisy), np.zeros_like(noisy)
+        ctx.reset_stats()
+        ctx.bm3d_lf(hard, wien, h_noisy, mask, h_basic, h_den, 64, 64, 3)
+        res.append((h_noisy, h_basic, h_den, int(ctx.stats().groups)))
+    for r in res[1:]:
+        assert r[3] == res[0][3] > 0
+        assert np.array_equal(r[0], res[0][0]) and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2])
+    assert not res[0][2][3].any()
+    assert O.psnr_lf(res[0][2][mask != 0], clean[mask != 0]) > O.psnr_lf(noisy[mask != 0], clean[mask != 0]) + 5
+
+
 # ------------------------------------------------------------------------------------------------
 # the headline's window pass at its own size against the oracle
 # ------------------------------------------------------------------------------------------------
