@@ -715,35 +715,53 @@ __device__ __forceinline__ void sadct9_inv_lds(float* v, ShRef sh, TbPtr tb) {
 
 /* General aw x aw angular window (aswSize 2: 5x5): the same transforms with run-time sizes, generic kernel only.
  * dct_4d_process / dct_4d_inverse (core:1862-1954) and sadct_4d_process / _inverse (core:1969-2264) on one vector. */
-__device__ __noinline__ void dctw_fwd(float* x, int aw, TbPtr tb) {
-    float t[kMaxA];
-    for (int s = 0; s < aw; s++)
-        for (int u = 0; u < aw; u++) {
+/* The angular DCT of a 5x5 / 7x7 window (dct_4d_process / dct_4d_inverse, core:1862-1954) with the window side a compile-time
+ * constant: the vector and the intermediate in registers, the loops unrolled.  (Rounds 2-3 had call forms that walked a scratch
+ * vector with run-time indices: a 5x5 window's group kernel took 24-30 ms per 304^2 pass, a 7x7 window's 73-78 ms.) */
+template <int AW>
+__device__ __forceinline__ void dctw_fwd_t(float (&x)[AW * AW], TbPtr tb) {
+    float t[AW * AW];
+#pragma unroll
+    for (int s = 0; s < AW; s++)
+#pragma unroll
+        for (int u = 0; u < AW; u++) {
             float acc = 0.0f;
-            for (int j = 0; j < aw; j++) acc += x[s * aw + j] * tb->cosw[u * aw + j];
-            t[s * aw + u] = 2.0f * acc;
+#pragma unroll
+            for (int j = 0; j < AW; j++) acc += x[s * AW + j] * tb->cosw[u * AW + j];
+            t[s * AW + u] = 2.0f * acc;
         }
-    for (int v = 0; v < aw; v++)
-        for (int u = 0; u < aw; u++) {
+#pragma unroll
+    for (int v = 0; v < AW; v++)
+#pragma unroll
+        for (int u = 0; u < AW; u++) {
             float acc = 0.0f;
-            for (int j = 0; j < aw; j++) acc += t[j * aw + u] * tb->cosw[v * aw + j];
-            x[v * aw + u] = 2.0f * acc * tb->cn4[v * aw + u];
+#pragma unroll
+            for (int j = 0; j < AW; j++) acc += t[j * AW + u] * tb->cosw[v * AW + j];
+            x[v * AW + u] = 2.0f * acc * tb->cn4[v * AW + u];
         }
 }
-__device__ __noinline__ void dctw_inv(float* x, int aw, TbPtr tb) {
-    float t[kMaxA];
-    for (int i = 0; i < aw * aw; i++) x[i] *= tb->cni4[i];
-    for (int s = 0; s < aw; s++)
-        for (int j = 0; j < aw; j++) {
+template <int AW>
+__device__ __forceinline__ void dctw_inv_t(float (&x)[AW * AW], TbPtr tb) {
+    float t[AW * AW];
+#pragma unroll
+    for (int i = 0; i < AW * AW; i++) x[i] *= tb->cni4[i];
+#pragma unroll
+    for (int s = 0; s < AW; s++)
+#pragma unroll
+        for (int j = 0; j < AW; j++) {
             float acc = 0.0f;
-            for (int u = 1; u < aw; u++) acc += x[s * aw + u] * tb->cosw[u * aw + j];
-            t[s * aw + j] = x[s * aw] + 2.0f * acc;
+#pragma unroll
+            for (int u = 1; u < AW; u++) acc += x[s * AW + u] * tb->cosw[u * AW + j];
+            t[s * AW + j] = x[s * AW] + 2.0f * acc;
         }
-    for (int i = 0; i < aw; i++)
-        for (int j = 0; j < aw; j++) {
+#pragma unroll
+    for (int i = 0; i < AW; i++)
+#pragma unroll
+        for (int j = 0; j < AW; j++) {
             float acc = 0.0f;
-            for (int v = 1; v < aw; v++) acc += t[v * aw + j] * tb->cosw[v * aw + i];
-            x[i * aw + j] = (t[j] + 2.0f * acc) * tb->coef4inv;
+#pragma unroll
+            for (int v = 1; v < AW; v++) acc += t[v * AW + j] * tb->cosw[v * AW + i];
+            x[i * AW + j] = (t[j] + 2.0f * acc) * tb->coef4inv;
         }
 }
 __device__ __noinline__ void sadctw_fwd(float* v, int aw, ShRef sh, TbPtr tb) {
@@ -1466,10 +1484,24 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
                     if (do_dct4) dct9_fwd(x, tb); else sadct9_fwd(x, sh, tb);
 #pragma unroll
                     for (int st = 0; st < 9; st++) S[(n * A + st) * k2 + pq] = x[st];
-                } else {   /* 5x5 / 7x7 window */
+                } else if (do_dct4 && A == 25) {   /* 5x5 / 7x7 window, plain DCT: in registers */
+                    float x[25];
+#pragma unroll
+                    for (int st = 0; st < 25; st++) x[st] = S[(n * 25 + st) * k2 + pq];
+                    dctw_fwd_t<5>(x, tb);
+#pragma unroll
+                    for (int st = 0; st < 25; st++) S[(n * 25 + st) * k2 + pq] = x[st];
+                } else if (do_dct4) {
+                    float x[49];
+#pragma unroll
+                    for (int st = 0; st < 49; st++) x[st] = S[(n * 49 + st) * k2 + pq];
+                    dctw_fwd_t<7>(x, tb);
+#pragma unroll
+                    for (int st = 0; st < 49; st++) S[(n * 49 + st) * k2 + pq] = x[st];
+                } else {   /* shape-adaptive: the call form */
                     float x[kMaxA];
                     for (int st = 0; st < A; st++) x[st] = S[(n * A + st) * k2 + pq];
-                    if (do_dct4) dctw_fwd(x, aw, tb); else sadctw_fwd(x, aw, sh, tb);
+                    sadctw_fwd(x, aw, sh, tb);
                     for (int st = 0; st < A; st++) S[(n * A + st) * k2 + pq] = x[st];
                 }
             }
@@ -1532,10 +1564,24 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
                 if (do_dct4) dct9_inv(x, tb); else sadct9_inv(x, sh, tb);
 #pragma unroll
                 for (int st = 0; st < 9; st++) F[(n * A + st) * k2 + pq] = x[st];
+            } else if (do_dct4 && A == 25) {
+                float x[25];
+#pragma unroll
+                for (int st = 0; st < 25; st++) x[st] = F[(n * 25 + st) * k2 + pq];
+                dctw_inv_t<5>(x, tb);
+#pragma unroll
+                for (int st = 0; st < 25; st++) F[(n * 25 + st) * k2 + pq] = x[st];
+            } else if (do_dct4) {
+                float x[49];
+#pragma unroll
+                for (int st = 0; st < 49; st++) x[st] = F[(n * 49 + st) * k2 + pq];
+                dctw_inv_t<7>(x, tb);
+#pragma unroll
+                for (int st = 0; st < 49; st++) F[(n * 49 + st) * k2 + pq] = x[st];
             } else {
                 float x[kMaxA];
                 for (int st = 0; st < A; st++) x[st] = F[(n * A + st) * k2 + pq];
-                if (do_dct4) dctw_inv(x, aw, tb); else sadctw_inv(x, aw, sh, tb);
+                sadctw_inv(x, aw, sh, tb);
                 for (int st = 0; st < A; st++) F[(n * A + st) * k2 + pq] = x[st];
             }
         }
