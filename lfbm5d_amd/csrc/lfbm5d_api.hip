@@ -84,6 +84,7 @@ struct lfbm5d_ctx {
     /* per-pass work buffers (grow only) */
     DevBuf t_noisy, t_basic, t_tnum, t_tden, und_num, und_den;   /* tile mode: one tile of the window, the tiles' interiors */
     DevBuf scan_lcol;                      /* second-generation scan: hand-off columns */
+    DevBuf sub_flags, sub_cnt;             /* subset passes: the device-side reference list's scratch and count */
     int last_scan_version = 0;
     /* what a pass derives from its geometry alone (reference grid, transform tables, the table kernel's workgroup list):
      * cached, one set per step slot so that the windows of both steps of a two-step job can alternate on a lane without
@@ -319,6 +320,31 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     unsigned R = gc.n_ref_rows * gc.n_ref_cols;
     const unsigned R_full = R;
     std::vector<unsigned> row_start;   /* subset path: first reference of every listed row (+ end) */
+    /* the list on the device (round 4): the flagged patches of the regular grid in raster order -- what the host loop below
+     * produces, without the copy of the plane and the 4 M comparisons a pass (1 / 0.4 ms of host time, a third of a greyscale job).
+     * Row shards need the rows' first entries on the host and keep the host form */
+    const bool dev_list = !centre && c->pass_world == 1 && std::memcmp(key, gc.rslot_key, sizeof(key)) == 0 && std::getenv("LFBM5D_SUBSET_LIST_HOST") == nullptr;
+    if (dev_list) {
+        HIPCK(c, c->sub_flags.reserve((size_t)R_full));
+        HIPCK(c, c->sub_cnt.reserve(sizeof(unsigned)));
+        HIPCK(c, gc.refs.reserve((size_t)R_full * sizeof(unsigned)));
+        unsigned* const d_cnt = c->sub_cnt.as<unsigned>();
+        HIPCK(c, launch_subset_list(s, d_den + (size_t)pst * C * plane, Wb, k, nHW, P->p, gc.n_ref_rows, gc.n_ref_cols, Hb - k - nHW, Wb - k - nHW,
+                                    reinterpret_cast<unsigned char*>(c->sub_flags.p), gc.refs.as<unsigned>(), d_cnt));
+        HIPCK(c, hipMemcpyAsync(&R, d_cnt, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIPCK(c, hipStreamSynchronize(s));
+        std::memset(gc.grid_key, 0, sizeof(gc.grid_key));   /* the cached regular grid is gone */
+        gc.last_refs_host.resize(R);
+        if (R == 0) { c->last_n_refs = 0; return 0; }   /* nothing left to denoise (core:160-165) */
+        HIPCK(c, hipMemcpyAsync(gc.last_refs_host.data(), gc.refs.p, R * sizeof(unsigned), hipMemcpyDeviceToHost, s));   /* lfbm5d_last_bm */
+        HIPCK(c, hipStreamSynchronize(s));
+        row_start.assign({0u, R});
+        if (N > 1 && std::getenv("LFBM5D_SUBSET_SCAN_V1")) {   /* (the test hook's table kernel stores through the position map) */
+            HIPCK(c, c->refmap.reserve(plane * sizeof(int)));
+            HIPCK(c, launch_fill_i32(s, c->refmap.as<int>(), -1, plane));
+            HIPCK(c, launch_refmap(s, gc.refs.as<unsigned>(), R, c->refmap.as<int>()));
+        }
+    } else
     if (!centre) {
         /* Subset path (core:157-158, utilities_LF.cpp:1000-1099): only reference patches whose k x k
          * footprint still holds an exactly-zero weight in channel 0 of den[pst]; one extra column /
@@ -1487,7 +1513,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
     for (GeomCache& g : c->gc) { g.refs.release(); g.rslot.release(); g.tb.release(); g.scan_wgs.release(); }
     DevBuf* bufs[] = {&c->est, &c->g_num2, &c->g_den2, &c->n2, &c->e_basic, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->gshape, &c->counters, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->sub_flags, &c->sub_cnt, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->gshape, &c->counters, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch, &c->scan_lcol};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

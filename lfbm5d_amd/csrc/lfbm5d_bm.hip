@@ -789,7 +789,56 @@ __global__ void k_refmap(const unsigned* __restrict__ refs, unsigned n_refs, int
     if (i < n_refs) refmap[refs[i]] = (int)i;
 }
 
+/* The reference list of a subset pass (core:157-158, utilities_LF.cpp:1000-1099) on the device: the patches of the regular grid
+ * whose k x k footprint still holds an exactly-zero weight in den0 (channel 0 of den[pst]), in raster order.  k_subset_flags: one
+ * wavefront per grid patch; k_subset_compact: one workgroup, ordered compaction (every thread a run of consecutive patches, an
+ * exclusive scan of the runs' counts through LDS). */
+__global__ __launch_bounds__(256) void k_subset_flags(const float* __restrict__ den0, int Wb, int k, int nHW, int p, int n_rows, int n_cols,
+                                                       int last_r, int last_c, unsigned char* __restrict__ flags) {
+    const int ref = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ref >= n_rows * n_cols) return;
+    const int gi = ref / n_cols, gj = ref - gi * n_cols;
+    const int y = gi == n_rows - 1 ? last_r : nHW + gi * p, x = gj == n_cols - 1 ? last_c : nHW + gj * p;
+    bool zero = false;
+    for (int e = lane; e < k * k; e += 64) zero = zero || den0[(size_t)(y + e / k) * Wb + x + e % k] == 0.0f;
+    const unsigned long long any = __ballot(zero);
+    if (lane == 0) flags[ref] = any ? 1 : 0;
+}
+__global__ __launch_bounds__(1024) void k_subset_compact(const unsigned char* __restrict__ flags, int Wb, int nHW, int p, int n_rows, int n_cols,
+                                                          int last_r, int last_c, unsigned* __restrict__ refs, unsigned* __restrict__ count) {
+    __shared__ unsigned part[1024];
+    const int R = n_rows * n_cols, tid = threadIdx.x, per = (R + 1023) / 1024, b = tid * per, e = min(b + per, R);
+    unsigned n = 0;
+    for (int i = b; i < e; i++) n += flags[i];
+    part[tid] = n;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {   /* inclusive scan */
+        const unsigned v = tid >= o ? part[tid - o] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned w = part[tid] - n;
+    for (int i = b; i < e; i++)
+        if (flags[i]) {
+            const int gi = i / n_cols, gj = i - gi * n_cols;
+            const int y = gi == n_rows - 1 ? last_r : nHW + gi * p, x = gj == n_cols - 1 ? last_c : nHW + gj * p;
+            refs[w++] = (unsigned)(y * Wb + x);
+        }
+    if (tid == 1023) *count = part[1023];
+}
+
 } /* namespace */
+
+hipError_t launch_subset_list(hipStream_t s, const float* den0, unsigned Wb, unsigned k, unsigned nHW, unsigned p, unsigned n_rows,
+                              unsigned n_cols, unsigned last_r, unsigned last_c, unsigned char* flags, unsigned* refs, unsigned* count) {
+    const unsigned R = n_rows * n_cols;
+    hipLaunchKernelGGL(k_subset_flags, dim3((R + 3) / 4), dim3(256), 0, s, den0, (int)Wb, (int)k, (int)nHW, (int)p, (int)n_rows, (int)n_cols,
+                       (int)last_r, (int)last_c, flags);
+    hipLaunchKernelGGL(k_subset_compact, dim3(1), dim3(1024), 0, s, flags, (int)Wb, (int)nHW, (int)p, (int)n_rows, (int)n_cols, (int)last_r,
+                       (int)last_c, refs, count);
+    return hipGetLastError();
+}
 
 hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, int* refmap) {
     hipLaunchKernelGGL(k_refmap, dim3((n_refs + 255) / 256), dim3(256), 0, s, refs, n_refs, refmap);

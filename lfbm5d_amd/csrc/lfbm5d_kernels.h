@@ -234,6 +234,10 @@ hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsig
 hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned long long mask_bits,
                                  unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count);
 hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, int* refmap);
+/* subset pass: the regular grid's patches (rows / columns nHW + i p, the last forced to last_r / last_c) whose footprint holds a zero
+ * of den0, in raster order -> refs, their number -> count; flags: n_rows * n_cols bytes of scratch */
+hipError_t launch_subset_list(hipStream_t s, const float* den0, unsigned Wb, unsigned k, unsigned nHW, unsigned p, unsigned n_rows,
+                              unsigned n_cols, unsigned last_r, unsigned last_c, unsigned char* flags, unsigned* refs, unsigned* count);
 hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a);
 /* second generation (lfbm5d_scan2.hip): which kernel a configuration gets (1 or 2), the workgroup list and LDS size of a
  * launch, the hand-off row length, the launch itself and the arg-min over its table layout */

@@ -458,9 +458,12 @@ def test_subset_passes_on_the_full_grid_scan_equal_the_position_map_form(ctx, mo
     P1 = core.make_params(25.0, 2.7, 4, 5, 2, 8, 4, "dct", "sadct", "haar", color_space="rgb")
     P2 = core.make_params(25.0, 2.7, 8, 5, 2, 8, 3, "dct", "sadct", "haar", color_space="rgb")
     res = []
-    for v1 in (False, True):
+    for v1 in (False, True, None):
         if v1:
             monkeypatch.setenv("LFBM5D_SUBSET_SCAN_V1", "1")
+        elif v1 is None:   # ... and the passes' reference lists built on the host (rounds 1-3) instead of on the device
+            monkeypatch.delenv("LFBM5D_SUBSET_SCAN_V1")
+            monkeypatch.setenv("LFBM5D_SUBSET_LIST_HOST", "1")
         d_noisy = torch.from_numpy(noisy).cuda()
         d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
         ctx.reset_stats()
@@ -468,8 +471,9 @@ def test_subset_passes_on_the_full_grid_scan_equal_the_position_map_form(ctx, mo
         ctx.step2(P2, d_noisy, mask, d_basic, d_den, L.ROWMAJOR, 5, 5, 1, 64, 72, 1)
         s = ctx.stats()
         res.append((d_basic.cpu().numpy(), d_den.cpu().numpy(), int(s.passes), int(s.groups)))
-    assert res[0][2] == res[1][2] > 10 and res[0][3] == res[1][3]
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for r in res[1:]:
+        assert res[0][2] == r[2] > 10 and res[0][3] == r[3]
+        assert np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1])
     assert O.psnr_lf(res[0][1][mask != 0], clean[mask != 0]) > O.psnr_lf(noisy[mask != 0], clean[mask != 0]) + 5
 
 
