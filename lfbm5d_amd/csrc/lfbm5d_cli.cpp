@@ -37,6 +37,9 @@
 #include <sstream>
 #include <string>
 #include <vector>
+#include <thread>
+#include <atomic>
+#include <mutex>
 
 #include "../../include/lfbm5d.h"
 #include "png_min.h"
@@ -56,6 +59,23 @@ struct Mt {
     double res53() { const unsigned long a = g() >> 5, b = g() >> 6; return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0); }
 };
 
+/* The SAIs are files of their own: decoded / encoded by a few threads (PNG inflate / deflate is the command's wall time once the
+ * filter runs on a GPU: 18 ms per 512 x 512 colour image and thread).  LFBM5D_IO_THREADS (default: the machine's cores, at most
+ * 16; 1: one after the other like the reference).  fn(i) -> false stops the loop and fails it. */
+template <class F> bool parallel_sais(unsigned n, F fn) {
+    const char* e = getenv("LFBM5D_IO_THREADS");
+    unsigned nt = e && *e ? (unsigned)std::max(1, atoi(e)) : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = std::min(nt, std::max(1u, n));
+    std::atomic<unsigned> next(0);
+    std::atomic<bool> ok(true);
+    auto work = [&]() { for (unsigned i = next++; i < n && ok; i = next++) if (!fn(i)) ok = false; };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; i++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    return ok;
+}
+
 string sai_path(const char* dir, const char* name, const char* sep, unsigned s, unsigned t) {
     ostringstream o;
     o << dir << "/" << name << sep << setfill('0') << setw(2) << s << sep << setfill('0') << setw(2) << t << ".png";
@@ -67,30 +87,36 @@ int load_LF(const char* dir, const char* name, const char* sep, vector<vector<fl
             unsigned ang_major, unsigned aw, unsigned ah, unsigned s0, unsigned t0, unsigned& W, unsigned& H, unsigned& C) {
     mask.assign(aw * ah, 0u);
     LF.assign(aw * ah, vector<float>());
-    bool first = true;
     cout << endl;
-    for (unsigned s = 0; s < ah; s++)
-        for (unsigned t = 0; t < aw; t++) {
-            const string p = sai_path(dir, name, sep, s + s0, t + t0);
-            cout << "\rRead input image " << p << flush;
-            vector<float> img;
-            size_t w, h, c;
-            if (!png_read_planar_f32(p, img, w, h, c)) {
-                cout << endl << "error :: " << p << " not found or not a correct png image." << endl;
-                return EXIT_FAILURE;
-            }
-            if (c == 2) c = 1; /* drop alpha */
-            if (c > 2) {       /* really colour? (utilities_LF.cpp:118-125) */
-                size_t k = 0; float acc = 0.0f;
-                while (k < w * h && img[k] == img[w * h + k] && img[k] == img[2 * w * h + k]) { acc += img[k] + img[w * h + k] + img[2 * w * h + k]; k++; }
-                c = (k == w * h && acc > 0.0f) ? 1 : 3;
-            }
-            if (first) { W = (unsigned)w; H = (unsigned)h; C = (unsigned)c; first = false; }
-            if (w != W || h != H || c != C) { cout << endl << "error :: SAIs of different sizes" << endl; return EXIT_FAILURE; }
-            const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah;
-            LF[st].assign(img.begin(), img.begin() + w * h * c);
-            for (float v : LF[st]) if (v) { mask[st] = 1; break; }
+    std::vector<size_t> ws(aw * ah, 0), hs(aw * ah, 0), cs(aw * ah, 0);
+    std::mutex out;
+    string bad;
+    const bool ok = parallel_sais(aw * ah, [&](unsigned i) {
+        const unsigned s = i / aw, t = i % aw;
+        const string p = sai_path(dir, name, sep, s + s0, t + t0);
+        { std::lock_guard<std::mutex> g(out); cout << "\rRead input image " << p << flush; }
+        vector<float> img;
+        size_t w, h, c;
+        if (!png_read_planar_f32(p, img, w, h, c)) { std::lock_guard<std::mutex> g(out); if (bad.empty()) bad = p; return false; }
+        if (c == 2) c = 1; /* drop alpha */
+        if (c > 2) {       /* really colour? (utilities_LF.cpp:118-125) */
+            size_t k = 0; float acc = 0.0f;
+            while (k < w * h && img[k] == img[w * h + k] && img[k] == img[2 * w * h + k]) { acc += img[k] + img[w * h + k] + img[2 * w * h + k]; k++; }
+            c = (k == w * h && acc > 0.0f) ? 1 : 3;
         }
+        const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah;
+        ws[st] = w; hs[st] = h; cs[st] = c;
+        LF[st].assign(img.begin(), img.begin() + w * h * c);
+        for (float v : LF[st]) if (v) { mask[st] = 1; break; }
+        return true;
+    });
+    if (!ok) { cout << endl << "error :: " << bad << " not found or not a correct png image." << endl; return EXIT_FAILURE; }
+    {   /* all SAIs of the first one's size (the first in the reference's reading order: s, t = 0, 0) */
+        const unsigned st0 = 0;
+        W = (unsigned)ws[st0]; H = (unsigned)hs[st0]; C = (unsigned)cs[st0];
+        for (unsigned st = 0; st < aw * ah; st++)
+            if (ws[st] != W || hs[st] != H || cs[st] != C) { cout << endl << "error :: SAIs of different sizes" << endl; return EXIT_FAILURE; }
+    }
     cout << endl << " Light field size :" << endl << " - awidth         = " << aw << endl << " - aheight        = " << ah << endl
          << " - width          = " << W << endl << " - height         = " << H << endl << " - nb of channels = " << C << endl;
     return EXIT_SUCCESS;
@@ -99,16 +125,20 @@ int load_LF(const char* dir, const char* name, const char* sep, vector<vector<fl
 /* save_LF + save_image, utilities_LF.cpp:182-231, utilities.cpp:118-142 */
 int save_LF(const char* dir, const char* name, const char* sep, const vector<vector<float> >& LF, unsigned ang_major,
             unsigned aw, unsigned ah, unsigned s0, unsigned t0, unsigned W, unsigned H, unsigned C) {
-    vector<float> tmp((size_t)W * H * C);
-    for (unsigned s = 0; s < ah; s++)
-        for (unsigned t = 0; t < aw; t++) {
-            const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah;
-            const string p = sai_path(dir, name, sep, s + s0, t + t0);
-            cout << "\rWrite image " << p << flush;
-            if (LF[st].size() != tmp.size()) { std::fill(tmp.begin(), tmp.end(), 0.0f); }
-            else for (size_t k = 0; k < tmp.size(); k++) tmp[k] = LF[st][k] > 255.0f ? 255.0f : (LF[st][k] < 0.0f ? 0.0f : LF[st][k]);
-            if (!png_write_planar_f32(p, tmp.data(), W, H, C)) { cout << "... failed to save png image " << p << endl; return EXIT_FAILURE; }
-        }
+    std::mutex out;
+    string bad;
+    const bool ok = parallel_sais(aw * ah, [&](unsigned i) {
+        const unsigned s = i / aw, t = i % aw;
+        const unsigned st = ang_major == LFBM5D_ROWMAJOR ? s * aw + t : s + t * ah;
+        const string p = sai_path(dir, name, sep, s + s0, t + t0);
+        { std::lock_guard<std::mutex> g(out); cout << "\rWrite image " << p << flush; }
+        vector<float> tmp((size_t)W * H * C, 0.0f);
+        if (LF[st].size() == tmp.size())
+            for (size_t k = 0; k < tmp.size(); k++) tmp[k] = LF[st][k] > 255.0f ? 255.0f : (LF[st][k] < 0.0f ? 0.0f : LF[st][k]);
+        if (!png_write_planar_f32(p, tmp.data(), W, H, C)) { std::lock_guard<std::mutex> g(out); if (bad.empty()) bad = p; return false; }
+        return true;
+    });
+    if (!ok) { cout << "... failed to save png image " << bad << endl; return EXIT_FAILURE; }
     cout << endl;
     return EXIT_SUCCESS;
 }
