@@ -191,19 +191,38 @@ void diff_LF(const vector<vector<float> >& A, const vector<vector<float> >& B, c
     }
 }
 
-/* add_noise_LF, utilities_LF.cpp:244-263 + add_noise, utilities.cpp:154-185 */
+/* add_noise_LF, utilities_LF.cpp:244-263 + add_noise, utilities.cpp:154-185.  The reference seeds a generator per SAI from the clock
+ * and the process id: the SAIs' streams are independent and are drawn by the I/O thread pool (the SAI's index added to the seed:
+ * threads that start within one millisecond must not share one).  LFBM5D_SEED (tests, benchmarks) is ONE stream through the SAIs
+ * in order: its uniforms are drawn in order, SAI by SAI, and only their Box-Muller transform is spread over the threads. */
 void add_noise_LF(const vector<vector<float> >& LF, const vector<unsigned>& mask, vector<vector<float> >& LF_noisy, float sigma) {
     const char* seed = getenv("LFBM5D_SEED");
-    Mt fixed(seed ? strtoul(seed, nullptr, 10) : 0);
+    auto gauss = [sigma](double x, double y) { return (float)((double)sigma * sqrt(-2.0 * log(x)) * cos(2.0 * M_PI * y)); };
+    if (!seed) {
+        parallel_sais((unsigned)LF.size(), [&](unsigned st) {
+            if (!mask[st]) return true;
+            timeval tp; gettimeofday(&tp, nullptr);
+            Mt g(tp.tv_sec * 1000 + tp.tv_usec / 1000 + (unsigned long)getpid() + st);
+            for (size_t q = 0; q < LF[st].size(); q++) {
+                const double x = g.res53(), y = g.res53();
+                LF_noisy[st][q] = LF[st][q] + gauss(x, y);
+            }
+            return true;
+        });
+        return;
+    }
+    Mt g(strtoul(seed, nullptr, 10));
+    vector<double> u;
     for (size_t st = 0; st < LF.size(); st++) {
         if (!mask[st]) continue;
-        timeval tp; gettimeofday(&tp, nullptr);
-        Mt per(tp.tv_sec * 1000 + tp.tv_usec / 1000 + (unsigned long)getpid());
-        Mt& g = seed ? fixed : per;
-        for (size_t q = 0; q < LF[st].size(); q++) {
-            const double x = g.res53(), y = g.res53();
-            LF_noisy[st][q] = LF[st][q] + (float)((double)sigma * sqrt(-2.0 * log(x)) * cos(2.0 * M_PI * y));
-        }
+        const size_t n = LF[st].size();
+        u.resize(2 * n);
+        for (size_t q = 0; q < 2 * n; q++) u[q] = g.res53();
+        const unsigned parts = 16;
+        parallel_sais(parts, [&](unsigned part) {
+            for (size_t q = n * part / parts; q < n * (part + 1) / parts; q++) LF_noisy[st][q] = LF[st][q] + gauss(u[2 * q], u[2 * q + 1]);
+            return true;
+        });
     }
 }
 

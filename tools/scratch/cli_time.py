@@ -19,7 +19,7 @@ args = [os.path.join(ROOT, "lfbm5d_amd", "LFBM5Ddenoising"), src, "SAI", "_", st
         f"{tmp}/denoised", f"{tmp}/diff", "8", "18", "6", "16", "4", "id", "sadct", "haar", "0", "16", "18", "6", "8", "4",
         "dct", "sadct", "haar", "0", "opp", "0", f"{tmp}/m.txt"]
 t0 = time.time()
-out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, LFBM5D_SEED="1"))
+out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, LFBM5D_SEED="1") if os.environ.get("CLI_SEEDED", "1") == "1" else dict(os.environ))
 print(f"CLI wall {time.time()-t0:.2f} s rc {out.returncode}")
 for l in out.stdout.split("\n"):
-    if "elapsed" in l or "time" in l.lower(): print("  ", l.strip())
+    if "elapsed" in l or "time" in l.lower() or "done in" in l: print("  ", l.strip()[:120])
