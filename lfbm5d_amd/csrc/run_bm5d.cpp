@@ -6,9 +6,13 @@
  */
 #include "run_bm5d.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
+#include <thread>
 
 #include "../../include/lfbm5d.h"
 
@@ -26,19 +30,33 @@ lfbm5d_ctx* context() {
     return ctx;
 }
 
-void flatten(const std::vector<std::vector<float> >& LF, const std::vector<unsigned>& mask, size_t img,
-             std::vector<float>& flat) {
-    flat.assign(LF.size() * img, 0.0f);
-    for (size_t st = 0; st < LF.size(); st++)
-        if (mask[st] && LF[st].size() == img) std::memcpy(&flat[st * img], LF[st].data(), img * sizeof(float));
+/* the SAIs of the reference's vector-of-vectors light field <-> one flat buffer, by a few threads: at 17 x 17 x 512 x 512 x 3 a light
+ * field is 0.9 GB and a step moves three to five of them -- one thread's memcpy of that is longer than the step on the GPU */
+template <class F> void for_sais(size_t n, F fn) {
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), std::max<size_t>(1, n));
+    std::atomic<size_t> next(0);
+    auto work = [&]() { for (size_t i = next++; i < n; i = next++) fn(i); };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; i++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
 }
-void unflatten(std::vector<std::vector<float> >& LF, const std::vector<unsigned>& mask, size_t img,
-               const std::vector<float>& flat) {
-    for (size_t st = 0; st < LF.size(); st++) {
-        if (!mask[st]) continue;
+/* flat buffers: uninitialised storage (every byte is written by flatten or by the library's device-to-host copy) */
+typedef std::unique_ptr<float[]> Flat;
+Flat flat_alloc(size_t n) { return Flat(new float[n]); }
+void flatten(const std::vector<std::vector<float> >& LF, const std::vector<unsigned>& mask, size_t img, Flat& flat) {
+    flat = flat_alloc(LF.size() * img);
+    for_sais(LF.size(), [&](size_t st) {
+        if (mask[st] && LF[st].size() == img) std::memcpy(&flat[st * img], LF[st].data(), img * sizeof(float));
+        else std::memset(&flat[st * img], 0, img * sizeof(float));
+    });
+}
+void unflatten(std::vector<std::vector<float> >& LF, const std::vector<unsigned>& mask, size_t img, const Flat& flat) {
+    for_sais(LF.size(), [&](size_t st) {
+        if (!mask[st]) return;
         if (LF[st].size() != img) LF[st].resize(img);
         std::memcpy(LF[st].data(), &flat[st * img], img * sizeof(float));
-    }
+    });
 }
 
 lfbm5d_params make(float sigma, float lambda, unsigned N, unsigned nSim, unsigned nDisp, unsigned k, unsigned p,
@@ -76,10 +94,10 @@ int run_bm5d_1st_step(const float sigma, const float lambdaHard5D, std::vector<s
     lfbm5d_set_tiles(ctx, tiles_for(nb_threads));
     if (LF_basic.size() != asize) LF_basic.resize(asize); /* bm5d.cpp:129-130 */
     const size_t img = (size_t)width * height * chnls;
-    std::vector<float> noisy, basic(asize * img, 0.0f);
+    Flat noisy, basic = flat_alloc(asize * img);
     flatten(LF_noisy, LF_SAI_mask, img, noisy);
     const lfbm5d_params P = make(sigma, lambdaHard5D, NHard, nSim, nDisp, kHard, pHard, useSD, tau_2D, tau_4D, tau_5D, color_space);
-    if (lfbm5d_step1_host(ctx, &P, noisy.data(), LF_SAI_mask.data(), basic.data(), ang_major, awidth, aheight, anHard,
+    if (lfbm5d_step1_host(ctx, &P, noisy.get(), LF_SAI_mask.data(), basic.get(), ang_major, awidth, aheight, anHard,
                           width, height, chnls) != 0) {
         std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
         return EXIT_FAILURE;
@@ -106,11 +124,11 @@ int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_no
     lfbm5d_set_tiles(ctx, tiles_for(nb_threads));
     if (LF_denoised.size() != asize) LF_denoised.resize(asize); /* bm5d.cpp:823-824 */
     const size_t img = (size_t)width * height * chnls;
-    std::vector<float> noisy, basic, den(asize * img, 0.0f);
+    Flat noisy, basic, den = flat_alloc(asize * img);
     flatten(LF_noisy, LF_SAI_mask, img, noisy);
     flatten(LF_basic, LF_SAI_mask, img, basic);
     const lfbm5d_params P = make(sigma, 0.0f, NWien, nSim, nDisp, kWien, pWien, useSD, tau_2D, tau_4D, tau_5D, color_space);
-    if (lfbm5d_step2_host(ctx, &P, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), ang_major, awidth, aheight,
+    if (lfbm5d_step2_host(ctx, &P, noisy.get(), LF_SAI_mask.data(), basic.get(), den.get(), ang_major, awidth, aheight,
                           anWien, width, height, chnls) != 0) {
         std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
         return EXIT_FAILURE;
@@ -142,11 +160,11 @@ int run_bm5d(const float sigma, const float lambdaHard5D, std::vector<std::vecto
     if (LF_basic.size() != asize) LF_basic.resize(asize);
     if (LF_denoised.size() != asize) LF_denoised.resize(asize);
     const size_t img = (size_t)width * height * chnls;
-    std::vector<float> noisy, basic(asize * img, 0.0f), den(asize * img, 0.0f);
+    Flat noisy, basic = flat_alloc(asize * img), den = flat_alloc(asize * img);
     flatten(LF_noisy, LF_SAI_mask, img, noisy);
     const lfbm5d_params P1 = make(sigma, lambdaHard5D, NHard, nSimHard, nDispHard, kHard, pHard, useSDHard, tau_2D_hard, tau_4D_hard, tau_5D_hard, color_space);
     const lfbm5d_params P2 = make(sigma, 0.0f, NWien, nSimWien, nDispWien, kWien, pWien, useSDWien, tau_2D_wien, tau_4D_wien, tau_5D_wien, color_space);
-    if (lfbm5d_denoise_host(ctx, &P1, &P2, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), ang_major, awidth, aheight,
+    if (lfbm5d_denoise_host(ctx, &P1, &P2, noisy.get(), LF_SAI_mask.data(), basic.get(), den.get(), ang_major, awidth, aheight,
                             anHard, anWien, width, height, chnls) != 0) {
         std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
         return EXIT_FAILURE;
@@ -176,14 +194,14 @@ int run_bm3d_LF(const float sigma, std::vector<std::vector<float> >& LF_noisy, s
     if (LF_basic.size() != asize) LF_basic.resize(asize);       /* bm3d_LF.cpp:99-102 */
     if (LF_denoised.size() != asize) LF_denoised.resize(asize);
     const size_t img = (size_t)width * height * chnls;
-    std::vector<float> noisy, basic(asize * img, 0.0f), den(asize * img, 0.0f);
+    Flat noisy, basic = flat_alloc(asize * img), den = flat_alloc(asize * img);
     flatten(LF_noisy, LF_SAI_mask, img, noisy);
     lfbm5d_bm3d_params Hd, Wn;
     Hd.sigma = sigma; Hd.lambda3D = lambdaHard3D; Hd.N = NHard; Hd.nHW = nHard; Hd.k = kHard; Hd.p = pHard;
     Hd.useSD = useSD_h ? 1u : 0u; Hd.tau_2D = tau_2D_hard; Hd.color_space = color_space;
     Wn = Hd; Wn.N = NWien; Wn.nHW = nWien; Wn.k = kWien; Wn.p = pWien; Wn.useSD = useSD_w ? 1u : 0u; Wn.tau_2D = tau_2D_wien;
     std::cout << " - > Running BM3D filter on every " << (sub_img_name ? sub_img_name : "SAI") << " (GPU)" << std::endl;
-    if (lfbm5d_bm3d_lf_host(ctx, &Hd, &Wn, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), (unsigned)asize, width,
+    if (lfbm5d_bm3d_lf_host(ctx, &Hd, &Wn, noisy.get(), LF_SAI_mask.data(), basic.get(), den.get(), (unsigned)asize, width,
                             height, chnls) != 0) {
         std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
         return EXIT_FAILURE;
