@@ -574,31 +574,57 @@ __device__ __forceinline__ void r01_small3(const float (&x)[3], float (&y)[3], i
  * makes every group shape-adaptive, bm5d.cpp:276-280: with the call form such a 560^2 pass took 13.6 instead of 0.94 ms in the
  * HT group kernel and 9.3 instead of 1.1 ms in the Wiener one.) */
 __device__ __forceinline__ float pick3(float a, float b, float c, int i) { return i == 0 ? a : (i == 1 ? b : c); }
+/* the length-N transforms with N a compile-time constant (the run length is a scalar: one uniform branch per row / column selects
+ * the instance; a full row -- two of three in a window with one empty SAI -- needs no gather at all) */
+template <int N> __device__ __forceinline__ void r10_n(const float (&x)[3], float (&y)[3], TbPtr tb) {
+#pragma unroll
+    for (int u = 0; u < N; u++) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < N; j++) a += x[j] * tb->cos1[N][u * N + j];
+        y[u] = 2.0f * a;
+    }
+}
+template <int N> __device__ __forceinline__ void r01_n(const float (&x)[3], float (&y)[3], TbPtr tb) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        float a = 0.0f;
+#pragma unroll
+        for (int u = 1; u < N; u++) a += x[u] * tb->cos1[N][u * N + j];
+        y[j] = x[0] + 2.0f * a;
+    }
+}
 __device__ __forceinline__ void sadct9_fwd_sel(float (&v)[9], ShRef sh, TbPtr tb) {
     float x[3], y[3];
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const int n = sh.row_n[s];
+        if (n == 3) {   /* idx = 0, 1, 2 */
+            x[0] = v[s * 3]; x[1] = v[s * 3 + 1]; x[2] = v[s * 3 + 2];
+            r10_n<3>(x, y, tb);
 #pragma unroll
-        for (int t = 0; t < 3; t++) x[t] = pick3(v[s * 3], v[s * 3 + 1], v[s * 3 + 2], sh.idx[s * 3 + t]);
-        if (n == 1) v[s * 3] = x[0];
-        else if (n > 1) {
-            r10_small3(x, y, n, tb);
-#pragma unroll
-            for (int t = 0; t < 3; t++) if (t < n) v[s * 3 + t] = y[t] * tb->cn1[n][t];
-        }
+            for (int t = 0; t < 3; t++) v[s * 3 + t] = y[t] * tb->cn1[3][t];
+        } else if (n == 2) {
+            x[0] = pick3(v[s * 3], v[s * 3 + 1], v[s * 3 + 2], sh.idx[s * 3]);
+            x[1] = pick3(v[s * 3], v[s * 3 + 1], v[s * 3 + 2], sh.idx[s * 3 + 1]);
+            r10_n<2>(x, y, tb);
+            v[s * 3] = y[0] * tb->cn1[2][0]; v[s * 3 + 1] = y[1] * tb->cn1[2][1];
+        } else if (n == 1) v[s * 3] = pick3(v[s * 3], v[s * 3 + 1], v[s * 3 + 2], sh.idx[s * 3]);
     }
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int n = sh.col_n[t];
+        if (n == 3) {
+            x[0] = v[t]; x[1] = v[3 + t]; x[2] = v[6 + t];
+            r10_n<3>(x, y, tb);
 #pragma unroll
-        for (int s2 = 0; s2 < 3; s2++) x[s2] = pick3(v[t], v[3 + t], v[6 + t], sh.idx_col[s2 * 3 + t]);
-        if (n == 1) v[t] = x[0];
-        else if (n > 1) {
-            r10_small3(x, y, n, tb);
-#pragma unroll
-            for (int s2 = 0; s2 < 3; s2++) if (s2 < n) v[s2 * 3 + t] = y[s2] * tb->cn1[n][s2];
-        }
+            for (int s2 = 0; s2 < 3; s2++) v[s2 * 3 + t] = y[s2] * tb->cn1[3][s2];
+        } else if (n == 2) {
+            x[0] = pick3(v[t], v[3 + t], v[6 + t], sh.idx_col[t]);
+            x[1] = pick3(v[t], v[3 + t], v[6 + t], sh.idx_col[3 + t]);
+            r10_n<2>(x, y, tb);
+            v[t] = y[0] * tb->cn1[2][0]; v[3 + t] = y[1] * tb->cn1[2][1];
+        } else if (n == 1) v[t] = pick3(v[t], v[3 + t], v[6 + t], sh.idx_col[t]);
     }
     const float coef = 0.5f * 0.70710678118654752f;
 #pragma unroll
@@ -610,20 +636,25 @@ __device__ __forceinline__ void sadct9_inv_sel(float (&v)[9], ShRef sh, TbPtr tb
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int n = sh.col_n[t];
-        if (n == 1) { y[0] = v[t] * coef; y[1] = 0.0f; y[2] = 0.0f; }
-        else if (n > 1) {
+        if (n == 3) {   /* rows 0, 1, 2: in place */
 #pragma unroll
-            for (int s2 = 0; s2 < 3; s2++) x[s2] = s2 < n ? v[s2 * 3 + t] * tb->cni1[n][s2] * coef : 0.0f;
-            r01_small3(x, y, n, tb);
+            for (int s2 = 0; s2 < 3; s2++) x[s2] = v[s2 * 3 + t] * tb->cni1[3][s2] * coef;
+            r01_n<3>(x, y, tb);
 #pragma unroll
-            for (int s2 = 0; s2 < 3; s2++) y[s2] *= tb->c1inv[n];
-        }
-        if (n >= 1) {   /* v[idx_col[s2][t]][t] = y[s2] for s2 < n: the destinations are distinct rows */
+            for (int s2 = 0; s2 < 3; s2++) v[s2 * 3 + t] = y[s2] * tb->c1inv[3];
+        } else if (n >= 1) {
+            if (n == 1) { y[0] = v[t] * coef; y[1] = 0.0f; }
+            else {
+                x[0] = v[t] * tb->cni1[2][0] * coef; x[1] = v[3 + t] * tb->cni1[2][1] * coef;
+                r01_n<2>(x, y, tb);
+                y[0] *= tb->c1inv[2]; y[1] *= tb->c1inv[2];
+            }
+            /* v[idx_col[s2][t]][t] = y[s2] for s2 < n: the destinations are distinct rows */
 #pragma unroll
             for (int r = 0; r < 3; r++) {
                 float w = v[r * 3 + t];
-#pragma unroll
-                for (int s2 = 0; s2 < 3; s2++) w = (s2 < n && sh.idx_col[s2 * 3 + t] == r) ? y[s2] : w;
+                w = sh.idx_col[t] == r ? y[0] : w;
+                w = (n == 2 && sh.idx_col[3 + t] == r) ? y[1] : w;
                 v[r * 3 + t] = w;
             }
         }
@@ -631,20 +662,24 @@ __device__ __forceinline__ void sadct9_inv_sel(float (&v)[9], ShRef sh, TbPtr tb
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         const int n = sh.row_n[s];
-        if (n == 1) { y[0] = v[s * 3]; y[1] = 0.0f; y[2] = 0.0f; }
-        else if (n > 1) {
+        if (n == 3) {
 #pragma unroll
-            for (int t = 0; t < 3; t++) x[t] = t < n ? v[s * 3 + t] * tb->cni1[n][t] : 0.0f;
-            r01_small3(x, y, n, tb);
+            for (int t = 0; t < 3; t++) x[t] = v[s * 3 + t] * tb->cni1[3][t];
+            r01_n<3>(x, y, tb);
 #pragma unroll
-            for (int t = 0; t < 3; t++) y[t] *= tb->c1inv[n];
-        }
-        if (n >= 1) {
+            for (int t = 0; t < 3; t++) v[s * 3 + t] = y[t] * tb->c1inv[3];
+        } else if (n >= 1) {
+            if (n == 1) { y[0] = v[s * 3]; y[1] = 0.0f; }
+            else {
+                x[0] = v[s * 3] * tb->cni1[2][0]; x[1] = v[s * 3 + 1] * tb->cni1[2][1];
+                r01_n<2>(x, y, tb);
+                y[0] *= tb->c1inv[2]; y[1] *= tb->c1inv[2];
+            }
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 float w = v[s * 3 + q];
-#pragma unroll
-                for (int t = 0; t < 3; t++) w = (t < n && sh.idx[s * 3 + t] == q) ? y[t] : w;
+                w = sh.idx[s * 3] == q ? y[0] : w;
+                w = (n == 2 && sh.idx[s * 3 + 1] == q) ? y[1] : w;
                 v[s * 3 + q] = w;
             }
         }
