@@ -2155,7 +2155,9 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
                 __syncthreads();
             }
             T16_MARK();
-            group_id_compute<NS, HAAR, 1>(a, c, sh, use_sadct, V, wacc[0], s1[0], s2[0], work + tid * 9);
+            /* the shape-adaptive transform inline: in registers in the wavelet kernel (4.2 -> 3.0 ms per pass of shape-adaptive groups), on LDS
+             * scratch in the DCT kernel, whose register allocation the register form upsets (69 spills, +20 % on ordinary groups) */
+            group_id_compute<NS, HAAR, BIOR ? 2 : 1>(a, c, sh, use_sadct, V, wacc[0], s1[0], s2[0], work + tid * 9);
             __syncthreads();
             T16_MARK();
 #pragma unroll
