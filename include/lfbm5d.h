@@ -222,6 +222,24 @@ int lfbm5d_denoise_host(lfbm5d_ctx* ctx, const lfbm5d_params* P1, const lfbm5d_p
                         const unsigned* h_mask, float* h_basic, float* h_denoised, unsigned ang_major,
                         unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H, unsigned C);
 
+/* The same with the caller's light fields as ONE HOST POINTER PER SAI -- h_x[st] = &LF_x[st][0], C*H*W floats each, exactly the
+ * reference's vector<vector<float>> (src/bm5d.h:11-62) without a flat copy; entries of empty SAIs are ignored (may be NULL).
+ * The flat forms above are these with pointers into one buffer.  On one rank with the window graph (colour light fields) the
+ * SAIs are STREAMED: a SAI goes up when the first window that needs it is enqueued (forward colour transform behind the copy),
+ * its outputs come down as soon as the last window on it has run, while the other windows compute -- the interval the reference
+ * times (main.cpp:189-201, :241-247) then costs a few per cent more than device-resident buffers instead of the 20 % four
+ * blocking copies of the light field cost.  Pageable memory is fine.  Everything else about the call (in / out arguments, result
+ * bit-identical to the device form) is unchanged; LFBM5D_HOST_BLOCKING=1 selects the upload-all / download-all form. */
+int lfbm5d_step1_host_sai(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* const* h_noisy, const unsigned* h_mask,
+                          float* const* h_basic, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
+                          unsigned W, unsigned H, unsigned C);
+int lfbm5d_step2_host_sai(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* const* h_noisy, const unsigned* h_mask,
+                          float* const* h_basic, float* const* h_denoised, unsigned ang_major, unsigned awidth,
+                          unsigned aheight, unsigned an, unsigned W, unsigned H, unsigned C);
+int lfbm5d_denoise_host_sai(lfbm5d_ctx* ctx, const lfbm5d_params* P1, const lfbm5d_params* P2, float* const* h_noisy,
+                            const unsigned* h_mask, float* const* h_basic, float* const* h_denoised, unsigned ang_major,
+                            unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H, unsigned C);
+
 /* ---- inner seam: one core pass on a mirror-padded angular window, device pointers ----
  * == bm5d_1st_step (step = 1) / bm5d_2nd_step (step = 2) (bm5d_core_processing.h:6-80).
  * Buffers are [A][C*Wb*Hb], A = aw*ah; d_basic may be NULL for step 1; d_num / d_den are

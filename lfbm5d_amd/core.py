@@ -107,6 +107,10 @@ def lib():
     L.lfbm5d_step2_device.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
     L.lfbm5d_step1_host.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
     L.lfbm5d_step2_host.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
+    # host seam with one pointer per SAI (what the reference's vector<vector<float>> is): arrays of float*
+    L.lfbm5d_step1_host_sai.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
+    L.lfbm5d_step2_host_sai.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
+    L.lfbm5d_denoise_host_sai.argtypes = [vp, C.POINTER(Params), C.POINTER(Params), fp, up, fp, fp] + [C.c_uint] * 8
     L.lfbm5d_pass_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint, C.c_uint, C.c_uint,
                                      C.c_uint, C.c_uint, fp, fp, fp, fp, up, up, C.c_uint, C.c_uint]
     L.lfbm5d_last_bm.argtypes = [vp, up, vp, vp, vp, vp, vp]
@@ -228,6 +232,18 @@ def _dev_ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def _sai_ptrs(arrays, mask):
+    """float*[asize] over a list of per-SAI float32 arrays (entries of empty SAIs may be None)."""
+    out = (C.c_void_p * len(arrays))()
+    for i, a in enumerate(arrays):
+        if a is None or not mask[i]:
+            continue
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous):
+            raise LfBm5dError("per-SAI host buffers must be contiguous float32 numpy arrays")
+        out[i] = a.ctypes.data
+    return out
+
+
 class Context:
     """lfbm5d_ctx: one per process / GPU."""
 
@@ -299,7 +315,9 @@ class Context:
         m = _u32(mask)
         mp = m.ctypes.data_as(C.POINTER(C.c_uint))
         tail = (ang_major, awidth, aheight, an, W, H, Cc)
-        if isinstance(noisy, np.ndarray):
+        if isinstance(noisy, (list, tuple)):   # one float32 array per SAI, like the reference's vector<vector<float>>
+            self._ck(self._L.lfbm5d_step1_host_sai(self._h, C.byref(P), _sai_ptrs(noisy, m), mp, _sai_ptrs(basic, m), *tail))
+        elif isinstance(noisy, np.ndarray):
             self._ck(self._L.lfbm5d_step1_host(self._h, C.byref(P), noisy.ctypes.data_as(C.c_void_p), mp,
                                                basic.ctypes.data_as(C.c_void_p), *tail))
         else:
@@ -309,7 +327,9 @@ class Context:
         m = _u32(mask)
         mp = m.ctypes.data_as(C.POINTER(C.c_uint))
         tail = (ang_major, awidth, aheight, an, W, H, Cc)
-        if isinstance(noisy, np.ndarray):
+        if isinstance(noisy, (list, tuple)):
+            self._ck(self._L.lfbm5d_step2_host_sai(self._h, C.byref(P), _sai_ptrs(noisy, m), mp, _sai_ptrs(basic, m), _sai_ptrs(denoised, m), *tail))
+        elif isinstance(noisy, np.ndarray):
             self._ck(self._L.lfbm5d_step2_host(self._h, C.byref(P), noisy.ctypes.data_as(C.c_void_p), mp,
                                                basic.ctypes.data_as(C.c_void_p),
                                                denoised.ctypes.data_as(C.c_void_p), *tail))
@@ -322,7 +342,10 @@ class Context:
         m = _u32(mask)
         mp = m.ctypes.data_as(C.POINTER(C.c_uint))
         tail = (ang_major, awidth, aheight, an1, an2, W, H, Cc)
-        if isinstance(noisy, np.ndarray):
+        if isinstance(noisy, (list, tuple)):
+            self._ck(self._L.lfbm5d_denoise_host_sai(self._h, C.byref(P1), C.byref(P2), _sai_ptrs(noisy, m), mp, _sai_ptrs(basic, m),
+                                                     _sai_ptrs(denoised, m), *tail))
+        elif isinstance(noisy, np.ndarray):
             self._ck(self._L.lfbm5d_denoise_host(self._h, C.byref(P1), C.byref(P2), noisy.ctypes.data_as(C.c_void_p), mp,
                                                  basic.ctypes.data_as(C.c_void_p), denoised.ctypes.data_as(C.c_void_p), *tail))
         else:
@@ -446,3 +469,36 @@ def run_bm3d_LF(sigma, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, width, heig
     wien = make_bm3d_params(sigma, lambdaHard3D, NWien, nWien, kWien, pWien, tau_2D_wien, useSD_w, color_space)
     (ctx or _ctx()).bm3d_lf(hard, wien, LF_noisy, LF_SAI_mask, LF_basic, LF_denoised, width, height, chnls)
     return 0
+
+
+_TAU = {"id": 4, "dct": 5, "sadct": 6, "bior": 7, "hw": 8, "hadamard": 8, "haar": 9}
+_CS = {"yuv": 0, "ycbcr": 1, "opp": 2, "rgb": 3}
+
+
+def dropin_probe(noisy, mask, awidth, aheight, width, height, chnls, sigma, lambda_, hard, wien, color_space="opp", ang_major=ROWMAJOR,
+                 an=(1, 1), one_job=False, reps=1):
+    """Time the reference's own interval through the C++ drop-in (liblfbm5d_dropin.so: run_bm5d_1st_step + run_bm5d_2nd_step on
+    vector<vector<float>> light fields, main.cpp:189-201 + :241-247; one_job: run_bm5d).  hard / wien = (N, nSim, nDisp, k, p,
+    tau_2D, tau_4D, tau_5D[, useSD]).  Returns (ms [reps][2], noisy, basic, denoised) -- the light fields as the calls leave them."""
+    path = os.path.join(os.path.dirname(library_path()), "liblfbm5d_dropin.so")
+    if not os.path.exists(path):
+        raise LfBm5dError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    D = C.CDLL(path)
+    D.lfbm5d_dropin_probe.argtypes = ([C.c_int] + [C.c_void_p] * 5 + [C.c_uint] * 8 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_uint,
+                                      C.c_int, C.c_void_p])
+
+    def pk(t):
+        t = tuple(t)
+        v = [t[0], t[1], t[2], t[3], t[4], int(t[8]) if len(t) > 8 else 0, _TAU[t[5]], _TAU[t[6]], _TAU[t[7]]]
+        return np.array(v, np.uint32)
+    noisy = np.ascontiguousarray(noisy, np.float32)
+    m = _u32(mask)
+    n_out, b_out, d_out = np.zeros_like(noisy), np.zeros_like(noisy), np.zeros_like(noisy)
+    ms = np.zeros((reps, 2), np.float64)
+    h, w = pk(hard), pk(wien)
+    rc = D.lfbm5d_dropin_probe(1 if one_job else 0, noisy.ctypes.data, m.ctypes.data, n_out.ctypes.data, b_out.ctypes.data, d_out.ctypes.data,
+                               ang_major, awidth, aheight, an[0], an[1], width, height, chnls, sigma, lambda_, h.ctypes.data, w.ctypes.data,
+                               _CS[color_space] if isinstance(color_space, str) else int(color_space), reps, ms.ctypes.data)
+    if rc != 0:
+        raise LfBm5dError("drop-in probe failed (message on stdout)")
+    return ms, n_out, b_out, d_out

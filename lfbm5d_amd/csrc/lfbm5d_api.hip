@@ -65,6 +65,14 @@ struct GeomCache {
 constexpr int kDefaultLanes = 2;
 constexpr size_t kEstLead = 64;   /* floats of slack in front of the estimate planes */
 
+/* The caller's light fields of a *_host entry point: one host pointer per SAI (ignored for empty SAIs).  `basic` is an input of
+ * run_bm5d_2nd_step only; `out` is the denoised light field of the second step (unused by the first, whose result is `basic`). */
+struct HostIO {
+    float* const* noisy = nullptr;
+    float* const* basic = nullptr;
+    float* const* out = nullptr;
+};
+
 struct lfbm5d_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -94,6 +102,13 @@ struct lfbm5d_ctx {
     DevBuf est, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gofs, gok, gshape, counters, small, t_num, t_den, d_mask;
     /* step-level buffers (g_num2 / g_den2 / n2: second step of a two-step job; e_basic: an emulated rank's own basic estimate) */
     DevBuf g_num, g_den, g_num2, g_den2, n2, e_basic, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
+    /* streamed host seam (lfbm5d_*_host): the caller's light fields as host pointers per SAI, set for the duration of a job; the
+     * job's inputs as they arrived (what a redo of the job starts from: the streamed outputs overwrite the caller's copies SAI by
+     * SAI); the streams the uploads / downloads go through */
+    const struct HostIO* io = nullptr;
+    bool io_streamed = false;              /* the graph has uploaded the inputs (and, when it completed, delivered the outputs) SAI by SAI */
+    DevBuf pristine, pristine_b;
+    hipStream_t io_in = nullptr, io_out = nullptr;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
     /* window lanes (run_step, pipelined form): extra contexts on the same device, each with its own stream, window
      * buffers and per-pass work buffers; owned by this context */
@@ -103,7 +118,7 @@ struct lfbm5d_ctx {
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     std::vector<PassEvents> pending;
     /* last pass (inspection) */
-    unsigned last_n_refs = 0, last_N = 0, last_A = 0; size_t last_plane = 0;
+    unsigned last_n_refs = 0, last_N = 0, last_A = 0; size_t last_plane = 0; int last_gslot = 0;   /* geometry slot of that pass */
 };
 
 namespace {
@@ -274,6 +289,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
               unsigned Hb, unsigned C, const float* d_noisy, const float* d_basic, float* d_num,
               float* d_den, const unsigned* h_mask, const unsigned* h_proc, unsigned cst, unsigned pst,
               bool bm3d = false) {
+    /* the graph form's "estimate already formed" flag belongs to this call only: consumed before anything can fail, so that an early
+     * error return cannot leave it set for the next pass on this context */
+    const bool est_ready = c->est_ready;
+    c->est_ready = false;
     if (validate(c, step, P, aw, ah, C, bm3d)) return 1;
     if (step == 2 && !d_basic) return fail(c, "step 2 needs the basic estimate");
     const unsigned A = aw * ah, k = P->k, k2 = k * k, N = P->N, nHW = P->nSim + P->nDisp;
@@ -434,8 +453,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
 
     /* current estimate for matching, channel 0 (core:167-170) */
     const float* sub = step == 1 ? d_noisy : d_basic;
-    if (!c->est_ready) HIPCK(c, launch_estimate_multi(s, d_num, d_den, sub, est, plane, C, A, mask_bits));
-    c->est_ready = false;
+    if (!est_ready) HIPCK(c, launch_estimate_multi(s, d_num, d_den, sub, est, plane, C, A, mask_bits));
     /* multi-GPU: ranks > 0 accumulate their shard into zeroed buffers; the all-reduce restores
      * base + all contributions on every rank */
     if (c->pass_world > 1 && c->pass_rank > 0) {
@@ -563,7 +581,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     c->stats.groups += n_groups;
     c->stats.launches_group += n_groups ? 1 : 0;
     c->stats.launches_aggregate += n_groups ? 1 : 0;
-    c->last_n_refs = R; c->last_N = Nst; c->last_A = A; c->last_plane = plane;
+    c->last_n_refs = R; c->last_N = Nst; c->last_A = A; c->last_plane = plane; c->last_gslot = c->gslot;
     return 0;
 }
 
@@ -608,6 +626,29 @@ using plan::plan_windows;
  * The reference decides after every pass whether the window is complete (coverage count, bm5d.cpp:370-382); for colour light
  * fields one centre pass always suffices.  The graph form assumes that, copies every window's
  * count to pinned memory and checks them all at the end (*complete). */
+/* the blocking form of the host seam (jobs outside the single-rank window graph): every SAI of the caller's light field(s) up
+ * before the job, every output down after it */
+int io_upload_all(lfbm5d_ctx* c, const HostIO* io, const unsigned* h_mask, unsigned asize, size_t img, float* d_noisy, float* d_basic_in) {
+    for (unsigned st = 0; st < asize; st++) {
+        if (!h_mask[st]) continue;
+        HIPCK(c, hipMemcpyAsync(d_noisy + (size_t)st * img, io->noisy[st], img * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        if (d_basic_in) HIPCK(c, hipMemcpyAsync(d_basic_in + (size_t)st * img, io->basic[st], img * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int io_download_all(lfbm5d_ctx* c, const HostIO* io, const unsigned* h_mask, unsigned asize, size_t img, const float* d_noisy,
+                    const float* d_basic, const float* d_out) {
+    for (unsigned st = 0; st < asize; st++) {
+        if (!h_mask[st]) continue;
+        HIPCK(c, hipMemcpyAsync(io->noisy[st], d_noisy + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (d_basic) HIPCK(c, hipMemcpyAsync(io->basic[st], d_basic + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (d_out) HIPCK(c, hipMemcpyAsync(io->out[st], d_out + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 struct GraphJob {
     int n_steps = 1;
     int step[2] = {1, 2};                          /* the reference step every slot runs */
@@ -619,6 +660,13 @@ struct GraphJob {
     float* g_den[2] = {nullptr, nullptr};
     float* d_out = nullptr;                        /* several ranks: the last slot's estimate, formed per SAI by its owner and exchanged */
     const unsigned* d_mask = nullptr;
+    /* streamed host seam (one rank): the caller's SAIs are uploaded in the order the windows first use them -- forward colour
+     * transform (and, two-step jobs, the round trip the second step reads) per SAI behind the copy -- and every SAI's outputs leave
+     * as soon as the last window on it is done; d_noisy = the light-field buffer noisy[0] points to (the in / out LF_noisy) */
+    const HostIO* io = nullptr;
+    float* d_noisy = nullptr;
+    float* pristine = nullptr; float* pristine_b = nullptr;
+    unsigned color_space = LFBM5D_RGB;
 };
 
 int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsigned* h_mask, unsigned awidth, unsigned aheight,
@@ -683,12 +731,56 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
     std::vector<RankState> states(emulate ? (size_t)nranks : 1);
     /* two-step jobs: SAIs no window of the first step touches (LFBM5D_MAX_WINDOWS) keep the first step's input as their basic
      * estimate (bm5d.cpp:405 with den == 0), i.e. what the second step reads as noisy */
+    /* the streamed host seam runs on one rank (several ranks: the caller uploads first and downloads at the end) */
+    const HostIO* const io = (nranks == 1 && !emulate) ? J.io : nullptr;
+    const int Ls = J.n_steps - 1;   /* the slot whose sums are the job's result */
+    const bool colour_io = C == 3 && J.color_space != LFBM5D_RGB;
     std::vector<unsigned> untouched_all;
     if (two) for (unsigned st = 0; st < asize; st++) if (h_mask[st] && G.last_touch[0][st] < 0) untouched_all.push_back(st);
-    for (unsigned st : untouched_all)
-        HIPCK(c, hipMemcpyAsync(J.d_basic + (size_t)st * img, J.noisy[1] + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!io)
+        for (unsigned st : untouched_all)
+            HIPCK(c, hipMemcpyAsync(J.d_basic + (size_t)st * img, J.noisy[1] + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
     hipEvent_t ev_setup = get_event(c);
     HIPCK(c, hipEventRecord(ev_setup, s));   /* the caller's colour transforms and zeroed sums */
+    /* ---- streamed host seam: uploads ---- */
+    std::vector<char> up(io ? asize : 0, 0);
+    std::vector<hipEvent_t> ev_up(io ? asize : 0, nullptr);
+    std::vector<std::vector<unsigned>> outs(io ? NN : 0);   /* per node: the SAIs whose outputs are final behind it */
+    std::vector<hipEvent_t> ev_out(io ? NN : 0, nullptr);
+    std::vector<unsigned> out_nodes;
+    if (io) {
+        if (!c->io_in) HIPCK(c, hipStreamCreateWithFlags(&c->io_in, hipStreamNonBlocking));
+        if (!c->io_out) HIPCK(c, hipStreamCreateWithFlags(&c->io_out, hipStreamNonBlocking));
+        HIPCK(c, hipStreamWaitEvent(c->io_in, ev_setup, 0));
+        for (unsigned st = 0; st < asize; st++)
+            if (h_mask[st] && G.last_touch[Ls][st] >= 0) outs[(size_t)G.last_touch[Ls][st]].push_back(st);
+        c->io_streamed = true;
+    }
+    const bool basic_in = io && !two && J.step[0] == 2;   /* run_bm5d_2nd_step alone: LF_basic is an input */
+    /* one SAI of the caller's light field(s) into HBM and into the form the windows read: what run_bm5d_* does to the whole light
+     * field at entry (bm5d.cpp:133, :827-830), per SAI; the copy is from pageable memory, i.e. it returns when the data has left */
+    auto upload = [&](unsigned st) -> int {
+        hipStream_t xs = c->io_in;
+        const size_t off = (size_t)st * img;
+        float* const dn = J.d_noisy + off;
+        HIPCK(c, hipMemcpyAsync(dn, io->noisy[st], img * sizeof(float), hipMemcpyHostToDevice, xs));
+        HIPCK(c, hipMemcpyAsync(J.pristine + off, dn, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+        if (basic_in) {
+            HIPCK(c, hipMemcpyAsync(J.d_basic + off, io->basic[st], img * sizeof(float), hipMemcpyHostToDevice, xs));
+            HIPCK(c, hipMemcpyAsync(J.pristine_b + off, J.d_basic + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+        }
+        if (colour_io) {
+            HIPCK(c, launch_color_lf(xs, dn, img, 1, J.d_mask + st, J.color_space, W * H, 1));
+            if (basic_in) HIPCK(c, launch_color_lf(xs, J.d_basic + off, img, 1, J.d_mask + st, J.color_space, W * H, 1));
+            if (two) HIPCK(c, launch_color_roundtrip_lf(xs, dn, const_cast<float*>(J.noisy[1]) + off, img, 1, J.d_mask + st, J.color_space, W * H));
+        }
+        if (two && G.last_touch[0][st] < 0)   /* no first-step window: the basic estimate is the step's input (bm5d.cpp:405, den == 0) */
+            HIPCK(c, hipMemcpyAsync(J.d_basic + off, J.noisy[1] + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+        ev_up[st] = get_event(c);
+        HIPCK(c, hipEventRecord(ev_up[st], xs));
+        up[st] = 1;
+        return 0;
+    };
     for (size_t r = 0; r < states.size(); r++) {
         RankState& S = states[r];
         S.rank = emulate ? (int)r : c->rank;
@@ -767,6 +859,12 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
                 if (G.nodes[(size_t)p].lane != nd.lane) HIPCK(c, hipStreamWaitEvent(ls, done[(size_t)p], 0));
                 return 0;
             };
+            if (io)   /* the SAIs this window is the first to use: into HBM now, the window waits for them on its lane */
+                for (unsigned st : nd.sai)
+                    if (!up[st]) {
+                        if (upload(st)) return 1;
+                        HIPCK(c, hipStreamWaitEvent(ls, ev_up[st], 0));
+                    }
             for (size_t i = 0; i < nd.sai.size(); i++) {
                 const int pw = nd.prev[i];
                 if (pw >= 0) {
@@ -829,6 +927,17 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             done[n] = get_event(c);
             HIPCK(c, hipEventRecord(done[n], ls));
             mine[n] = 1;
+            if (io && !outs[n].empty()) {   /* the SAIs nobody touches after this window: their outputs, in the form the caller gets them */
+                for (size_t o0 = 0; o0 < outs[n].size(); o0 += (size_t)kMaxA) {
+                    SaiList ol; ol.n = 0;
+                    for (size_t q = o0; q < outs[n].size() && ol.n < (unsigned)kMaxA; q++) ol.st[ol.n++] = outs[n][q];
+                    HIPCK(c, launch_output_multi(ls, S->g_num[Ls], S->g_den[Ls], J.step[Ls] == 1 ? J.noisy[Ls] : S->basic, J.d_out,
+                                                 J.step[Ls] == 2 ? S->basic : nullptr, J.noisy[Ls], J.d_noisy, img, ol, J.color_space, W * H, colour_io ? 1 : 0));
+                }
+                ev_out[n] = get_event(c);
+                HIPCK(c, hipEventRecord(ev_out[n], ls));
+                out_nodes.push_back(n);
+            }
             if (Lw.x != c) { c->lane_windows += 1; c->stats.lane_windows += 1; }
         }
         /* the messages this window's result feeds, in the order every rank issues them */
@@ -872,6 +981,43 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             }
         }
     }
+    if (io) {
+        /* ---- streamed host seam: downloads.  Everything is enqueued; this thread now delivers every SAI's outputs as the window
+         * that makes them final completes (pageable destinations: the copies block, which is all this thread has left to do) */
+        for (unsigned st = 0; st < asize; st++)   /* SAIs no window uses (LFBM5D_MAX_WINDOWS): still part of the result */
+            if (h_mask[st] && !up[st] && upload(st)) return 1;
+        auto download = [&](unsigned st) -> int {
+            const size_t off = (size_t)st * img;
+            HIPCK(c, hipMemcpyAsync(io->noisy[st], J.d_noisy + off, img * sizeof(float), hipMemcpyDeviceToHost, c->io_out));
+            if (J.step[Ls] == 2) {
+                HIPCK(c, hipMemcpyAsync(io->basic[st], J.d_basic + off, img * sizeof(float), hipMemcpyDeviceToHost, c->io_out));
+                HIPCK(c, hipMemcpyAsync(io->out[st], J.d_out + off, img * sizeof(float), hipMemcpyDeviceToHost, c->io_out));
+            } else
+                HIPCK(c, hipMemcpyAsync(io->basic[st], J.d_out + off, img * sizeof(float), hipMemcpyDeviceToHost, c->io_out));
+            return 0;
+        };
+        for (unsigned n : out_nodes) {
+            HIPCK(c, hipEventSynchronize(ev_out[n]));
+            for (unsigned st : outs[n]) if (download(st)) return 1;
+        }
+        HIPCK(c, hipStreamSynchronize(c->io_in));
+        /* SAIs without a window in the result's step keep that step's input (bm5d.cpp:405 / :1106 with den == 0): formed once every
+         * window is done (a two-step job may still finalise their basic estimate late) */
+        std::vector<unsigned> rest;
+        for (unsigned st = 0; st < asize; st++) if (h_mask[st] && G.last_touch[Ls][st] < 0) rest.push_back(st);
+        if (!rest.empty()) {
+            for (RankState& S : states) for (Lane& Lq : S.lanes) HIPCK(c, hipStreamSynchronize(Lq.x->stream));
+            for (size_t o0 = 0; o0 < rest.size(); o0 += (size_t)kMaxA) {
+                SaiList ol; ol.n = 0;
+                for (size_t q = o0; q < rest.size() && ol.n < (unsigned)kMaxA; q++) ol.st[ol.n++] = rest[q];
+                HIPCK(c, launch_output_multi(c->io_in, J.g_num[Ls], J.g_den[Ls], J.step[Ls] == 1 ? J.noisy[Ls] : J.d_basic, J.d_out,
+                                             J.step[Ls] == 2 ? J.d_basic : nullptr, J.noisy[Ls], J.d_noisy, img, ol, J.color_space, W * H, colour_io ? 1 : 0));
+            }
+            HIPCK(c, hipStreamSynchronize(c->io_in));
+            for (unsigned st : rest) if (download(st)) return 1;
+        }
+        HIPCK(c, hipStreamSynchronize(c->io_out));
+    }
     /* drain: every lane, every exchange stream */
     for (RankState& S : states) {
         for (Lane& Lq : S.lanes) HIPCK(c, hipStreamSynchronize(Lq.x->stream));
@@ -888,7 +1034,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         const float pct = (float)covered * 100.0f / (float)n_mask / (float)(H - J.P[sl]->k + 1) / (float)(W - J.P[sl]->k + 1);
         if (!(pct >= 100.0f)) complete = 0;
     }
-    if (std::getenv("LFBM5D_FORCE_REDO") && nranks == 1 && !two) complete = 0;   /* test hook: exercise the sequential redo */
+    if (std::getenv("LFBM5D_FORCE_REDO") && nranks == 1) complete = 0;   /* test hook: exercise the sequential redo */
     /* fold the other lanes' / emulated ranks' counters and event times into this context */
     auto fold_all = [&](lfbm5d_ctx* x) -> int {
         drain_events(x);
@@ -908,7 +1054,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
     }
     if (two && fold_all(c)) return 1;   /* (single steps: run_step folds slot 0 of this context itself) */
     if (nranks > 1 && !emulate) {   /* all ranks must agree before the collective below */
-        HIPCK(c, c->small.reserve((asize + 8) * sizeof(unsigned)));
+        HIPCK(c, c->small.reserve((asize + 8 + kWinCounters) * sizeof(unsigned)));
         int* d_flag = reinterpret_cast<int*>(c->small.as<unsigned>());
         HIPCK(c, hipMemcpyAsync(d_flag, &complete, sizeof(int), hipMemcpyHostToDevice, s));
         if (ncclAllReduce(d_flag, d_flag, 1, ncclInt, ncclMin, c->comm, s) != ncclSuccess) return fail(c, "ncclAllReduce(flag) failed");
@@ -971,7 +1117,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
 /* bm5d.cpp:165-407 (step 1) / :861-1106 (step 2) on device-resident buffers */
 int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
              float* d_basic, float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight,
-             unsigned an, unsigned W, unsigned H, unsigned C) {
+             unsigned an, unsigned W, unsigned H, unsigned C, const HostIO* io = nullptr) {
     const unsigned asize = awidth * aheight;
     const unsigned cs = aheight / 2, ct = awidth / 2;
     const unsigned cst = ang_major == LFBM5D_ROWMAJOR ? cs * awidth + ct : cs + ct * aheight;
@@ -996,15 +1142,22 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     HIPCK(c, c->d_mask.reserve(asize * sizeof(unsigned)));
     unsigned* d_mask = c->d_mask.as<unsigned>();
     HIPCK(c, hipMemcpyAsync(d_mask, h_mask, asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
-    if (C == 3 && P->color_space != LFBM5D_RGB) {
-        HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P->color_space, W * H, 1));
-        if (step == 2) HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P->color_space, W * H, 1));
-    }
+    /* transformation of the whole light field(s) at entry (bm5d.cpp:133, :827-830) -- unless the window graph streams the caller's
+     * SAIs in and transforms them one by one (decided below) */
+    auto forward_colour = [&]() -> int {
+        if (C == 3 && P->color_space != LFBM5D_RGB) {
+            HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P->color_space, W * H, 1));
+            if (step == 2) HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P->color_space, W * H, 1));
+        }
+        return 0;
+    };
     HIPCK(c, c->g_num.reserve(asize * img * sizeof(float)));
     HIPCK(c, c->g_den.reserve(asize * img * sizeof(float)));
     HIPCK(c, hipMemsetAsync(c->g_num.p, 0, asize * img * sizeof(float), s));
     HIPCK(c, hipMemsetAsync(c->g_den.p, 0, asize * img * sizeof(float), s));
-    HIPCK(c, c->small.reserve((asize + 8) * sizeof(unsigned)));
+    /* sized for run_graph's use too (its lanes add kWinCounters words): a later, larger reserve would free the block the
+     * pointers below -- and lane0's -- refer to */
+    HIPCK(c, c->small.reserve((asize + 8 + kWinCounters) * sizeof(unsigned)));
     float* g_num = c->g_num.as<float>(); float* g_den = c->g_den.as<float>();
     unsigned* d_small = c->small.as<unsigned>();
     std::vector<unsigned> h_cnt(asize + 8, (unsigned)img), h_tmp(asize + 8), h_one(8);   /* den starts all zero */
@@ -1030,7 +1183,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         if (step == 2) HIPCK(c, x->w_basic.reserve(Aw * imgb * sizeof(float)));
         HIPCK(c, x->w_num.reserve(Aw * imgb * sizeof(float)));
         HIPCK(c, x->w_den.reserve(Aw * imgb * sizeof(float)));
-        HIPCK(c, x->small.reserve((asize + 8) * sizeof(unsigned)));
+        HIPCK(c, x->small.reserve((asize + 8 + kWinCounters) * sizeof(unsigned)));
         L.x = x; L.w_noisy = x->w_noisy.as<float>(); L.w_basic = x->w_basic.as<float>();
         L.w_num = x->w_num.as<float>(); L.w_den = x->w_den.as<float>(); L.d_small = x->small.as<unsigned>();
         L.g_num = g_num; L.g_den = g_den;   /* the light field's sums this lane's windows read and update */
@@ -1279,20 +1432,39 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         return fail(c, "whole steps on several ranks: this light field needs data-driven passes (greyscale, or an empty SAI at a "
                        "window centre); set LFBM5D_STEP_SHARDING=rows");
     if (graph_mode && c->world > 1 && emu <= 1 && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+    /* host seam: the single-rank graph takes the caller's SAIs in and out as its windows need and finish them; every other form
+     * gets the whole light field(s) first */
+    const bool streamable = io && graph_mode && nranks == 1 && std::getenv("LFBM5D_HOST_BLOCKING") == nullptr;
+    bool streamed_out = false;
+    if (streamable) {
+        HIPCK(c, c->pristine.reserve(asize * img * sizeof(float)));
+        if (step == 2) HIPCK(c, c->pristine_b.reserve(asize * img * sizeof(float)));
+    } else {
+        if (io && io_upload_all(c, io, h_mask, asize, img, d_noisy, step == 2 ? d_basic : nullptr)) return 1;
+        if (forward_colour()) return 1;
+    }
     bool graph_done = false;
     if (graph_mode) {
         GraphJob J;
         J.n_steps = 1; J.step[0] = step; J.P[0] = P; J.an[0] = an; J.noisy[0] = d_noisy; J.d_basic = d_basic;
         J.g_num[0] = g_num; J.g_den[0] = g_den; J.d_out = d_out; J.d_mask = d_mask;
+        J.io = streamable ? io : nullptr; J.d_noisy = d_noisy; J.pristine = c->pristine.as<float>(); J.pristine_b = c->pristine_b.as<float>();
+        J.color_space = P->color_space;
         int complete = 1;
         if (run_graph(c, J, G, h_mask, awidth, aheight, ang_major, W, H, C, nranks, emu > 1, &complete)) return 1;
         if (complete) {
             for (const plan::Node& nd : G.nodes) c->last_windows.push_back(nd.pst);
             graph_done = true;
+            streamed_out = streamable;
         } else if (nranks > 1) {
             return fail(c, "a window needed more than its centre pass: set LFBM5D_STEP_SHARDING=rows for this light field");
         } else {
             /* some window needed more than its centre pass: redo the step window after window */
+            if (streamable) {   /* ... from the light field(s) as they arrived: the streamed form has transformed them back SAI by SAI */
+                HIPCK(c, hipMemcpyAsync(d_noisy, c->pristine.p, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+                if (step == 2) HIPCK(c, hipMemcpyAsync(d_basic, c->pristine_b.p, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+                if (forward_colour()) return 1;
+            }
             HIPCK(c, hipMemsetAsync(g_num, 0, asize * img * sizeof(float), s));
             HIPCK(c, hipMemsetAsync(g_den, 0, asize * img * sizeof(float), s));
             for (unsigned st = 0; st < asize; st++) proc[st] = !h_mask[st];
@@ -1378,14 +1550,17 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     }
     /* final estimate (bm5d.cpp:405) and inverse colour transforms (bm5d.cpp:711-714 / :1414-1418) */
     const float* sub = step == 1 ? d_noisy : d_basic;
-    if (!(graph_done && nranks > 1))   /* (the multi-rank graph form has formed and exchanged the estimates already) */
-        HIPCK(c, launch_estimate_lf(s, g_num, g_den, sub, d_out, img, asize, d_mask));
-    if (C == 3 && P->color_space != LFBM5D_RGB) {
-        HIPCK(c, launch_color_lf(s, d_out, img, asize, d_mask, P->color_space, W * H, 0));
-        if (step == 2) HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P->color_space, W * H, 0));
-        HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P->color_space, W * H, 0));
+    if (!streamed_out) {   /* (the streamed host seam has formed, transformed and delivered every SAI's outputs already) */
+        if (!(graph_done && nranks > 1))   /* (the multi-rank graph form has formed and exchanged the estimates already) */
+            HIPCK(c, launch_estimate_lf(s, g_num, g_den, sub, d_out, img, asize, d_mask));
+        if (C == 3 && P->color_space != LFBM5D_RGB) {
+            HIPCK(c, launch_color_lf(s, d_out, img, asize, d_mask, P->color_space, W * H, 0));
+            if (step == 2) HIPCK(c, launch_color_lf(s, d_basic, img, asize, d_mask, P->color_space, W * H, 0));
+            HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P->color_space, W * H, 0));
+        }
     }
     HIPCK(c, hipStreamSynchronize(s));
+    if (io && !streamed_out && io_download_all(c, io, h_mask, asize, img, d_noisy, step == 2 ? d_basic : d_out, step == 2 ? d_out : nullptr)) return 1;
     drain_events(c);
     return fold_counters(c, P, Aw, C, step);
 }
@@ -1398,7 +1573,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
  * alternative multi-GPU schemes) take the two calls. */
 int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask, float* d_basic,
                 float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
-                unsigned C) {
+                unsigned C, const HostIO* io = nullptr) {
     const unsigned asize = awidth * aheight;
     const char* emu_s = std::getenv("LFBM5D_EMULATE_WORLD");
     const int emu = emu_s ? std::atoi(emu_s) : 0;
@@ -1421,13 +1596,19 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
         plan::build(h_mask, awidth, aheight, ang_major, sd, 2, nranks, emu > 1 ? 1 : n_lanes, max_windows, G);
         if (!G.centre_ok || G.nodes.empty()) fused = false;
     }
-    if (!fused) {
+    const size_t img = (size_t)C * W * H;
+    /* the two calls one after the other, on light fields that are in HBM as a whole */
+    auto two_calls = [&]() -> int {
         if (run_step(c, 1, P1, d_noisy, h_mask, nullptr, d_basic, ang_major, awidth, aheight, an1, W, H, C)) return 1;
-        return run_step(c, 2, P2, d_noisy, h_mask, d_basic, d_out, ang_major, awidth, aheight, an2, W, H, C);
+        if (run_step(c, 2, P2, d_noisy, h_mask, d_basic, d_out, ang_major, awidth, aheight, an2, W, H, C)) return 1;
+        return io ? io_download_all(c, io, h_mask, asize, img, d_noisy, d_basic, d_out) : 0;
+    };
+    if (!fused) {
+        if (io && io_upload_all(c, io, h_mask, asize, img, d_noisy, nullptr)) return 1;
+        return two_calls();
     }
     if (c->world > 1 && emu <= 1 && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
     hipStream_t s = c->stream;
-    const size_t img = (size_t)C * W * H;
     const bool colour = P1->color_space != LFBM5D_RGB;
     HIPCK(c, c->d_mask.reserve(asize * sizeof(unsigned)));
     unsigned* d_mask = c->d_mask.as<unsigned>();
@@ -1435,14 +1616,25 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
     GraphJob J;
     J.n_steps = 2; J.step[0] = 1; J.step[1] = 2; J.P[0] = P1; J.P[1] = P2; J.an[0] = an1; J.an[1] = an2;
     J.d_basic = d_basic; J.d_out = d_out; J.d_mask = d_mask;
+    /* host seam: the single-rank graph takes the caller's SAIs in and out as its windows need and finish them */
+    const bool streamable = io && nranks == 1 && std::getenv("LFBM5D_HOST_BLOCKING") == nullptr;
+    if (io && !streamable && io_upload_all(c, io, h_mask, asize, img, d_noisy, nullptr)) return 1;
+    /* the light field as it arrived: what the fallback below starts from (on one rank) */
+    if (nranks == 1) {
+        HIPCK(c, c->pristine.reserve(asize * img * sizeof(float)));
+        if (!streamable) HIPCK(c, hipMemcpyAsync(c->pristine.p, d_noisy, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    J.io = streamable ? io : nullptr; J.d_noisy = d_noisy; J.pristine = c->pristine.as<float>(); J.color_space = P1->color_space;
     /* what the first step reads: forward(noisy) (bm5d.cpp:133); what the second step reads: forward(inverse(that))
      * (bm5d.cpp:713, :827): both live for the whole job, the second in a buffer of its own */
     J.noisy[0] = d_noisy; J.noisy[1] = d_noisy;
     if (colour) {
-        HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P1->color_space, W * H, 1));
         HIPCK(c, c->n2.reserve(asize * img * sizeof(float)));
-        HIPCK(c, hipMemcpyAsync(c->n2.p, d_noisy, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));   /* (empty SAIs too) */
-        HIPCK(c, launch_color_roundtrip_lf(s, d_noisy, c->n2.as<float>(), img, asize, d_mask, P1->color_space, W * H));
+        if (!streamable) {   /* (the streamed form does this SAI by SAI behind every upload) */
+            HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P1->color_space, W * H, 1));
+            HIPCK(c, hipMemcpyAsync(c->n2.p, d_noisy, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));   /* (empty SAIs too) */
+            HIPCK(c, launch_color_roundtrip_lf(s, d_noisy, c->n2.as<float>(), img, asize, d_mask, P1->color_space, W * H));
+        }
         J.noisy[1] = c->n2.as<float>();
     }
     DevBuf* nb[2] = {&c->g_num, &c->g_num2}; DevBuf* db[2] = {&c->g_den, &c->g_den2};
@@ -1457,8 +1649,15 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
     c->last_windows.clear();
     int complete = 1;
     if (run_graph(c, J, G, h_mask, awidth, aheight, ang_major, W, H, C, nranks, emu > 1, &complete)) return 1;
-    if (!complete) return fail(c, "a window needed more than its centre pass: run the two steps one after the other (LFBM5D_FUSED=0)");
+    if (!complete) {
+        /* some window needed more than its centre pass (the graph form assumes one): on one rank the job is redone as the two
+         * calls, window after window, from the light field as it arrived */
+        if (nranks > 1) return fail(c, "a window needed more than its centre pass: run the two steps one after the other (LFBM5D_FUSED=0)");
+        HIPCK(c, hipMemcpyAsync(d_noisy, c->pristine.p, asize * img * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return two_calls();
+    }
     for (const plan::Node& nd : G.nodes) c->last_windows.push_back(nd.pst);
+    if (streamable) { HIPCK(c, hipStreamSynchronize(s)); return 0; }   /* (every SAI's outputs have been formed and delivered) */
     /* final estimate (bm5d.cpp:1106) and the closing inverse colour transforms of both steps' outputs (bm5d.cpp:1414-1418) */
     if (nranks == 1) HIPCK(c, launch_estimate_lf(s, J.g_num[1], J.g_den[1], d_basic, d_out, img, asize, d_mask));
     if (colour) {
@@ -1468,7 +1667,7 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
         HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P1->color_space, W * H, 0));
     }
     HIPCK(c, hipStreamSynchronize(s));
-    return 0;
+    return io ? io_download_all(c, io, h_mask, asize, img, d_noisy, d_basic, d_out) : 0;
 }
 
 } /* namespace */
@@ -1781,59 +1980,89 @@ int lfbm5d_denoise_device(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_p
     return run_denoise(c, P1, P2, d_noisy, h_mask, d_basic, d_denoised, ang_major, awidth, aheight, an1, an2, W, H, C);
 }
 
+/* ---- host seam.  The *_host_sai entry points take the caller's light fields as ONE HOST POINTER PER SAI (what a
+ * vector<vector<float>> is); the flat forms below are the same with pointers into one buffer.  On one rank with the window graph
+ * the SAIs travel as the graph needs and finishes them; otherwise the whole light fields go up first and come down last. ---- */
+namespace {
+int host_job(lfbm5d_ctx* c, int kind /* 1 | 2: the step, 3: both */, const lfbm5d_params* P1, const lfbm5d_params* P2, float* const* h_noisy,
+             const unsigned* h_mask, float* const* h_basic, float* const* h_out, unsigned ang_major, unsigned awidth, unsigned aheight,
+             unsigned an1, unsigned an2, unsigned W, unsigned H, unsigned C) {
+    (void)hipSetDevice(c->device);
+    const unsigned asize = awidth * aheight;
+    for (unsigned st = 0; st < asize; st++)
+        if (h_mask[st] && (!h_noisy[st] || !h_basic[st] || (kind != 1 && !h_out[st]))) return fail(c, "host seam: NULL pointer for a non-empty SAI");
+    const size_t bytes = (size_t)asize * C * W * H * sizeof(float);
+    HIPCK(c, c->h2d_noisy.reserve(bytes));
+    HIPCK(c, c->h2d_basic.reserve(bytes));
+    if (kind != 1) HIPCK(c, c->h2d_out.reserve(bytes));
+    HostIO io; io.noisy = h_noisy; io.basic = h_basic; io.out = h_out;
+    c->io_streamed = false;
+    float* const dn = c->h2d_noisy.as<float>(); float* const db = c->h2d_basic.as<float>(); float* const dd = c->h2d_out.as<float>();
+    if (kind == 1) return run_step(c, 1, P1, dn, h_mask, nullptr, db, ang_major, awidth, aheight, an1, W, H, C, &io);
+    if (kind == 2) return run_step(c, 2, P2, dn, h_mask, db, dd, ang_major, awidth, aheight, an2, W, H, C, &io);
+    return run_denoise(c, P1, P2, dn, h_mask, db, dd, ang_major, awidth, aheight, an1, an2, W, H, C, &io);
+}
+/* pointers into flat [asize][C*H*W] buffers; the outputs of empty SAIs read as zeros (what the flat form has always returned) */
+void flat_ptrs(std::vector<float*>& v, float* base, const unsigned* h_mask, unsigned asize, size_t img, bool zero_empty) {
+    v.resize(asize);
+    for (unsigned st = 0; st < asize; st++) {
+        v[st] = base ? base + (size_t)st * img : nullptr;
+        if (base && zero_empty && !h_mask[st]) std::memset(v[st], 0, img * sizeof(float));
+    }
+}
+} /* namespace */
+
+int lfbm5d_denoise_host_sai(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* const* h_noisy, const unsigned* h_mask,
+                            float* const* h_basic, float* const* h_denoised, unsigned ang_major, unsigned awidth, unsigned aheight,
+                            unsigned an1, unsigned an2, unsigned W, unsigned H, unsigned C) {
+    if (!c || !P1 || !P2 || !h_mask || !h_noisy || !h_basic || !h_denoised) return 1;
+    return host_job(c, 3, P1, P2, h_noisy, h_mask, h_basic, h_denoised, ang_major, awidth, aheight, an1, an2, W, H, C);
+}
+int lfbm5d_step1_host_sai(lfbm5d_ctx* c, const lfbm5d_params* P, float* const* h_noisy, const unsigned* h_mask, float* const* h_basic,
+                          unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an, unsigned W, unsigned H, unsigned C) {
+    if (!c || !P || !h_mask || !h_noisy || !h_basic) return 1;
+    return host_job(c, 1, P, nullptr, h_noisy, h_mask, h_basic, nullptr, ang_major, awidth, aheight, an, an, W, H, C);
+}
+int lfbm5d_step2_host_sai(lfbm5d_ctx* c, const lfbm5d_params* P, float* const* h_noisy, const unsigned* h_mask, float* const* h_basic,
+                          float* const* h_denoised, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an, unsigned W, unsigned H,
+                          unsigned C) {
+    if (!c || !P || !h_mask || !h_noisy || !h_basic || !h_denoised) return 1;
+    return host_job(c, 2, nullptr, P, h_noisy, h_mask, h_basic, h_denoised, ang_major, awidth, aheight, an, an, W, H, C);
+}
+
 int lfbm5d_denoise_host(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* h_noisy, const unsigned* h_mask,
                         float* h_basic, float* h_denoised, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1,
                         unsigned an2, unsigned W, unsigned H, unsigned C) {
-    if (!c || !P1 || !P2 || !h_mask) return 1;
-    (void)hipSetDevice(c->device);
-    const size_t bytes = (size_t)awidth * aheight * C * W * H * sizeof(float);
-    HIPCK(c, c->h2d_noisy.reserve(bytes));
-    HIPCK(c, c->h2d_basic.reserve(bytes));
-    HIPCK(c, c->h2d_out.reserve(bytes));
-    HIPCK(c, hipMemcpy(c->h2d_noisy.p, h_noisy, bytes, hipMemcpyHostToDevice));
-    HIPCK(c, hipMemsetAsync(c->h2d_basic.p, 0, bytes, c->stream));
-    HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
-    if (run_denoise(c, P1, P2, c->h2d_noisy.as<float>(), h_mask, c->h2d_basic.as<float>(), c->h2d_out.as<float>(), ang_major, awidth, aheight,
-                    an1, an2, W, H, C)) return 1;
-    HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
-    HIPCK(c, hipMemcpy(h_basic, c->h2d_basic.p, bytes, hipMemcpyDeviceToHost));
-    HIPCK(c, hipMemcpy(h_denoised, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));
-    return 0;
+    if (!c || !P1 || !P2 || !h_mask || !h_noisy || !h_basic || !h_denoised) return 1;
+    const size_t img = (size_t)C * W * H;
+    std::vector<float*> pn, pb, pd;
+    flat_ptrs(pn, h_noisy, h_mask, awidth * aheight, img, false);
+    flat_ptrs(pb, h_basic, h_mask, awidth * aheight, img, true);
+    flat_ptrs(pd, h_denoised, h_mask, awidth * aheight, img, true);
+    return host_job(c, 3, P1, P2, pn.data(), h_mask, pb.data(), pd.data(), ang_major, awidth, aheight, an1, an2, W, H, C);
 }
 
 int lfbm5d_step1_host(lfbm5d_ctx* c, const lfbm5d_params* P, float* h_noisy, const unsigned* h_mask,
                       float* h_basic, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an,
                       unsigned W, unsigned H, unsigned C) {
-    if (!c || !P) return 1;
-    (void)hipSetDevice(c->device);
-    const size_t bytes = (size_t)awidth * aheight * C * W * H * sizeof(float);
-    HIPCK(c, c->h2d_noisy.reserve(bytes));
-    HIPCK(c, c->h2d_out.reserve(bytes));
-    HIPCK(c, hipMemcpy(c->h2d_noisy.p, h_noisy, bytes, hipMemcpyHostToDevice));
-    HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
-    if (run_step(c, 1, P, c->h2d_noisy.as<float>(), h_mask, nullptr, c->h2d_out.as<float>(), ang_major, awidth, aheight, an, W, H, C)) return 1;
-    HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
-    HIPCK(c, hipMemcpy(h_basic, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));
-    return 0;
+    if (!c || !P || !h_mask || !h_noisy || !h_basic) return 1;
+    const size_t img = (size_t)C * W * H;
+    std::vector<float*> pn, pb;
+    flat_ptrs(pn, h_noisy, h_mask, awidth * aheight, img, false);
+    flat_ptrs(pb, h_basic, h_mask, awidth * aheight, img, true);
+    return host_job(c, 1, P, nullptr, pn.data(), h_mask, pb.data(), nullptr, ang_major, awidth, aheight, an, an, W, H, C);
 }
 
 int lfbm5d_step2_host(lfbm5d_ctx* c, const lfbm5d_params* P, float* h_noisy, const unsigned* h_mask,
                       float* h_basic, float* h_denoised, unsigned ang_major, unsigned awidth,
                       unsigned aheight, unsigned an, unsigned W, unsigned H, unsigned C) {
-    if (!c || !P) return 1;
-    (void)hipSetDevice(c->device);
-    const size_t bytes = (size_t)awidth * aheight * C * W * H * sizeof(float);
-    HIPCK(c, c->h2d_noisy.reserve(bytes));
-    HIPCK(c, c->h2d_basic.reserve(bytes));
-    HIPCK(c, c->h2d_out.reserve(bytes));
-    HIPCK(c, hipMemcpy(c->h2d_noisy.p, h_noisy, bytes, hipMemcpyHostToDevice));
-    HIPCK(c, hipMemcpy(c->h2d_basic.p, h_basic, bytes, hipMemcpyHostToDevice));
-    HIPCK(c, hipMemsetAsync(c->h2d_out.p, 0, bytes, c->stream));
-    if (run_step(c, 2, P, c->h2d_noisy.as<float>(), h_mask, c->h2d_basic.as<float>(), c->h2d_out.as<float>(), ang_major, awidth, aheight, an, W, H, C)) return 1;
-    HIPCK(c, hipMemcpy(h_noisy, c->h2d_noisy.p, bytes, hipMemcpyDeviceToHost));
-    HIPCK(c, hipMemcpy(h_basic, c->h2d_basic.p, bytes, hipMemcpyDeviceToHost));
-    HIPCK(c, hipMemcpy(h_denoised, c->h2d_out.p, bytes, hipMemcpyDeviceToHost));
-    return 0;
+    if (!c || !P || !h_mask || !h_noisy || !h_basic || !h_denoised) return 1;
+    const size_t img = (size_t)C * W * H;
+    std::vector<float*> pn, pb, pd;
+    flat_ptrs(pn, h_noisy, h_mask, awidth * aheight, img, false);
+    flat_ptrs(pb, h_basic, h_mask, awidth * aheight, img, false);
+    flat_ptrs(pd, h_denoised, h_mask, awidth * aheight, img, true);
+    return host_job(c, 2, nullptr, P, pn.data(), h_mask, pb.data(), pd.data(), ang_major, awidth, aheight, an, an, W, H, C);
 }
 
 /* ---- per-SAI BM3D (LFBM3Ddenoising) ---- */
@@ -1976,7 +2205,7 @@ int lfbm5d_last_bm(lfbm5d_ctx* c, unsigned* n_refs, unsigned* h_refs, unsigned* 
     const unsigned R = c->last_n_refs;
     if (n_refs) *n_refs = R;
     if (!R) return 0;
-    if (h_refs) std::memcpy(h_refs, c->gc[c->gslot].last_refs_host.data(), R * sizeof(unsigned));
+    if (h_refs) std::memcpy(h_refs, c->gc[c->last_gslot].last_refs_host.data(), R * sizeof(unsigned));
     if (h_self_idx) HIPCK(c, hipMemcpy(h_self_idx, c->self_idx.p, (size_t)R * c->last_N * sizeof(unsigned), hipMemcpyDeviceToHost));
     if (h_self_cnt) HIPCK(c, hipMemcpy(h_self_cnt, c->self_cnt.p, (size_t)R * sizeof(unsigned), hipMemcpyDeviceToHost));
     if (h_best) HIPCK(c, hipMemcpy(h_best, c->best.p, c->last_A * c->last_plane * sizeof(unsigned), hipMemcpyDeviceToHost));

@@ -202,6 +202,12 @@ struct SaiList { unsigned st[kMaxA]; unsigned n; };
  * colour round trip); light fields with three channels of n_px pixels */
 hipError_t launch_finalize_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* basic, size_t sai_stride,
                                  const SaiList& L, unsigned cs, unsigned n_px, int colour);
+/* streamed host seam: the outputs of the light-field SAIs L.st[0 .. L.n) whose sums are final -- out = inverse(den ? num / den : sub),
+ * basic = inverse(basic) in place (NULL: the step has no pilot), noisy_dst = inverse(noisy_src) (colour = 0: no transforms); three
+ * channels of n_px pixels; sub may be basic, noisy_src may be noisy_dst */
+hipError_t launch_output_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* out, float* basic,
+                               const float* noisy_src, float* noisy_dst, size_t sai_stride, const SaiList& L, unsigned cs, unsigned n_px,
+                               int colour);
 hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,
                                   const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N);
 hipError_t launch_unsymetrize_multi(hipStream_t s, float* dst, size_t dst_stride, const float* src, size_t src_stride,

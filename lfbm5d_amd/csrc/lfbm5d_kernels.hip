@@ -179,6 +179,40 @@ __global__ void k_finalize_multi(const float* __restrict__ num, const float* __r
     basic[o] = e[0]; basic[o + n] = e[1]; basic[o + 2 * (size_t)n] = e[2];
 }
 
+/* Streamed host seam (lfbm5d_*_host with the window graph): everything a step -- or the two-step job -- leaves in the caller's
+ * light fields for the SAIs whose sums have just become final, pixel by pixel what the tail of run_bm5d_* does for the whole
+ * light field: the estimate (bm5d.cpp:405 / :1106) and the closing inverse colour transforms of the result, of the basic estimate
+ * (second step) and of LF_noisy (bm5d.cpp:711-714, :1414-1418).  In-place operands are read before anything is written.
+ * blockIdx.y = entry of L. */
+__global__ void k_output_multi(const float* __restrict__ num, const float* __restrict__ den, const float* sub, float* out,
+                               float* basic, const float* noisy_src, float* noisy_dst, size_t sai_stride, SaiList L, unsigned cs,
+                               unsigned n, int colour) {
+    const unsigned st = L.st[blockIdx.y];
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = (size_t)st * sai_stride + i;
+    float e[3], b[3] = {0.f, 0.f, 0.f}, v[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float d = den[o + (size_t)c * n];
+        e[c] = d ? __fdiv_rn(num[o + (size_t)c * n], d) : sub[o + (size_t)c * n];
+        if (basic) b[c] = basic[o + (size_t)c * n];
+        v[c] = noisy_src[o + (size_t)c * n];
+    }
+    if (colour) {
+        float x, y, z;
+        color_px(cs, 0, e[0], e[1], e[2], x, y, z); e[0] = x; e[1] = y; e[2] = z;
+        color_px(cs, 0, b[0], b[1], b[2], x, y, z); b[0] = x; b[1] = y; b[2] = z;
+        color_px(cs, 0, v[0], v[1], v[2], x, y, z); v[0] = x; v[1] = y; v[2] = z;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        out[o + (size_t)c * n] = e[c];
+        if (basic) basic[o + (size_t)c * n] = b[c];
+        noisy_dst[o + (size_t)c * n] = v[c];
+    }
+}
+
 __global__ void k_copy_rect(float* __restrict__ dst, size_t dst_stride, int dW, int dH, int dx0, int dy0,
                             const float* __restrict__ src, size_t src_stride, int sW, int sH, int sx0, int sy0,
                             int w, int h, int C, unsigned long long mask_bits) {
@@ -3868,6 +3902,14 @@ hipError_t launch_finalize_multi(hipStream_t s, const float* num, const float* d
                                  const SaiList& L, unsigned cs, unsigned n_px, int colour) {
     if (!L.n) return hipSuccess;
     hipLaunchKernelGGL(k_finalize_multi, dim3((n_px + 255) / 256, L.n), dim3(256), 0, s, num, den, sub, basic, sai_stride, L, cs, n_px, colour);
+    return hipGetLastError();
+}
+hipError_t launch_output_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* out, float* basic,
+                               const float* noisy_src, float* noisy_dst, size_t sai_stride, const SaiList& L, unsigned cs, unsigned n_px,
+                               int colour) {
+    if (!L.n) return hipSuccess;
+    hipLaunchKernelGGL(k_output_multi, dim3((n_px + 255) / 256, L.n), dim3(256), 0, s, num, den, sub, out, basic, noisy_src, noisy_dst,
+                       sai_stride, L, cs, n_px, colour);
     return hipGetLastError();
 }
 hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t seg,

@@ -1,7 +1,8 @@
 /*
  * run_bm5d.cpp -- the reference's outer seam (src/bm5d.h:11-62) on top of the C-ABI.
- * Host side only: flattens the vector-of-vectors light field, calls lfbm5d_step{1,2}_host
- * (which stages through HBM and runs every kernel on the GPU), copies the results back.
+ * Host side only: hands the library one pointer per SAI -- the vectors' own storage, no flat copy -- through
+ * lfbm5d_step{1,2}_host_sai / lfbm5d_denoise_host_sai, which stream the SAIs through HBM as the window graph needs and
+ * finishes them and run every kernel on the GPU (round 5; rounds 1-4 flattened, copied four light fields and unflattened).
  * Error behaviour follows the reference: message on stdout, EXIT_FAILURE.
  */
 #include "run_bm5d.h"
@@ -59,6 +60,20 @@ void unflatten(std::vector<std::vector<float> >& LF, const std::vector<unsigned>
     });
 }
 
+/* one pointer per SAI into the caller's vectors; output vectors of non-empty SAIs get their size first (the reference resizes
+ * them where it forms the estimates, utilities_LF.cpp:936-941), empty SAIs are left alone */
+std::vector<float*> sai_ptrs(std::vector<std::vector<float> >& LF, const std::vector<unsigned>& mask, size_t img, bool output) {
+    std::vector<float*> p(LF.size(), nullptr);
+    if (output) for_sais(LF.size(), [&](size_t st) { if (mask[st] && LF[st].size() != img) LF[st].resize(img); });
+    for (size_t st = 0; st < LF.size(); st++) if (mask[st] && LF[st].size() == img) p[st] = LF[st].data();
+    return p;
+}
+bool inputs_ok(const std::vector<float*>& p, const std::vector<unsigned>& mask, const char* who) {
+    for (size_t st = 0; st < p.size(); st++)
+        if (mask[st] && !p[st]) { std::cout << who << ": a non-empty SAI does not hold width*height*chnls values" << std::endl; return false; }
+    return true;
+}
+
 lfbm5d_params make(float sigma, float lambda, unsigned N, unsigned nSim, unsigned nDisp, unsigned k, unsigned p,
                    bool useSD, unsigned t2, unsigned t4, unsigned t5, unsigned cs) {
     lfbm5d_params P;
@@ -94,16 +109,14 @@ int run_bm5d_1st_step(const float sigma, const float lambdaHard5D, std::vector<s
     lfbm5d_set_tiles(ctx, tiles_for(nb_threads));
     if (LF_basic.size() != asize) LF_basic.resize(asize); /* bm5d.cpp:129-130 */
     const size_t img = (size_t)width * height * chnls;
-    Flat noisy, basic = flat_alloc(asize * img);
-    flatten(LF_noisy, LF_SAI_mask, img, noisy);
+    const std::vector<float*> noisy = sai_ptrs(LF_noisy, LF_SAI_mask, img, false), basic = sai_ptrs(LF_basic, LF_SAI_mask, img, true);
+    if (!inputs_ok(noisy, LF_SAI_mask, "run_bm5d_1st_step")) return EXIT_FAILURE;
     const lfbm5d_params P = make(sigma, lambdaHard5D, NHard, nSim, nDisp, kHard, pHard, useSD, tau_2D, tau_4D, tau_5D, color_space);
-    if (lfbm5d_step1_host(ctx, &P, noisy.get(), LF_SAI_mask.data(), basic.get(), ang_major, awidth, aheight, anHard,
-                          width, height, chnls) != 0) {
+    if (lfbm5d_step1_host_sai(ctx, &P, noisy.data(), LF_SAI_mask.data(), basic.data(), ang_major, awidth, aheight, anHard,
+                              width, height, chnls) != 0) {
         std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
         return EXIT_FAILURE;
     }
-    unflatten(LF_noisy, LF_SAI_mask, img, noisy);
-    unflatten(LF_basic, LF_SAI_mask, img, basic);
     return EXIT_SUCCESS;
 }
 
@@ -124,18 +137,15 @@ int run_bm5d_2nd_step(const float sigma, std::vector<std::vector<float> >& LF_no
     lfbm5d_set_tiles(ctx, tiles_for(nb_threads));
     if (LF_denoised.size() != asize) LF_denoised.resize(asize); /* bm5d.cpp:823-824 */
     const size_t img = (size_t)width * height * chnls;
-    Flat noisy, basic, den = flat_alloc(asize * img);
-    flatten(LF_noisy, LF_SAI_mask, img, noisy);
-    flatten(LF_basic, LF_SAI_mask, img, basic);
+    const std::vector<float*> noisy = sai_ptrs(LF_noisy, LF_SAI_mask, img, false), basic = sai_ptrs(LF_basic, LF_SAI_mask, img, false),
+                              den = sai_ptrs(LF_denoised, LF_SAI_mask, img, true);
+    if (!inputs_ok(noisy, LF_SAI_mask, "run_bm5d_2nd_step") || !inputs_ok(basic, LF_SAI_mask, "run_bm5d_2nd_step")) return EXIT_FAILURE;
     const lfbm5d_params P = make(sigma, 0.0f, NWien, nSim, nDisp, kWien, pWien, useSD, tau_2D, tau_4D, tau_5D, color_space);
-    if (lfbm5d_step2_host(ctx, &P, noisy.get(), LF_SAI_mask.data(), basic.get(), den.get(), ang_major, awidth, aheight,
-                          anWien, width, height, chnls) != 0) {
+    if (lfbm5d_step2_host_sai(ctx, &P, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), ang_major, awidth, aheight,
+                              anWien, width, height, chnls) != 0) {
         std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
         return EXIT_FAILURE;
     }
-    unflatten(LF_noisy, LF_SAI_mask, img, noisy);
-    unflatten(LF_basic, LF_SAI_mask, img, basic);
-    unflatten(LF_denoised, LF_SAI_mask, img, den);
     return EXIT_SUCCESS;
 }
 
@@ -160,18 +170,16 @@ int run_bm5d(const float sigma, const float lambdaHard5D, std::vector<std::vecto
     if (LF_basic.size() != asize) LF_basic.resize(asize);
     if (LF_denoised.size() != asize) LF_denoised.resize(asize);
     const size_t img = (size_t)width * height * chnls;
-    Flat noisy, basic = flat_alloc(asize * img), den = flat_alloc(asize * img);
-    flatten(LF_noisy, LF_SAI_mask, img, noisy);
+    const std::vector<float*> noisy = sai_ptrs(LF_noisy, LF_SAI_mask, img, false), basic = sai_ptrs(LF_basic, LF_SAI_mask, img, true),
+                              den = sai_ptrs(LF_denoised, LF_SAI_mask, img, true);
+    if (!inputs_ok(noisy, LF_SAI_mask, "run_bm5d")) return EXIT_FAILURE;
     const lfbm5d_params P1 = make(sigma, lambdaHard5D, NHard, nSimHard, nDispHard, kHard, pHard, useSDHard, tau_2D_hard, tau_4D_hard, tau_5D_hard, color_space);
     const lfbm5d_params P2 = make(sigma, 0.0f, NWien, nSimWien, nDispWien, kWien, pWien, useSDWien, tau_2D_wien, tau_4D_wien, tau_5D_wien, color_space);
-    if (lfbm5d_denoise_host(ctx, &P1, &P2, noisy.get(), LF_SAI_mask.data(), basic.get(), den.get(), ang_major, awidth, aheight,
-                            anHard, anWien, width, height, chnls) != 0) {
+    if (lfbm5d_denoise_host_sai(ctx, &P1, &P2, noisy.data(), LF_SAI_mask.data(), basic.data(), den.data(), ang_major, awidth, aheight,
+                                anHard, anWien, width, height, chnls) != 0) {
         std::cout << "LFBM5D GPU backend: " << lfbm5d_last_error(ctx) << std::endl;
         return EXIT_FAILURE;
     }
-    unflatten(LF_noisy, LF_SAI_mask, img, noisy);
-    unflatten(LF_basic, LF_SAI_mask, img, basic);
-    unflatten(LF_denoised, LF_SAI_mask, img, den);
     return EXIT_SUCCESS;
 }
 
@@ -210,4 +218,50 @@ int run_bm3d_LF(const float sigma, std::vector<std::vector<float> >& LF_noisy, s
     unflatten(LF_basic, LF_SAI_mask, img, basic);
     unflatten(LF_denoised, LF_SAI_mask, img, den);
     return EXIT_SUCCESS;
+}
+
+/* Measurement hook (bench.py `seam.dropin_vectors`, tests): the interval the reference times -- main.cpp:189-201 around
+ * run_bm5d_1st_step plus :241-247 around run_bm5d_2nd_step -- through THIS file's functions on vector<vector<float>> light fields
+ * built from a flat copy, output vectors sized beforehand like main.cpp:158-165 does.  mode 0: the two calls, 1: run_bm5d (one job).
+ * hard / wien = {N, nSim, nDisp, k, p, useSD, tau_2D, tau_4D, tau_5D}.  ms_out[2 * rep + {0, 1}] = the two intervals (mode 1: the job,
+ * 0).  The last repetition's light fields are copied to the non-NULL flat outputs. */
+#include <chrono>
+extern "C" int lfbm5d_dropin_probe(int mode, const float* noisy_flat, const unsigned* mask, float* noisy_out, float* basic_out,
+                                   float* denoised_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned anHard,
+                                   unsigned anWien, unsigned width, unsigned height, unsigned chnls, float sigma, float lambda,
+                                   const unsigned* hard, const unsigned* wien, unsigned color_space, int reps, double* ms_out) {
+    const size_t asize = (size_t)awidth * aheight, img = (size_t)width * height * chnls;
+    std::vector<unsigned> m(mask, mask + asize);
+    std::vector<std::vector<float> > LF_noisy(asize), LF_basic(asize), LF_denoised(asize);
+    for_sais(asize, [&](size_t st) { LF_noisy[st].resize(img, 0.0f); LF_basic[st].resize(img, 0.0f); LF_denoised[st].resize(img, 0.0f); });
+    typedef std::chrono::steady_clock clk;
+    for (int r = 0; r < reps; r++) {
+        for_sais(asize, [&](size_t st) { std::memcpy(LF_noisy[st].data(), noisy_flat + st * img, img * sizeof(float)); });
+        const clk::time_point t0 = clk::now();
+        clk::time_point t1 = t0, t2 = t0;
+        if (mode == 1) {
+            if (run_bm5d(sigma, lambda, LF_noisy, m, LF_basic, LF_denoised, ang_major, awidth, aheight, anHard, anWien, width, height, chnls,
+                         hard[0], hard[1], hard[2], hard[3], hard[4], hard[5] != 0, hard[6], hard[7], hard[8],
+                         wien[0], wien[1], wien[2], wien[3], wien[4], wien[5] != 0, wien[6], wien[7], wien[8], color_space, 1) != EXIT_SUCCESS) return 1;
+            t1 = t2 = clk::now();
+        } else {
+            if (run_bm5d_1st_step(sigma, lambda, LF_noisy, m, LF_basic, ang_major, awidth, aheight, anHard, width, height, chnls, hard[0], hard[1],
+                                  hard[2], hard[3], hard[4], hard[5] != 0, hard[6], hard[7], hard[8], color_space, 1) != EXIT_SUCCESS) return 1;
+            t1 = clk::now();
+            if (run_bm5d_2nd_step(sigma, LF_noisy, m, LF_basic, LF_denoised, ang_major, awidth, aheight, anWien, width, height, chnls, wien[0],
+                                  wien[1], wien[2], wien[3], wien[4], wien[5] != 0, wien[6], wien[7], wien[8], color_space, 1) != EXIT_SUCCESS) return 1;
+            t2 = clk::now();
+        }
+        if (ms_out) {
+            ms_out[2 * r] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            ms_out[2 * r + 1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        }
+    }
+    for_sais(asize, [&](size_t st) {
+        if (!m[st]) return;
+        if (noisy_out) std::memcpy(noisy_out + st * img, LF_noisy[st].data(), img * sizeof(float));
+        if (basic_out) std::memcpy(basic_out + st * img, LF_basic[st].data(), img * sizeof(float));
+        if (denoised_out) std::memcpy(denoised_out + st * img, LF_denoised[st].data(), img * sizeof(float));
+    });
+    return 0;
 }
