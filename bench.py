@@ -23,6 +23,11 @@ Prints ONE JSON line on rank 0.
              Wiener and flags fractions above 1 (the byte model credits traffic the gather-form aggregation
              never makes); `traffic` / `frac_physical` are the PMC-measured HBM bytes of the same kernels
              (profiles/traffic_latest.json, collected with tools/collect_profiles.sh on this workload).
+  seam       the same job through the reference's own seam, measured outside the timed region (the headline `value` stays the
+             device-resident rate): `host_flat` = lfbm5d_denoise_host on pageable numpy buffers; `dropin_vectors` =
+             run_bm5d_1st_step + run_bm5d_2nd_step of liblfbm5d_dropin.so on vector<vector<float>> light fields, i.e. the
+             interval the reference times (main.cpp:189-201, :241-247), and run_bm5d (one job).  Since round 5 the SAIs are
+             streamed through the window graph.
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference: kind "port") on the GPU box's host
              cores: the first windows of each step of the SAME noisy light field (up to 3, bounded by a
              time limit), extrapolated by the window count; untiled parity mode.
@@ -154,7 +159,9 @@ def psnr_delta_vs_cpu(cb, clean, noisy0, basic_full, run_gpu):
         pc, pg = psnr(cpu_est[touched]), psnr(g_est[touched])
         d = np.abs(cpu_est[touched].astype(np.float64) - g_est[touched])
         out[key] = {"windows": int(n_win), "touched_sais": int(len(touched)), "touched_sets_identical": bool(np.array_equal(touched, g_touched)),
-                    "psnr_cpu_db": pc, "psnr_gpu_db": pg, "delta_db": pg - pc, "max_abs_diff": float(d.max()), "mean_abs_diff": float(d.mean())}
+                    "psnr_cpu_db": pc, "psnr_gpu_db": pg, "delta_db": pg - pc, "max_abs_diff": float(d.max()), "mean_abs_diff": float(d.mean()),
+                    "pixels_compared": int(d.size), "pixels_off_by_more_than_1": int((d > 1.0).sum()),
+                    "pixels_off_by_more_than_0p1": int((d > 0.1).sum())}
     return {"basic": out["basic"]["delta_db"], "denoised": out["denoised"]["delta_db"], "detail": out,
             "note": "GPU minus CPU (oracle, untiled), mean PSNR over the SAIs the sampled windows touched, same MT19937 noise; "
                     "the Wiener leg of both runs starts from the GPU's full basic estimate"}
@@ -213,6 +220,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="lf17x17x512x512_sigma25", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-seam", action="store_true", help="skip the host-seam measurements (`seam` in the line; +3 s)")
     ap.add_argument("--parity-check", action="store_true",
                     help="also run the centre window of each step through the oracle and the C-ABI and report the differences (+20 s)")
     ap.add_argument("--lanes", type=int, default=0, help="window lanes of the timed region (0: the library's default, 2)")
@@ -387,6 +395,32 @@ def main():
             except Exception:
                 traffic = None
 
+        valu = None
+        vpath = os.path.join(ROOT, "profiles", "valu_latest.json")
+        if os.path.exists(vpath):
+            try:
+                vj = json.load(open(vpath))
+                if args.workload == vj.get("workload"):
+                    valu = vj
+            except Exception:
+                valu = None
+        # SURVEY 8d's compulsory floor of a window pass: every window image read once, num / den read and written once
+        comp = {}
+        for kind, pk, S in (("ht", wl["p1"], 1), ("wiener", wl["p2"], 2)):
+            nHW = pk[1] + pk[2]
+            comp[kind] = (S + 4) * 4.0 * 9 * 3 * (W + 2 * nHW) * (H + 2 * nHW)
+        SIMDS, CLK = 1024, 2.4e9      # 256 CUs x 4 SIMD-32; a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md)
+
+        def valu_frac(classes, ms):
+            """share of the chip's VALU issue slots the kernels of `classes` use during `ms` (their time alone on the GPU)"""
+            if not valu or ms <= 0:
+                return None
+            k = valu.get("kernels", {})
+            if any(c not in k for c in classes):
+                return None
+            insts = sum(k[c]["valu_insts_per_launch"] for c in classes)
+            return {"valu_insts": insts, "valu_frac": insts * 2.0 / (SIMDS * CLK * ms * 1e-3)}
+
         def pair(kind):
             a = roof[kind]
             n = max(1, int(a.get("launches_group", 0)))
@@ -402,6 +436,35 @@ def main():
                 tb = traffic["per_step"][kind]["hbm_bytes_per_launch"]
                 d["traffic"] = tb
                 d["frac_physical"] = tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None
+                d["traffic_over_compulsory"] = tb / comp[kind]
+            d["compulsory_bytes"] = comp[kind]
+            # what binds: per kernel class of this pass, the share of VALU issue slots it uses next to the share of the HBM peak it
+            # moves (PMC bytes of the class / its time); neither near 1 = latency- / occupancy-bound
+            n_p = max(1, int(a.get("passes", 0)))
+            cls = {"block_matching": ((f"scan/{kind}", "select", "argmin"), a.get("ms_bm", 0.0) / n_p),
+                   "group": ((f"group/{kind}",), d["ms_group"]), "aggregate": ((f"aggregate/{kind}",), d["ms_aggregate"])}
+            bound = {}
+            for cname, (classes, cms) in cls.items():
+                e = {"ms": cms}
+                v = valu_frac(classes, cms)
+                if v:
+                    e.update(v)
+                if traffic and cms > 0:
+                    tk = traffic.get("kernels", {})
+                    by_c = 0.0
+                    for c in classes:
+                        kk = tk.get(c) or tk.get(c.split("/")[0] + "/both")
+                        if kk:
+                            by_c += (kk["fetch_bytes_per_launch_x2"] if c.startswith("group") else kk["fetch_bytes_per_launch_raw"]) + kk["write_bytes_per_launch"]
+                    if by_c:
+                        e["hbm_bytes"] = by_c
+                        e["hbm_frac"] = by_c / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if "valu_frac" in e or "hbm_frac" in e:
+                    vf, hf = e.get("valu_frac", 0.0), e.get("hbm_frac", 0.0)
+                    e["closest_bound"] = ("valu issue" if vf >= hf else "hbm") + f" at {max(vf, hf):.2f} -- " + (
+                        "bound by it" if max(vf, hf) > 0.7 else "latency / occupancy: neither the VALUs nor HBM are saturated")
+                bound[cname] = e
+            d["bound_by_class"] = bound
             return d
         ph, pw = pair("ht"), pair("wiener")
         n_all = ph["launches"] + pw["launches"]
@@ -434,6 +497,11 @@ def main():
                          "traffic": t_bytes,
                          "frac_physical": (t_bytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (t_bytes and pair_ms > 0) else None,
                          "traffic_source": (traffic or {}).get("source"),
+                         "compulsory_bytes": (comp["ht"] * ph["launches"] + comp["wiener"] * pw["launches"]) / n_all,
+                         "valu_source": (valu or {}).get("source"),
+                         "valu_frac": (lambda v: v["valu_frac"] if v else None)(valu_frac(("group/ht", "aggregate/ht", "group/wiener", "aggregate/wiener"), 2 * pair_ms)),
+                         "valu_note": "VALU wave-instructions (rocprofv3 --pmc SQ_INSTS_VALU of this command, profiles/valu_latest.json) x 2 cycles / "
+                                      "(1024 SIMDs x 2.4 GHz x live kernel time); per kernel class under per_step.*.bound_by_class",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pair_ms, "launches": n_all,
                          "measured_with": ((f"the timed region ({lanes_timed} lane{'s' if lanes_timed != 1 else ''}"
                                             + ("; kernels of different windows overlap, the intervals are not kernel-alone times)" if lanes_timed != 1 else ")"))
@@ -457,6 +525,35 @@ def main():
             "lane_windows_per_step": tot["lane_windows"] / args.steps, "messages_per_step": tot["messages"] / args.steps,
             "psnr": {"noisy": psnr_lf(noisy0), "basic": psnr_lf(basic), "denoised": psnr_lf(den)},
         }
+        if not args.no_seam and world == 1:
+            # the job through the reference's own seam (host memory in and out), outside the timed region
+            try:
+                seam = {"note": "pageable host memory, SAIs streamed through the window graph (upload at first use, outputs behind the last "
+                                "window on a SAI); value above = device-resident buffers; outputs compared with the timed region's"}
+                n_src = noisy_h if noisy_h is not None else noisy0.cpu().numpy()
+                den_ref = den.cpu().numpy()
+                hb, hd = np.zeros_like(n_src), np.zeros_like(n_src)
+                best = None
+                for _ in range(2):
+                    hn = n_src.copy()
+                    t1 = time.perf_counter()
+                    ctx.denoise(P1, P2, hn, mask, hb, hd, L.ROWMAJOR, aw, ah, 1, 1, W, H, 3)
+                    dt = time.perf_counter() - t1
+                    best = dt if best is None else min(best, dt)
+                seam["host_flat"] = {"entry": "lfbm5d_denoise_host", "ms_per_step": best * 1e3, "value": total_mp / best,
+                                     "vs_device": best * 1e3 / ms_per_step, "identical_to_device": bool(np.array_equal(hd, den_ref))}
+                del hb, hd, hn
+                for key, one_job in (("dropin_vectors", False), ("dropin_vectors_one_job", True)):
+                    msv, _, _, dd = core.dropin_probe(n_src, mask, aw, ah, W, H, 3, sigma, 2.7, wl["p1"], wl["p2"], one_job=one_job, reps=2)
+                    tt = float(msv[1].sum()) * 1e-3
+                    seam[key] = {"entry": ("run_bm5d (both steps as one job)" if one_job else
+                                           "run_bm5d_1st_step + run_bm5d_2nd_step (src/bm5d.h:11-62; the interval of main.cpp:189-201 + :241-247)"),
+                                 "ms_per_step": tt * 1e3, "ms_calls": [float(msv[1, 0]), float(msv[1, 1])], "value": total_mp / tt,
+                                 "vs_device": tt * 1e3 / ms_per_step, "identical_to_device": bool(np.array_equal(dd, den_ref))}
+                    del dd
+                out["seam"] = seam
+            except Exception as e:  # noqa: BLE001
+                out["seam"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is timed on rank 0 of the 1-GPU run only
             try:
                 n_h = noisy_h if noisy_h is not None else noisy0.cpu().numpy()

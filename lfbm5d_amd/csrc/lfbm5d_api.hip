@@ -727,6 +727,9 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             c->err += " (multi-GPU step aborted: the RCCL communicators of this context were torn down, call lfbm5d_comm_init again)";
         }
     } abort_guard{c, nranks > 1 && !emulate};
+    /* ... and on one rank an error return must not leave kernels of other lanes running on the caller's buffers (which the caller
+     * is free to release once the call has failed): wait for whatever has been enqueued */
+    struct DrainOnError { bool armed; ~DrainOnError() { if (armed) (void)hipDeviceSynchronize(); } } drain_guard{true};
 
     std::vector<RankState> states(emulate ? (size_t)nranks : 1);
     /* two-step jobs: SAIs no window of the first step touches (LFBM5D_MAX_WINDOWS) keep the first step's input as their basic
@@ -1024,6 +1027,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         for (int ch = 0; ch < 2; ch++) if (S.x->cs[ch]) HIPCK(c, hipStreamSynchronize(S.x->cs[ch]));
     }
     HIPCK(c, hipStreamSynchronize(s));
+    drain_guard.armed = false;
     int complete = 1;
     for (size_t n = 0; n < NN; n++) {
         if (!mine[n]) continue;
@@ -2120,6 +2124,8 @@ int run_bm3d_lf(lfbm5d_ctx* c, const lfbm5d_bm3d_params* Hd, const lfbm5d_bm3d_p
         c->lanes.push_back(x);
     }
     HIPCK(c, hipStreamSynchronize(c->stream));   /* the caller's stream has produced d_noisy */
+    /* an error return must not leave other lanes' kernels running on the caller's buffers */
+    struct DrainOnError { bool armed; ~DrainOnError() { if (armed) (void)hipDeviceSynchronize(); } } drain_guard{true};
     unsigned turn = 0;
     for (unsigned st = 0; st < asize; st++) {
         if (!h_mask[st]) continue;
@@ -2157,6 +2163,7 @@ int run_bm3d_lf(lfbm5d_ctx* c, const lfbm5d_bm3d_params* Hd, const lfbm5d_bm3d_p
         c->stats.launches_group += x->stats.launches_group; c->stats.launches_aggregate += x->stats.launches_aggregate;
         std::memset(&x->stats, 0, sizeof(x->stats));
     }
+    drain_guard.armed = false;   /* every lane has been synchronised above */
     return bm3d_fold(c, Wn, C, 2);
 }
 } /* namespace */

@@ -523,6 +523,15 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
 #else
 #define S2_MARK(i) do {} while (0)
 #endif
+#if defined(LFBM5D_PHASE_TIMING) && LFBM5D_PHASE_TIMING >= 2   /* finer: inside a steady chunk of the disparity search (reported in the self search's slots) */
+        long long tq[4] = {0, 0, 0, 0};
+        long long qlast = 0;
+#define S2_Q0() do { asm volatile("" ::: "memory"); qlast = (long long)__builtin_readcyclecounter(); } while (0)
+#define S2_QMARK(i) do { asm volatile("" ::: "memory"); const long long tn = (long long)__builtin_readcyclecounter(); tq[i] += tn - qlast; qlast = tn; } while (0)
+#else
+#define S2_Q0() do {} while (0)
+#define S2_QMARK(i) do {} while (0)
+#endif
         auto body16 = [&](auto fl_tag, const int t0) {
             constexpr bool EDGE = decltype(fl_tag)::value;
             /* per-lane step numbers relative to this group of sixteen (compared with small constants below) */
@@ -532,7 +541,9 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
             for (int ch = 0; ch < 2; ch++) {
                 const int tc = t0 + 8 * ch;
                 const v4f lc[2] = {*reinterpret_cast<const v4f*>(lcw + ch * NW * 8), *reinterpret_cast<const v4f*>(lcw + ch * NW * 8 + 4)};
+                if (!EDGE) S2_Q0();
                 if (COMB && tc > 0) reduce_chunk((tc >> 3) - 1);
+                if (!EDGE) S2_QMARK(0);
                 const float* pA = colA + slot1;
                 const float* pB = colB + slot2;
 #pragma unroll
@@ -612,6 +623,7 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
                     /* hand-off column for the next strip: rows 1 + t - 63 of this strip's last column */
                     if (!(LFBM5D_S2_EXP & 2)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, out), rL, voffL, 0, 0);
                     voffL += 16;
+                    if (!EDGE) S2_QMARK(1 + gq);
                 }
                 slot1 += 8; slot1 = min(slot1, slot1 - (unsigned)RR1);
                 slot2 += 8; slot2 = min(slot2, slot2 - (unsigned)RR2);
@@ -635,11 +647,19 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
         if (COMB && nsteps > 0) reduce_chunk(((nsteps + 15) >> 4) * 2 - 1);   /* the last chunk's values (the barrier behind it has been passed) */
         row0_left = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(S0), last_lane));
 #ifdef LFBM5D_PHASE_TIMING
+#if LFBM5D_PHASE_TIMING >= 2
+        if (lane == 0 && a.dbg && live && STEREO) {
+            for (int i = 0; i < 4; i++) atomicAdd(&a.dbg[i], (unsigned long long)tk[i]);
+            atomicAdd(&a.dbg[4], 1ull);
+            for (int i = 0; i < 3; i++) atomicAdd(&a.dbg[6 + i], (unsigned long long)tq[i]);
+        }
+#else
         if (lane == 0 && a.dbg && live) {
             const int base = STEREO ? 0 : 6;
             for (int i = 0; i < 4; i++) atomicAdd(&a.dbg[base + i], (unsigned long long)tk[i]);
             atomicAdd(&a.dbg[base + 4], 1ull);
         }
+#endif
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
