@@ -259,7 +259,7 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
     if (bm3d) {   /* per-SAI BM3D flavour: one image, search band = search window, Hadamard along the stack */
         if (aw != 1 || ah != 1) return fail(c, "BM3D works on single images");
         if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
-        if (P->k != 8 && P->k != 12 && P->k != 16) return fail(c, "unsupported: patch size k must be 8, 12 or 16");
+        if (P->k < 2 || P->k > (unsigned)kMaxK) return fail(c, "unsupported: patch size k outside 2..32");
         if (P->tau_2D != LFBM5D_DCT && P->tau_2D != LFBM5D_BIOR) return fail(c, "BM3D: tau_2D must be dct or bior");
         if (P->tau_2D == LFBM5D_BIOR && !is_pow2(P->k)) return fail(c, "bior1.5 needs a power-of-two patch size");
         if (!is_pow2(P->N) || P->N < 2 || P->N > (unsigned)kMaxN3) return fail(c, "unsupported: BM3D N must be a power of two in 2..32");
@@ -268,7 +268,9 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
     }
     if (aw != ah || (aw != 3 && aw != 5 && aw != 7)) return fail(c, "unsupported: angular search window must be 3x3, 5x5 or 7x7 (aswSize 1 to 3)");
     if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
-    if (P->k != 8 && P->k != 12 && P->k != 16) return fail(c, "unsupported: patch size k must be 8, 12 or 16");
+    /* any patch size the reference would run (utilities_LF.cpp:1214, :1255; Kaiser window: all ones unless k is 8 or 12, bm3d.cpp:1144-1146);
+     * 8, 12 and 16 have dedicated table kernels, 8 and 16 dedicated group kernels, everything else the general forms.  32 bounds the tables */
+    if (P->k < 2 || P->k > (unsigned)kMaxK) return fail(c, "unsupported: patch size k outside 2..32");
     if (P->tau_2D == LFBM5D_BIOR && !is_pow2(P->k)) return fail(c, "bior1.5 needs a power-of-two patch size");
     if (P->tau_2D != LFBM5D_ID && P->tau_2D != LFBM5D_DCT && P->tau_2D != LFBM5D_BIOR) return fail(c, "bad tau_2D");
     if (P->tau_4D != LFBM5D_ID && P->tau_4D != LFBM5D_DCT && P->tau_4D != LFBM5D_SADCT) return fail(c, "bad tau_4D");
@@ -427,7 +429,25 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->self_cnt.reserve((size_t)R * sizeof(unsigned)));
     HIPCK(c, c->best.reserve(A * plane * sizeof(unsigned)));
     HIPCK(c, c->shape.reserve(A * plane));
-    HIPCK(c, c->filt.reserve((size_t)R * Nst * A * C * k2 * sizeof(float)));
+    /* The filtered patches of a pass -- R x N x A x C x k^2 floats, 3.5 GB at the headline's hard-thresholding window -- exist between the
+     * group kernel and the aggregation only, and the aggregation adds up in raster order of the reference patches: a pass can be cut
+     * into BANDS of reference rows, group kernel and aggregation launched band after band, with sums bit-identical to the single
+     * launch and a buffer of one band.  Bands are taken when the whole buffer would pass kFiltCapBytes (large angular windows: a 9x9
+     * window with 16x16 patches is 31 GB) or the aggregation's 32-bit patch offsets, or when LFBM5D_BAND_MB asks (experiments: a band
+     * that stays in the 256 MB Infinity Cache between its two kernels). */
+    const size_t per_group = (size_t)Nst * A * C * k2;   /* floats */
+    unsigned band_groups = R;
+    {
+        constexpr size_t kFiltCapBytes = (size_t)12 << 30;
+        size_t cap = std::min<size_t>(kFiltCapBytes, (size_t)0xfff00000ull * sizeof(float));   /* 32-bit float offsets inside a band */
+        if (const char* e = std::getenv("LFBM5D_BAND_MB")) { const long mb = std::atol(e); if (mb > 0) cap = std::min<size_t>(cap, (size_t)mb << 20); }
+        const size_t row_groups = centre ? gc.n_ref_cols : 1;   /* bands are whole rows of the reference grid (a list: any cut) */
+        if ((size_t)R * per_group * sizeof(float) > cap) {
+            const size_t rows_fit = std::max<size_t>(1, cap / (per_group * sizeof(float) * row_groups));
+            band_groups = (unsigned)std::min<size_t>(R, rows_fit * row_groups);
+        }
+    }
+    HIPCK(c, c->filt.reserve((size_t)band_groups * per_group * sizeof(float)));
     HIPCK(c, c->wgt.reserve((size_t)R * C * sizeof(float)));
     HIPCK(c, c->aggpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
@@ -477,7 +497,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R_sc * NsS * NsS));
     /* which generation of the table kernel, and its workgroup list: functions of the search geometry (and of the two
      * environment switches bm_scan_version reads), cached with it */
-    const char* const env_v1 = std::getenv("LFBM5D_SCAN_V1"); const char* const env_ft = std::getenv("LFBM5D_SCAN_FULL_TABLES");
+    const char* env_v1 = std::getenv("LFBM5D_SCAN_V1"); const char* const env_ft = std::getenv("LFBM5D_SCAN_FULL_TABLES");
+    if (const char* env_any = std::getenv("LFBM5D_SCAN_ANY")) if (env_any[0] && env_any[0] != '0') env_v1 = env_any;
     const unsigned skey[8] = {sa.n_self, sa.n_stereo, sa.nSim, sa.nDisp, sa.k, Hb, Wb,
                               1u | ((centre || full_scan) ? 0u : 2u) | ((env_v1 && env_v1[0] && env_v1[0] != '0') ? 4u : 0u) | ((env_ft && env_ft[0] && env_ft[0] != '0') ? 8u : 0u)};
     const bool scan_changed = std::memcmp(skey, gc.scan_key, sizeof(skey)) != 0;
@@ -541,7 +562,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.noisy = d_noisy; ga.basic = d_basic; ga.num = d_num; ga.den = d_den;
     ga.refs = gc.refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
     ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = gc.tb.as<GroupTables>();
-    ga.filt = c->filt.as<float>(); ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gofs = c->gofs.as<unsigned>(); ga.gok = c->gok.as<unsigned>(); ga.gshape = c->gshape.p; ga.n_refs_total = R; ga.counters = d_counters;
+    ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gofs = c->gofs.as<unsigned>(); ga.gok = c->gok.as<unsigned>(); ga.gshape = c->gshape.p; ga.n_refs_total = R; ga.counters = d_counters;
     ga.ref_begin = ref_begin; ga.n_groups = n_groups;
     ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
     ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;
@@ -553,20 +574,38 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         HIPCK(c, c->gscratch.reserve(sb));
         ga.scratch = c->gscratch.as<float>(); ga.scratch_floats = sb / sizeof(float);
     }
-    if (n_groups) HIPCK(c, launch_group(s, ga));
-    HIPCK(c, hipEventRecord(pe.e[2], s));
-
     AggArgs aa;
     std::memset(&aa, 0, sizeof(aa));
-    aa.num = d_num; aa.den = d_den; aa.filt = ga.filt; aa.filt_bytes = (unsigned long long)R * Nst * A * C * k2 * sizeof(float); aa.wgt = ga.wgt; aa.aggpos = ga.aggpos; aa.n_refs_total = R; aa.refs = ga.refs;
+    aa.num = d_num; aa.den = d_den; aa.wgt = ga.wgt; aa.aggpos = ga.aggpos; aa.n_refs_total = R; aa.refs = ga.refs;
     aa.self_idx = ga.self_idx; aa.self_cnt = ga.self_cnt; aa.best = ga.best; aa.shape = ga.shape; aa.tb = ga.tb;
     aa.ref_begin = ref_begin; aa.n_groups = n_groups; aa.n_ref_rows = gc.n_ref_rows; aa.n_ref_cols = gc.n_ref_cols;
     aa.Wb = Wb; aa.Hb = Hb; aa.C = C; aa.A = A; aa.k = k; aa.N = Nst; aa.pst = pst; aa.p = P->p;
     aa.nHW = nHW; aa.nSim = P->nSim; aa.nDisp = P->nDisp;
     aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D; aa.irregular = centre ? 0u : 1u;
     aa.wchan0 = (bm3d && P->useSD) ? 1u : 0u;
-    if (n_groups) HIPCK(c, launch_aggregate(s, aa));
-    HIPCK(c, hipEventRecord(pe.e[3], s));
+    if (n_groups <= band_groups) {   /* the whole pass (or this rank's rows) at once */
+        ga.filt = c->filt.as<float>() - (size_t)ref_begin * per_group;   /* (the group kernels index filt by absolute group number) */
+        aa.filt = c->filt.as<float>(); aa.filt_bytes = (unsigned long long)n_groups * per_group * sizeof(float);
+        if (n_groups) HIPCK(c, launch_group(s, ga));
+        HIPCK(c, hipEventRecord(pe.e[2], s));
+        if (n_groups) HIPCK(c, launch_aggregate(s, aa));
+        HIPCK(c, hipEventRecord(pe.e[3], s));
+    } else {
+        /* band after band; the two event intervals then cover the first band's group kernel / everything behind it */
+        bool first = true;
+        for (unsigned b0 = ref_begin; b0 < ref_begin + n_groups; b0 += band_groups) {
+            const unsigned nb = std::min(band_groups, ref_begin + n_groups - b0);
+            ga.ref_begin = b0; ga.n_groups = nb; ga.filt = c->filt.as<float>() - (size_t)b0 * per_group;
+            aa.ref_begin = b0; aa.n_groups = nb; aa.filt = c->filt.as<float>(); aa.filt_bytes = (unsigned long long)nb * per_group * sizeof(float);
+            HIPCK(c, launch_group(s, ga));
+            if (first) HIPCK(c, hipEventRecord(pe.e[2], s));
+            first = false;
+            HIPCK(c, launch_aggregate(s, aa));
+            c->stats.launches_group += 1; c->stats.launches_aggregate += 1;
+        }
+        c->stats.launches_group -= 1; c->stats.launches_aggregate -= 1;   /* (one of each is counted below) */
+        HIPCK(c, hipEventRecord(pe.e[3], s));
+    }
 
     if (c->comm && c->pass_reduce) { /* sum the window's aggregation buffers over the ranks (xGMI) */
         const size_t cnt = (size_t)A * C * plane;

@@ -561,6 +561,159 @@ __global__ __launch_bounds__(64) LFBM5D_SCAN_WAVES_ATTR void k_bm_scan(ScanArgs 
     else scan_body<K, 0, WIDE>(a, (int)blockIdx.x, lds);
 }
 
+/* ---- any patch size (round 5) ----
+ * The table kernels above are instantiated for 8-, 12- and 16-pixel patches (register FIFOs and ring geometry are compile-time);
+ * the reference takes any kHard / kWien (utilities_LF.cpp:1214, :1255).  Every other patch size runs this plain form of the same
+ * mapping: one wavefront per displacement table, lane = column of a 64-column strip, rows skewed across the lanes so that the
+ * recurrence's neighbours are the lane's own previous value and a one-lane shift -- the SAME operations in the SAME order, hence
+ * the same tables bit for bit -- with the four squared differences of a step read straight from the estimate (no ring, no FIFO:
+ * eight uncoalesced loads per step).  About 2 ms per 560 x 560 pass where the dedicated kernels take 0.8: a fallback, not a
+ * tuned path.  Outputs in the first-generation layout (skewed disparity tables, score stores through the grid / position map). */
+template <int MODE>
+__device__ __forceinline__ void scan_any_body(const ScanArgs& a, const int bid, float* lds) {
+    constexpr bool stereo = MODE == 2;
+    constexpr bool irregular = MODE == 1;
+    const int lane = threadIdx.x;
+    const int K = (int)a.k;
+    const int half = stereo ? (int)a.nDisp : (int)a.nSim;
+    const int trim = stereo ? K - 1 : 0;
+    const int W = a.W, H = a.H, b = stereo ? (int)a.nDisp : (int)a.nHW;
+    const int Ns = 2 * half + 1, ncand = Ns * Ns;
+    const int nrows = H - 2 * b - trim, ncols = W - 2 * b - trim;
+    int di, dj;
+    DiffImg D;
+    const size_t WH = (size_t)W * H;
+    if (stereo) {
+        const int slot = bid / ncand, ddk = bid % ncand;
+        di = ddk / Ns; dj = ddk % Ns;
+        D.i1 = a.est + (size_t)a.pst * WH;
+        D.i2 = a.est + (size_t)a.st_of_slot[slot] * WH;
+        D.dk = di * W + dj - half * (1 + W);
+    } else {
+        di = bid / Ns; dj = bid % Ns;
+        D.i1 = D.i2 = a.est + (size_t)a.pst * WH;
+        D.dk = di * W + dj - half;
+    }
+    D.W = W; D.H = H; D.b = b;
+    const size_t tstride = stereo ? stereo_table_stride(a.W, a.H, a.k, a.nDisp) : 0;
+    float* table = stereo ? a.tables + (size_t)bid * tstride : nullptr;
+    const int SR = nrows + 63;
+    const int djs = dj - half;
+    const int ord_fwd = dj * Ns + di;
+    const int ord_bwd = (-djs + half) * Ns + (half + 1) + (half - di);
+    const int gR = a.n_ref_rows, gC = a.n_ref_cols, gP = a.p, gN = a.nHW;
+    const int lastR = H - K - gN, lastC = W - K - gN;
+    auto emit = [&](int y, int x, float S) {
+        if (stereo) { table[((size_t)((x - b) / 64) * SR + (y - b) + (x - b) % 64) * 64 + (x - b) % 64] = S; return; }
+        if (irregular) {
+            const int r = a.refmap[y * W + x];
+            if (r >= 0) a.scores[(size_t)r * ncand + ord_fwd] = S;
+            const int yy = y + di, xx = x + djs;
+            if (di > 0 && yy < H && xx >= 0 && xx < W) {
+                const int r2 = a.refmap[yy * W + xx];
+                if (r2 >= 0) a.scores[(size_t)r2 * ncand + ord_bwd] = S;
+            }
+            return;
+        }
+        const int cx = grid_index(x, gC, lastC, gN, gP);
+        if (cx >= 0) {
+            const int ry = grid_index(y, gR, lastR, gN, gP);
+            if (ry >= 0) a.scores[(size_t)(ry * gC + cx) * ncand + ord_fwd] = S;
+        }
+        if (di > 0) {
+            const int cx2 = grid_index(x + djs, gC, lastC, gN, gP);
+            if (cx2 >= 0) {
+                const int ry2 = grid_index(y + di, gR, lastR, gN, gP);
+                if (ry2 >= 0) a.scores[(size_t)(ry2 * gC + cx2) * ncand + ord_bwd] = S;
+            }
+        }
+    };
+    float* Lprev = lds;                   /* [nrows] column left of the current strip */
+    float* Lnext = lds + nrows;           /* [nrows] last column of the current strip */
+    float* tbuf = lds + 2 * nrows;        /* [64][K] terms of the first-row / first-column chains; the corner's K x K differences */
+
+    /* corner (core:3344-3352): K x K terms added one after the other */
+    for (int e = lane; e < K * K; e += 64) tbuf[e] = D(b + e / K, b + e % K);
+    __syncthreads();
+    float corner = 0.0f;
+    for (int e = 0; e < K * K; e++) corner += tbuf[e];
+    __syncthreads();
+    if (lane == 0) { Lnext[0] = corner; emit(b, b, corner); }
+    /* first column (core:3367-3372): S[i][b] = S[i-1][b] + sum_q (D[i-1+K][b+q] - D[i-1][b+q]), the K terms one after the other */
+    {
+        float carry = corner;
+        for (int i0 = 1; i0 < nrows; i0 += 64) {
+            const int i = i0 + lane;
+            for (int q = 0; q < K; q++) tbuf[lane * K + q] = i < nrows ? D(b + i - 1 + K, b + q) - D(b + i - 1, b + q) : 0.0f;
+            __syncthreads();
+            const int m = min(64, nrows - i0);
+            float mine = 0.0f;
+            for (int l = 0; l < m; l++) {
+                float cand = carry;
+                for (int q = 0; q < K; q++) cand += tbuf[l * K + q];
+                carry = cand;
+                if (lane == l) mine = carry;
+            }
+            if (i < nrows) { Lnext[i] = mine; emit(b + i, b, mine); }
+            __syncthreads();
+        }
+    }
+    /* strips of 64 columns from table column 1 on; the column left of a strip: the first column, then the previous strip's last */
+    const int nstrips = (ncols - 1 + 63) / 64;
+    for (int strip = 0; strip < nstrips; strip++) {
+        { float* t = Lprev; Lprev = Lnext; Lnext = t; }
+        __syncthreads();
+        const int cb = b + 1 + 64 * strip;
+        const int x = cb + lane;
+        const bool col_ok = x < b + ncols;
+        const int last_lane = min(63, ncols - 2 - 64 * strip);
+        /* first row (core:3354-3362): S[b][x] = S[b][x-1] + sum_p (D[b+p][x-1+K] - D[b+p][x-1]), chained across the lanes */
+        for (int p = 0; p < K; p++) tbuf[lane * K + p] = col_ok ? D(b + p, x - 1 + K) - D(b + p, x - 1) : 0.0f;
+        __syncthreads();
+        float S0 = 0.0f;
+        {
+            float carry = Lprev[0];
+            for (int l = 0; l <= last_lane; l++) {
+                float cand = carry;
+                for (int p = 0; p < K; p++) cand += tbuf[l * K + p];
+                carry = cand;
+                if (lane == l) S0 = carry;
+            }
+        }
+        if (col_ok) emit(b, x, S0);
+        if (lane == last_lane) Lnext[0] = S0;
+        /* the remaining rows: lane l works on table row 1 + t - l at step t (core:3375-3383, same association) */
+        float cur = S0, leftprev = Lprev[0];
+        const int nsteps = (nrows - 1) + last_lane;
+        for (int t = 0; t < nsteps; t++) {
+            const int r = 1 + t - lane;
+            float nb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cur), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+            if (lane == 0) nb = Lprev[min(max(r, 0), nrows - 1)];
+            if (col_ok && r >= 1 && r <= nrows - 1) {
+                const int y = b + r;
+                float S = nb + cur;
+                S = S - leftprev;
+                S = S + D(y + K - 1, x + K - 1);
+                S = S - D(y + K - 1, x - 1);
+                S = S - D(y - 1, x + K - 1);
+                S = S + D(y - 1, x - 1);
+                emit(y, x, S);
+                cur = S;
+                if (lane == last_lane) Lnext[r] = S;
+            }
+            leftprev = nb;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bm_scan_any(ScanArgs a) {
+    extern __shared__ float lds[];
+    if (blockIdx.x >= a.n_self) scan_any_body<2>(a, (int)(blockIdx.x - a.n_self), lds);
+    else if (a.refmap) scan_any_body<1>(a, (int)blockIdx.x, lds);
+    else scan_any_body<0>(a, (int)blockIdx.x, lds);
+}
+
 /* order-preserving float -> uint map (scores can be slightly negative after cancellation) */
 __device__ __forceinline__ unsigned f2ord(float f) {
     const unsigned u = __float_as_uint(f);
@@ -860,11 +1013,17 @@ hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
 #endif
 #define LFBM5D_SCAN(K_) do { if (wide) hipLaunchKernelGGL((k_bm_scan<K_, true>), dim3(n), dim3(64), lds, s, a); \
                              else      hipLaunchKernelGGL((k_bm_scan<K_, false>), dim3(n), dim3(64), lds, s, a); } while (0)
-    switch (a.k) {
+    /* LFBM5D_SCAN_ANY: test hook, the plain any-patch-size kernel for 8 / 12 / 16 too (compared bit for bit with the dedicated ones) */
+    const char* any_s = getenv("LFBM5D_SCAN_ANY");
+    switch ((any_s && any_s[0] && any_s[0] != '0') ? 0u : a.k) {
         case 8:  LFBM5D_SCAN(8); break;
         case 12: LFBM5D_SCAN(12); break;
         case 16: LFBM5D_SCAN(16); break;
-        default: return hipErrorInvalidValue;
+        default: {   /* any other patch size: the plain form (k_bm_scan_any) */
+            const size_t lds_any = (size_t)(2 * nrows + 64 * std::max(a.k, 16u) + 64) * sizeof(float);
+            hipLaunchKernelGGL(k_bm_scan_any, dim3(n), dim3(64), lds_any, s, a);
+            break;
+        }
     }
 #undef LFBM5D_SCAN
     return hipGetLastError();

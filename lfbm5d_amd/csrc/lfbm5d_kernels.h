@@ -11,7 +11,7 @@
 
 namespace lfbm5d {
 
-constexpr int kMaxK = 16;       /* patch side supported by the group kernel */
+constexpr int kMaxK = 32;       /* largest patch side (dedicated kernels: 8, 12, 16; the general forms take any) */
 constexpr int kMaxA = 49;       /* SAIs per angular window: 3x3 (an = 1, every dedicated kernel), 5x5 or 7x7 (an = 2, 3: generic kernel) */
 constexpr int kA3 = 9;          /* ... of the 3x3 window the dedicated kernels are written for */
 constexpr int kMaxAw = 7;       /* side of the largest window */
@@ -56,7 +56,8 @@ struct GroupArgs {
     const unsigned* best;       /* [A][Wb*Hb] disparity match */
     const unsigned char* shape; /* [A][Wb*Hb] */
     const GroupTables* tb;
-    float* filt;                /* [R][N][A][C][k2] filtered patches (pixel domain) */
+    float* filt;                /* [R][N][A][C][k2] filtered patches (pixel domain), indexed by the ABSOLUTE group number: a launch over the groups
+                                 * [ref_begin, ref_begin + n_groups) whose buffer holds only those passes (buffer - ref_begin * N*A*C*k2) */
     float* wgt;                 /* [R][C] aggregation weights */
     unsigned* aggpos;           /* [A][R][N] where each filtered patch is aggregated (0xffffffff: nowhere) */
     unsigned* gpos;             /* [R][N][A] window position of every patch of every group (pre-pass output) */
@@ -81,7 +82,7 @@ struct GroupArgs {
 struct AggArgs {
     float* num;
     float* den;
-    const float* filt;
+    const float* filt;               /* the launch's groups only: [g - ref_begin][N][A][C][k2] */
     unsigned long long filt_bytes;   /* size of filt: below 4 GiB the gathers go through a buffer resource */
     const float* wgt;
     const unsigned* aggpos;     /* [A][R][N] */

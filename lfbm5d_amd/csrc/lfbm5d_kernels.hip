@@ -1299,12 +1299,102 @@ __device__ void inv2d_dct(float* S, float* tmp, int np, TbPtr tb) {
     __syncthreads();
 }
 
+/* patches of more coefficients than the workgroup has threads (k > 16): one patch at a time, the threads stride over its coefficients;
+ * the same sums in the same order as the general form below */
+__device__ void fwd2d_big(float* S, float* Tm, int np, int k, unsigned tau2, TbPtr tb) {
+    const int k2 = k * k, tid = threadIdx.x;
+    for (int patch = 0; patch < np; patch++) {
+        float* X = S + (size_t)patch * k2;
+        if (tau2 == 5) {
+            for (int pq = tid; pq < k2; pq += kThreads) { const int i = pq / k, j = pq % k; float a = 0.0f; for (int t = 0; t < k; t++) a += X[i * k + t] * tb->cos2[j * k + t]; Tm[pq] = 2.0f * a; }
+            __syncthreads();
+            for (int pq = tid; pq < k2; pq += kThreads) { const int i = pq / k, j = pq % k; float a = 0.0f; for (int t = 0; t < k; t++) a += Tm[t * k + j] * tb->cos2[i * k + t]; X[pq] = 2.0f * a * tb->cn2[pq]; }
+            __syncthreads();
+        } else {
+            for (int N1 = k; N1 > 1; N1 /= 2) {
+                const int N2 = N1 / 2;
+                for (int pq = tid; pq < k2; pq += kThreads) {
+                    const int i = pq / k, j = pq % k;
+                    if (i < N1 && j < N1) {
+                        const bool lo = j < N2; const int jj = lo ? j : j - N2;
+                        TbFloats f = lo ? tb->lpd : tb->hpd;
+                        float a = 0.0f;
+                        for (int t = 0; t < 10; t++) a += X[i * k + per_ext(t + 2 * jj, 4, N1)] * f[t];
+                        Tm[pq] = a;
+                    }
+                }
+                __syncthreads();
+                for (int pq = tid; pq < k2; pq += kThreads) {
+                    const int i = pq / k, j = pq % k;
+                    if (i < N1 && j < N1) {
+                        const bool lo = i < N2; const int ii = lo ? i : i - N2;
+                        TbFloats f = lo ? tb->lpd : tb->hpd;
+                        float a = 0.0f;
+                        for (int t = 0; t < 10; t++) a += Tm[per_ext(t + 2 * ii, 4, N1) * k + j] * f[t];
+                        X[pq] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+}
+__device__ void inv2d_big(float* S, float* Tm, int np, int k, unsigned tau2, TbPtr tb) {
+    const int k2 = k * k, tid = threadIdx.x;
+    for (int patch = 0; patch < np; patch++) {
+        float* X = S + (size_t)patch * k2;
+        if (tau2 == 5) {
+            for (int pq = tid; pq < k2; pq += kThreads) {
+                const int i = pq / k, j = pq % k;
+                float a = 0.0f;
+                for (int v = 1; v < k; v++) a += X[i * k + v] * tb->cni2[i * k + v] * tb->cos2[v * k + j];
+                Tm[pq] = X[i * k] * tb->cni2[i * k] + 2.0f * a;
+            }
+            __syncthreads();
+            for (int pq = tid; pq < k2; pq += kThreads) {
+                const int i = pq / k, j = pq % k;
+                float a = 0.0f;
+                for (int u = 1; u < k; u++) a += Tm[u * k + j] * tb->cos2[u * k + i];
+                X[pq] = tb->coef2inv * (Tm[j] + 2.0f * a);
+            }
+            __syncthreads();
+        } else {
+            for (int N1 = 2; N1 <= k; N1 *= 2) {
+                const int N2 = N1 / 2;
+                for (int pq = tid; pq < k2; pq += kThreads) {
+                    const int i = pq / k, j = pq % k;
+                    if (i < N1 && j < N1) {
+                        const int m = i / 2; TbFloats f = (i & 1) ? tb->lpr : tb->hpr;
+                        float a = 0.0f;
+                        for (int t = 0; t < 10; t++) a += f[t] * X[((t * N2 + m) % N1) * k + j];
+                        Tm[pq] = a;
+                    }
+                }
+                __syncthreads();
+                for (int pq = tid; pq < k2; pq += kThreads) {
+                    const int i = pq / k, j = pq % k;
+                    if (i < N1 && j < N1) {
+                        const int m = j / 2; TbFloats f = (j & 1) ? tb->lpr : tb->hpr;
+                        float a = 0.0f;
+                        for (int t = 0; t < 10; t++) a += f[t] * Tm[i * k + (t * N2 + m) % N1];
+                        X[pq] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+}
+
 __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr tb) {
+    if (k * k > kThreads) return fwd2d_big(S, tmp, np, k, tau2, tb);
     if (tau2 == 5) {
         if (k == 8) return fwd2d_dct<8>(S, tmp, np, tb);
         if (k == 12) return fwd2d_dct<12>(S, tmp, np, tb);
-        return fwd2d_dct<16>(S, tmp, np, tb);
-    }
+        if (k == 16) return fwd2d_dct<16>(S, tmp, np, tb);
+    }   /* (other sizes: the run-time form below) */
     if (tau2 == 7 && k == 16) return bior2d_fast<16, true>(S, tmp, np, tb);
     if (tau2 == 7 && k == 8) return bior2d_fast<8, true>(S, tmp, np, tb);
     const int k2 = k * k, tid = threadIdx.x;
@@ -1346,10 +1436,11 @@ __device__ void fwd2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr 
     __syncthreads();
 }
 __device__ void inv2d(float* S, float* tmp, int np, int k, unsigned tau2, TbPtr tb) {
+    if (k * k > kThreads) return inv2d_big(S, tmp, np, k, tau2, tb);
     if (tau2 == 5) {
         if (k == 8) return inv2d_dct<8>(S, tmp, np, tb);
         if (k == 12) return inv2d_dct<12>(S, tmp, np, tb);
-        return inv2d_dct<16>(S, tmp, np, tb);
+        if (k == 16) return inv2d_dct<16>(S, tmp, np, tb);
     }
     if (tau2 == 7 && k == 16) return bior2d_fast<16, false>(S, tmp, np, tb);
     if (tau2 == 7 && k == 8) return bior2d_fast<8, false>(S, tmp, np, tb);
@@ -3643,7 +3734,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
     constexpr int kAggCap = kAggFlush + kAggPF * 64 + kAggU;   /* + padding of the last round */
     __shared__ uint4 hit_a[kAggCap];       /* (py << 16) | px, offset of the patch in filt, weights of channels 0 and 1 */
     __shared__ float hit_w2[kAggCap];      /* weight of channel 2 */
-    __shared__ float kai[WINDOWED ? kMaxK * kMaxK : 1];
+    __shared__ float kai[WINDOWED ? 256 : 1];   /* Kaiser windows exist for 8x8 and 12x12 patches only (bm3d.cpp:1101-1146) */
     const int lane = threadIdx.x;
     /* XCD-aware renumbering: hardware deals consecutive workgroup ids round-robin to the 8 XCDs */
     const unsigned gx = (a.Wb + TW - 1) / TW, gy = (a.Hb + TH - 1) / TH, total_wg = gx * gy * a.A;
@@ -3676,14 +3767,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
     int c_lo = lo_idx(tx0 - k + 1 - reach), c_hi = hi_idx(tx0 + TW - 1 + reach, (int)a.n_ref_cols, last_c);
     if (r_lo > (int)a.n_ref_rows - 1) r_lo = (int)a.n_ref_rows - 1; /* the forced last index may sit closer than p */
     if (c_lo > (int)a.n_ref_cols - 1) c_lo = (int)a.n_ref_cols - 1;
+    /* a launch covers the groups [ref_begin, ref_begin + n_groups): whole rows of the reference grid (a band of a pass processed band by
+     * band, a rank's share of a row-sharded pass) -- only those rows' candidates are enumerated, and a tile none of them can reach
+     * returns before it has touched num / den.  Bands launched in raster order add up in the reference's order (core:484-528): the sums
+     * do not depend on how a pass is cut. */
+    if (!a.irregular && a.n_ref_cols) {
+        r_lo = max(r_lo, (int)(a.ref_begin / a.n_ref_cols));
+        r_hi = min(r_hi, (int)((a.ref_begin + a.n_groups - 1) / a.n_ref_cols));
+    }
+    const int ncols_span = c_hi - c_lo + 1;
+    /* (an irregular list -- subset passes -- is in raster order too: the launch's slice of it) */
+    const int n_rr = a.irregular ? (int)a.n_groups : ((r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span : 0);
+    const int n_cand = n_rr << logN;
+    if (n_cand == 0) return;
 
     float accn[3] = {0, 0, 0}, accd[3] = {0, 0, 0};
     const size_t pix = (size_t)st * C * plane + (size_t)y * a.Wb + x;
     if (inside) for (int c = 0; c < C; c++) { accn[c] = a.num[pix + c * plane]; accd[c] = a.den[pix + c * plane]; }
 
-    const int ncols_span = c_hi - c_lo + 1;
-    const int n_rr = a.irregular ? (int)a.n_refs_total : ((r_hi >= r_lo && c_hi >= c_lo) ? (r_hi - r_lo + 1) * ncols_span : 0);
-    const int n_cand = n_rr << logN;
     /* rr / ncols_span by multiplication: exact while rr < 2^20 / ncols_span (rr is a few hundred) */
     const bool mul_div = !a.irregular && (long long)n_rr * ncols_span < (1 << 20);
     const unsigned div_m = ((1u << 20) + (unsigned)max(ncols_span, 1) - 1) / (unsigned)max(ncols_span, 1);
@@ -3771,7 +3872,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
             if (e < n_cand && (unsigned)lane >= l0 && (unsigned)lane < l1) {
                 n0 = (unsigned)e & (unsigned)(N - 1);
                 const unsigned rr = (unsigned)e >> logN;
-                if (a.irregular) g = rr;
+                if (a.irregular) g = a.ref_begin + rr;
                 else {
                     unsigned q = __umul24(rr, div_m) >> 20;
                     if (!mul_div) { asm volatile("" ::: "memory"); q = rr / (unsigned)ncols_span; }
@@ -3795,8 +3896,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
             if (m4) {
                 unsigned slot = nh + below(b0) + 2u * below(b1) + 4u * below(b2);
                 size_t wbase; unsigned off;
-                if (small24) { wbase = __umul24(g, (unsigned)C); off = __umul24(__umul24((g << logN) + n0, (unsigned)A) + (unsigned)st, (unsigned)(C * k2)); }
-                else { asm volatile("" ::: "memory"); wbase = (size_t)g * C; off = (((g << logN) + n0) * A + st) * C * k2; }
+                const unsigned gl = g - a.ref_begin;   /* filt holds the launch's groups: [g - ref_begin][n][st][c][k2] */
+                if (small24) { wbase = __umul24(g, (unsigned)C); off = __umul24(__umul24((gl << logN) + n0, (unsigned)A) + (unsigned)st, (unsigned)(C * k2)); }
+                else { asm volatile("" ::: "memory"); wbase = (size_t)g * C; off = (((gl << logN) + n0) * A + st) * C * k2; }
                 float w[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) w[c] = c < C ? a.wgt[wbase + (a.wchan0 ? 0 : c)] : 0.0f;
@@ -3829,7 +3931,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
             if (e < n_cand) {
                 const unsigned n = (unsigned)e & (unsigned)(N - 1), rr = (unsigned)e >> logN;
                 nn[u] = n;
-                if (a.irregular) g[u] = rr;   /* the list is in raster order too (row lists, then columns) */
+                if (a.irregular) g[u] = a.ref_begin + rr;   /* the list is in raster order too (row lists, then columns) */
                 else {
                     /* 24-bit multiplies (full rate): rr, q < 2^20 and div_m <= 2^20 under mul_div; grid rows / columns < 2^16 */
                     unsigned q = __umul24(rr, div_m) >> 20;
@@ -3864,8 +3966,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
             if (hit[u]) {
                 const unsigned slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
                 unsigned off;
-                if (small24) off = __umul24(__umul24((g[u] << logN) + nn[u], (unsigned)A) + (unsigned)st, (unsigned)(C * k2));
-                else { asm volatile("" ::: "memory"); off = (((g[u] << logN) + nn[u]) * A + st) * C * k2; }
+                const unsigned gl = g[u] - a.ref_begin;
+                if (small24) off = __umul24(__umul24((gl << logN) + nn[u], (unsigned)A) + (unsigned)st, (unsigned)(C * k2));
+                else { asm volatile("" ::: "memory"); off = (((gl << logN) + nn[u]) * A + st) * C * k2; }
                 hit_a[slot] = make_uint4(p[u], off, __float_as_uint(w[u][0]), __float_as_uint(w[u][1]));
                 hit_w2[slot] = w[u][2];
             }
@@ -4025,7 +4128,7 @@ hipError_t prepare_group_kernels() {
 constexpr unsigned kBigBlocks = 1024;   /* persistent workgroups of k_group_big (four per CU) */
 static size_t group_tmp_floats(const GroupArgs& a) {
     /* the 2-D stage's work area: one patch per wave-quarter for the generic path, [patch][k][k+1] for bior1.5 */
-    return (a.tau2 == 7 && (a.k == 8 || a.k == 16)) ? (size_t)(kThreads / a.k) * a.k * (a.k + 1) : 256;
+    return (a.tau2 == 7 && (a.k == 8 || a.k == 16)) ? (size_t)(kThreads / a.k) * a.k * (a.k + 1) : std::max<size_t>(256, (size_t)a.k * a.k);
 }
 size_t group_lds_bytes(const GroupArgs& a) {
     const size_t stack = (size_t)a.N * a.A * a.k * a.k;

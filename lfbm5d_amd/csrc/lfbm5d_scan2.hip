@@ -772,6 +772,7 @@ template <int K> size_t scan2_lds_bytes(const ScanArgs& a, int rh_max, int ch_ma
  * search windows whose rings do not fit) or LFBM5D_SCAN_V1 asks for round 2's kernel. */
 int bm_scan_version(const ScanArgs& a) {
     if (const char* e = std::getenv("LFBM5D_SCAN_V1")) if (e[0] && e[0] != '0') return 1;
+    if (const char* e = std::getenv("LFBM5D_SCAN_ANY")) if (e[0] && e[0] != '0') return 1;   /* (test hook: the any-patch-size kernel, first-generation layout) */
     if (a.k != 8 && a.k != 16) return 1;
     if (a.n_self && a.refmap) return 1;
     /* the loader wave addresses all planes of the estimate through ONE buffer resource with 32-bit offsets */

@@ -86,6 +86,14 @@ PASS_CASES = [
     ("ht-wide-n1-p3", 1, 50.0, (1, 9, 3, 16, 3, "bior", "sadct", "haar"), (72, 150), 0),
     ("ht-tall-id-p3", 1, 25.0, (8, 8, 3, 16, 3, "id", "sadct", "haar"), (150, 72), 0),
     ("wien-wide-n8-p3", 2, 25.0, (8, 9, 3, 8, 3, "dct", "sadct", "haar"), (72, 150), 0),
+    # patch sizes without dedicated kernels (round 5; the reference takes any kHard / kWien, utilities_LF.cpp:1214, :1255, with an
+    # all-ones "Kaiser" window, bm3d.cpp:1144-1146): the plain table kernel + the general group kernel
+    ("ht-k10-dct", 1, 25.0, (4, 6, 2, 10, 4, "dct", "sadct", "haar"), 72, 0),
+    ("ht-k6-id-n8", 1, 25.0, (8, 6, 2, 6, 3, "id", "sadct", "haar"), 64, 0),
+    ("wien-k10-dct", 2, 25.0, (8, 6, 2, 10, 4, "dct", "sadct", "haar"), 72, 0),
+    ("ht-k32-bior", 1, 25.0, (2, 6, 2, 32, 8, "bior", "sadct", "haar"), 112, 0),
+    ("wien-k32-dct", 2, 25.0, (2, 6, 2, 32, 8, "dct", "dct", "hw"), 112, 0),
+    ("ht-k4-bior", 1, 25.0, (4, 5, 2, 4, 2, "bior", "sadct", "haar"), 48, 0),
 ]
 
 
