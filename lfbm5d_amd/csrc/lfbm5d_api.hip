@@ -225,9 +225,9 @@ void build_tables(GroupTables& t, unsigned k, unsigned aw, unsigned ah) {
         }
     for (unsigned u = 0; u < 3; u++)
         for (unsigned j = 0; j < 3; j++) t.cos3[u * 3 + j] = (float)std::cos(kPi * (j + 0.5) * u / 3.0);
-    for (unsigned u = 0; u < aw && aw <= (unsigned)kMaxAw; u++)
+    for (unsigned u = 0; u < aw && aw <= (unsigned)kBigAw; u++)
         for (unsigned j = 0; j < aw; j++) t.cosw[u * aw + j] = (float)std::cos(kPi * (j + 0.5) * u / (double)aw);
-    for (unsigned n = 1; n <= (unsigned)kMaxAw; n++) {
+    for (unsigned n = 1; n <= (unsigned)kBigAw; n++) {
         for (unsigned u = 0; u < n; u++)
             for (unsigned j = 0; j < n; j++) t.cos1[n][u * n + j] = (float)std::cos(kPi * (j + 0.5) * u / n);
         const float c1 = (float)((float)kSqrt2 / std::sqrt((double)n));
@@ -266,7 +266,10 @@ int validate(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsig
         if (P->nSim < 1 || P->nSim > 48 || P->p < 1) return fail(c, "bad search window / step");
         return 0;
     }
-    if (aw != ah || (aw != 3 && aw != 5 && aw != 7)) return fail(c, "unsupported: angular search window must be 3x3, 5x5 or 7x7 (aswSize 1 to 3)");
+    /* any odd window side up to 17 (aswSize 1 .. 8): 3x3 on the dedicated kernels, 5x5 and 7x7 on the generic kernel's register forms,
+     * 9x9 and more on its general forms (run-time transform sizes, stacks in HBM: slow, but the reference's whole range for light
+     * fields of up to 17x17 SAIs, bm5d.cpp:119-124) */
+    if (aw != ah || aw < 3 || !(aw & 1) || aw > (unsigned)kBigAw) return fail(c, "unsupported: angular search window must be a square of 3 .. 17 SAIs a side (aswSize 1 to 8)");
     if (C != 1 && C != 3) return fail(c, "unsupported: chnls must be 1 or 3");
     /* any patch size the reference would run (utilities_LF.cpp:1214, :1255; Kaiser window: all ones unless k is 8 or 12, bm3d.cpp:1144-1146);
      * 8, 12 and 16 have dedicated table kernels, 8 and 16 dedicated group kernels, everything else the general forms.  32 bounds the tables */
@@ -312,10 +315,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     const float thr = tauMatch * k * k;                                                                  /* core:3315 */
     float lambda = P->lambda;
     if (!bm3d && step == 1 && P->tau_2D == LFBM5D_ID && P->tau_4D == LFBM5D_DCT) lambda /= (float)kSqrt2; /* core:206-207 */
-    unsigned long long mask_bits = 0, proc_bits = 0;
-    for (unsigned st = 0; st < A; st++) { if (h_mask[st]) mask_bits |= 1ull << st; if (h_proc[st]) proc_bits |= 1ull << st; }
+    SaiMask mask_bits = sai_mask_none(), proc_bits = sai_mask_none();
+    for (unsigned st = 0; st < A; st++) { if (h_mask[st]) mask_bits.set(st); if (h_proc[st]) proc_bits.set(st); }
     if (pst >= A || cst >= A) return fail(c, "cst / pst outside the angular window");
-    if (!((mask_bits >> pst) & 1)) return fail(c, "processed SAI is empty");
+    if (!mask_bits.test(pst)) return fail(c, "processed SAI is empty");
 
     /* reference grid (core:149-156); cached while the geometry is unchanged */
     const bool centre = pst == cst;
@@ -409,8 +412,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     }
 
     const unsigned NsS = 2 * P->nSim + 1, NsD = 2 * P->nDisp + 1;
-    unsigned slots[kMaxA]; unsigned n_slots = 0;
-    for (unsigned st = 0; st < A; st++) if (st != pst && ((mask_bits >> st) & 1)) slots[n_slots++] = st;
+    unsigned slots[kBigA]; unsigned n_slots = 0;
+    for (unsigned st = 0; st < A; st++) if (st != pst && mask_bits.test(st)) slots[n_slots++] = st;
     const unsigned Nst = N > 1 ? N : 1;
     /* slack on both sides: the scan's 16-byte row loads start one column left of the band (one float before
      * the first plane for the left-most displacement) and overrun the last row by less than a ring row */
@@ -453,7 +456,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->gpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gofs.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gok.reserve((size_t)R * Nst * sizeof(unsigned)));
-    HIPCK(c, c->gshape.reserve((size_t)R * kShapeInfoBytes));
+    HIPCK(c, c->gshape.reserve((size_t)R * (A > (unsigned)kMaxA ? kShapeInfoBigBytes : kShapeInfoBytes)));
     HIPCK(c, gc.tb.reserve(sizeof(GroupTables)));
     if (!c->counters.p) {   /* [step slot][16]: sum nSx, shape-adaptive groups, development clocks */
         HIPCK(c, c->counters.reserve(32 * sizeof(unsigned long long)));
@@ -885,7 +888,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             sum_xfer[X.from][(size_t)(std::find(pn.sai.begin(), pn.sai.end(), X.sai) - pn.sai.begin())] = (int)xi;
         } else basic_xfer[(size_t)X.to_rank][X.sai] = (int)xi;
     }
-    std::vector<unsigned long long> win_bits(NN, 0);
+    std::vector<SaiMask> win_bits(NN, sai_mask_none());
     std::vector<char> mine(NN, 0);
     ncclComm_t comms[2] = {c->comm, c->comm2 ? c->comm2 : c->comm};
     size_t xi = 0, n_msgs = 0;
@@ -940,7 +943,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
                     const unsigned slot = ang_major == LFBM5D_ROWMAJOR ? si * g.asw + ti : si + ti * g.asw;
                     mask_w[slot] = h_mask[st];
                     wl.st[slot] = h_mask[st] ? st : 0xffffffffu;
-                    if (h_mask[st]) win_bits[n] |= 1ull << slot;
+                    if (h_mask[st]) win_bits[n].set(slot);
                     proc_w[slot] = !h_mask[st];
                 }
             const bool wien = J.step[sl] == 2;
@@ -970,9 +973,9 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             HIPCK(c, hipEventRecord(done[n], ls));
             mine[n] = 1;
             if (io && !outs[n].empty()) {   /* the SAIs nobody touches after this window: their outputs, in the form the caller gets them */
-                for (size_t o0 = 0; o0 < outs[n].size(); o0 += (size_t)kMaxA) {
+                for (size_t o0 = 0; o0 < outs[n].size(); o0 += (size_t)kBigA) {
                     SaiList ol; ol.n = 0;
-                    for (size_t q = o0; q < outs[n].size() && ol.n < (unsigned)kMaxA; q++) ol.st[ol.n++] = outs[n][q];
+                    for (size_t q = o0; q < outs[n].size() && ol.n < (unsigned)kBigA; q++) ol.st[ol.n++] = outs[n][q];
                     HIPCK(c, launch_output_multi(ls, S->g_num[Ls], S->g_den[Ls], J.step[Ls] == 1 ? J.noisy[Ls] : S->basic, J.d_out,
                                                  J.step[Ls] == 2 ? S->basic : nullptr, J.noisy[Ls], J.d_noisy, img, ol, J.color_space, W * H, colour_io ? 1 : 0));
                 }
@@ -1049,9 +1052,9 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         for (unsigned st = 0; st < asize; st++) if (h_mask[st] && G.last_touch[Ls][st] < 0) rest.push_back(st);
         if (!rest.empty()) {
             for (RankState& S : states) for (Lane& Lq : S.lanes) HIPCK(c, hipStreamSynchronize(Lq.x->stream));
-            for (size_t o0 = 0; o0 < rest.size(); o0 += (size_t)kMaxA) {
+            for (size_t o0 = 0; o0 < rest.size(); o0 += (size_t)kBigA) {
                 SaiList ol; ol.n = 0;
-                for (size_t q = o0; q < rest.size() && ol.n < (unsigned)kMaxA; q++) ol.st[ol.n++] = rest[q];
+                for (size_t q = o0; q < rest.size() && ol.n < (unsigned)kBigA; q++) ol.st[ol.n++] = rest[q];
                 HIPCK(c, launch_output_multi(c->io_in, J.g_num[Ls], J.g_den[Ls], J.step[Ls] == 1 ? J.noisy[Ls] : J.d_basic, J.d_out,
                                              J.step[Ls] == 2 ? J.d_basic : nullptr, J.noisy[Ls], J.d_noisy, img, ol, J.color_space, W * H, colour_io ? 1 : 0));
             }
@@ -1071,7 +1074,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
     for (size_t n = 0; n < NN; n++) {
         if (!mine[n]) continue;
         const int sl = G.nodes[n].s;
-        const unsigned n_mask = (unsigned)__builtin_popcountll(win_bits[n]);
+        const unsigned n_mask = win_bits[n].count();
         unsigned covered = 0;
         for (unsigned q = 0; q < kWinCounters; q++) covered += c->h_counts[n * kWinCounters + q];
         const float pct = (float)covered * 100.0f / (float)n_mask / (float)(H - J.P[sl]->k + 1) / (float)(W - J.P[sl]->k + 1);
@@ -1216,7 +1219,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
      * runs whatever further passes the window needs (greyscale light fields) and adds the window back to the light field. */
     struct Lane { lfbm5d_ctx* x; float* w_noisy; float* w_basic; float* w_num; float* w_den; unsigned* d_small; float* g_num; float* g_den; };
     struct WinState {
-        unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, rem_w = 0, tot_w = 0, pst_w = 0; unsigned long long win_bits = 0;
+        unsigned ps = 0, pt = 0; int cs_w = 0, mins = 0, ct_w = 0, mint = 0; unsigned cst_w = 0, rem_w = 0, tot_w = 0, pst_w = 0; SaiMask win_bits = sai_mask_none();
         std::vector<unsigned> st_idx, mask_w, proc_w; SaiList sl; lfbm5d_params Pw; bool counted = false;
         unsigned* h_count_dst = nullptr;   /* pinned word the coverage count is copied to (default: the lane's) */
         float tile_pct = 0.0f;             /* tile mode: sum of the tiles' LF_denoised_percent of the last pass */
@@ -1267,7 +1270,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
         HIPCK(c, x->und_den.reserve(Aw * img * sizeof(float)));
         float* tn = x->t_noisy.as<float>(); float* tb = x->t_basic.as<float>();
         float* tu = x->t_tnum.as<float>(); float* td = x->t_tden.as<float>();
-        const unsigned n_mask = (unsigned)__builtin_popcountll(ws.win_bits);
+        const unsigned n_mask = ws.win_bits.count();
         ws.tile_pct = 0.0f;
         const unsigned long long passes0 = x->stats.passes;   /* a window pass counts once, not once per tile */
         for (unsigned kt = 0; kt < tl_nw * tl_nh; kt++) {
@@ -1331,11 +1334,11 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
                 else ws.st_idx[si + ti * asw] = S + T * aheight;
             }
         ws.sl.n = Aw;
-        ws.win_bits = 0;
+        ws.win_bits = sai_mask_none();
         for (unsigned i = 0; i < Aw; i++) {
             ws.mask_w[i] = h_mask[ws.st_idx[i]];
             ws.sl.st[i] = ws.mask_w[i] ? ws.st_idx[i] : 0xffffffffu;
-            if (ws.mask_w[i]) ws.win_bits |= 1ull << i;
+            if (ws.mask_w[i]) ws.win_bits.set(i);
         }
         HIPCK(c, launch_symetrize_multi(ls, d_noisy, img, L.w_noisy, imgb, ws.sl, W, H, C, nHW));
         if (step == 2) HIPCK(c, launch_symetrize_multi(ls, d_basic, img, L.w_basic, imgb, ws.sl, W, H, C, nHW));
@@ -1385,7 +1388,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
             HIPCK(c, hipStreamSynchronize(ls));
             ws.counted = false;
             /* LF_denoised_percent (utilities_LF.cpp:967-995): counts (i,j,c) triples, divides without C */
-            const unsigned n_mask = (unsigned)__builtin_popcountll(ws.win_bits);
+            const unsigned n_mask = ws.win_bits.count();
             const float pct = (float)L.x->h_small[0] * 100.0f / (float)n_mask / (float)(H - P->k + 1) / (float)(W - P->k + 1);
             if (n_tiles > 1 ? ws.tile_pct >= 100.0f * (float)(tl_nw * tl_nh) /* bm5d.cpp:668-672 */ : pct >= 100.0f)
                 for (unsigned i = 0; i < Aw; i++)

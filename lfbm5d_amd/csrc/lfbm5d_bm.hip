@@ -886,7 +886,7 @@ __global__ void k_self_trivial(const unsigned* __restrict__ refs, unsigned n_ref
 
 /* argmin over the (2 nDisp+1)^2 displacement tables (core:3581-3608); ties keep scan order
  * (dj outer, di inner), the order the reference pushes candidates in.  grid.y = table slot. */
-struct ArgminArgs { const float* tables; size_t tstride; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp; float thr; unsigned* best; unsigned char* shape; };
+struct ArgminArgs { const float* tables; size_t tstride; unsigned st_of_slot[kBigA]; int W, H, k, nDisp; float thr; unsigned* best; unsigned char* shape; };
 __global__ __launch_bounds__(256) void k_stereo_argmin(ArgminArgs a) {
     /* The tables are skewed (scan kernel, store stage): entry [strip][q][l] holds table row q - l of column 64 strip + l.
      * A thread takes four consecutive lanes l0 .. l0+3 of one skewed row q (one 16-byte load per table), eight tables in
@@ -1052,7 +1052,7 @@ hipError_t launch_stereo_argmin(hipStream_t s, const float* tables, const unsign
     const unsigned n = ((span_c + 63) / 64) * (span_r + 63) * 16;   /* groups of four lanes of every skewed row */
     ArgminArgs a;
     a.tables = tables; a.tstride = stereo_table_stride(W, H, k, nDisp); a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.thr = thr; a.best = best; a.shape = shape;
-    for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
+    for (unsigned i = 0; i < n_slots && i < (unsigned)kBigA; i++) a.st_of_slot[i] = st_of_slot[i];
     hipLaunchKernelGGL(k_stereo_argmin, dim3((n + 255) / 256, n_slots), dim3(256), 0, s, a);
     return hipGetLastError();
 }

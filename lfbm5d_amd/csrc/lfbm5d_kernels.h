@@ -12,9 +12,23 @@
 namespace lfbm5d {
 
 constexpr int kMaxK = 32;       /* largest patch side (dedicated kernels: 8, 12, 16; the general forms take any) */
-constexpr int kMaxA = 49;       /* SAIs per angular window: 3x3 (an = 1, every dedicated kernel), 5x5 or 7x7 (an = 2, 3: generic kernel) */
+constexpr int kMaxA = 49;       /* SAIs per angular window of the register forms: 3x3 (an = 1, every dedicated kernel), 5x5 or 7x7 (an = 2, 3: generic kernel) */
 constexpr int kA3 = 9;          /* ... of the 3x3 window the dedicated kernels are written for */
-constexpr int kMaxAw = 7;       /* side of the largest window */
+constexpr int kMaxAw = 7;       /* side of the largest such window */
+/* larger windows (aswSize 4 .. 8: 9x9 .. 17x17 SAIs; the reference takes any window that fits the light field, bm5d.cpp:119-124): the
+ * general forms -- run-time transform sizes, vectors in scratch memory, stacks in HBM -- slow, but no refusal */
+constexpr int kBigAw = 17;
+constexpr int kBigA = kBigAw * kBigAw;
+constexpr int kMaskWords = (kBigA + 63) / 64;
+/* one bit per SAI of an angular window */
+struct SaiMask {
+    unsigned long long w[kMaskWords];
+    __host__ __device__ bool test(unsigned i) const { return (w[i >> 6] >> (i & 63)) & 1ull; }
+    __host__ __device__ void set(unsigned i) { w[i >> 6] |= 1ull << (i & 63); }
+    __host__ __device__ unsigned count() const { unsigned n = 0; for (int i = 0; i < kMaskWords; i++) n += (unsigned)__builtin_popcountll(w[i]); return n; }
+    __host__ __device__ bool holds_all(unsigned n) const { for (unsigned i = 0; i < n; i++) if (!test(i)) return false; return true; }
+};
+inline SaiMask sai_mask_none() { SaiMask m; for (int i = 0; i < kMaskWords; i++) m.w[i] = 0; return m; }
 constexpr int kMaxN = 16;      /* max similar patches (power of two) of the light-field core and its dedicated kernels */
 constexpr int kMaxN3 = 32;     /* ... of the per-SAI BM3D flavour (generic group kernel only) */
 
@@ -26,14 +40,14 @@ struct GroupTables {
     float cn2[kMaxK * kMaxK];   /* coef_norm      (2-D patch DCT) */
     float cni2[kMaxK * kMaxK];  /* coef_norm_inv                  */
     float cos2[kMaxK * kMaxK];  /* cos(pi (j+1/2) u / k) at [u*k + j] */
-    float cn4[kMaxA];           /* coef_norm_4d */
-    float cni4[kMaxA];
+    float cn4[kBigA];           /* coef_norm_4d */
+    float cni4[kBigA];
     float cos3[9];              /* cos(pi (j+1/2) u / 3) */
-    float cosw[kMaxA];          /* cos(pi (j+1/2) u / aw) at [u*aw + j] for the window side aw (general angular DCT) */
-    float cos1[kMaxAw + 1][kMaxA]; /* SADCT: cos(pi (j+1/2) u / n) at [n][u*n + j], n = 1..7 */
-    float cn1[kMaxAw + 1][kMaxAw]; /* SADCT 1-D norms for length n (core:3229-3252) */
-    float cni1[kMaxAw + 1][kMaxAw];
-    float c1inv[kMaxAw + 1];    /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
+    float cosw[kBigA];          /* cos(pi (j+1/2) u / aw) at [u*aw + j] for the window side aw (general angular DCT) */
+    float cos1[kBigAw + 1][kBigA]; /* SADCT: cos(pi (j+1/2) u / n) at [n][u*n + j], n = 1..aw */
+    float cn1[kBigAw + 1][kBigAw]; /* SADCT 1-D norms for length n (core:3229-3252) */
+    float cni1[kBigAw + 1][kBigAw];
+    float c1inv[kBigAw + 1];    /* 0.5 * SQRT2_INV / sqrt(n) (core:2190) */
     float cos5[5][256];         /* 5th-dimension DCT: cos(pi (j+1/2) u / n) at [log2 n][u*n + j], n = 1..16 */
     float cos5x[1024];          /* ... and for n = 32 (generic kernel only) */
     float cn5_0[6], cn5[6];     /* coef_norm of preProcess_5d (core:3262-3276), [log2 n] */
@@ -43,7 +57,8 @@ struct GroupTables {
     float coef4inv;             /* 1 / (2 sqrt(aw) sqrt(ah))      (core:1945)     */
 };
 
-constexpr unsigned kShapeInfoBytes = (5 * kMaxA + 2 * kMaxAw + 1) * 4;
+constexpr unsigned kShapeInfoBytes = (5 * kMaxA + 2 * kMaxAw + 1) * 4;          /* per-group SADCT record, windows of up to 7x7 SAIs */
+constexpr unsigned kShapeInfoBigBytes = (5 * kBigA + 2 * kBigAw + 1) * 4;      /* ... larger windows */
 
 struct GroupArgs {
     const float* noisy;         /* [A][C][Hb][Wb] */
@@ -63,12 +78,12 @@ struct GroupArgs {
     unsigned* gpos;             /* [R][N][A] window position of every patch of every group (pre-pass output) */
     unsigned* gofs;             /* [R][N][A] the same as a byte offset into channel 0 of the patch's SAI (0 for an absent patch), and ...        */
     unsigned* gok;              /* [R][N] ... bit st set where patch (n, st) is there: what the register-resident HT kernel's scalar loads need */
-    void* gshape;               /* [R] kShapeInfoBytes each: SADCT bookkeeping of the group (pre-pass output) */
+    void* gshape;               /* [R] kShapeInfoBytes (A > 49: kShapeInfoBigBytes) each: SADCT bookkeeping of the group (pre-pass output) */
     unsigned n_refs_total;
     unsigned long long* counters; /* [0] sum nSx, [1] sadct groups */
     unsigned ref_begin, n_groups;
     unsigned Wb, Hb, C, A, k, N, pst;
-    unsigned long long mask_bits, proc_bits;   /* bit st: SAI st of the window is there / already processed */
+    SaiMask mask_bits, proc_bits;   /* bit st: SAI st of the window is there / already processed */
     unsigned tau2, tau4, tau5, useSD;
     unsigned fill_quirk;        /* 1 on the centre path: patches at column Wb-k read as zeros (core:1697) */
     int step;
@@ -96,7 +111,7 @@ struct AggArgs {
     unsigned ref_begin, n_groups;   /* groups [ref_begin, ref_begin + n_groups) of this rank */
     unsigned n_ref_rows, n_ref_cols;
     unsigned Wb, Hb, C, A, k, N, pst, p, nHW, nSim, nDisp;
-    unsigned long long mask_bits, proc_bits; unsigned tau4;
+    SaiMask mask_bits, proc_bits; unsigned tau4;
     unsigned irregular;         /* reference list is not the regular grid (subset path): scan every reference */
     unsigned wchan0;            /* every channel uses channel 0's group weight (sd_weighting of bm3d.cpp:1345-1373) */
 };
@@ -169,7 +184,7 @@ struct ScanArgs {
     /* stereo */
     unsigned long long* dbg;    /* development builds (LFBM5D_PHASE_TIMING): phase clocks; else unused */
     float* tables;              /* [n_slots][Ns*Ns][stereo_table_stride]: strip-major [strip][row][64 columns] */
-    unsigned st_of_slot[kMaxA];
+    unsigned st_of_slot[kBigA];
     /* second-generation kernel */
     unsigned est_planes;        /* SAIs in est */
     const Scan2Wg* wgs;         /* [n_wgs] workgroup descriptors (device) */
@@ -198,7 +213,7 @@ hipError_t launch_crop(hipStream_t s, float* dst, const float* src, unsigned W, 
 hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub,
                            float* est, size_t n);
 /* all SAIs of an angular window in one launch: slot i of the window <-> SAI L.st[i] of the light field */
-struct SaiList { unsigned st[kMaxA]; unsigned n; };
+struct SaiList { unsigned st[kBigA]; unsigned n; };
 /* two-step jobs: basic[st] = forward(inverse(den ? num / den : sub)) for the light-field SAIs L.st[0 .. L.n) (colour = 0: no
  * colour round trip); light fields with three channels of n_px pixels */
 hipError_t launch_finalize_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* basic, size_t sai_stride,
@@ -225,12 +240,12 @@ hipError_t launch_window_begin(hipStream_t s, const float* noisy, const float* b
 hipError_t launch_window_end(hipStream_t s, float* num, float* den, size_t lf_stride, const float* w_num, const float* w_den, size_t w_stride,
                              const SaiList& L, unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count);
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
-                                 size_t plane, unsigned C, unsigned A, unsigned long long mask_bits);
+                                 size_t plane, unsigned C, unsigned A, const SaiMask& mask_bits);
 /* w x h rectangle of every channel of n_slots images: dst image (dW x dH, slots dst_stride apart) at (dx0, dy0) <- src image
  * (sW x sH) at (sx0, sy0).  The reference's sub_divide / undivide_LF (utilities.cpp:312-395, utilities_LF.cpp:438-515) */
 hipError_t launch_copy_rect(hipStream_t s, float* dst, size_t dst_stride, unsigned dW, unsigned dH, unsigned dx0, unsigned dy0,
                             const float* src, size_t src_stride, unsigned sW, unsigned sH, unsigned sx0, unsigned sy0,
-                            unsigned w, unsigned h, unsigned C, unsigned n_slots, unsigned long long mask_bits);
+                            unsigned w, unsigned h, unsigned C, unsigned n_slots, const SaiMask& mask_bits);
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n);
 hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n);
 hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   /* dst += src */
@@ -238,7 +253,7 @@ hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   
 hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsigned n_seg,
                               unsigned* counts);
 /* LF_denoised_percent numerator on a padded window image (utilities_LF.cpp:985-992) */
-hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned long long mask_bits,
+hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, const SaiMask& mask_bits,
                                  unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count);
 hipError_t launch_refmap(hipStream_t s, const unsigned* refs, unsigned n_refs, int* refmap);
 /* subset pass: the regular grid's patches (rows / columns nHW + i p, the last forced to last_r / last_c) whose footprint holds a zero

@@ -135,9 +135,9 @@ __global__ void k_estimate(const float* __restrict__ num, const float* __restric
 
 /* matching estimate (channel 0) of every non-empty SAI of a window: blockIdx.y = SAI */
 __global__ void k_estimate_multi(const float* __restrict__ num, const float* __restrict__ den, const float* __restrict__ sub,
-                                 float* __restrict__ est, size_t plane, unsigned C, unsigned long long mask_bits) {
+                                 float* __restrict__ est, size_t plane, unsigned C, SaiMask mask_bits) {
     const unsigned st = blockIdx.y;
-    if (!((mask_bits >> st) & 1)) return;
+    if (!mask_bits.test(st)) return;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= plane) return;
     const size_t o = (size_t)st * C * plane + i;
@@ -215,8 +215,8 @@ __global__ void k_output_multi(const float* __restrict__ num, const float* __res
 
 __global__ void k_copy_rect(float* __restrict__ dst, size_t dst_stride, int dW, int dH, int dx0, int dy0,
                             const float* __restrict__ src, size_t src_stride, int sW, int sH, int sx0, int sy0,
-                            int w, int h, int C, unsigned long long mask_bits) {
-    if (!((mask_bits >> blockIdx.y) & 1)) return;      /* blockIdx.y = window slot */
+                            int w, int h, int C, SaiMask mask_bits) {
+    if (!mask_bits.test(blockIdx.y)) return;      /* blockIdx.y = window slot */
     const size_t total = (size_t)w * h * C;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -257,10 +257,10 @@ __global__ void k_count_zeros(const float* __restrict__ den, size_t seg, unsigne
     if (threadIdx.x == 0 && t) atomicAdd(&counts[blockIdx.y], t);
 }
 
-__global__ void k_count_denoised(const float* __restrict__ den, size_t sai_stride, unsigned long long mask_bits, int W, int H, int C, int N, int k,
+__global__ void k_count_denoised(const float* __restrict__ den, size_t sai_stride, SaiMask mask_bits, int W, int H, int C, int N, int k,
                                  unsigned* __restrict__ count) {
     __shared__ unsigned red[4];
-    if (!((mask_bits >> blockIdx.y) & 1)) return;      /* blockIdx.y = window slot */
+    if (!mask_bits.test(blockIdx.y)) return;      /* blockIdx.y = window slot */
     den += blockIdx.y * sai_stride;
     const int w = W + 2 * N, h = H + 2 * N;
     const int sw = W - k + 1, sh = H - k + 1;
@@ -358,16 +358,23 @@ __global__ __launch_bounds__(256) void k_window_end(WinEndArgs a) {
 
 constexpr int kThreads = 256;
 
-struct ShapeInfo {           /* SADCT bookkeeping of one group (core:302-323, :2036-2049, :2102-2104) */
-    int mask[kMaxA], idx[kMaxA], mask_col[kMaxA], idx_col[kMaxA], mask_dct[kMaxA];   /* [s * aw + t], aw = window side */
-    int row_n[kMaxAw], col_n[kMaxAw];
+template <int MA, int MW>
+struct ShapeInfoT {          /* SADCT bookkeeping of one group (core:302-323, :2036-2049, :2102-2104) */
+    int mask[MA], idx[MA], mask_col[MA], idx_col[MA], mask_dct[MA];   /* [s * aw + t], aw = window side */
+    int row_n[MW], col_n[MW];
     int use_sadct;
 };
-static_assert(sizeof(ShapeInfo) == kShapeInfoBytes, "GroupArgs::gshape stride");
+typedef ShapeInfoT<kMaxA, kMaxAw> ShapeInfo;        /* windows of up to 7x7 SAIs */
+typedef ShapeInfoT<kBigA, kBigAw> ShapeInfoBig;     /* larger windows (general forms only) */
+static_assert(sizeof(ShapeInfo) == kShapeInfoBytes && sizeof(ShapeInfoBig) == kShapeInfoBigBytes, "GroupArgs::gshape stride");
 /* the per-group ShapeInfo written by the pre-pass is constant during the group kernels: scalar loads */
 typedef const __attribute__((address_space(4))) ShapeInfo& ShRef;
+typedef const __attribute__((address_space(4))) ShapeInfoBig& ShRefBig;
+/* side of a square window of A SAIs */
+__device__ __forceinline__ int window_side(int A) { int w = 1; while (w * w < A) w++; return w; }
 
-__device__ void build_shape(ShapeInfo& sh, const int* m, int aw) {
+template <class SH>
+__device__ void build_shape(SH& sh, const int* m, int aw) {
     const int A = aw * aw;
     int size = 0;
     for (int i = 0; i < A; i++) { sh.mask[i] = m[i]; sh.idx[i] = 0; sh.mask_col[i] = 0; sh.idx_col[i] = 0; sh.mask_dct[i] = 0; size += m[i]; }
@@ -833,8 +840,39 @@ __device__ __forceinline__ void dctw_inv_t(float (&x)[AW * AW], TbPtr tb) {
             x[i * AW + j] = (t[j] + 2.0f * acc) * tb->coef4inv;
         }
 }
-__device__ __noinline__ void sadctw_fwd(float* v, int aw, ShRef sh, TbPtr tb) {
-    float x[kMaxAw], y[kMaxAw];
+/* ... and with a run-time window side, on a vector in scratch memory (windows larger than 7x7) */
+__device__ __noinline__ void dctw_fwd_rt(float* x, float* t, int aw, TbPtr tb) {
+    for (int s = 0; s < aw; s++)
+        for (int u = 0; u < aw; u++) {
+            float acc = 0.0f;
+            for (int j = 0; j < aw; j++) acc += x[s * aw + j] * tb->cosw[u * aw + j];
+            t[s * aw + u] = 2.0f * acc;
+        }
+    for (int v = 0; v < aw; v++)
+        for (int u = 0; u < aw; u++) {
+            float acc = 0.0f;
+            for (int j = 0; j < aw; j++) acc += t[j * aw + u] * tb->cosw[v * aw + j];
+            x[v * aw + u] = 2.0f * acc * tb->cn4[v * aw + u];
+        }
+}
+__device__ __noinline__ void dctw_inv_rt(float* x, float* t, int aw, TbPtr tb) {
+    for (int i = 0; i < aw * aw; i++) x[i] *= tb->cni4[i];
+    for (int s = 0; s < aw; s++)
+        for (int j = 0; j < aw; j++) {
+            float acc = 0.0f;
+            for (int u = 1; u < aw; u++) acc += x[s * aw + u] * tb->cosw[u * aw + j];
+            t[s * aw + j] = x[s * aw] + 2.0f * acc;
+        }
+    for (int i = 0; i < aw; i++)
+        for (int j = 0; j < aw; j++) {
+            float acc = 0.0f;
+            for (int v = 1; v < aw; v++) acc += t[v * aw + j] * tb->cosw[v * aw + i];
+            x[i * aw + j] = (t[j] + 2.0f * acc) * tb->coef4inv;
+        }
+}
+template <class SHR>
+__device__ __noinline__ void sadctw_fwd(float* v, int aw, SHR sh, TbPtr tb) {
+    float x[kBigAw], y[kBigAw];
     for (int s = 0; s < aw; s++) {
         const int n = sh.row_n[s];
         if (n == 1) v[s * aw] = v[s * aw + sh.idx[s * aw]];
@@ -856,8 +894,9 @@ __device__ __noinline__ void sadctw_fwd(float* v, int aw, ShRef sh, TbPtr tb) {
     const float coef = 0.5f * 0.70710678118654752f;
     for (int i = 0; i < aw * aw; i++) v[i] *= (float)sh.mask_dct[i] * coef;
 }
-__device__ __noinline__ void sadctw_inv(float* v, int aw, ShRef sh, TbPtr tb) {
-    float x[kMaxAw], y[kMaxAw];
+template <class SHR>
+__device__ __noinline__ void sadctw_inv(float* v, int aw, SHR sh, TbPtr tb) {
+    float x[kBigAw], y[kBigAw];
     const float coef = 2.0f * 1.41421356237309505f;
     for (int t = 0; t < aw; t++) {
         const int n = sh.col_n[t];
@@ -1510,7 +1549,7 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
     const bool want_ofs = A == 9 && a.tau2 == 4 && a.step == 1 && (size_t)A * a.C * plane * 4 < 0x7fffffffull;
     unsigned bits = 0;
     for (int st = 0; st < A; st++) {
-        const bool masked = (a.mask_bits >> st) & 1;
+        const bool masked = a.mask_bits.test((unsigned)st);
         unsigned p = 0xffffffffu;
         if (n < nSx && masked) p = (st == (int)a.pst) ? ind_pst : a.best[(size_t)st * plane + ind_pst];
         /* gather position: patches whose column equals Wb-k read the reference's never-filled table
@@ -1531,7 +1570,9 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
     }
     if (want_ofs) a.gok[(size_t)g * N + n] = bits;
 }
+template <bool BIG>   /* BIG: windows of more than 7x7 SAIs (records of kShapeInfoBigBytes, built in place in global memory) */
 __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
+    typedef typename std::conditional<BIG, ShapeInfoBig, ShapeInfo>::type SH;
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_groups) return;
     const unsigned g = a.ref_begin + i;
@@ -1539,13 +1580,26 @@ __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     const unsigned k_r = a.refs[g];
     /* only what the group kernels read is written: the first A entries of each array (the record is sized for a 7x7
      * window, a 3x3 one uses a fifth of it), and nothing but the flag when the angular transform is not shape-adaptive */
-    ShapeInfo* out = reinterpret_cast<ShapeInfo*>(a.gshape) + g;
+    SH* out = reinterpret_cast<SH*>(a.gshape) + g;
     if (a.tau4 != 6) { out->use_sadct = 0; return; }
-    ShapeInfo sh;
-    const int A = (int)a.A, aw = A == 9 ? 3 : A == 25 ? 5 : 7;
-    int m[kMaxA], full = 0;
+    const int A = (int)a.A, aw = window_side(A);
+    if (BIG) {
+        int* m = out->mask_dct;   /* (scratch until build_shape overwrites it: the shape goes in through a second array) */
+        int full = 0;
+        for (int st = 0; st < A; st++) {
+            const bool masked = a.mask_bits.test((unsigned)st);
+            m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
+            full += m[st];
+        }
+        if (full == A) { out->use_sadct = 0; return; }
+        for (int st = 0; st < A; st++) out->mask[st] = m[st];
+        build_shape(*out, out->mask, aw);
+        return;
+    }
+    SH sh;
+    int m[BIG ? 1 : kMaxA], full = 0;
     for (int st = 0; st < A; st++) {
-        const bool masked = (a.mask_bits >> st) & 1;
+        const bool masked = a.mask_bits.test((unsigned)st);
         m[st] = (st == (int)a.pst || (masked && a.shape[(size_t)st * plane + k_r])) ? 1 : 0;
         full += m[st];
     }
@@ -1564,6 +1618,10 @@ __device__ __forceinline__ ShRef group_shape(const GroupArgs& a, unsigned g) {
     return *reinterpret_cast<const __attribute__((address_space(4))) ShapeInfo*>(
         (const __attribute__((address_space(4))) char*)a.gshape + (size_t)g * sizeof(ShapeInfo));
 }
+__device__ __forceinline__ ShRefBig group_shape_big(const GroupArgs& a, unsigned g) {
+    return *reinterpret_cast<const __attribute__((address_space(4))) ShapeInfoBig*>(
+        (const __attribute__((address_space(4))) char*)a.gshape + (size_t)g * sizeof(ShapeInfoBig));
+}
 
 /* One (group, channel) of the generic path.  S0 / S1: the group's stack(s) [n][st][pq] -- in LDS (k_group) or, when the
  * stacks do not fit the 160 KiB, in a per-workgroup slice of an HBM scratch buffer (k_group_big); tmp: the 2-D stage's
@@ -1577,12 +1635,12 @@ __device__ __forceinline__ unsigned xcd_group_index(const GroupArgs& a) {
     return (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
 }
 
-template <int STEP>
+template <int STEP, bool BIG = false>
 __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned g, const int c, float* S0, float* S1, float* tmp,
                                               unsigned* pos, float (*red)[kThreads / 64]) {
     const int tid = threadIdx.x;
     const int k = a.k, k2 = k * k, A = a.A, N = a.N;
-    const int aw = A == 9 ? 3 : A == 25 ? 5 : 7;
+    const int aw = window_side(A);
     const int nSx = (int)a.self_cnt[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
     const int stack = nSx * A * k2;
@@ -1590,7 +1648,8 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
 
     /* patch positions (core:286-299) and the SADCT shape of this group (core:302-323): from the pre-pass */
     for (int i = tid; i < nSx * A; i += kThreads) pos[i] = a.gpos[(size_t)g * N * A + i];   /* up to 32 x 9 > 256 */
-    ShRef sh = group_shape(a, g);
+    typename std::conditional<BIG, ShRefBig, ShRef>::type sh = [&]() -> typename std::conditional<BIG, ShRefBig, ShRef>::type {
+        if constexpr (BIG) return group_shape_big(a, g); else return group_shape(a, g); }();
     __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
 
@@ -1637,6 +1696,12 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
             const int n = f / k2, pq = f % k2;
             for (int s = 0; s < (STEP == 2 ? 2 : 1); s++) {
                 float* S = s ? S1 : S0;
+                if constexpr (BIG) {   /* more than 7x7 SAIs: run-time sizes, the vector in scratch memory */
+                    float x[kBigA], t[kBigA];
+                    for (int st = 0; st < A; st++) x[st] = S[(size_t)(n * A + st) * k2 + pq];
+                    if (do_dct4) dctw_fwd_rt(x, t, aw, tb); else sadctw_fwd<ShRefBig>(x, aw, sh, tb);
+                    for (int st = 0; st < A; st++) S[(size_t)(n * A + st) * k2 + pq] = x[st];
+                } else
                 if (A == 9) {
                     float x[9];
 #pragma unroll
@@ -1661,7 +1726,7 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
                 } else {   /* shape-adaptive: the call form */
                     float x[kMaxA];
                     for (int st = 0; st < A; st++) x[st] = S[(n * A + st) * k2 + pq];
-                    sadctw_fwd(x, aw, sh, tb);
+                    if constexpr (!BIG) sadctw_fwd<ShRef>(x, aw, sh, tb);
                     for (int st = 0; st < A; st++) S[(n * A + st) * k2 + pq] = x[st];
                 }
             }
@@ -1717,6 +1782,12 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
     if (do_dct4 || do_sa4) {
         for (int f = tid; f < nSx * k2; f += kThreads) {
             const int n = f / k2, pq = f % k2;
+            if constexpr (BIG) {
+                float x[kBigA], t[kBigA];
+                for (int st = 0; st < A; st++) x[st] = F[(size_t)(n * A + st) * k2 + pq];
+                if (do_dct4) dctw_inv_rt(x, t, aw, tb); else sadctw_inv<ShRefBig>(x, aw, sh, tb);
+                for (int st = 0; st < A; st++) F[(size_t)(n * A + st) * k2 + pq] = x[st];
+            } else
             if (A == 9) {
                 float x[9];
 #pragma unroll
@@ -1741,7 +1812,7 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
             } else {
                 float x[kMaxA];
                 for (int st = 0; st < A; st++) x[st] = F[(n * A + st) * k2 + pq];
-                sadctw_inv(x, aw, sh, tb);
+                if constexpr (!BIG) sadctw_inv<ShRef>(x, aw, sh, tb);
                 for (int st = 0; st < A; st++) F[(n * A + st) * k2 + pq] = x[st];
             }
         }
@@ -1771,17 +1842,18 @@ __global__ __launch_bounds__(kThreads) void k_group(GroupArgs a) {
  * with 16x16 patches): a persistent launch, every workgroup owns a slice of an HBM scratch buffer for its stack(s) and
  * walks over (group, channel) items.  Global memory written by a workgroup is visible to it after a barrier (one CU, one
  * vector L1), so the phases are the LDS kernel's, only slower; the 2-D stage's work area stays in LDS. */
-template <int STEP>
-__global__ __launch_bounds__(kThreads) void k_group_big(GroupArgs a, float* scratch, unsigned long long slice_floats) {
+template <int STEP, bool BIG>
+__global__ __launch_bounds__(kThreads) void k_group_big(GroupArgs a, float* scratch, unsigned long long slice_floats, unsigned tmp_floats) {
     extern __shared__ float lds[];
-    __shared__ unsigned pos[kMaxN3 * kMaxA];
+    __shared__ unsigned pos_small[BIG ? 1 : kMaxN3 * kMaxA];
     __shared__ float red[3][kThreads / 64];
+    unsigned* pos = BIG ? reinterpret_cast<unsigned*>(lds + tmp_floats) : pos_small;   /* BIG: N x A positions behind the 2-D work area */
     float* S0 = scratch + (size_t)blockIdx.x * slice_floats;
     const unsigned items = a.n_groups * a.C;
     for (unsigned it = blockIdx.x; it < items; it += gridDim.x) {
         const unsigned g = a.ref_begin + it / a.C;
         const int stack = (int)a.self_cnt[g] * (int)a.A * (int)(a.k * a.k);
-        group_generic<STEP>(a, g, (int)(it % a.C), S0, STEP == 2 ? S0 + stack : nullptr, lds, pos, red);
+        group_generic<STEP, BIG>(a, g, (int)(it % a.C), S0, STEP == 2 ? S0 + stack : nullptr, lds, pos, red);
         __syncthreads();   /* pos / red / the scratch slice are reused by the next item */
     }
 }
@@ -3743,8 +3815,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
     if (lin2 >= total_wg) return;
     const int st = (int)(lin2 / (gx * gy));
     const int tile_y = (int)((lin2 / gx) % gy), tile_x = (int)(lin2 % gx);
-    if ((a.proc_bits >> st) & 1) return;      /* procSAI[st] != 0: skipped (core:486) */
-    if (!((a.mask_bits >> st) & 1)) return;
+    if (a.proc_bits.test((unsigned)st)) return;      /* procSAI[st] != 0: skipped (core:486) */
+    if (!a.mask_bits.test((unsigned)st)) return;
     const int tx0 = tile_x * TW, ty0 = tile_y * TH;
     const int x = tx0 + lane % TW, y = ty0 + lane / TW;
     const bool inside = x < (int)a.Wb && y < (int)a.Hb;
@@ -4022,7 +4094,7 @@ hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den,
 }
 hipError_t launch_copy_rect(hipStream_t s, float* dst, size_t dst_stride, unsigned dW, unsigned dH, unsigned dx0, unsigned dy0,
                             const float* src, size_t src_stride, unsigned sW, unsigned sH, unsigned sx0, unsigned sy0,
-                            unsigned w, unsigned h, unsigned C, unsigned n_slots, unsigned long long mask_bits) {
+                            unsigned w, unsigned h, unsigned C, unsigned n_slots, const SaiMask& mask_bits) {
     hipLaunchKernelGGL(k_copy_rect, dim3(grid1d((size_t)w * h * C).x, n_slots), dim3(256), 0, s, dst, dst_stride, (int)dW, (int)dH, (int)dx0,
                        (int)dy0, src, src_stride, (int)sW, (int)sH, (int)sx0, (int)sy0, (int)w, (int)h, (int)C, mask_bits);
     return hipGetLastError();
@@ -4069,7 +4141,7 @@ hipError_t launch_window_end(hipStream_t s, float* num, float* den, size_t lf_st
     return hipGetLastError();
 }
 hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* est,
-                                 size_t plane, unsigned C, unsigned A, unsigned long long mask_bits) {
+                                 size_t plane, unsigned C, unsigned A, const SaiMask& mask_bits) {
     hipLaunchKernelGGL(k_estimate_multi, dim3(grid1d(plane).x, A), dim3(256), 0, s, num, den, sub, est, plane, C, mask_bits);
     return hipGetLastError();
 }
@@ -4095,7 +4167,7 @@ hipError_t launch_count_zeros(hipStream_t s, const float* den, size_t seg, unsig
     hipLaunchKernelGGL(k_count_zeros, dim3(gx, n_seg), dim3(256), 0, s, den, seg, counts);
     return hipGetLastError();
 }
-hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, unsigned long long mask_bits,
+hipError_t launch_count_denoised(hipStream_t s, const float* den, size_t sai_stride, unsigned n_slots, const SaiMask& mask_bits,
                                  unsigned W, unsigned H, unsigned C, unsigned N, unsigned k, unsigned* count) {
     hipLaunchKernelGGL(k_count_denoised, dim3(128, n_slots), dim3(256), 0, s, den, sai_stride, mask_bits, (int)W, (int)H, (int)C, (int)N, (int)k, count);
     return hipGetLastError();
@@ -4145,16 +4217,17 @@ static bool group_uses_generic(const GroupArgs& a) {   /* mirrors launch_group's
     return true;
 }
 size_t group_scratch_bytes(const GroupArgs& a) {
-    if (!group_uses_generic(a) || group_lds_bytes(a) <= (size_t)kGenericLdsLimit) return 0;
+    if (!group_uses_generic(a) || (group_lds_bytes(a) <= (size_t)kGenericLdsLimit && a.A <= (unsigned)kMaxA)) return 0;
     return (size_t)kBigBlocks * (a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);
 }
 hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     /* geometry pre-pass: patch positions, aggregation positions, angular shapes */
     hipLaunchKernelGGL(k_group_pos, grid1d((size_t)a.n_groups * a.N), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_group_shape, grid1d(a.n_groups), dim3(256), 0, s, a);
+    const bool bigA = a.A > (unsigned)kMaxA;
+    if (bigA) hipLaunchKernelGGL(k_group_shape<true>, grid1d(a.n_groups), dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL(k_group_shape<false>, grid1d(a.n_groups), dim3(256), 0, s, a);
     /* a window with an empty SAI: tau_4D is the shape-adaptive transform (bm5d.cpp:276-280) and every group uses it */
-    const unsigned long long full = a.A >= 64 ? ~0ull : (1ull << a.A) - 1ull;
-    const bool all_sa = a.tau4 == 6 && (a.mask_bits & full) != full && getenv("LFBM5D_NO_SA_KERNELS") == nullptr;
+    const bool all_sa = a.tau4 == 6 && !a.mask_bits.holds_all(a.A) && getenv("LFBM5D_NO_SA_KERNELS") == nullptr;
     /* LFBM5D_GROUP_GENERIC: test hook, every configuration through the generic LDS kernel (the dedicated kernels' cross-check) */
     const bool generic_only = getenv("LFBM5D_GROUP_GENERIC") != nullptr;
     /* no 2-D transform and a stack small enough for registers: register-resident kernel */
@@ -4236,13 +4309,18 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         return hipGetLastError();
     }
     const size_t lds = group_lds_bytes(a);
-    if (lds > (size_t)kGenericLdsLimit) {   /* stacks in HBM scratch slices, persistent workgroups */
+    if (lds > (size_t)kGenericLdsLimit || bigA) {   /* stacks in HBM scratch slices, persistent workgroups */
         const unsigned long long slice = (unsigned long long)(a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k;
         if (!a.scratch || a.scratch_floats < slice * kBigBlocks) return hipErrorInvalidValue;
         const unsigned blocks = std::min<unsigned>(kBigBlocks, a.n_groups * a.C);
-        const size_t ltmp = group_tmp_floats(a) * sizeof(float);
-        if (a.step == 2) hipLaunchKernelGGL(k_group_big<2>, dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice);
-        else             hipLaunchKernelGGL(k_group_big<1>, dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice);
+        const unsigned tf = (unsigned)group_tmp_floats(a);
+        const size_t ltmp = (size_t)tf * sizeof(float) + (bigA ? (size_t)a.N * a.A * sizeof(unsigned) : 0);
+        if (bigA) {
+            if (a.step == 2) hipLaunchKernelGGL((k_group_big<2, true>), dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice, tf);
+            else             hipLaunchKernelGGL((k_group_big<1, true>), dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice, tf);
+        }
+        else if (a.step == 2) hipLaunchKernelGGL((k_group_big<2, false>), dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice, tf);
+        else                  hipLaunchKernelGGL((k_group_big<1, false>), dim3(blocks), dim3(kThreads), ltmp, s, a, a.scratch, slice, tf);
         return hipGetLastError();
     }
     if (a.step == 2) hipLaunchKernelGGL(k_group<2>, dim3(a.n_groups, a.C), dim3(kThreads), lds, s, a);

@@ -707,7 +707,7 @@ __global__ __launch_bounds__((kS2NW + kS2NL) * 64) void k_bm_scan2(ScanArgs a) {
 /* argmin over the (2 nDisp+1)^2 displacement tables (core:3581-3608) in the second-generation layout
  * [strip][Q / 4][lane][Q % 4], Q = table row + lane + 3: a thread takes the four entries of one lane (one 16-byte load per
  * table) = four consecutive rows of one column; ties keep scan order (dj outer, di inner). */
-struct Argmin2Args { const float* tables; size_t tstride; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp, SRq; float thr; unsigned* best; unsigned char* shape; };
+struct Argmin2Args { const float* tables; size_t tstride; unsigned st_of_slot[kBigA]; int W, H, k, nDisp, SRq; float thr; unsigned* best; unsigned char* shape; };
 __global__ __launch_bounds__(256) void k_stereo_argmin2(Argmin2Args a) {
     const int W = a.W, H = a.H, nDisp = a.nDisp;
     const int span_c = W - 2 * nDisp - a.k + 1, span_r = H - 2 * nDisp - a.k + 1;
@@ -878,7 +878,7 @@ hipError_t launch_bm_scan2(hipStream_t s, const ScanArgs& a, size_t lds, bool co
 /* arg-min of the combined form: over the (value, order) pairs of a slot's workgroups, position by position; the edge
  * positions (column 0, row 0 of every strip's first column) over the per-table edge arrays.  Ties: the smaller scan order
  * (core:3581-3608). */
-struct Argmin3Args { const float* tables; unsigned st_of_slot[kMaxA]; int W, H, k, nDisp, n_slots, nwg_slot; float thr; unsigned* best; unsigned char* shape; };
+struct Argmin3Args { const float* tables; unsigned st_of_slot[kBigA]; int W, H, k, nDisp, n_slots, nwg_slot; float thr; unsigned* best; unsigned char* shape; };
 __global__ __launch_bounds__(256) void k_stereo_argmin3(Argmin3Args a) {
     const int W = a.W, H = a.H, nDisp = a.nDisp;
     const int span_c = W - 2 * nDisp - a.k + 1, span_r = H - 2 * nDisp - a.k + 1;
@@ -951,7 +951,7 @@ hipError_t launch_stereo_argmin3(hipStream_t s, const float* tables, const unsig
                                  unsigned* best, unsigned char* shape) {
     Argmin3Args a;
     a.tables = tables; a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.n_slots = (int)n_slots; a.nwg_slot = (int)nwg_slot; a.thr = thr; a.best = best; a.shape = shape;
-    for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
+    for (unsigned i = 0; i < n_slots && i < (unsigned)kBigA; i++) a.st_of_slot[i] = st_of_slot[i];
     const unsigned span_c = W - 2 * nDisp - k + 1, span_r = H - 2 * nDisp - k + 1;
     const unsigned nstrips = (span_c - 1 + 63) / 64;
     const unsigned n = nstrips * stereo_part_chunks(H, k, nDisp) * 256 + 16 * (span_r + nstrips);
@@ -967,7 +967,7 @@ hipError_t launch_stereo_argmin2(hipStream_t s, const float* tables, const unsig
     a.tables = tables; a.tstride = stereo_table_stride2(W, H, k, nDisp); a.W = (int)W; a.H = (int)H; a.k = (int)k; a.nDisp = (int)nDisp; a.thr = thr; a.best = best; a.shape = shape;
     a.SRq = (int)stereo_table_srq(H, k, nDisp);
     const unsigned n = ((span_c - 1 + 63) / 64) * a.SRq * 64 + a.SRq;
-    for (unsigned i = 0; i < n_slots && i < (unsigned)kMaxA; i++) a.st_of_slot[i] = st_of_slot[i];
+    for (unsigned i = 0; i < n_slots && i < (unsigned)kBigA; i++) a.st_of_slot[i] = st_of_slot[i];
     hipLaunchKernelGGL(k_stereo_argmin2, dim3((n + 255) / 256, n_slots), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -40,6 +40,7 @@ double now_s() {
 /* FFTW r2r kinds restated (published definitions; see header)                                 */
 /* ------------------------------------------------------------------------------------------ */
 const unsigned kMaxDct = 64;
+const unsigned kMaxAng = 17 * 17;   /* SAIs of the largest angular window (17 x 17: aswSize 8) */
 struct CosTables {
     std::vector<double> t[kMaxDct + 1]; /* t[n][k*n + j] = cos(pi (j+1/2) k / n) */
     CosTables() {
@@ -290,14 +291,14 @@ void dct2d_inv(float* patch, unsigned k, const Norms2D& nm) {
 }
 /* core:1862-1901 */
 void dct4d_fwd(float* v, unsigned aw, unsigned ah, const Norms4D& nm) {
-    double a[kMaxDct];
+    double a[kMaxAng];
     for (unsigned i = 0; i < aw * ah; i++) a[i] = v[i];
     r2r_2d(a, ah, aw, true);
     for (unsigned i = 0; i < aw * ah; i++) v[i] = (float)a[i] * nm.cn[i];
 }
 /* core:1913-1954 (the [pq][st] -> [st][pq] transposition is a layout matter handled by callers) */
 void dct4d_inv(float* v, unsigned aw, unsigned ah, const Norms4D& nm) {
-    double a[kMaxDct];
+    double a[kMaxAng];
     for (unsigned i = 0; i < aw * ah; i++) a[i] = (double)(v[i] * nm.cni[i]);
     r2r_2d(a, ah, aw, false);
     const float coef = 1.0f / (std::sqrt((float)aw) * std::sqrt((float)ah) * 2.0f);

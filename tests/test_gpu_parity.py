@@ -798,13 +798,34 @@ def test_7x7_window_pass_matches_oracle(ctx, case):
     _wide_window_pass(ctx, case, 7)
 
 
-@pytest.mark.parametrize("ah,aw,an", [(5, 5, 2), (7, 6, 2), (8, 7, 3)])
+# 9x9 and 11x11 angular windows (aswSize 4, 5; round 5): the general forms -- run-time transform sizes, vectors in scratch memory,
+# stacks in HBM -- for every window the reference takes on light fields of up to 17x17 SAIs (bm5d.cpp:119-124, :215-218)
+ASW4_CASES = [
+    ("ht-id-sadct-haar", 1, (4, 5, 2, 8, 4, "id", "sadct", "haar"), 48, ()),
+    ("ht-dct-dct-hw-holes", 1, (4, 5, 2, 8, 4, "dct", "dct", "hw"), 48, (0, 13, 41, 80)),
+    ("ht-bior-sadct-haar-holes", 1, (2, 5, 2, 8, 4, "bior", "sadct", "haar"), 48, (5, 44, 77)),
+    ("wien-dct-sadct-haar", 2, (4, 5, 2, 8, 4, "dct", "sadct", "haar"), 48, ()),
+]
+
+
+@pytest.mark.parametrize("case", ASW4_CASES, ids=[c[0] for c in ASW4_CASES])
+def test_9x9_window_pass_matches_oracle(ctx, case):
+    """aswSize 4: one core pass on a 9x9 angular window (81 SAIs, 80 disparity searches) against the oracle."""
+    _wide_window_pass(ctx, case, 9)
+
+
+def test_11x11_window_pass_matches_oracle(ctx):
+    _wide_window_pass(ctx, ("ht-id-sadct-haar-holes", 1, (2, 4, 2, 8, 4, "id", "sadct", "haar"), 40, (7, 61, 120)), 11)
+    _wide_window_pass(ctx, ("wien-dct-dct-haar", 2, (2, 4, 2, 8, 4, "dct", "dct", "haar"), 40, ()), 11)
+
+
+@pytest.mark.parametrize("ah,aw,an", [(5, 5, 2), (7, 6, 2), (8, 7, 3), (9, 10, 4)])
 def test_whole_steps_with_5x5_windows_match_oracle(ctx, ah, aw, an):
     """aswSize 2 and 3: the window schedule with 5x5 / 7x7 windows (compute_LF_angular_search_window's clamping at the
     borders), both steps against the oracle: same windows, PSNR within 0.01 dB."""
     import lfbm5d_amd as L
     from lfbm5d_amd import core
-    Hs = Ws = 72 if an == 2 else 64
+    Hs = Ws = 72 if an == 2 else (64 if an == 3 else 48)
     lf = Hh.textured_lf(ah, aw, Hs, Ws)
     clean, noisy = Hh.noisy_lf(lf, 25.0)
     mask = np.ones(ah * aw, np.uint32)
@@ -876,7 +897,7 @@ def test_unsupported_configurations_fail_loudly(ctx):
     import lfbm5d_amd as L
     from lfbm5d_amd import core
     t = torch.zeros((25, 3 * 32 * 32), device="cuda")
-    with pytest.raises(L.LfBm5dError, match="angular search window"):
+    with pytest.raises(L.LfBm5dError, match="angular search window"):   # a 7x7 window on a 5x5 light field: the reference's own refusal (bm5d.cpp:119-124)
         ctx.step1(core.make_params(25, 2.7, 4, 4, 2, 8, 4, "id", "sadct", "haar"), t, np.ones(25, np.uint32), t.clone(),
                   L.ROWMAJOR, 5, 5, 3, 32, 32, 3)
     with pytest.raises(L.LfBm5dError, match="power of two"):
