@@ -124,6 +124,15 @@ int lfbm5d_comm_unique_id(void* id_out /* LFBM5D_UNIQUE_ID_BYTES */);
  * environment BEFORE the HIP runtime initialises -- ROCm maps streams onto 4 hardware queues by default, and a send that
  * waits for its peer must not sit in front of a compute stream on the same queue; bench.py does it for itself) */
 int lfbm5d_comm_init(lfbm5d_ctx* ctx, const void* id, int rank, int world);
+/* TESTS ONLY -- the exchange of the window graph between PROCESSES THAT SHARE ONE GPU.  RCCL refuses several ranks on one device, so
+ * the multi-rank form could never run between real processes on a one-GPU box; this second transport plays every message of the
+ * graph with the same issue order, event gating, channels and abort path as the RCCL form (lfbm5d_api.hip, run_graph), only the
+ * bytes move differently: the receiver's exchange stream waits for a word the sender publishes behind its window (device memory
+ * both processes map through hipIpcMemHandle), copies the SAI out of the sender's buffers and publishes "taken".  Rendezvous
+ * (handles, the completion vote, the closing barriers) goes through small files in `rendezvous_dir`, which must be empty and
+ * visible to all ranks.  A peer that dies ends the job with return value 1 after `timeout_s` (<= 0: 30 s), never with a hung GPU.
+ * After this call lfbm5d_step*_device / lfbm5d_denoise_device run as rank `rank` of `world`; results are bit-identical to one rank. */
+int lfbm5d_comm_init_ipc(lfbm5d_ctx* ctx, int rank, int world, const char* rendezvous_dir, double timeout_s);
 /* Diagnostics: all-reduce n floats on the context's stream through the context's communicator (or a
  * one-rank communicator created for the call) and verify the sums.  Returns 0 when RCCL works here. */
 int lfbm5d_comm_selftest(lfbm5d_ctx* ctx, unsigned n);

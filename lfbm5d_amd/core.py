@@ -88,6 +88,7 @@ def lib():
     L.lfbm5d_stream.restype = vp
     L.lfbm5d_comm_unique_id.argtypes = [vp]
     L.lfbm5d_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.lfbm5d_comm_init_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_double]
     L.lfbm5d_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.lfbm5d_set_tiles.argtypes = [vp, C.c_int]
     L.lfbm5d_comm_ranks.argtypes = [vp]
@@ -281,6 +282,11 @@ class Context:
     def comm_init(self, unique_id, rank, world):
         buf = (C.c_ubyte * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
         self._ck(self._L.lfbm5d_comm_init(self._h, buf, rank, world))
+
+    def comm_init_ipc(self, rank, world, rendezvous_dir, timeout_s=30.0):
+        """Tests only: this process is rank `rank` of `world` processes sharing ONE GPU; the window graph's messages travel through
+        IPC-mapped device buffers instead of RCCL (include/lfbm5d.h)."""
+        self._ck(self._L.lfbm5d_comm_init_ipc(self._h, rank, world, os.fsencode(rendezvous_dir), float(timeout_s)))
 
     def comm_selftest(self, n=1 << 20):
         """All-reduce n floats through RCCL on the context's stream and check the sums."""

@@ -14,7 +14,11 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <fstream>
+#include <thread>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -105,6 +109,14 @@ struct lfbm5d_ctx {
     /* streamed host seam (lfbm5d_*_host): the caller's light fields as host pointers per SAI, set for the duration of a job; the
      * job's inputs as they arrived (what a redo of the job starts from: the streamed outputs overwrite the caller's copies SAI by
      * SAI); the streams the uploads / downloads go through */
+    /* second transport of the window-graph exchange, for tests: the ranks are PROCESSES ON ONE GPU (RCCL refuses that), a message is a
+     * device copy out of the peer's buffers (hipIpcMemHandle) gated by words in mapped device memory; same graph, issue order, event
+     * gating and abort path as the RCCL form (lfbm5d_comm_init_ipc) */
+    bool ipc = false;
+    std::string ipc_dir; double ipc_timeout_s = 30.0; unsigned ipc_epoch = 0;
+    DevBuf ipc_flags, ipc_out;
+    struct IpcPeer { unsigned char handle[7][64]; void* ptr[7]; };   /* flags, g_num[0..1], g_den[0..1], basic, out -- as this process maps them */
+    std::vector<IpcPeer> ipc_peers;
     const struct HostIO* io = nullptr;
     bool io_streamed = false;              /* the graph has uploaded the inputs (and, when it completed, delivered the outputs) SAI by SAI */
     DevBuf pristine, pristine_b;
@@ -691,6 +703,66 @@ int io_download_all(lfbm5d_ctx* c, const HostIO* io, const unsigned* h_mask, uns
     return 0;
 }
 
+/* ---- rendezvous of the two-processes-on-one-GPU transport: small files in a directory both processes see ---- */
+constexpr unsigned kIpcMaxMsgs = 4096;   /* gating words: ready[kIpcMaxMsgs], taken[kIpcMaxMsgs], error */
+bool ipc_put(const std::string& dir, const std::string& name, const void* data, size_t bytes) {
+    const std::string tmp = dir + "/." + name + ".tmp", fin = dir + "/" + name;
+    { std::ofstream f(tmp, std::ios::binary); if (!f) return false; f.write(reinterpret_cast<const char*>(data), (std::streamsize)bytes); if (!f) return false; }
+    return std::rename(tmp.c_str(), fin.c_str()) == 0;
+}
+bool ipc_get(const std::string& dir, const std::string& name, void* data, size_t bytes, double timeout_s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        std::ifstream f(dir + "/" + name, std::ios::binary);
+        if (f) { f.read(reinterpret_cast<char*>(data), (std::streamsize)bytes); if (f.gcount() == (std::streamsize)bytes) return true; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return false;
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    }
+}
+/* every rank publishes `mine`, returns everybody's (a barrier when nobody reads the values) */
+int ipc_allgather(lfbm5d_ctx* c, const char* tag, int mine, std::vector<int>& all) {
+    const std::string base = std::string(tag) + "." + std::to_string(c->ipc_epoch) + ".";
+    if (!ipc_put(c->ipc_dir, base + std::to_string(c->rank), &mine, sizeof(int))) return fail(c, "ipc transport: cannot write to the rendezvous directory");
+    all.assign((size_t)c->world, 0);
+    for (int r = 0; r < c->world; r++)
+        if (!ipc_get(c->ipc_dir, base + std::to_string(r), &all[(size_t)r], sizeof(int), c->ipc_timeout_s))
+            return fail(c, "ipc transport: rank " + std::to_string(r) + " did not reach '" + tag + "' within the watchdog (peer gone?)");
+    return 0;
+}
+/* publish this rank's buffers, map every peer's (re-opened only when a peer's allocation changed) */
+int ipc_exchange_handles(lfbm5d_ctx* c, void* const (&mine)[7]) {
+    lfbm5d_ctx::IpcPeer me;
+    std::memset(&me, 0, sizeof(me));
+    for (int i = 0; i < 7; i++)
+        if (mine[i]) {
+            hipIpcMemHandle_t h;
+            HIPCK(c, hipIpcGetMemHandle(&h, mine[i]));
+            static_assert(sizeof(h) <= 64, "handle size");
+            std::memcpy(me.handle[i], &h, sizeof(h));
+        }
+    const std::string base = "handles." + std::to_string(c->ipc_epoch) + ".";
+    if (!ipc_put(c->ipc_dir, base + std::to_string(c->rank), me.handle, sizeof(me.handle))) return fail(c, "ipc transport: cannot write to the rendezvous directory");
+    c->ipc_peers.resize((size_t)c->world);
+    for (int r = 0; r < c->world; r++) {
+        if (r == c->rank) continue;
+        unsigned char hs[7][64];
+        if (!ipc_get(c->ipc_dir, base + std::to_string(r), hs, sizeof(hs), c->ipc_timeout_s))
+            return fail(c, "ipc transport: rank " + std::to_string(r) + " did not publish its buffers within the watchdog (peer gone?)");
+        lfbm5d_ctx::IpcPeer& P = c->ipc_peers[(size_t)r];
+        static const unsigned char zero[64] = {0};
+        for (int i = 0; i < 7; i++) {
+            if (P.ptr[i] && std::memcmp(P.handle[i], hs[i], 64) == 0) continue;
+            if (P.ptr[i]) { (void)hipIpcCloseMemHandle(P.ptr[i]); P.ptr[i] = nullptr; }
+            std::memcpy(P.handle[i], hs[i], 64);
+            if (std::memcmp(hs[i], zero, 64) == 0) continue;
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, hs[i], sizeof(h));
+            HIPCK(c, hipIpcOpenMemHandle(&P.ptr[i], h, hipIpcMemLazyEnablePeerAccess));
+        }
+    }
+    return 0;
+}
+
 struct GraphJob {
     int n_steps = 1;
     int step[2] = {1, 2};                          /* the reference step every slot runs */
@@ -778,6 +850,9 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
      * estimate (bm5d.cpp:405 with den == 0), i.e. what the second step reads as noisy */
     /* the streamed host seam runs on one rank (several ranks: the caller uploads first and downloads at the end) */
     const HostIO* const io = (nranks == 1 && !emulate) ? J.io : nullptr;
+    const bool ipc = c->ipc && nranks > 1 && !emulate;   /* ranks = processes on this GPU */
+    if (ipc && G.xfers.size() > kIpcMaxMsgs) return fail(c, "ipc transport: too many messages");
+    if (ipc) c->ipc_epoch += 1;
     const int Ls = J.n_steps - 1;   /* the slot whose sums are the job's result */
     const bool colour_io = C == 3 && J.color_space != LFBM5D_RGB;
     std::vector<unsigned> untouched_all;
@@ -868,6 +943,26 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             }
     }
     auto local = [&](int r) -> RankState* { return emulate ? &states[(size_t)r] : (r == c->rank ? &states[0] : nullptr); };
+    if (ipc) {
+        /* what peers read lives in buffers of this context (the caller's may be slices of an allocator's blocks, which have no IPC
+         * handle of their own): the basic estimate of a two-step job, the outputs formed at the end */
+        RankState& S0 = states[0];
+        if (two) {
+            HIPCK(c, c->e_basic.reserve(asize * img * sizeof(float)));
+            S0.basic = c->e_basic.as<float>();
+            for (unsigned st : untouched_all)
+                HIPCK(c, hipMemcpyAsync(S0.basic + (size_t)st * img, J.noisy[1] + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        HIPCK(c, c->ipc_out.reserve(asize * img * sizeof(float)));
+        HIPCK(c, hipMemsetAsync(c->ipc_flags.as<unsigned>() + 2 * kIpcMaxMsgs, 0, sizeof(unsigned), s));
+        HIPCK(c, hipStreamSynchronize(s));
+        void* const mine_bufs[7] = {c->ipc_flags.p, S0.g_num[0], two ? (void*)S0.g_num[1] : nullptr, S0.g_den[0], two ? (void*)S0.g_den[1] : nullptr,
+                                    two ? (void*)S0.basic : nullptr, c->ipc_out.p};
+        if (ipc_exchange_handles(c, mine_bufs)) return 1;
+    }
+    unsigned* const ipc_own = c->ipc_flags.as<unsigned>();
+    auto ipc_peer = [&](int r, int slot) -> float* { return reinterpret_cast<float*>(c->ipc_peers[(size_t)r].ptr[slot]); };
+    std::vector<size_t> ipc_sent;   /* messages this rank sent: their "taken" words are waited for before the drain */
     if (c->h_counts_cap < NN * kWinCounters) {
         if (c->h_counts) (void)hipHostFree(c->h_counts);
         c->h_counts = nullptr; c->h_counts_cap = 0;
@@ -990,7 +1085,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             const plan::Xfer& X = G.xfers[xi];
             /* one channel when the second communicator could not be created: two streams on one communicator would break the
              * common issue order the exchange relies on */
-            const int ra = r, rb = X.to_rank, ch = (emulate || c->comm2) ? X.channel : 0;
+            const int ra = r, rb = X.to_rank, ch = (emulate || c->comm2 || ipc) ? X.channel : 0;
             RankState* Sa = local(ra); RankState* Sb = local(rb);
             const size_t off = (size_t)X.sai * img;
             const int xsl = nd.s;
@@ -1004,6 +1099,28 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
                     HIPCK(c, hipMemcpyAsync(Sb->basic + off, Sa->basic + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
                 arrived[xi] = get_event(c);
                 HIPCK(c, hipEventRecord(arrived[xi], xs));
+                n_msgs++;
+            } else if (ipc && (Sa || Sb)) {
+                /* the same message between two processes on one GPU: the sender publishes "ready" behind its window, the receiver's
+                 * exchange stream waits for the word, copies the SAI out of the sender's (mapped) buffers and publishes "taken" */
+                hipStream_t xs = c->cs[ch];
+                const unsigned ep = c->ipc_epoch;
+                if (Sa) {
+                    HIPCK(c, hipStreamWaitEvent(xs, done[n], 0));
+                    HIPCK(c, launch_ipc_set(xs, ipc_own + xi, ep));
+                    ipc_sent.push_back(xi);
+                } else {
+                    const unsigned* const pf = reinterpret_cast<const unsigned*>(c->ipc_peers[(size_t)ra].ptr[0]);
+                    HIPCK(c, launch_ipc_wait(xs, pf + xi, ep, ipc_own + 2 * kIpcMaxMsgs, c->ipc_timeout_s));
+                    if (X.kind == 0) {
+                        HIPCK(c, hipMemcpyAsync(Sb->g_num[xsl] + off, ipc_peer(ra, 1 + xsl) + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                        HIPCK(c, hipMemcpyAsync(Sb->g_den[xsl] + off, ipc_peer(ra, 3 + xsl) + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                    } else
+                        HIPCK(c, hipMemcpyAsync(Sb->basic + off, ipc_peer(ra, 5) + off, img * sizeof(float), hipMemcpyDeviceToDevice, xs));
+                    HIPCK(c, launch_ipc_set(xs, ipc_own + kIpcMaxMsgs + xi, ep));
+                    arrived[xi] = get_event(c);
+                    HIPCK(c, hipEventRecord(arrived[xi], xs));
+                }
                 n_msgs++;
             } else if (Sa || Sb) {
                 hipStream_t xs = c->cs[ch];
@@ -1063,12 +1180,25 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         }
         HIPCK(c, hipStreamSynchronize(c->io_out));
     }
+    if (ipc) {   /* a send is complete when the peer has taken the SAI (what an RCCL send's completion means) */
+        for (size_t xs_i : ipc_sent) {
+            const plan::Xfer& X = G.xfers[xs_i];
+            const int ch = X.channel;
+            const unsigned* const pf = reinterpret_cast<const unsigned*>(c->ipc_peers[(size_t)X.to_rank].ptr[0]);
+            HIPCK(c, launch_ipc_wait(c->cs[ch], pf + kIpcMaxMsgs + xs_i, c->ipc_epoch, ipc_own + 2 * kIpcMaxMsgs, c->ipc_timeout_s));
+        }
+    }
     /* drain: every lane, every exchange stream */
     for (RankState& S : states) {
         for (Lane& Lq : S.lanes) HIPCK(c, hipStreamSynchronize(Lq.x->stream));
         for (int ch = 0; ch < 2; ch++) if (S.x->cs[ch]) HIPCK(c, hipStreamSynchronize(S.x->cs[ch]));
     }
     HIPCK(c, hipStreamSynchronize(s));
+    if (ipc) {
+        unsigned err = 0;
+        HIPCK(c, hipMemcpy(&err, ipc_own + 2 * kIpcMaxMsgs, sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (err) return fail(c, "ipc transport: a peer did not deliver / take a message within the watchdog");
+    }
     drain_guard.armed = false;
     int complete = 1;
     for (size_t n = 0; n < NN; n++) {
@@ -1099,6 +1229,11 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         std::memset(&x->stats, 0, sizeof(x->stats));
     }
     if (two && fold_all(c)) return 1;   /* (single steps: run_step folds slot 0 of this context itself) */
+    if (ipc) {
+        std::vector<int> all;
+        if (ipc_allgather(c, "complete", complete, all)) return 1;
+        for (int v : all) complete = std::min(complete, v);
+    } else
     if (nranks > 1 && !emulate) {   /* all ranks must agree before the collective below */
         HIPCK(c, c->small.reserve((asize + 8 + kWinCounters) * sizeof(unsigned)));
         int* d_flag = reinterpret_cast<int*>(c->small.as<unsigned>());
@@ -1124,13 +1259,33 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
                 own[st] = (h_mask[st] && G.last_touch[ls][st] >= 0 && G.nodes[(size_t)G.last_touch[ls][st]].rank == S.rank) ? 1u : 0u;
             HIPCK(c, S.x->d_own.reserve(asize * sizeof(unsigned)));
             HIPCK(c, hipMemcpyAsync(S.x->d_own.p, own.data(), asize * sizeof(unsigned), hipMemcpyHostToDevice, s));
-            HIPCK(c, launch_estimate_lf(s, S.g_num[ls], S.g_den[ls], sub, J.d_out, img, asize, S.x->d_own.as<unsigned>()));
+            HIPCK(c, launch_estimate_lf(s, S.g_num[ls], S.g_den[ls], sub, ipc ? c->ipc_out.as<float>() : J.d_out, img, asize, S.x->d_own.as<unsigned>()));
             HIPCK(c, hipStreamSynchronize(s));   /* own is reused */
             if (two && emulate && S.x != c)      /* the basic estimates this emulated rank finalised: what the broadcast below moves between real ranks */
                 for (unsigned st = 0; st < asize; st++)
                     if (h_mask[st] && G.last_touch[0][st] >= 0 && G.nodes[(size_t)G.last_touch[0][st]].rank == S.rank)
                         HIPCK(c, hipMemcpyAsync(J.d_basic + (size_t)st * img, S.basic + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
+        if (ipc) {   /* every rank's outputs are formed: pull each SAI from the rank that holds it, then leave together */
+            std::vector<int> all;
+            if (ipc_allgather(c, "formed", 1, all)) return 1;
+            for (unsigned st = 0; st < asize; st++) {
+                if (!h_mask[st]) continue;
+                if (G.last_touch[ls][st] >= 0) {
+                    const int r = G.nodes[(size_t)G.last_touch[ls][st]].rank;
+                    const float* src = r == c->rank ? c->ipc_out.as<float>() : ipc_peer(r, 6);
+                    HIPCK(c, hipMemcpyAsync(J.d_out + (size_t)st * img, src + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+                }
+                if (two && G.last_touch[0][st] >= 0) {
+                    const int r = G.nodes[(size_t)G.last_touch[0][st]].rank;
+                    const float* src = r == c->rank ? states[0].basic : ipc_peer(r, 5);
+                    HIPCK(c, hipMemcpyAsync(J.d_basic + (size_t)st * img, src + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+                } else if (two)
+                    HIPCK(c, hipMemcpyAsync(J.d_basic + (size_t)st * img, states[0].basic + (size_t)st * img, img * sizeof(float), hipMemcpyDeviceToDevice, s));
+            }
+            HIPCK(c, hipStreamSynchronize(s));
+            if (ipc_allgather(c, "pulled", 1, all)) return 1;
+        } else
         if (!emulate) {
             hipEvent_t e0 = get_event(c), e1 = get_event(c);
             HIPCK(c, hipEventRecord(e0, s));
@@ -1477,7 +1632,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     if (!graph_mode && nranks > 1 && !by_rows && !by_blocks)
         return fail(c, "whole steps on several ranks: this light field needs data-driven passes (greyscale, or an empty SAI at a "
                        "window centre); set LFBM5D_STEP_SHARDING=rows");
-    if (graph_mode && c->world > 1 && emu <= 1 && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+    if (graph_mode && c->world > 1 && emu <= 1 && !c->comm && !c->ipc) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
     /* host seam: the single-rank graph takes the caller's SAIs in and out as its windows need and finish them; every other form
      * gets the whole light field(s) first */
     const bool streamable = io && graph_mode && nranks == 1 && std::getenv("LFBM5D_HOST_BLOCKING") == nullptr;
@@ -1653,7 +1808,7 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
         if (io && io_upload_all(c, io, h_mask, asize, img, d_noisy, nullptr)) return 1;
         return two_calls();
     }
-    if (c->world > 1 && emu <= 1 && !c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+    if (c->world > 1 && emu <= 1 && !c->comm && !c->ipc) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
     hipStream_t s = c->stream;
     const bool colour = P1->color_space != LFBM5D_RGB;
     HIPCK(c, c->d_mask.reserve(asize * sizeof(unsigned)));
@@ -1753,6 +1908,10 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     c->lanes.clear();
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (lfbm5d_ctx::IpcPeer& P : c->ipc_peers) for (void* q : P.ptr) if (q) (void)hipIpcCloseMemHandle(q);
+    c->ipc_flags.release(); c->ipc_out.release(); c->pristine.release(); c->pristine_b.release();
+    if (c->io_in) (void)hipStreamDestroy(c->io_in);
+    if (c->io_out) (void)hipStreamDestroy(c->io_out);
     if (c->comm2) ncclCommDestroy(c->comm2);
     if (c->comm) ncclCommDestroy(c->comm);
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
@@ -1799,6 +1958,20 @@ int lfbm5d_comm_init(lfbm5d_ctx* c, const void* idb, int rank, int world) {
     /* second channel of the window-graph exchange: same ranks, independent progress.  Optional (one channel is only slower) */
     if (ncclCommSplit(c->comm, 0, rank, &c->comm2, nullptr) != ncclSuccess) c->comm2 = nullptr;
     return 0;
+}
+
+int lfbm5d_comm_init_ipc(lfbm5d_ctx* c, int rank, int world, const char* rendezvous_dir, double timeout_s) {
+    if (!c || world < 1 || rank < 0 || rank >= world || !rendezvous_dir) return 1;
+    (void)hipSetDevice(c->device);
+    c->rank = rank; c->world = world;
+    if (world == 1) return 0;
+    c->ipc = true; c->ipc_dir = rendezvous_dir; c->ipc_timeout_s = timeout_s > 0 ? timeout_s : 30.0; c->ipc_epoch = 0;
+    HIPCK(c, c->ipc_flags.reserve((2 * kIpcMaxMsgs + 16) * sizeof(unsigned)));
+    HIPCK(c, hipMemset(c->ipc_flags.p, 0, (2 * kIpcMaxMsgs + 16) * sizeof(unsigned)));
+    c->ipc_peers.assign((size_t)world, lfbm5d_ctx::IpcPeer());
+    for (lfbm5d_ctx::IpcPeer& P : c->ipc_peers) std::memset(&P, 0, sizeof(P));
+    std::vector<int> all;   /* every rank is there (and has zeroed its gating words) before anybody's first job */
+    return ipc_allgather(c, "init", 1, all);
 }
 
 int lfbm5d_plan_windows(unsigned awidth, unsigned aheight, unsigned an, unsigned ang_major, const unsigned* mask,

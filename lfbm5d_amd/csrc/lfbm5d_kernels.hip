@@ -213,6 +213,24 @@ __global__ void k_output_multi(const float* __restrict__ num, const float* __res
     }
 }
 
+/* Two processes on one GPU (the exchange's second transport, tests only: RCCL refuses two ranks on one device): a message is gated
+ * by words in device memory both processes map (hipIpcMemHandle).  set: publish `v` behind everything queued on the stream; wait:
+ * hold the stream until the word has reached `want` -- or until timeout_ticks of the 100 MHz clock have passed (a dead peer must end
+ * in an error return, never in a hung GPU): then *err is set, and every later wait of the job returns at once. */
+__global__ void k_ipc_set(unsigned* p, unsigned v) {
+    __threadfence_system();
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_ipc_wait(const unsigned* p, unsigned want, unsigned* err, unsigned long long timeout_ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        __builtin_amdgcn_s_sleep(64);
+    }
+    __threadfence_system();
+}
+
 __global__ void k_copy_rect(float* __restrict__ dst, size_t dst_stride, int dW, int dH, int dx0, int dy0,
                             const float* __restrict__ src, size_t src_stride, int sW, int sH, int sx0, int sy0,
                             int w, int h, int C, SaiMask mask_bits) {
@@ -4085,6 +4103,14 @@ hipError_t launch_output_multi(hipStream_t s, const float* num, const float* den
     if (!L.n) return hipSuccess;
     hipLaunchKernelGGL(k_output_multi, dim3((n_px + 255) / 256, L.n), dim3(256), 0, s, num, den, sub, out, basic, noisy_src, noisy_dst,
                        sai_stride, L, cs, n_px, colour);
+    return hipGetLastError();
+}
+hipError_t launch_ipc_set(hipStream_t s, unsigned* p, unsigned v) {
+    hipLaunchKernelGGL(k_ipc_set, dim3(1), dim3(1), 0, s, p, v);
+    return hipGetLastError();
+}
+hipError_t launch_ipc_wait(hipStream_t s, const unsigned* p, unsigned want, unsigned* err, double timeout_s) {
+    hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(1), 0, s, p, want, err, (unsigned long long)(timeout_s * 1e8));
     return hipGetLastError();
 }
 hipError_t launch_estimate_lf(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t seg,
