@@ -224,7 +224,7 @@ hipError_t launch_finalize_multi(hipStream_t s, const float* num, const float* d
 hipError_t launch_output_multi(hipStream_t s, const float* num, const float* den, const float* sub, float* out, float* basic,
                                const float* noisy_src, float* noisy_dst, size_t sai_stride, const SaiList& L, unsigned cs, unsigned n_px,
                                int colour);
-/* the gating words of the two-processes-on-one-GPU transport (k_ipc_set / k_ipc_wait in lfbm5d_kernels.hip) */
+/* the gating words of the two-processes-on-one-GPU transport (k_ipc_set / k_ipc_wait in lfbm5d_window.hip) */
 hipError_t launch_ipc_set(hipStream_t s, unsigned* p, unsigned v);
 hipError_t launch_ipc_wait(hipStream_t s, const unsigned* p, unsigned want, unsigned* err, double timeout_s);
 hipError_t launch_symetrize_multi(hipStream_t s, const float* src, size_t src_stride, float* dst, size_t dst_stride,

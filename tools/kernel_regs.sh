@@ -1,8 +1,8 @@
 #!/bin/bash
 # Register / scratch usage of the group and aggregation kernels (cross-compile, no GPU needed).
 cd "$(dirname "$0")/../lfbm5d_amd/csrc"
-f=${1:-lfbm5d_kernels.hip}
-extra=""; [ "$f" = lfbm5d_bm.hip ] && extra="-ffp-contract=off"
+f=${1:-lfbm5d_group_ht.hip}
+extra=""; [ "$f" = lfbm5d_bm.hip -o "$f" = lfbm5d_scan2.hip ] && extra="-ffp-contract=off"
 hipcc -O3 --offload-arch=gfx950 -std=c++17 $extra -S --cuda-device-only -o /tmp/kregs.s $f 2>&1 | grep -E "error" -A3
 python3 - <<'PY'
 import re
