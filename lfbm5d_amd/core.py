@@ -88,7 +88,8 @@ def lib():
     L.lfbm5d_stream.restype = vp
     L.lfbm5d_comm_unique_id.argtypes = [vp]
     L.lfbm5d_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
-    L.lfbm5d_comm_init_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_double]
+    if hasattr(L, "lfbm5d_comm_init_ipc"):   # (absent from older builds loaded through LFBM5D_HIP_LIB for A/B runs)
+        L.lfbm5d_comm_init_ipc.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.c_double]
     L.lfbm5d_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.lfbm5d_set_tiles.argtypes = [vp, C.c_int]
     L.lfbm5d_comm_ranks.argtypes = [vp]
@@ -109,9 +110,10 @@ def lib():
     L.lfbm5d_step1_host.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
     L.lfbm5d_step2_host.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
     # host seam with one pointer per SAI (what the reference's vector<vector<float>> is): arrays of float*
-    L.lfbm5d_step1_host_sai.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
-    L.lfbm5d_step2_host_sai.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
-    L.lfbm5d_denoise_host_sai.argtypes = [vp, C.POINTER(Params), C.POINTER(Params), fp, up, fp, fp] + [C.c_uint] * 8
+    if hasattr(L, "lfbm5d_denoise_host_sai"):
+        L.lfbm5d_step1_host_sai.argtypes = [vp, C.POINTER(Params), fp, up, fp] + tail
+        L.lfbm5d_step2_host_sai.argtypes = [vp, C.POINTER(Params), fp, up, fp, fp] + tail
+        L.lfbm5d_denoise_host_sai.argtypes = [vp, C.POINTER(Params), C.POINTER(Params), fp, up, fp, fp] + [C.c_uint] * 8
     L.lfbm5d_pass_device.argtypes = [vp, C.c_int, C.POINTER(Params), C.c_uint, C.c_uint, C.c_uint,
                                      C.c_uint, C.c_uint, fp, fp, fp, fp, up, up, C.c_uint, C.c_uint]
     L.lfbm5d_last_bm.argtypes = [vp, up, vp, vp, vp, vp, vp]
