@@ -20,6 +20,8 @@ namespace lfbm5d {
  * configuration is not theirs */
 hipError_t launch_group_ht(hipStream_t s, const GroupArgs& a, bool all_sa, bool* launched);
 hipError_t launch_group_wiener(hipStream_t s, const GroupArgs& a, bool all_sa, bool* launched);
+hipError_t launch_group_wide(hipStream_t s, const GroupArgs& a, bool* launched);   /* lfbm5d_group_wide.hip: HT, tau_2D = id, 5x5 / 7x7 windows */
+hipError_t prepare_group_wide();
 hipError_t prepare_group_ht();
 hipError_t prepare_group_wiener();
 constexpr int kDedicatedLdsLimit = 160 * 1024 - 4096;

@@ -334,6 +334,7 @@ hipError_t prepare_group_kernels() {
     }
     hipError_t e = prepare_group_ht();
     if (e == hipSuccess) e = prepare_group_wiener();
+    if (e == hipSuccess) e = prepare_group_wide();
     return e;
 }
 
@@ -348,6 +349,7 @@ size_t group_lds_bytes(const GroupArgs& a) {
 }
 static bool group_uses_generic(const GroupArgs& a) {   /* mirrors the dispatch of launch_group_ht / launch_group_wiener */
     if (getenv("LFBM5D_GROUP_GENERIC") != nullptr) return true;
+    if ((a.A == 25 || a.A == 49) && a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull) return false;   /* lfbm5d_group_wide.hip */
     if (a.A != 9 && !(a.bm3d && a.A == 1)) return true;
     if (a.A == 9 && a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) return false;
     if (a.A == 9 && (a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1) return false;
@@ -374,6 +376,8 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         hipError_t e = launch_group_ht(s, a, all_sa, &launched);
         if (launched) return e;
         e = launch_group_wiener(s, a, all_sa, &launched);
+        if (launched) return e;
+        e = launch_group_wide(s, a, &launched);
         if (launched) return e;
     }
     const size_t lds = group_lds_bytes(a);

@@ -732,6 +732,9 @@ ASW2_CASES = [
     # 16x16 patches, N = 8: 8 x 25 x 256 floats = 200 KiB per stack -> the HBM-scratch form of the generic kernel
     ("ht-bior-sadct-haar-k16", 1, (8, 6, 2, 16, 4, "bior", "sadct", "haar"), 72, ()),
     ("wien-dct-sadct-haar-n16", 2, (16, 6, 2, 8, 4, "dct", "sadct", "haar"), 64, ()),
+    # the README's HT parameters on a wide window: the slab kernel of lfbm5d_group_wide.hip (round 5)
+    ("ht-id-sadct-haar-k16-n8", 1, (8, 6, 2, 16, 4, "id", "sadct", "haar"), 72, ()),
+    ("ht-id-sadct-hw-k12-holes", 1, (4, 6, 2, 12, 4, "id", "sadct", "hw"), 64, (2, 20)),
 ]
 
 
@@ -789,6 +792,8 @@ ASW3_CASES = [
     ("ht-dct-dct-hw", 1, (8, 5, 2, 8, 4, "dct", "dct", "hw"), 56, ()),
     ("wien-dct-sadct-haar", 2, (8, 5, 2, 8, 4, "dct", "sadct", "haar"), 56, ()),
     ("wien-bior-sadct-dct5-holes", 2, (4, 5, 2, 8, 4, "bior", "sadct", "dct"), 56, (8, 40)),
+    ("ht-id-dct-haar-k12-n4", 1, (4, 5, 2, 12, 4, "id", "dct", "haar"), 64, ()),
+    ("ht-id-sadct-haar-k16-n8", 1, (8, 5, 2, 16, 4, "id", "sadct", "haar"), 64, ()),
 ]
 
 
