@@ -599,34 +599,34 @@ __device__ __noinline__ void sadctw_inv(float* v, int aw, SHR sh, TbPtr tb) {
 }
 
 /* lib_transforms.cpp:403-471 / :290-321 on a register vector of compile-time length */
-template <int NS> __device__ __forceinline__ void haar_fwd(float* v) {
+template <int NS, class T> __device__ __forceinline__ void haar_fwd(T* v) {   /* T = float, or v2f: two fibres per lane */
     const float s = 0.70710678118654752f;
 #pragma unroll
     for (int n = NS; n > 1; n /= 2) {
-        float t[NS > 1 ? NS : 1];
+        T t[NS > 1 ? NS : 1];
 #pragma unroll
         for (int i = 0; i < n / 2; i++) { t[i] = (v[2 * i] + v[2 * i + 1]) * s; t[n / 2 + i] = (v[2 * i] - v[2 * i + 1]) * s; }
 #pragma unroll
         for (int i = 0; i < n; i++) v[i] = t[i];
     }
 }
-template <int NS> __device__ __forceinline__ void haar_inv(float* v) {
+template <int NS, class T> __device__ __forceinline__ void haar_inv(T* v) {
     const float s = 0.70710678118654752f;
 #pragma unroll
     for (int h = 1; h < NS; h *= 2) {
-        float t[NS > 1 ? NS : 1];
+        T t[NS > 1 ? NS : 1];
 #pragma unroll
         for (int i = 0; i < h; i++) { t[2 * i] = (v[i] + v[h + i]) * s; t[2 * i + 1] = (v[i] - v[h + i]) * s; }
 #pragma unroll
         for (int i = 0; i < 2 * h; i++) v[i] = t[i];
     }
 }
-template <int NS> __device__ __forceinline__ void hadamard(float* v) {
+template <int NS, class T> __device__ __forceinline__ void hadamard(T* v) {
     /* sums to the first half, differences to the second, recurse on both: log2(NS) levels of
      * the same butterfly applied block-wise */
 #pragma unroll
     for (int n = NS; n > 1; n /= 2) {
-        float t[NS > 1 ? NS : 1];
+        T t[NS > 1 ? NS : 1];
 #pragma unroll
         for (int b = 0; b < NS; b += n)
 #pragma unroll
@@ -641,12 +641,12 @@ template <int NS> __device__ __forceinline__ void hadamard(float* v) {
 /* 5th-dimension DCT of a fibre (tau_5D = dct): REDFT10 * coef_norm / coef_norm_inv * REDFT01 * coef
  * (core:2546-2593, norms preProcess_5d core:3262-3276) */
 template <int NS> __device__ __forceinline__ int log2c() { return NS == 1 ? 0 : NS == 2 ? 1 : NS == 4 ? 2 : NS == 8 ? 3 : NS == 16 ? 4 : 5; }
-template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, TbPtr tb) {
+template <int NS, class T> __device__ __forceinline__ void dct5_fwd(T* v, TbPtr tb) {
     TbFloats ct = NS == 32 ? tb->cos5x : tb->cos5[NS == 32 ? 0 : log2c<NS>()];
-    float y[NS];
+    T y[NS];
 #pragma unroll
     for (int u = 0; u < NS; u++) {
-        float a = 0.0f;
+        T a = T{};
 #pragma unroll
         for (int j = 0; j < NS; j++) a += v[j] * ct[u * NS + j];
         y[u] = 2.0f * a * (u == 0 ? tb->cn5_0[log2c<NS>()] : tb->cn5[log2c<NS>()]);
@@ -654,13 +654,13 @@ template <int NS> __device__ __forceinline__ void dct5_fwd(float* v, TbPtr tb) {
 #pragma unroll
     for (int u = 0; u < NS; u++) v[u] = y[u];
 }
-template <int NS> __device__ __forceinline__ void dct5_inv(float* v, TbPtr tb) {
+template <int NS, class T> __device__ __forceinline__ void dct5_inv(T* v, TbPtr tb) {
     TbFloats ct = NS == 32 ? tb->cos5x : tb->cos5[NS == 32 ? 0 : log2c<NS>()];
-    float y[NS];
-    const float x0 = v[0] * 1.41421356237309505f;   /* coef_norm_inv[0] = sqrt2, others 1 */
+    T y[NS];
+    const T x0 = v[0] * 1.41421356237309505f;   /* coef_norm_inv[0] = sqrt2, others 1 */
 #pragma unroll
     for (int j = 0; j < NS; j++) {
-        float a = 0.0f;
+        T a = T{};
 #pragma unroll
         for (int u = 1; u < NS; u++) a += v[u] * ct[u * NS + j];
         y[j] = (x0 + 2.0f * a) * tb->c5inv[log2c<NS>()];

@@ -3,15 +3,20 @@
  * (aswSize 2 / 3; core:277-481 with aheight x awidth from bm5d.cpp:215-218), round 5.
  *
  * With no 2-D transform a pixel of the patches never mixes with other pixels, so a (group, channel) is processed in SLABS of
- * pixels: the slab's nSx x A x SLAB stack lives in LDS (51 KB for a 5x5 window and 64 pixels, 50 KB for 7x7 and 32) --
- *   gather the slab's pixels of every patch (pixel fastest: 256 / 128 contiguous bytes per patch row piece);
- *   the aw x aw angular DCT as two separable passes over the stack -- item = (match, row of the block, pixel), then (match, column,
- *   pixel): aw values per thread, so registers never limit the occupancy (a thread holding all 49 values of a 7x7 block needed 325);
- *   the fibres along the matches: Haar / Hadamard / DCT, hard threshold, inverse (filter5, shared with the general kernel);
- *   the inverse angular passes, the second writing the filtered pixels straight to `filt`
- * -- slab after slab, the survivor count carried over for the group weight.  The general kernel keeps the whole 200 KB stack of
- * such a group in an HBM scratch slice and took 5.8 / 12.8 ms per 304^2 pass (5x5 / 7x7) where this one takes well under 1 / 2 ms;
- * same transforms in the same order, hence the same results.
+ * pixels, a workgroup per slab: the slab's nSx x A x SLAB stack lives in LDS (51 KB for a 5x5 window and 64 pixels, 50 KB for 7x7
+ * and 32: three workgroups per CU) --
+ *   gather the slab's pixels of every patch: 16-byte loads (4-byte aligned) of four pixels of a patch row, all 13 of a thread in
+ *   flight at once, the patch positions read straight from the table (no LDS round trip, no barrier before the first image load);
+ *   the aw x aw angular DCT as two separable passes over the stack -- item = (match, row of the block, pixel PAIR), then (match,
+ *   column, pair): aw packed values per thread (a thread holding all 49 values of a 7x7 block needed 325 registers; the fused form
+ *   of the 5x5 block spills at 168);
+ *   the fibres along the matches, two per lane: Haar / Hadamard / DCT, hard threshold, inverse;
+ *   the inverse angular passes, the second writing four filtered pixels per 16-byte store straight to `filt`.
+ * The general kernel keeps the whole 200 KB stack of such a group in an HBM scratch slice: 5.8 / 12.8 ms per 304^2 pass (5x5 / 7x7,
+ * k = 16, N = 8) where this one takes 1.19 / 2.87 ms; same operations in the same order per value, hence the same results.
+ * Where the time goes now (in-kernel clocks of a sample of workgroups, profiles/r05_d_wide_window.txt): a workgroup lives 14 us of
+ * which the gather is 4, the four angular passes 6, the fibres 2.7; VALU issue is ~55 % busy at three waves per SIMD (1900 VALU
+ * instructions per wave, a fifth of them the transforms' FMAs), and `filt` itself is 2.3 / 4.5 GB per pass.
  */
 #include "lfbm5d_group_device.h"
 
@@ -19,45 +24,122 @@ namespace lfbm5d {
 
 namespace {
 
+/* 5th-dimension filter of the hard-thresholding step (core:2408-2505 / :2281-2391) on TWO fibres per lane -- neighbouring pixels of
+ * the LDS stack: 8-byte LDS accesses and packed arithmetic, the same operations in the same order per fibre as filter5 /
+ * shrink_fibre.  The survivor count is a whole number: exact in any order. */
+template <int NS>
+__device__ __forceinline__ void filter5_pair(v2f* S2, int base, int stride, unsigned tau5, float T, bool in_shape, float& wacc, TbPtr tb) {
+    v2f o[NS];
+#pragma unroll
+    for (int n = 0; n < NS; n++) o[n] = S2[base + n * stride];
+    const bool haar = tau5 == 9, dct = tau5 == 5;
+    if (dct) dct5_fwd<NS>(o, tb);
+    else if (NS > 1) { if (haar) haar_fwd<NS>(o); else hadamard<NS>(o); }
+    if (in_shape) {
+        const float Th = haar ? T : (dct ? T * 2.0f : T * sqrtf((float)NS));   /* shrink_fibre */
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            if (fabsf(o[n].x) > Th) wacc += 1.0f; else o[n].x = 0.0f;
+            if (fabsf(o[n].y) > Th) wacc += 1.0f; else o[n].y = 0.0f;
+        }
+    }
+    if (dct) dct5_inv<NS>(o, tb);
+    else if (NS > 1) {
+        if (haar) haar_inv<NS>(o);
+        else {
+            hadamard<NS>(o);
+            const float hc = 1.0f / (float)NS;
+#pragma unroll
+            for (int n = 0; n < NS; n++) o[n] *= hc;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NS; n++) S2[base + n * stride] = o[n];
+}
+
 /* SPLIT: a workgroup per (group, channel, SLAB of pixels) -- blockIdx.z = slab -- instead of one per (group, channel) that walks the
  * slabs: four to eight times the workgroups, three of them per CU in different phases, so that gathers, transforms and stores of
  * different slabs overlap.  The survivor count of a (group, channel) is then summed with atomics in wgt (whole numbers: exact in any
  * order; the buffer is zeroed before the launch) and turned into the weight by k_group_idw_weight.  useSD (float sums whose value
  * depends on the order) keeps the walking form. */
 template <int AW, int SLAB, bool SPLIT>
-__global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {
+__global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 threads at six waves per SIMD: slower, 80 registers spill) */
     constexpr int A = AW * AW, NT = 256;
     extern __shared__ float S[];                      /* [n][st][SLAB] */
     __shared__ unsigned pos[8 * A];
     __shared__ float red[3][NT / 64];
+    __shared__ float cn4s[A], cni4s[A];               /* coef_norm_4d / coef_norm_inv_4d: indexed per thread in the column / row passes */
+    constexpr int P2 = SLAB / 2;                      /* the angular passes work on pixel PAIRS: v_pk_fma_f32, 8-byte LDS accesses */
+    v2f* const S2 = reinterpret_cast<v2f*>(S);
     const int tid = threadIdx.x;
     const unsigned gi = xcd_group_index(a);
     if (gi >= a.n_groups) return;
-    const unsigned g = a.ref_begin + gi;
+    const unsigned g = a.ref_begin + gi, slab = blockIdx.z;
     const int c = blockIdx.y;
     const int k = a.k, k2 = k * k, N = a.N;
-    const int nSx = (int)a.self_cnt[g];
     const size_t plane = (size_t)a.Wb * a.Hb;
     const TbPtr tb = (TbPtr)a.tb;
-    for (int i = tid; i < nSx * A; i += NT) pos[i] = a.gpos[(size_t)g * N * A + i];
+    if (tid < A) { cn4s[tid] = tb->cn4[tid]; cni4s[tid] = tb->cni4[tid]; }   /* (first read behind the barrier that follows the gather) */
+    const int nSx = (int)a.self_cnt[g];
+    /* prologue: everything the workgroup needs from memory is requested at once -- the group's size and shape, sigma, the norm
+     * tables, and the positions of the patches each thread will fetch (16-byte gather: straight into registers, no LDS round trip
+     * and no barrier before the first image load) */
+    constexpr int QS = SLAB / 4, GQ = (8 * A * QS + NT - 1) / NT;   /* 16-byte loads per thread: 13 */
+    unsigned pv[GQ];
+    const bool quads = (k & 3) == 0;
+    if (quads) {
+#pragma unroll
+        for (int u = 0; u < GQ; u++) pv[u] = a.gpos[(size_t)g * N * A + min((tid + u * NT) / QS, N * A - 1)];
+    } else
+        for (int i = tid; i < N * A; i += NT) pos[i] = a.gpos[(size_t)g * N * A + i];
     ShRef sh = group_shape(a, g);
-    __syncthreads();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
     const float sig = a.sigma[c];
     const float T = a.lambda * sig * 1.41421356237309505f;   /* core:2431 */
     const float sig2 = sig * sig;
+    if (!quads) __syncthreads();
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     float* const out = a.filt + (size_t)g * N * A * a.C * k2;
     const float* const img = a.noisy + (size_t)c * plane;
-    for (int p0 = SPLIT ? (int)blockIdx.z * SLAB : 0; p0 < (SPLIT ? min(k2, ((int)blockIdx.z + 1) * SLAB) : k2); p0 += SLAB) {
+#ifdef LFBM5D_WIDE_PHASES   /* development builds (with -DLFBM5D_WIDE_PHASES, which makes lfbm5d_api.hip print them): cycles per phase of the slab loop, summed over the workgroups */
+    long long tq[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+    const long long treal0 = (long long)__builtin_amdgcn_s_memrealtime();
+#define WIDE_MARK(i) do { asm volatile("" ::: "memory"); const long long tn = (long long)__builtin_readcyclecounter(); tq[i] += tn - tlast; tlast = tn; } while (0)
+#else
+#define WIDE_MARK(i) do {} while (0)
+#endif
+    for (int p0 = SPLIT ? (int)slab * SLAB : 0; p0 < (SPLIT ? min(k2, ((int)slab + 1) * SLAB) : k2); p0 += SLAB) {
         const int npx = min(SLAB, k2 - p0);
         /* gather (core:286-299): item = (patch, pixel), pixel fastest */
-        {
+        if (quads) {   /* four pixels of a patch row per 16-byte load (4-byte aligned), every load of the slab in flight at once */
+            constexpr int G = GQ;
+            const int total = nSx * A * QS;           /* <= 8 * 25 * 16 = 3200, 8 * 49 * 8 = 3136: at most 13 per thread */
+            const unsigned cplane = (unsigned)(a.C * plane);   /* (window images of up to 2^31 floats: launch_group_wide) */
+            const int px = 4 * (tid % QS), pq = p0 + px;   /* NT is a multiple of QS: the same pixels for every load of the thread */
+            const unsigned poff = (unsigned)(pq / k) * a.Wb + (unsigned)(pq % k);
+            f4u v[G];
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const int e = tid + u * NT, ns = e / QS;
+                v[u] = f4u{{0.0f, 0.0f, 0.0f, 0.0f}};
+                if (e < total && pv[u] != 0xffffffffu && px < npx) v[u] = *reinterpret_cast<const f4u*>(img + ((unsigned)(ns % A) * cplane + pv[u] + poff));
+            }
+#ifdef LFBM5D_WIDE_PHASES
+            WIDE_MARK(9);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WIDE_MARK(6);
+#endif
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const int e = tid + u * NT;
+                if (e < total) *reinterpret_cast<v4f*>(S + 4 * e) = v4f{v[u].v[0], v[u].v[1], v[u].v[2], v[u].v[3]};
+            }
+        } else {
             constexpr int G = 10;   /* loads in flight per thread */
             const int total = nSx * A * SLAB;
-            const unsigned cplane = (unsigned)(a.C * plane);   /* (window images of up to 2^31 floats: lfbm5d_api.hip keeps A * C * plane * 4 below 2 GiB for this kernel) */
+            const unsigned cplane = (unsigned)(a.C * plane);
             for (int e0 = tid; e0 < total; e0 += NT * G) {
                 float v[G];
 #pragma unroll
@@ -75,43 +157,43 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {
             }
         }
         __syncthreads();
+        WIDE_MARK(0);
         if (do_dct4) {
             /* forward angular DCT (dct_4d_process, core:1862-1901), separable: rows of the aw x aw block ... */
-#pragma unroll 2
-            for (int e = tid; e < nSx * AW * SLAB; e += NT) {
-                const int px = e % SLAB, r = e / SLAB, s = r % AW, n = r / AW;
-                float* row = S + (size_t)(n * A + s * AW) * SLAB + px;
-                float x[AW], t[AW];
+            for (int e = tid; e < nSx * AW * P2; e += NT) {
+                const int pp = e % P2, r = e / P2;                       /* r = match * AW + row of the block */
+                v2f* row = S2 + (size_t)r * AW * P2 + pp;
+                v2f x[AW], t[AW];
 #pragma unroll
-                for (int j = 0; j < AW; j++) x[j] = row[j * SLAB];
+                for (int j = 0; j < AW; j++) x[j] = row[j * P2];
 #pragma unroll
                 for (int u = 0; u < AW; u++) {
-                    float acc = 0.0f;
+                    v2f acc = {0.0f, 0.0f};
 #pragma unroll
                     for (int j = 0; j < AW; j++) acc += x[j] * tb->cosw[u * AW + j];
                     t[u] = 2.0f * acc;
                 }
 #pragma unroll
-                for (int u = 0; u < AW; u++) row[u * SLAB] = t[u];
+                for (int u = 0; u < AW; u++) row[u * P2] = t[u];
             }
             __syncthreads();
+            WIDE_MARK(1);
             /* ... then columns, times coef_norm_4d */
-#pragma unroll 2
-            for (int e = tid; e < nSx * AW * SLAB; e += NT) {
-                const int px = e % SLAB, r = e / SLAB, u = r % AW, n = r / AW;
-                float* col = S + (size_t)(n * A + u) * SLAB + px;
-                float t[AW], x[AW];
+            for (int e = tid; e < nSx * AW * P2; e += NT) {
+                const int pp = e % P2, r = e / P2, u = r % AW, n = r / AW;
+                v2f* col = S2 + (size_t)(n * A + u) * P2 + pp;
+                v2f t[AW], x[AW];
 #pragma unroll
-                for (int j = 0; j < AW; j++) t[j] = col[j * AW * SLAB];
+                for (int j = 0; j < AW; j++) t[j] = col[j * AW * P2];
 #pragma unroll
                 for (int v = 0; v < AW; v++) {
-                    float acc = 0.0f;
+                    v2f acc = {0.0f, 0.0f};
 #pragma unroll
                     for (int j = 0; j < AW; j++) acc += t[j] * tb->cosw[v * AW + j];
-                    x[v] = 2.0f * acc * tb->cn4[v * AW + u];
+                    x[v] = 2.0f * acc * cn4s[v * AW + u];
                 }
 #pragma unroll
-                for (int v = 0; v < AW; v++) col[v * AW * SLAB] = x[v];
+                for (int v = 0; v < AW; v++) col[v * AW * P2] = x[v];
             }
             __syncthreads();
         } else if (do_sa4) {   /* the rare shape-adaptive groups: the call form, one (match, pixel) vector per thread */
@@ -124,55 +206,97 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {
             }
             __syncthreads();
         }
-        /* the fibres along the matches (core:371-410) */
-        for (int f = tid; f < A * SLAB; f += NT) {
-            const int st = f / SLAB, q = f % SLAB;
-            if (q >= npx) continue;
-            const bool in_shape = !use_sadct || sh.mask_dct[st];
-            const int base = st * SLAB + q, stride = A * SLAB;
-            switch (nSx) {
-                case 1:  filter5<1, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
-                case 2:  filter5<2, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
-                case 4:  filter5<4, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
-                default: filter5<8, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+        WIDE_MARK(2);
+        /* the fibres along the matches (core:371-410): pairs of pixels; the standard-deviation weights (useSD: float sums whose
+         * value depends on the order) keep the one-fibre form and its order */
+        if (!SPLIT && a.useSD) {
+            for (int f = tid; f < A * SLAB; f += NT) {
+                const int st = f / SLAB, q = f % SLAB;
+                if (q >= npx) continue;
+                const bool in_shape = !use_sadct || sh.mask_dct[st];
+                const int base = st * SLAB + q, stride = A * SLAB;
+                switch (nSx) {
+                    case 1:  filter5<1, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                    case 2:  filter5<2, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                    case 4:  filter5<4, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                    default: filter5<8, 1>(S, nullptr, base, stride, a.tau5, T, sig2, in_shape, wacc, s1, s2, tb); break;
+                }
+            }
+        } else {
+            for (int f = tid; f < A * P2; f += NT) {
+                const int st = f / P2, q2 = f % P2;
+                if (2 * q2 >= npx) continue;   /* (an odd tail pixel's partner holds zeros: they stay zeros and count nothing) */
+                const bool in_shape = !use_sadct || sh.mask_dct[st];
+                const int base = st * P2 + q2, stride = A * P2;
+                switch (nSx) {
+                    case 1:  filter5_pair<1>(S2, base, stride, a.tau5, T, in_shape, wacc, tb); break;
+                    case 2:  filter5_pair<2>(S2, base, stride, a.tau5, T, in_shape, wacc, tb); break;
+                    case 4:  filter5_pair<4>(S2, base, stride, a.tau5, T, in_shape, wacc, tb); break;
+                    default: filter5_pair<8>(S2, base, stride, a.tau5, T, in_shape, wacc, tb); break;
+                }
             }
         }
         __syncthreads();
+        WIDE_MARK(3);
         if (do_dct4) {
             /* inverse angular DCT (dct_4d_inverse, core:1913-1954): times coef_norm_inv, rows ... */
-#pragma unroll 2
-            for (int e = tid; e < nSx * AW * SLAB; e += NT) {
-                const int px = e % SLAB, r = e / SLAB, s = r % AW, n = r / AW;
-                float* row = S + (size_t)(n * A + s * AW) * SLAB + px;
-                float x[AW], t[AW];
+            for (int e = tid; e < nSx * AW * P2; e += NT) {
+                const int pp = e % P2, r = e / P2, s = r % AW;
+                v2f* row = S2 + (size_t)r * AW * P2 + pp;
+                v2f x[AW], t[AW];
 #pragma unroll
-                for (int u = 0; u < AW; u++) x[u] = row[u * SLAB] * tb->cni4[s * AW + u];
+                for (int u = 0; u < AW; u++) x[u] = row[u * P2] * cni4s[s * AW + u];
 #pragma unroll
                 for (int j = 0; j < AW; j++) {
-                    float acc = 0.0f;
+                    v2f acc = {0.0f, 0.0f};
 #pragma unroll
                     for (int u = 1; u < AW; u++) acc += x[u] * tb->cosw[u * AW + j];
                     t[j] = x[0] + 2.0f * acc;
                 }
 #pragma unroll
-                for (int j = 0; j < AW; j++) row[j * SLAB] = t[j];
+                for (int j = 0; j < AW; j++) row[j * P2] = t[j];
             }
             __syncthreads();
-            /* ... then columns, and the filtered pixels straight out: filt[g][n][st][c][pq] */
-#pragma unroll 2
-            for (int e = tid; e < nSx * AW * SLAB; e += NT) {
-                const int px = e % SLAB, r = e / SLAB, j = r % AW, n = r / AW;
-                const float* col = S + (size_t)(n * A + j) * SLAB + px;
-                float t[AW];
+            WIDE_MARK(4);
+            /* ... then columns, and the filtered pixels straight out: filt[g][n][st][c][pq] -- four pixels per thread and 16-byte
+             * stores where the patch area allows (the CU's store path is issue-bound: half the instructions of 8-byte stores) */
+            if ((k2 & 3) == 0) {
+                constexpr int P4 = SLAB / 4;
+                const v4f* const S4 = reinterpret_cast<const v4f*>(S);
+                for (int e = tid; e < nSx * AW * P4; e += NT) {
+                    const int pp = e % P4, r = e / P4, j = r % AW, n = r / AW, px = 4 * pp;
+                    const v4f* col = S4 + (size_t)(n * A + j) * P4 + pp;
+                    v4f t[AW];
 #pragma unroll
-                for (int v = 0; v < AW; v++) t[v] = col[v * AW * SLAB];
+                    for (int v = 0; v < AW; v++) t[v] = col[v * AW * P4];
+                    if (px < npx) {   /* (npx is a multiple of four here) */
+#pragma unroll
+                        for (int i = 0; i < AW; i++) {
+                            v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                            for (int v = 1; v < AW; v++) acc += t[v] * tb->cosw[v * AW + i];
+                            *reinterpret_cast<v4f*>(out + ((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px) = (t[0] + 2.0f * acc) * tb->coef4inv;
+                        }
+                    }
+                }
+            } else
+            for (int e = tid; e < nSx * AW * P2; e += NT) {
+                const int pp = e % P2, r = e / P2, j = r % AW, n = r / AW, px = 2 * pp;
+                const v2f* col = S2 + (size_t)(n * A + j) * P2 + pp;
+                v2f t[AW];
+#pragma unroll
+                for (int v = 0; v < AW; v++) t[v] = col[v * AW * P2];
                 if (px < npx) {
+                    const bool both = px + 1 < npx, even = (k2 & 1) == 0;   /* even patch area: every pair of `filt` is 8-byte aligned */
 #pragma unroll
                     for (int i = 0; i < AW; i++) {
-                        float acc = 0.0f;
+                        v2f acc = {0.0f, 0.0f};
 #pragma unroll
                         for (int v = 1; v < AW; v++) acc += t[v] * tb->cosw[v * AW + i];
-                        out[((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px] = (t[0] + 2.0f * acc) * tb->coef4inv;
+                        const v2f y = (t[0] + 2.0f * acc) * tb->coef4inv;
+                        float* o = out + ((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px;
+                        if (both && even) *reinterpret_cast<v2f*>(o) = y;
+                        else { o[0] = y.x; if (both) o[1] = y.y; }
                     }
                 }
             }
@@ -192,8 +316,14 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {
                 if (px < npx) out[((size_t)ns * a.C + c) * k2 + p0 + px] = S[e];
             }
         }
+        WIDE_MARK(7);
         __syncthreads();
+        WIDE_MARK(5);
     }
+#ifdef LFBM5D_WIDE_PHASES
+    if (tid == 0 && blockIdx.x % 64 == 5) {   /* a sample: same-address atomics of every workgroup would queue in L2 and slow every load */
+        for (int i = 0; i < 6; i++) atomicAdd(&a.counters[4 + i], (unsigned long long)tq[i]); atomicAdd(&a.counters[12], (unsigned long long)tq[6]); atomicAdd(&a.counters[13], (unsigned long long)tq[7]); atomicAdd(&a.counters[14], (unsigned long long)tq[8]); atomicAdd(&a.counters[15], (unsigned long long)tq[9]); atomicAdd(&a.counters[10], 1ull); atomicAdd(&a.counters[11], (unsigned long long)((long long)__builtin_amdgcn_s_memrealtime() - treal0)); }
+#endif
     /* group weight (core:412-421, sd_weighting_5d core:3140-3173) */
     for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
@@ -210,7 +340,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {
             wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
         if (SPLIT) { if (w != 0.0f) atomicAdd(&a.wgt[(size_t)g * a.C + c], w); }
         else a.wgt[(size_t)g * a.C + c] = wx;
-        if (c == 0 && (!SPLIT || blockIdx.z == 0)) {
+        if (c == 0 && (!SPLIT || slab == 0)) {
             atomicAdd(&a.counters[0], (unsigned long long)nSx);
             if (use_sadct) atomicAdd(&a.counters[1], 1ull);
         }
