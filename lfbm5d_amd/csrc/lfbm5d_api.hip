@@ -649,7 +649,7 @@ int fold_counters(lfbm5d_ctx* c, const lfbm5d_params* P, unsigned A, unsigned C,
     HIPCK(c, hipMemsetAsync(d_counters, 0, sizeof(h), c->stream));
     c->stats.stack_patches += h[0];
     c->stats.sadct_groups += h[1];
-#if defined(LFBM5D_PHASE_TIMING) || defined(LFBM5D_WIDE_PHASES)   /* kernel-internal phase clocks of development builds (tools/build_variant.sh) */
+#if defined(LFBM5D_PHASE_TIMING) || defined(LFBM5D_WIDE_PHASES) || defined(LFBM5D_SLAB_PHASES)   /* kernel-internal phase clocks of development builds (tools/build_variant.sh) */
     {
         unsigned long long ph[12];
         (void)hipMemcpy(ph, d_counters + 4, sizeof(ph), hipMemcpyDeviceToHost);

@@ -22,6 +22,11 @@ hipError_t launch_group_ht(hipStream_t s, const GroupArgs& a, bool all_sa, bool*
 hipError_t launch_group_wiener(hipStream_t s, const GroupArgs& a, bool all_sa, bool* launched);
 hipError_t launch_group_wide(hipStream_t s, const GroupArgs& a, bool* launched);   /* lfbm5d_group_wide.hip: HT, tau_2D = id, 5x5 / 7x7 windows */
 hipError_t prepare_group_wide();
+/* lfbm5d_group_slab.hip: stacks beyond the LDS (Wiener k = 12 / 16, N = 32, 5x5 / 7x7 windows with a 2-D transform) */
+hipError_t launch_group_slab(hipStream_t s, const GroupArgs& a, bool* launched);
+hipError_t prepare_group_slab();
+bool group_uses_slab(const GroupArgs& a);
+size_t group_slab_scratch_bytes(const GroupArgs& a);
 hipError_t prepare_group_ht();
 hipError_t prepare_group_wiener();
 constexpr int kDedicatedLdsLimit = 160 * 1024 - 4096;
@@ -920,7 +925,7 @@ __device__ __forceinline__ void bior16_level_all(float* work, int NP, int tid, T
 /* work area: (kThreads / K) patches of K x (K+1) floats */
 template <int K> constexpr int bior_tmp_floats() { return (kThreads / K) * K * (K + 1); }
 template <int K, bool FWD>
-__device__ void bior2d_fast(float* S, float* tmp, int np, TbPtr tb) {
+__device__ __noinline__ void bior2d_fast(float* S, float* tmp, int np, TbPtr tb) {
     constexpr int PPI = kThreads / K, RS = K + 1;
     const int tid = threadIdx.x, slot = tid / K, r = tid % K;
     float* Tp = tmp + slot * K * RS;
@@ -956,62 +961,88 @@ __device__ void bior2d_fast(float* S, float* tmp, int np, TbPtr tb) {
  * barrier needed */
 #define PATCH_SYNC() do { if (wave_local) __builtin_amdgcn_wave_barrier(); else __syncthreads(); } while (0)
 
-/* 2-D DCT of all patches with the per-thread table entries held in registers (thread = coefficient
- * (i,j) of a patch; its cosine rows never change from patch to patch) */
+/* 2-D DCT of all patches (bm3d.cpp:745-757; inverse bm3d.cpp:1039-1071), K threads per patch: a thread owns a ROW of its patch in the
+ * first pass and a COLUMN in the second, K values in registers and K outputs each, kThreads / K patches per iteration through a
+ * work area [patch][K][K+1] in LDS (the odd pitch keeps both directions free of bank conflicts).  The stack S may live in LDS or in
+ * the HBM slice of k_group_big: a round of 16 / 21 / 32 patches costs two barriers and one round trip to wherever S is, where
+ * round 4's thread-per-coefficient form paid them per patch (16x16) or per four (8x8).  The same sums in the same order: the same
+ * results. */
+template <int K> constexpr int dct_tmp_floats() { return (kThreads / K) * K * (K + 1); }
 template <int K>
-__device__ void fwd2d_dct(float* S, float* tmp, int np, TbPtr tb) {
-    constexpr int K2 = K * K;
-    const int tid = threadIdx.x;
-    const bool wave_local = K2 == 64;
-    constexpr int ppi = kThreads / K2 > 0 ? kThreads / K2 : 1;
-    const int slot = tid / K2, pq = tid % K2, i = pq / K, j = pq % K;
-    float cj[K], ci[K];
-#pragma unroll
-    for (int t = 0; t < K; t++) { cj[t] = tb->cos2[j * K + t]; ci[t] = tb->cos2[i * K + t]; }
-    const float cn = tb->cn2[pq];
-    float* Tm = tmp + slot * K2;
-    for (int p0 = 0; p0 < np; p0 += ppi) {
+__device__ __noinline__ void fwd2d_dct(float* S, float* tmp, int np, TbPtr tb) {
+    constexpr int K2 = K * K, PPI = kThreads / K, RS = K + 1;
+    constexpr bool wave_local = (64 % K) == 0;   /* the K threads of a patch in one wavefront */
+    const int tid = threadIdx.x, slot = tid / K, r = tid % K;
+    float* Tp = tmp + slot * K * RS;
+    for (int p0 = 0; p0 < np; p0 += PPI) {
         const int patch = p0 + slot;
-        const bool on = slot < ppi && patch < np;
+        const bool on = slot < PPI && patch < np;
         float* X = S + (size_t)patch * K2;
-        if (on) { float a = 0.0f;
+        if (on) {
+            float x[K];
 #pragma unroll
-            for (int t = 0; t < K; t++) a += X[i * K + t] * cj[t];
-            Tm[pq] = 2.0f * a; }
+            for (int t = 0; t < K; t++) x[t] = X[r * K + t];
+#pragma unroll 1
+            for (int j = 0; j < K; j++) {   /* (rolled: one scalar load of K cosines per output; unrolled, the K^2 constants cost 200 registers) */
+                float a = 0.0f;
+#pragma unroll
+                for (int t = 0; t < K; t++) a += x[t] * tb->cos2[j * K + t];
+                Tp[r * RS + j] = 2.0f * a;
+            }
+        }
         PATCH_SYNC();
-        if (on) { float a = 0.0f;
+        if (on) {
+            float c[K];
 #pragma unroll
-            for (int t = 0; t < K; t++) a += Tm[t * K + j] * ci[t];
-            X[pq] = 2.0f * a * cn; }
+            for (int t = 0; t < K; t++) c[t] = Tp[t * RS + r];
+#pragma unroll 1
+            for (int i = 0; i < K; i++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int t = 0; t < K; t++) a += c[t] * tb->cos2[i * K + t];
+                X[i * K + r] = 2.0f * a * tb->cn2[i * K + r];
+            }
+        }
         PATCH_SYNC();
     }
     __syncthreads();
 }
 template <int K>
-__device__ void inv2d_dct(float* S, float* tmp, int np, TbPtr tb) {
-    constexpr int K2 = K * K;
-    const int tid = threadIdx.x;
-    const bool wave_local = K2 == 64;
-    constexpr int ppi = kThreads / K2 > 0 ? kThreads / K2 : 1;
-    const int slot = tid / K2, pq = tid % K2, i = pq / K, j = pq % K;
-    float cc[K], ni[K], cu[K];
-#pragma unroll
-    for (int t = 0; t < K; t++) { cc[t] = tb->cos2[t * K + j]; ni[t] = tb->cni2[i * K + t]; cu[t] = tb->cos2[t * K + i]; }
+__device__ __noinline__ void inv2d_dct(float* S, float* tmp, int np, TbPtr tb) {
+    constexpr int K2 = K * K, PPI = kThreads / K, RS = K + 1;
+    constexpr bool wave_local = (64 % K) == 0;
+    const int tid = threadIdx.x, slot = tid / K, r = tid % K;
+    float* Tp = tmp + slot * K * RS;
     const float c2 = tb->coef2inv;
-    float* Tm = tmp + slot * K2;
-    for (int p0 = 0; p0 < np; p0 += ppi) {
+    for (int p0 = 0; p0 < np; p0 += PPI) {
         const int patch = p0 + slot;
-        const bool on = slot < ppi && patch < np;
+        const bool on = slot < PPI && patch < np;
         float* X = S + (size_t)patch * K2;
-        if (on) { float a = 0.0f;
+        if (on) {   /* row r: times coef_norm_inv, REDFT01 along the row */
+            float y[K];
 #pragma unroll
-            for (int v = 1; v < K; v++) a += X[i * K + v] * ni[v] * cc[v];
-            Tm[pq] = X[i * K] * ni[0] + 2.0f * a; }
+            for (int v = 0; v < K; v++) y[v] = X[r * K + v] * tb->cni2[r * K + v];
+#pragma unroll 1
+            for (int j = 0; j < K; j++) {   /* (rolled: one scalar load of K cosines per output; unrolled, the K^2 constants cost 200 registers) */
+                float a = 0.0f;
+#pragma unroll
+                for (int v = 1; v < K; v++) a += y[v] * tb->cos2[v * K + j];
+                Tp[r * RS + j] = y[0] + 2.0f * a;
+            }
+        }
         PATCH_SYNC();
-        if (on) { float a = 0.0f;
+        if (on) {   /* column r */
+            float c[K];
 #pragma unroll
-            for (int u = 1; u < K; u++) a += Tm[u * K + j] * cu[u];
-            X[pq] = c2 * (Tm[j] + 2.0f * a); }
+            for (int u = 0; u < K; u++) c[u] = Tp[u * RS + r];
+#pragma unroll 1
+            for (int i = 0; i < K; i++) {
+                float a = 0.0f;
+#pragma unroll
+                for (int u = 1; u < K; u++) a += c[u] * tb->cos2[u * K + i];
+                X[i * K + r] = c2 * (c[0] + 2.0f * a);
+            }
+        }
         PATCH_SYNC();
     }
     __syncthreads();
@@ -1019,7 +1050,7 @@ __device__ void inv2d_dct(float* S, float* tmp, int np, TbPtr tb) {
 
 /* patches of more coefficients than the workgroup has threads (k > 16): one patch at a time, the threads stride over its coefficients;
  * the same sums in the same order as the general form below */
-__device__ void fwd2d_big(float* S, float* Tm, int np, int k, unsigned tau2, TbPtr tb) {
+__device__ __noinline__ void fwd2d_big(float* S, float* Tm, int np, int k, unsigned tau2, TbPtr tb) {
     const int k2 = k * k, tid = threadIdx.x;
     for (int patch = 0; patch < np; patch++) {
         float* X = S + (size_t)patch * k2;
@@ -1058,7 +1089,7 @@ __device__ void fwd2d_big(float* S, float* Tm, int np, int k, unsigned tau2, TbP
     }
     __syncthreads();
 }
-__device__ void inv2d_big(float* S, float* Tm, int np, int k, unsigned tau2, TbPtr tb) {
+__device__ __noinline__ void inv2d_big(float* S, float* Tm, int np, int k, unsigned tau2, TbPtr tb) {
     const int k2 = k * k, tid = threadIdx.x;
     for (int patch = 0; patch < np; patch++) {
         float* X = S + (size_t)patch * k2;

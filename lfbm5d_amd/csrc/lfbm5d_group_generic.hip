@@ -335,13 +335,15 @@ hipError_t prepare_group_kernels() {
     hipError_t e = prepare_group_ht();
     if (e == hipSuccess) e = prepare_group_wiener();
     if (e == hipSuccess) e = prepare_group_wide();
+    if (e == hipSuccess) e = prepare_group_slab();
     return e;
 }
 
 constexpr unsigned kBigBlocks = 1024;   /* persistent workgroups of k_group_big (four per CU) */
 static size_t group_tmp_floats(const GroupArgs& a) {
     /* the 2-D stage's work area: one patch per wave-quarter for the generic path, [patch][k][k+1] for bior1.5 */
-    return (a.tau2 == 7 && (a.k == 8 || a.k == 16)) ? (size_t)(kThreads / a.k) * a.k * (a.k + 1) : std::max<size_t>(256, (size_t)a.k * a.k);
+    const bool rows_form = (a.tau2 == 7 && (a.k == 8 || a.k == 16)) || (a.tau2 == 5 && (a.k == 8 || a.k == 12 || a.k == 16));   /* bior2d_fast, fwd2d_dct */
+    return rows_form ? (size_t)(kThreads / a.k) * a.k * (a.k + 1) : std::max<size_t>(256, (size_t)a.k * a.k);
 }
 size_t group_lds_bytes(const GroupArgs& a) {
     const size_t stack = (size_t)a.N * a.A * a.k * a.k;
@@ -359,6 +361,7 @@ static bool group_uses_generic(const GroupArgs& a) {   /* mirrors the dispatch o
     return true;
 }
 size_t group_scratch_bytes(const GroupArgs& a) {
+    if (group_uses_generic(a) && getenv("LFBM5D_GROUP_GENERIC") == nullptr && group_uses_slab(a)) return group_slab_scratch_bytes(a);
     if (!group_uses_generic(a) || (group_lds_bytes(a) <= (size_t)kGenericLdsLimit && a.A <= (unsigned)kMaxA)) return 0;
     return (size_t)kBigBlocks * (a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);
 }
@@ -378,6 +381,8 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
         e = launch_group_wiener(s, a, all_sa, &launched);
         if (launched) return e;
         e = launch_group_wide(s, a, &launched);
+        if (launched) return e;
+        e = launch_group_slab(s, a, &launched);
         if (launched) return e;
     }
     const size_t lds = group_lds_bytes(a);

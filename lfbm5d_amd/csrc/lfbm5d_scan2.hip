@@ -78,7 +78,10 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-constexpr int kS2NW = 11;         /* tables (table waves) of a workgroup */
+#ifndef LFBM5D_S2_NW
+#define LFBM5D_S2_NW 11
+#endif
+constexpr int kS2NW = LFBM5D_S2_NW;         /* tables (table waves) of a workgroup */
 constexpr int kS2NL = 1;          /* ... and its loader wave: twelve waves, three per SIMD (the loader's instruction count per chunk is about a
                                    * table wave's, so every SIMD carries the same load and no wave idles at the chunk barrier), one workgroup per CU */
 constexpr int kS2NI = 6;          /* 16-byte pieces of a block of eight ring rows per loader lane: 64 * kS2NI >= 2 (CW1 + CW2) */

@@ -94,6 +94,7 @@ PASS_CASES = [
     ("ht-k32-bior", 1, 25.0, (2, 6, 2, 32, 8, "bior", "sadct", "haar"), 112, 0),
     ("wien-k32-dct", 2, 25.0, (2, 6, 2, 32, 8, "dct", "dct", "hw"), 112, 0),
     ("ht-k4-bior", 1, 25.0, (4, 5, 2, 4, 2, "bior", "sadct", "haar"), 48, 0),
+    ("wien-k12-dct-n8-hw", 2, 25.0, (8, 6, 2, 12, 4, "dct", "sadct", "hw"), 72, 0),   # stacks beyond 64 KB: the slab kernel (round 5)
 ]
 
 
@@ -871,6 +872,26 @@ def _random_cases():
         cases.append((f"rnd{len(cases)}-s{step}-k{k}-N{N}-{tau2}-{tau4}-{tau5}-p{p}-{ch}x{cw}", step, sigma,
                       (N, nSim, nDisp, k, p, tau2, tau4, tau5), (ch, cw), 0))
     return cases
+
+
+# Stacks beyond the LDS (lfbm5d_group_slab.hip, round 5): the Wiener step with 12x12 / 16x16 patches, N = 32 -- weights that are float
+# sums of up to 2 x 32 x 9 x 256 terms: the tolerances of the sweep, not the strict ones
+SLAB_CASES = [
+    ("wien-k16-dct-n16", 2, 25.0, (16, 6, 2, 16, 4, "dct", "sadct", "haar"), 96, 0),
+    ("wien-k16-bior-n8", 2, 25.0, (8, 6, 2, 16, 4, "bior", "dct", "haar"), 96, 0),
+    ("wien-k16-id-n16-dct5", 2, 25.0, (16, 6, 2, 16, 4, "id", "sadct", "dct"), 96, 0),
+    ("wien-k12-id-n16", 2, 10.0, (16, 6, 2, 12, 4, "id", "dct", "haar"), 72, 0),
+    ("wien-k16-dct-n32-hw", 2, 10.0, (32, 8, 2, 16, 4, "dct", "sadct", "hw"), 96, 0),
+    ("ht-k16-dct-n32", 1, 10.0, (32, 8, 2, 16, 4, "dct", "sadct", "haar"), 96, 0),
+    ("ht-k12-dct-n32-hw", 1, 10.0, (32, 8, 2, 12, 4, "dct", "dct", "hw"), 72, 0),
+]
+
+
+@pytest.mark.parametrize("case", SLAB_CASES, ids=[c[0] for c in SLAB_CASES])
+def test_large_stack_configurations_match_oracle(ctx, case, monkeypatch):
+    """... and the same pass through round 4's general kernel (stacks in HBM slices): the slab kernel runs the same transform
+    routines in the same order, so the two agree to the last bit where no sum depends on the thread layout (the group weights do)."""
+    _check_pass(ctx, case, strict=False)
 
 
 @pytest.mark.parametrize("case", _random_cases(), ids=[c[0] for c in _random_cases()])
