@@ -24,12 +24,12 @@ namespace lfbm5d {
 
 namespace {
 
-constexpr int kSlabFloats = 12288;    /* LDS stack of a slab: 48 KB, three workgroups per CU */
+constexpr int kSlabFloats = 18432;    /* LDS stack of a slab: 72 KB -- the registers (170-320) allow two workgroups per CU at most */
 constexpr unsigned kSlabBlocks = 1024;
 
 /* ---- 2-D transforms of the patches of a work area [patch][K][K+1], K threads per patch (thread r: row r, then column r) ---- */
 template <int K>
-__device__ __forceinline__ void dct_tp_rows(float* Tp, int r, bool fwd, TbPtr tb) {   /* first pass of fwd2d_dct / inv2d_dct */
+__device__ __forceinline__ void dct_tp_rows(float* Tp, int r, bool fwd, const float* nrm, TbPtr tb) {   /* first pass of fwd2d_dct / inv2d_dct */
     constexpr int RS = K + 1;
     float x[K];
     if (fwd) {
@@ -44,7 +44,7 @@ __device__ __forceinline__ void dct_tp_rows(float* Tp, int r, bool fwd, TbPtr tb
         }
     } else {
 #pragma unroll
-        for (int v = 0; v < K; v++) x[v] = Tp[r * RS + v] * tb->cni2[r * K + v];
+        for (int v = 0; v < K; v++) x[v] = Tp[r * RS + v] * nrm[v];   /* coef_norm_inv[r][v] */
 #pragma unroll 4
         for (int j = 0; j < K; j++) {
             float a = 0.0f;
@@ -55,18 +55,18 @@ __device__ __forceinline__ void dct_tp_rows(float* Tp, int r, bool fwd, TbPtr tb
     }
 }
 template <int K>
-__device__ __forceinline__ void dct_tp_cols(float* Tp, int r, bool fwd, TbPtr tb) {   /* second pass: column r, in place */
+__device__ __forceinline__ void dct_tp_cols(float* Tp, int r, bool fwd, const float* nrm, TbPtr tb) {   /* second pass: column r, in place */
     constexpr int RS = K + 1;
     float c[K];
 #pragma unroll
     for (int t = 0; t < K; t++) c[t] = Tp[t * RS + r];
     if (fwd) {
-#pragma unroll 4
-        for (int i = 0; i < K; i++) {
+#pragma unroll
+        for (int i = 0; i < K; i++) {   /* (unrolled: nrm stays in registers; the cosines of a row are one scalar load) */
             float a = 0.0f;
 #pragma unroll
             for (int t = 0; t < K; t++) a += c[t] * tb->cos2[i * K + t];
-            Tp[i * RS + r] = 2.0f * a * tb->cn2[i * K + r];
+            Tp[i * RS + r] = 2.0f * a * nrm[i];   /* coef_norm[i][r] */
         }
     } else {
         const float c2 = tb->coef2inv;
@@ -93,21 +93,30 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
     /* K = 8, 16: the K threads of a patch share a wavefront and no other thread touches their part of the work area -- no workgroup
      * barrier anywhere in the stage (a wave's DS operations execute in order), the waves drift apart and hide each other's loads */
     constexpr bool wave_local = (64 % K) == 0;
+    /* the per-thread norms, once per stage (indexed by the thread's row / column: vector loads, which inside the transform
+     * cost a memory round trip per output) */
+    float nrm[K];
+    if (tau2 == 5) {
+#pragma unroll
+        for (int t = 0; t < K; t++) nrm[t] = fwd ? tb->cn2[t * K + r] : tb->cni2[r * K + t];
+    }
 #define SLAB_SYNC() do { if (wave_local) __builtin_amdgcn_wave_barrier(); else __syncthreads(); } while (0)
+    /* the rows of the NEXT round of patches are requested before this round is transformed: their latency hides behind it */
+    float xn[K];
+    if (slot < PPI && slot < np) src(std::integral_constant<int, K>{}, slot, r, xn);
     for (int p0 = 0; p0 < np; p0 += PPI) {
         const int patch = p0 + slot;
         const bool on = slot < PPI && patch < np;
         if (on) {
-            float x[K];
-            src(std::integral_constant<int, K>{}, patch, r, x);
 #pragma unroll
-            for (int t = 0; t < K; t++) Tp[r * RS + t] = x[t];
+            for (int t = 0; t < K; t++) Tp[r * RS + t] = xn[t];
         }
+        if (slot < PPI && patch + PPI < np) src(std::integral_constant<int, K>{}, patch + PPI, r, xn);
         SLAB_SYNC();
         if (tau2 == 5) {
-            if (on) dct_tp_rows<K>(Tp, r, fwd, tb);
+            if (on) dct_tp_rows<K>(Tp, r, fwd, nrm, tb);
             SLAB_SYNC();
-            if (on) dct_tp_cols<K>(Tp, r, fwd, tb);
+            if (on) dct_tp_cols<K>(Tp, r, fwd, nrm, tb);
         } else if constexpr (K != 12) {
             if (on) bior_tp<K>(Tp, r, fwd, tb);
         }
