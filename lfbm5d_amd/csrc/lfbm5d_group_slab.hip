@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps fo
     const size_t plane = (size_t)a.Wb * a.Hb;
     const TbPtr tb = (TbPtr)a.tb;
     const bool id2 = a.tau2 == 4;
-    float* const slice = scratch + (size_t)blockIdx.x * slice_floats;   /* [stack][n * A + st][k2] coefficients */
+    float* const slice = id2 ? nullptr : scratch + (size_t)blockIdx.x * slice_floats;   /* [stack][n * A + st][k2] coefficients (tau_2D = id: none) */
     if (tid < A) { cn4s[tid] = tb->cn4[tid]; cni4s[tid] = tb->cni4[tid]; }
     const unsigned items = a.n_groups * a.C;
     for (unsigned it = blockIdx.x; it < items; it += gridDim.x) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps fo
         float* const S0 = lds;
         float* const S1 = lds + ((size_t)NSA << ls);
         float* const F = STEP == 2 ? S1 : S0;
-        float* const fslice = slice + (STEP == 2 ? (size_t)NSA * k2 : 0);   /* the filtered stack returns to its own place */
+        float* const fslice = id2 ? nullptr : slice + (STEP == 2 ? (size_t)NSA * k2 : 0);   /* the filtered stack returns to its own place */
         for (int s0 = 0; s0 < k2; s0 += SLAB) {
             const int npx = min(SLAB, k2 - s0);
             /* load: [stack][ns][q], q fastest */
