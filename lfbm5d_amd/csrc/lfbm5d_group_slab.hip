@@ -86,7 +86,13 @@ __device__ __forceinline__ void bior_tp(float* Tp, int r, bool fwd, TbPtr tb) { 
 
 /* One 2-D stage over `np` patches: `src(p, r, x)` delivers row r of patch p (K floats), `dst(p, r, x)` takes it. */
 template <int K, class SRC, class DST>
-__device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bool fwd, TbPtr tb, SRC src, DST dst) {
+__device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bool fwd, TbPtr tb, SRC src, DST dst, long long* sub = nullptr) {
+#ifdef LFBM5D_SLAB_PHASES
+    long long tl = (long long)__builtin_readcyclecounter();
+#define SUB_MARK(i) do { asm volatile("" ::: "memory"); const long long tn = (long long)__builtin_readcyclecounter(); if (sub) sub[i] += tn - tl; tl = tn; } while (0)
+#else
+#define SUB_MARK(i) do {} while (0)
+#endif
     constexpr int PPI = kThreads / K, RS = K + 1;
     const int tid = threadIdx.x, slot = tid / K, r = tid % K;
     float* Tp = tmp + slot * K * RS;
@@ -113,14 +119,17 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
         }
         if (slot < PPI && patch + PPI < np) src(std::integral_constant<int, K>{}, patch + PPI, r, xn);
         SLAB_SYNC();
+        SUB_MARK(0);
         if (tau2 == 5) {
             if (on) dct_tp_rows<K>(Tp, r, fwd, nrm, tb);
             SLAB_SYNC();
+            SUB_MARK(1);
             if (on) dct_tp_cols<K>(Tp, r, fwd, nrm, tb);
         } else if constexpr (K != 12) {
             if (on) bior_tp<K>(Tp, r, fwd, tb);
         }
         SLAB_SYNC();
+        SUB_MARK(2);
         if (on) {
             float x[K];
 #pragma unroll
@@ -128,8 +137,10 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
             dst(std::integral_constant<int, K>{}, patch, r, x);
         }
         SLAB_SYNC();
+        SUB_MARK(3);
     }
 #undef SLAB_SYNC
+#undef SUB_MARK
     __syncthreads();   /* (what the stage wrote is read by other waves next) */
 }
 
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps fo
         float* const out = a.filt + (size_t)g * N * A * a.C * k2;
         __syncthreads();
 #ifdef LFBM5D_SLAB_PHASES   /* development builds: cycles per stage, thread 0 of every 64th workgroup (lfbm5d_api.hip prints counters 4..15) */
-        long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
+        long long tq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
 #define SLAB_MARK(i) do { asm volatile("" ::: "memory"); const long long tn = (long long)__builtin_readcyclecounter(); tq[i] += tn - tlast; tlast = tn; } while (0)
 #else
 #define SLAB_MARK(i) do {} while (0)
@@ -192,9 +203,14 @@ __global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps fo
 #pragma unroll
                 for (int t = 0; t < K; t += 4) *reinterpret_cast<v4f*>(o + t) = v4f{x[t], x[t + 1], x[t + 2], x[t + 3]};
             };
-            if (k == 16) patches_2d<16>(lds, NST * NSA, a.tau2, true, tb, src, dst);
-            else if (k == 12) patches_2d<12>(lds, NST * NSA, a.tau2, true, tb, src, dst);
-            else patches_2d<8>(lds, NST * NSA, a.tau2, true, tb, src, dst);
+#ifdef LFBM5D_SLAB_PHASES
+            long long* const subp = tq + 8;
+#else
+            long long* const subp = nullptr;
+#endif
+            if (k == 16) patches_2d<16>(lds, NST * NSA, a.tau2, true, tb, src, dst, subp);
+            else if (k == 12) patches_2d<12>(lds, NST * NSA, a.tau2, true, tb, src, dst, subp);
+            else patches_2d<8>(lds, NST * NSA, a.tau2, true, tb, src, dst, subp);
             /* (the slice is read back by other threads of this workgroup: its writes go through the CU's write-through L1,
              * the barrier that ended patches_2d orders them) */
         }
@@ -449,7 +465,7 @@ __global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps fo
         __syncthreads();   /* pos / red / the LDS are reused by the next item */
         SLAB_MARK(6);
 #ifdef LFBM5D_SLAB_PHASES
-        if (tid == 0 && blockIdx.x % 64 == 5) { for (int i = 0; i < 7; i++) atomicAdd(&a.counters[4 + i], (unsigned long long)tq[i]); atomicAdd(&a.counters[11], 1ull); }
+        if (tid == 0 && blockIdx.x % 64 == 5) { for (int i = 0; i < 7; i++) atomicAdd(&a.counters[4 + i], (unsigned long long)tq[i]); atomicAdd(&a.counters[11], 1ull); for (int i = 0; i < 4; i++) atomicAdd(&a.counters[12 + i], (unsigned long long)tq[8 + i]); }
 #endif
     }
 }
