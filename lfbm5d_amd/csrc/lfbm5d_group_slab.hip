@@ -95,7 +95,7 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
 #endif
     constexpr int PPI = kThreads / K, RS = K + 1;
     const int tid = threadIdx.x, slot = tid / K, r = tid % K;
-    float* Tp = tmp + slot * K * RS;
+    float* Tp = tmp + slot * K * RS;   /* two work areas of PPI patches each */
     /* K = 8, 16: the K threads of a patch share a wavefront and no other thread touches their part of the work area -- no workgroup
      * barrier anywhere in the stage (a wave's DS operations execute in order), the waves drift apart and hide each other's loads */
     constexpr bool wave_local = (64 % K) == 0;
@@ -107,15 +107,24 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
         for (int t = 0; t < K; t++) nrm[t] = fwd ? tb->cn2[t * K + r] : tb->cni2[r * K + t];
     }
 #define SLAB_SYNC() do { if (wave_local) __builtin_amdgcn_wave_barrier(); else __syncthreads(); } while (0)
-    /* the rows of the NEXT round of patches are requested before this round is transformed: their latency hides behind it */
+    /* Software pipeline over the rounds: the rows of the NEXT round are requested before this round is transformed, and the results
+     * of the PREVIOUS round leave while this one is transformed (two work areas): the wait for the next rows -- vmcnt counts loads
+     * and stores in order -- then finds stores that have had a whole round to be acknowledged */
     float xn[K];
     if (slot < PPI && slot < np) src(std::integral_constant<int, K>{}, slot, r, xn);
+    float* TpPrev = Tp + PPI * K * RS;
     for (int p0 = 0; p0 < np; p0 += PPI) {
         const int patch = p0 + slot;
         const bool on = slot < PPI && patch < np;
         if (on) {
 #pragma unroll
             for (int t = 0; t < K; t++) Tp[r * RS + t] = xn[t];
+        }
+        if (p0 > 0 && slot < PPI) {   /* (the previous round was full) */
+            float x[K];
+#pragma unroll
+            for (int t = 0; t < K; t++) x[t] = TpPrev[r * RS + t];
+            dst(std::integral_constant<int, K>{}, patch - PPI, r, x);
         }
         if (slot < PPI && patch + PPI < np) src(std::integral_constant<int, K>{}, patch + PPI, r, xn);
         SLAB_SYNC();
@@ -130,13 +139,16 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
         }
         SLAB_SYNC();
         SUB_MARK(2);
-        if (on) {
+        { float* const sw = Tp; Tp = TpPrev; TpPrev = sw; }
+    }
+    {   /* the last round's results */
+        const int patch = ((np - 1) / PPI) * PPI + slot;
+        if (np > 0 && slot < PPI && patch < np) {
             float x[K];
 #pragma unroll
-            for (int t = 0; t < K; t++) x[t] = Tp[r * RS + t];
+            for (int t = 0; t < K; t++) x[t] = TpPrev[r * RS + t];
             dst(std::integral_constant<int, K>{}, patch, r, x);
         }
-        SLAB_SYNC();
         SUB_MARK(3);
     }
 #undef SLAB_SYNC
@@ -478,7 +490,7 @@ int slab_log2(const GroupArgs& a) {
 }
 size_t slab_lds_bytes(const GroupArgs& a) {
     const size_t stack = (size_t)((a.step == 2 ? 2 : 1) * a.N * a.A) << slab_log2(a);
-    const size_t work = a.tau2 == 4 ? 0 : (size_t)(kThreads / a.k) * a.k * (a.k + 1);
+    const size_t work = a.tau2 == 4 ? 0 : (size_t)2 * (kThreads / a.k) * a.k * (a.k + 1);   /* two work areas (patches_2d) */
     return std::max(stack, work) * sizeof(float);
 }
 
