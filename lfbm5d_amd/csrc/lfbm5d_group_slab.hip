@@ -35,7 +35,7 @@ __device__ __forceinline__ void dct_tp_rows(float* Tp, int r, bool fwd, const fl
     if (fwd) {
 #pragma unroll
         for (int t = 0; t < K; t++) x[t] = Tp[r * RS + t];
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < K; j++) {
             float a = 0.0f;
 #pragma unroll
@@ -45,7 +45,7 @@ __device__ __forceinline__ void dct_tp_rows(float* Tp, int r, bool fwd, const fl
     } else {
 #pragma unroll
         for (int v = 0; v < K; v++) x[v] = Tp[r * RS + v] * nrm[v];   /* coef_norm_inv[r][v] */
-#pragma unroll 4
+#pragma unroll
         for (int j = 0; j < K; j++) {
             float a = 0.0f;
 #pragma unroll
