@@ -281,13 +281,26 @@ __global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps fo
             /* angular transform forward (core:353-360) on both stacks */
             if (do_dct4 || do_sa4) {
                 if constexpr (WA == 3) {
+                    if (do_dct4) {   /* two pixels per lane: the scalar routine's operation sequence on packed values */
+                        v2f* const S2 = reinterpret_cast<v2f*>(lds);
+                        for (int f = tid; f < (NST * nSx) << (ls - 1); f += kThreads) {
+                            const int pp = f & (P2 - 1), sn = f >> (ls - 1);   /* sn = stack * nSx + n */
+                            v2f* B = S2 + ((size_t)sn * 9 << (ls - 1)) + pp;
+                            v2f x[9];
+#pragma unroll
+                            for (int st = 0; st < 9; st++) x[st] = B[st << (ls - 1)];
+                            dct9_fwd2(x, tb);
+#pragma unroll
+                            for (int st = 0; st < 9; st++) B[st << (ls - 1)] = x[st];
+                        }
+                    } else
                     for (int f = tid; f < (NST * nSx) << ls; f += kThreads) {
-                        const int q = f & (SLAB - 1), sn = f >> ls;   /* sn = stack * nSx + n */
+                        const int q = f & (SLAB - 1), sn = f >> ls;
                         float* B = lds + ((size_t)sn * 9 << ls) + q;
                         float x[9];
 #pragma unroll
                         for (int st = 0; st < 9; st++) x[st] = B[st << ls];
-                        if (do_dct4) dct9_fwd(x, tb); else sadct9_fwd(x, sh, tb);
+                        sadct9_fwd(x, sh, tb);
 #pragma unroll
                         for (int st = 0; st < 9; st++) B[st << ls] = x[st];
                     }
@@ -363,13 +376,26 @@ __global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps fo
             /* angular transform inverse (core:431-451) on the filtered stack */
             if (do_dct4 || do_sa4) {
                 if constexpr (WA == 3) {
+                    if (do_dct4) {
+                        v2f* const F2 = reinterpret_cast<v2f*>(F);
+                        for (int f = tid; f < nSx << (ls - 1); f += kThreads) {
+                            const int pp = f & (P2 - 1), n = f >> (ls - 1);
+                            v2f* B = F2 + ((size_t)n * 9 << (ls - 1)) + pp;
+                            v2f x[9];
+#pragma unroll
+                            for (int st = 0; st < 9; st++) x[st] = B[st << (ls - 1)];
+                            dct9_inv2(x, tb);
+#pragma unroll
+                            for (int st = 0; st < 9; st++) B[st << (ls - 1)] = x[st];
+                        }
+                    } else
                     for (int f = tid; f < nSx << ls; f += kThreads) {
                         const int q = f & (SLAB - 1), n = f >> ls;
                         float* B = F + ((size_t)n * 9 << ls) + q;
                         float x[9];
 #pragma unroll
                         for (int st = 0; st < 9; st++) x[st] = B[st << ls];
-                        if (do_dct4) dct9_inv(x, tb); else sadct9_inv(x, sh, tb);
+                        sadct9_inv(x, sh, tb);
 #pragma unroll
                         for (int st = 0; st < 9; st++) B[st << ls] = x[st];
                     }
