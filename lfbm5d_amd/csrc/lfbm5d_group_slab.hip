@@ -548,7 +548,7 @@ hipError_t prepare_group_slab() {
     const void* fns[] = {LFBM5D_SLAB_FNS(16), LFBM5D_SLAB_FNS(32)};
 #undef LFBM5D_SLAB_FNS
     for (const void* f : fns) {
-        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);   /* slab stack <= 72 KB, two work areas <= 35 KB */
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
