@@ -158,7 +158,8 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
 
 /* ---- the kernel ---- */
 template <int STEP, int WA, int MAXN>
-__global__ __launch_bounds__(kThreads) void k_group_slab(   /* (register caps for three / four waves per SIMD: +-10 %, spills at N = 32) */
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN > 16 ? 2 : 1, 8))) void k_group_slab(   /* N = 32: 256 registers, two workgroups per CU (caps
+                                                                                                                         * for three / four waves per SIMD: +-10 %) */
     GroupArgs a, float* scratch, unsigned long long slice_floats, int ls) {
     constexpr int A = WA * WA, NST = STEP == 2 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
