@@ -603,6 +603,86 @@ __device__ __noinline__ void sadctw_inv(float* v, int aw, SHR sh, TbPtr tb) {
     for (int i = 0; i < aw * aw; i++) v[i] *= (float)sh.mask[i];
 }
 
+/* The shape-adaptive angular transform (core:1969-2264) as SEPARABLE passes over a stack in LDS, two pixels per lane: a thread owns
+ * one row (then one column) of a match's aw x aw block -- `row` / `col` point at its first element, consecutive elements P / AW * P
+ * pairs apart.  The same products in the same order as sadctw_fwd / sadctw_inv (which hold the whole block of one pixel in private
+ * memory: hundreds of times slower on the 6 % shape-adaptive groups of a 9x9 window). */
+/* Out of line, so that the registers of this rare path are not the kernel's (inlined, the 9x9 instance needs 245 instead of 155 and
+ * the plain groups lose their occupancy); the pointers keep their address spaces -- LDS, constant -- through the call: ds_ and
+ * s_load instructions, not flat ones.  Outputs in registers, statically indexed; inputs re-read from LDS in run-time loops. */
+typedef __attribute__((address_space(3))) v2f* LdsV2;
+template <int AW, class SHR>
+__device__ __noinline__ void sadctw_rows_fwd2(LdsV2 row, int P, int s, SHR sh, TbPtr tb) {
+    const int n = sh.row_n[s];
+    if (n == 1) { row[0] = row[sh.idx[s * AW] * P]; return; }
+    if (n < 2) return;
+    v2f y[AW];
+#pragma unroll
+    for (int u = 0; u < AW; u++) if (u < n) {
+        v2f a = {0.0f, 0.0f};
+        for (int j = 0; j < n; j++) a += row[sh.idx[s * AW + j] * P] * tb->cos1[n][u * n + j];
+        y[u] = 2.0f * a;
+    }
+#pragma unroll
+    for (int t = 0; t < AW; t++) if (t < n) row[t * P] = y[t] * tb->cn1[n][t];
+}
+template <int AW, class SHR>
+__device__ __noinline__ void sadctw_cols_fwd2(LdsV2 col, int P, int t, SHR sh, TbPtr tb) {   /* ... and the closing scale by mask_dct */
+    const int n = sh.col_n[t];
+    if (n == 1) col[0] = col[sh.idx_col[t] * AW * P];
+    else if (n > 1) {
+        v2f y[AW];
+#pragma unroll
+        for (int u = 0; u < AW; u++) if (u < n) {
+            v2f a = {0.0f, 0.0f};
+            for (int j = 0; j < n; j++) a += col[sh.idx_col[j * AW + t] * AW * P] * tb->cos1[n][u * n + j];
+            y[u] = 2.0f * a;
+        }
+#pragma unroll
+        for (int q = 0; q < AW; q++) if (q < n) col[q * AW * P] = y[q] * tb->cn1[n][q];
+    }
+    const float coef = 0.5f * 0.70710678118654752f;
+#pragma unroll
+    for (int q = 0; q < AW; q++) col[q * AW * P] *= (float)sh.mask_dct[q * AW + t] * coef;
+}
+template <int AW, class SHR>
+__device__ __noinline__ void sadctw_cols_inv2(LdsV2 col, int P, int t, SHR sh, TbPtr tb) {
+    const int n = sh.col_n[t];
+    const float coef = 2.0f * 1.41421356237309505f;
+    if (n == 1) { const v2f v0 = col[0]; col[sh.idx_col[t] * AW * P] = v0 * coef; }
+    else if (n > 1) {
+        v2f y[AW];
+        const v2f x0 = col[0] * tb->cni1[n][0] * coef;
+#pragma unroll
+        for (int j = 0; j < AW; j++) if (j < n) {
+            v2f a = {0.0f, 0.0f};
+            for (int u = 1; u < n; u++) a += (col[u * AW * P] * tb->cni1[n][u] * coef) * tb->cos1[n][u * n + j];
+            y[j] = x0 + 2.0f * a;
+        }
+#pragma unroll
+        for (int q = 0; q < AW; q++) if (q < n) col[sh.idx_col[q * AW + t] * AW * P] = y[q] * tb->c1inv[n];
+    }
+}
+template <int AW, class SHR>
+__device__ __noinline__ void sadctw_rows_inv2(LdsV2 row, int P, int s, SHR sh, TbPtr tb) {   /* ... and the closing scale by mask */
+    const int n = sh.row_n[s];
+    if (n == 1) { const v2f v0 = row[0]; row[sh.idx[s * AW] * P] = v0; }
+    else if (n > 1) {
+        v2f y[AW];
+        const v2f x0 = row[0] * tb->cni1[n][0];
+#pragma unroll
+        for (int j = 0; j < AW; j++) if (j < n) {
+            v2f a = {0.0f, 0.0f};
+            for (int u = 1; u < n; u++) a += (row[u * P] * tb->cni1[n][u]) * tb->cos1[n][u * n + j];
+            y[j] = x0 + 2.0f * a;
+        }
+#pragma unroll
+        for (int t = 0; t < AW; t++) if (t < n) row[sh.idx[s * AW + t] * P] = y[t] * tb->c1inv[n];
+    }
+#pragma unroll
+    for (int t = 0; t < AW; t++) row[t * P] *= (float)sh.mask[s * AW + t];
+}
+
 /* lib_transforms.cpp:403-471 / :290-321 on a register vector of compile-time length */
 template <int NS, class T> __device__ __forceinline__ void haar_fwd(T* v) {   /* T = float, or v2f: two fibres per lane */
     const float s = 0.70710678118654752f;

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
         const int c = (int)(it % a.C);
         const int nSx = (int)a.self_cnt[g], NSA = nSx * A;
         for (int i = tid; i < NSA; i += kThreads) pos[i] = a.gpos[(size_t)g * N * A + i];
-        ShRef sh = group_shape(a, g);
+        typedef typename std::conditional<(WA > 7), ShRefBig, ShRef>::type SH;   /* (windows beyond 7x7: the large shape record) */
+        SH sh = [&]() -> SH { if constexpr (WA > 7) return group_shape_big(a, g); else return group_shape(a, g); }();
         const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
         const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
         const bool do_sa4 = !do_dct4 && a.tau4 == 6;
@@ -341,14 +342,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
 #pragma unroll
                         for (int v = 0; v < WA; v++) col[(v * WA) << (ls - 1)] = x[v];
                     }
-                } else {   /* shape-adaptive groups of the larger windows: the call form, one (match, pixel) vector per thread */
-                    for (int f = tid; f < (NST * nSx) << ls; f += kThreads) {
-                        const int q = f & (SLAB - 1), sn = f >> ls;
-                        float* B = lds + ((size_t)sn * A << ls) + q;
-                        float y[kMaxA];
-                        for (int st = 0; st < A; st++) y[st] = B[st << ls];
-                        sadctw_fwd<ShRef>(y, WA, sh, tb);
-                        for (int st = 0; st < A; st++) B[st << ls] = y[st];
+                } else {   /* shape-adaptive groups of the larger windows: the same separable form with the shape record's lengths */
+                    v2f* const S2 = reinterpret_cast<v2f*>(lds);
+                    for (int e = tid; e < (NST * nSx * WA) << (ls - 1); e += kThreads) {
+                        const int pp = e & (P2 - 1), r = e >> (ls - 1);
+                        sadctw_rows_fwd2<WA, SH>((LdsV2)(S2 + ((size_t)r * WA << (ls - 1)) + pp), P2, r % WA, sh, tb);
+                    }
+                    __syncthreads();
+                    for (int e = tid; e < (NST * nSx * WA) << (ls - 1); e += kThreads) {
+                        const int pp = e & (P2 - 1), r = e >> (ls - 1), u = r % WA, sn = r / WA;
+                        sadctw_cols_fwd2<WA, SH>((LdsV2)(S2 + ((size_t)(sn * A + u) << (ls - 1)) + pp), P2, u, sh, tb);
                     }
                 }
                 __syncthreads();
@@ -436,13 +439,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
                         for (int i = 0; i < WA; i++) col[(i * WA) << (ls - 1)] = y[i];
                     }
                 } else {
-                    for (int f = tid; f < nSx << ls; f += kThreads) {
-                        const int q = f & (SLAB - 1), n = f >> ls;
-                        float* B = F + ((size_t)n * A << ls) + q;
-                        float y[kMaxA];
-                        for (int st = 0; st < A; st++) y[st] = B[st << ls];
-                        sadctw_inv<ShRef>(y, WA, sh, tb);
-                        for (int st = 0; st < A; st++) B[st << ls] = y[st];
+                    v2f* const F2 = reinterpret_cast<v2f*>(F);
+                    for (int e = tid; e < (nSx * WA) << (ls - 1); e += kThreads) {
+                        const int pp = e & (P2 - 1), r = e >> (ls - 1), u = r % WA, n = r / WA;
+                        sadctw_cols_inv2<WA, SH>((LdsV2)(F2 + ((size_t)(n * A + u) << (ls - 1)) + pp), P2, u, sh, tb);
+                    }
+                    __syncthreads();
+                    for (int e = tid; e < (nSx * WA) << (ls - 1); e += kThreads) {
+                        const int pp = e & (P2 - 1), r = e >> (ls - 1);
+                        sadctw_rows_inv2<WA, SH>((LdsV2)(F2 + ((size_t)r * WA << (ls - 1)) + pp), P2, r % WA, sh, tb);
                     }
                 }
                 __syncthreads();
@@ -527,7 +532,7 @@ size_t slab_lds_bytes(const GroupArgs& a) {
  * from HBM slices or with one workgroup per CU. */
 bool group_uses_slab(const GroupArgs& a) {
     if (getenv("LFBM5D_NO_SLAB_KERNEL") != nullptr) return false;
-    if (a.bm3d || a.useSD || !(a.A == 9 || a.A == 25 || a.A == 49) || a.N > 32) return false;
+    if (a.bm3d || a.useSD || !(a.A == 9 || a.A == 25 || a.A == 49 || a.A == 81) || a.N > 32) return false;
     if (a.tau2 == 5 && !(a.k == 8 || a.k == 12 || a.k == 16)) return false;
     if (a.tau2 == 7 && !(a.k == 8 || a.k == 16)) return false;
     if (a.tau2 == 4 && a.k > 16) return false;
@@ -545,7 +550,8 @@ size_t group_slab_scratch_bytes(const GroupArgs& a) {
 hipError_t prepare_group_slab() {
 #define LFBM5D_SLAB_FNS(MAXN) reinterpret_cast<const void*>(&k_group_slab<1, 3, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 3, MAXN>), \
                               reinterpret_cast<const void*>(&k_group_slab<1, 5, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 5, MAXN>), \
-                              reinterpret_cast<const void*>(&k_group_slab<1, 7, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 7, MAXN>)
+                              reinterpret_cast<const void*>(&k_group_slab<1, 7, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 7, MAXN>), \
+                              reinterpret_cast<const void*>(&k_group_slab<1, 9, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 9, MAXN>)
     const void* fns[] = {LFBM5D_SLAB_FNS(16), LFBM5D_SLAB_FNS(32)};
 #undef LFBM5D_SLAB_FNS
     for (const void* f : fns) {
@@ -566,7 +572,7 @@ hipError_t launch_group_slab(hipStream_t s, const GroupArgs& a, bool* launched) 
     const size_t lds = slab_lds_bytes(a);
 #define LFBM5D_SLAB1(STEP, WA, MAXN) hipLaunchKernelGGL((k_group_slab<STEP, WA, MAXN>), dim3(blocks), dim3(kThreads), lds, s, a, a.scratch, slice, ls)
 #define LFBM5D_SLAB2(STEP, WA) do { if (a.N <= 16) LFBM5D_SLAB1(STEP, WA, 16); else LFBM5D_SLAB1(STEP, WA, 32); } while (0)
-#define LFBM5D_SLAB3(STEP) do { if (a.A == 9) LFBM5D_SLAB2(STEP, 3); else if (a.A == 25) LFBM5D_SLAB2(STEP, 5); else LFBM5D_SLAB2(STEP, 7); } while (0)
+#define LFBM5D_SLAB3(STEP) do { if (a.A == 9) LFBM5D_SLAB2(STEP, 3); else if (a.A == 25) LFBM5D_SLAB2(STEP, 5); else if (a.A == 49) LFBM5D_SLAB2(STEP, 7); else LFBM5D_SLAB2(STEP, 9); } while (0)
     if (a.step == 2) LFBM5D_SLAB3(2); else LFBM5D_SLAB3(1);
 #undef LFBM5D_SLAB3
 #undef LFBM5D_SLAB2

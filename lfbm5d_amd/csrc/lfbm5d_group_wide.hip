@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
         for (int u = 0; u < GQ; u++) pv[u] = a.gpos[(size_t)g * N * A + min((tid + u * NT) / QS, N * A - 1)];
     } else
         for (int i = tid; i < N * A; i += NT) pos[i] = a.gpos[(size_t)g * N * A + i];
-    ShRef sh = group_shape(a, g);
+    /* (windows beyond 7x7: the large shape record of the pre-pass) */
+    typedef typename std::conditional<(AW > 7), ShRefBig, ShRef>::type SH;
+    SH sh = [&]() -> SH { if constexpr (AW > 7) return group_shape_big(a, g); else return group_shape(a, g); }();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
@@ -196,13 +198,15 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
                 for (int v = 0; v < AW; v++) col[v * AW * P2] = x[v];
             }
             __syncthreads();
-        } else if (do_sa4) {   /* the rare shape-adaptive groups: the call form, one (match, pixel) vector per thread */
-            for (int e = tid; e < nSx * SLAB; e += NT) {
-                const int px = e % SLAB, n = e / SLAB;
-                float y[kMaxA];
-                for (int st = 0; st < A; st++) y[st] = S[(size_t)(n * A + st) * SLAB + px];
-                sadctw_fwd<ShRef>(y, AW, sh, tb);
-                for (int st = 0; st < A; st++) S[(size_t)(n * A + st) * SLAB + px] = y[st];
+        } else if (do_sa4) {   /* shape-adaptive groups: the same separable form, row / column lengths from the group's shape record */
+            for (int e = tid; e < nSx * AW * P2; e += NT) {
+                const int pp = e % P2, r = e / P2;
+                sadctw_rows_fwd2<AW, SH>((LdsV2)(S2 + (size_t)r * AW * P2 + pp), P2, r % AW, sh, tb);
+            }
+            __syncthreads();
+            for (int e = tid; e < nSx * AW * P2; e += NT) {
+                const int pp = e % P2, r = e / P2, u = r % AW, n = r / AW;
+                sadctw_cols_fwd2<AW, SH>((LdsV2)(S2 + (size_t)(n * A + u) * P2 + pp), P2, u, sh, tb);
             }
             __syncthreads();
         }
@@ -302,12 +306,14 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
             }
         } else {
             if (do_sa4) {
-                for (int e = tid; e < nSx * SLAB; e += NT) {
-                    const int px = e % SLAB, n = e / SLAB;
-                    float y[kMaxA];
-                    for (int st = 0; st < A; st++) y[st] = S[(size_t)(n * A + st) * SLAB + px];
-                    sadctw_inv<ShRef>(y, AW, sh, tb);
-                    for (int st = 0; st < A; st++) S[(size_t)(n * A + st) * SLAB + px] = y[st];
+                for (int e = tid; e < nSx * AW * P2; e += NT) {
+                    const int pp = e % P2, r = e / P2, u = r % AW, n = r / AW;
+                    sadctw_cols_inv2<AW, SH>((LdsV2)(S2 + (size_t)(n * A + u) * P2 + pp), P2, u, sh, tb);
+                }
+                __syncthreads();
+                for (int e = tid; e < nSx * AW * P2; e += NT) {
+                    const int pp = e % P2, r = e / P2;
+                    sadctw_rows_inv2<AW, SH>((LdsV2)(S2 + (size_t)r * AW * P2 + pp), P2, r % AW, sh, tb);
                 }
                 __syncthreads();
             }
@@ -360,7 +366,8 @@ __global__ void k_group_idw_weight(GroupArgs a) {
 
 hipError_t prepare_group_wide() {
     const void* fns[] = {reinterpret_cast<const void*>(&k_group_idw<5, 64, false>), reinterpret_cast<const void*>(&k_group_idw<7, 32, false>),
-                         reinterpret_cast<const void*>(&k_group_idw<5, 64, true>), reinterpret_cast<const void*>(&k_group_idw<7, 32, true>)};
+                         reinterpret_cast<const void*>(&k_group_idw<5, 64, true>), reinterpret_cast<const void*>(&k_group_idw<7, 32, true>),
+                         reinterpret_cast<const void*>(&k_group_idw<9, 16, false>), reinterpret_cast<const void*>(&k_group_idw<9, 16, true>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDedicatedLdsLimit);
         if (e != hipSuccess) return e;
@@ -370,19 +377,21 @@ hipError_t prepare_group_wide() {
 
 hipError_t launch_group_wide(hipStream_t s, const GroupArgs& a, bool* launched) {
     *launched = false;
-    if (!(a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (a.A == 25 || a.A == 49) && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull)) return hipSuccess;
+    if (!(a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (a.A == 25 || a.A == 49 || a.A == 81) && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull)) return hipSuccess;
     *launched = true;
     const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
     const unsigned k2 = a.k * a.k;
     if (a.useSD || getenv("LFBM5D_WIDE_NOSPLIT")) {
-        if (a.A == 25) hipLaunchKernelGGL((k_group_idw<5, 64, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 25 * 64 * sizeof(float), s, a);
-        else           hipLaunchKernelGGL((k_group_idw<7, 32, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 49 * 32 * sizeof(float), s, a);
+        if (a.A == 25)      hipLaunchKernelGGL((k_group_idw<5, 64, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 25 * 64 * sizeof(float), s, a);
+        else if (a.A == 49) hipLaunchKernelGGL((k_group_idw<7, 32, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 49 * 32 * sizeof(float), s, a);
+        else                hipLaunchKernelGGL((k_group_idw<9, 16, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 81 * 16 * sizeof(float), s, a);
         return hipGetLastError();
     }
     hipError_t e = hipMemsetAsync(a.wgt + (size_t)a.ref_begin * a.C, 0, (size_t)a.n_groups * a.C * sizeof(float), s);
     if (e != hipSuccess) return e;
-    if (a.A == 25) hipLaunchKernelGGL((k_group_idw<5, 64, true>), dim3(gx, a.C, (k2 + 63) / 64), dim3(256), (size_t)a.N * 25 * 64 * sizeof(float), s, a);
-    else           hipLaunchKernelGGL((k_group_idw<7, 32, true>), dim3(gx, a.C, (k2 + 31) / 32), dim3(256), (size_t)a.N * 49 * 32 * sizeof(float), s, a);
+    if (a.A == 25)      hipLaunchKernelGGL((k_group_idw<5, 64, true>), dim3(gx, a.C, (k2 + 63) / 64), dim3(256), (size_t)a.N * 25 * 64 * sizeof(float), s, a);
+    else if (a.A == 49) hipLaunchKernelGGL((k_group_idw<7, 32, true>), dim3(gx, a.C, (k2 + 31) / 32), dim3(256), (size_t)a.N * 49 * 32 * sizeof(float), s, a);
+    else                hipLaunchKernelGGL((k_group_idw<9, 16, true>), dim3(gx, a.C, (k2 + 15) / 16), dim3(256), (size_t)a.N * 81 * 16 * sizeof(float), s, a);
     hipLaunchKernelGGL(k_group_idw_weight, grid1d((size_t)a.n_groups * a.C), dim3(256), 0, s, a);
     return hipGetLastError();
 }

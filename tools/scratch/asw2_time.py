@@ -25,4 +25,4 @@ for step, pk in ((1, (8, 18, 6, 16, 4, "id", "sadct", "haar")), (2, (16, 18, 6, 
         ctx.core_pass(step, P, aw, aw, Wb, Hb, 3, noisy, basic, num, den, mask, proc, A // 2, A // 2)
     torch.cuda.synchronize()
     s = ctx.stats()
-    print(f"{aw}x{aw} window, step {step} {Wb}x{Hb}: bm {s.ms_bm/reps:.2f} group {s.ms_group/reps:.2f} agg {s.ms_aggregate/reps:.2f} ms/pass; groups {s.groups//reps}", flush=True)
+    print(f"{aw}x{aw} window, step {step} {Wb}x{Hb}: bm {s.ms_bm/reps:.2f} group {s.ms_group/reps:.2f} agg {s.ms_aggregate/reps:.2f} ms/pass; groups {s.groups//reps} (shape-adaptive {s.sadct_groups//reps})", flush=True)
