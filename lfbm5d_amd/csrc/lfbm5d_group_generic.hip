@@ -351,7 +351,9 @@ size_t group_lds_bytes(const GroupArgs& a) {
 }
 static bool group_uses_generic(const GroupArgs& a) {   /* mirrors the dispatch of launch_group_ht / launch_group_wiener */
     if (getenv("LFBM5D_GROUP_GENERIC") != nullptr) return true;
-    if ((a.A == 25 || a.A == 49 || a.A == 81) && a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull) return false;   /* lfbm5d_group_wide.hip */
+    bool wide_window = false;
+    for (unsigned w = 5; w <= 17; w += 2) wide_window |= a.A == w * w;
+    if (wide_window && a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull) return false;   /* lfbm5d_group_wide.hip */
     if (a.A != 9 && !(a.bm3d && a.A == 1)) return true;
     if (a.A == 9 && a.tau2 == 4 && a.N <= 8 && a.k * a.k <= 256 && a.step == 1) return false;
     if (a.A == 9 && (a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1) return false;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
     GroupArgs a, float* scratch, unsigned long long slice_floats, int ls) {
     constexpr int A = WA * WA, NST = STEP == 2 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ unsigned pos[MAXN * A];
+    __shared__ unsigned pos[MAXN * A < kSlabFloats / 4 ? MAXN * A : kSlabFloats / 4];   /* (group_uses_slab: N * A <= kSlabFloats / 4) */
     __shared__ float red[kThreads / 64];
     __shared__ float cn4s[A], cni4s[A];
     const int tid = threadIdx.x;
@@ -530,9 +530,14 @@ size_t slab_lds_bytes(const GroupArgs& a) {
 
 /* Which configurations the slab kernel takes (the dedicated kernels have been asked first): those the general kernel would run
  * from HBM slices or with one workgroup per CU. */
+static int slab_window_side(unsigned A) {   /* 3, 5, ... 17, or 0 */
+    for (int w = 3; w <= 17; w += 2) if (A == (unsigned)(w * w)) return w;
+    return 0;
+}
 bool group_uses_slab(const GroupArgs& a) {
     if (getenv("LFBM5D_NO_SLAB_KERNEL") != nullptr) return false;
-    if (a.bm3d || a.useSD || !(a.A == 9 || a.A == 25 || a.A == 49 || a.A == 81) || a.N > 32) return false;
+    const int wa = slab_window_side(a.A);
+    if (a.bm3d || a.useSD || !wa || a.N > (wa > 9 ? 16u : 32u)) return false;   /* (windows beyond 9x9: the N <= 16 instances only) */
     if (a.tau2 == 5 && !(a.k == 8 || a.k == 12 || a.k == 16)) return false;
     if (a.tau2 == 7 && !(a.k == 8 || a.k == 16)) return false;
     if (a.tau2 == 4 && a.k > 16) return false;
@@ -547,18 +552,28 @@ size_t group_slab_scratch_bytes(const GroupArgs& a) {
     return (size_t)kSlabBlocks * (a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);
 }
 
-hipError_t prepare_group_slab() {
-#define LFBM5D_SLAB_FNS(MAXN) reinterpret_cast<const void*>(&k_group_slab<1, 3, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 3, MAXN>), \
-                              reinterpret_cast<const void*>(&k_group_slab<1, 5, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 5, MAXN>), \
-                              reinterpret_cast<const void*>(&k_group_slab<1, 7, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 7, MAXN>), \
-                              reinterpret_cast<const void*>(&k_group_slab<1, 9, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, 9, MAXN>)
-    const void* fns[] = {LFBM5D_SLAB_FNS(16), LFBM5D_SLAB_FNS(32)};
-#undef LFBM5D_SLAB_FNS
+template <int WA, int MAXN>
+static hipError_t prepare_slab() {
+    const void* fns[] = {reinterpret_cast<const void*>(&k_group_slab<1, WA, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, WA, MAXN>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);   /* slab stack <= 72 KB, two work areas <= 35 KB */
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+hipError_t prepare_group_slab() {
+    hipError_t e = prepare_slab<3, 16>();
+#define LFBM5D_PS(WA, MAXN) if (e == hipSuccess) e = prepare_slab<WA, MAXN>()
+    LFBM5D_PS(3, 32); LFBM5D_PS(5, 16); LFBM5D_PS(5, 32); LFBM5D_PS(7, 16); LFBM5D_PS(7, 32); LFBM5D_PS(9, 16); LFBM5D_PS(9, 32);
+    LFBM5D_PS(11, 16); LFBM5D_PS(13, 16); LFBM5D_PS(15, 16); LFBM5D_PS(17, 16);
+#undef LFBM5D_PS
+    return e;
+}
+
+template <int WA, int MAXN>
+static void launch_slab(hipStream_t s, const GroupArgs& a, unsigned blocks, size_t lds, unsigned long long slice, int ls) {
+    if (a.step == 2) hipLaunchKernelGGL((k_group_slab<2, WA, MAXN>), dim3(blocks), dim3(kThreads), lds, s, a, a.scratch, slice, ls);
+    else             hipLaunchKernelGGL((k_group_slab<1, WA, MAXN>), dim3(blocks), dim3(kThreads), lds, s, a, a.scratch, slice, ls);
 }
 
 hipError_t launch_group_slab(hipStream_t s, const GroupArgs& a, bool* launched) {
@@ -570,13 +585,19 @@ hipError_t launch_group_slab(hipStream_t s, const GroupArgs& a, bool* launched) 
     const unsigned blocks = std::min<unsigned>(kSlabBlocks, a.n_groups * a.C);
     const int ls = slab_log2(a);
     const size_t lds = slab_lds_bytes(a);
-#define LFBM5D_SLAB1(STEP, WA, MAXN) hipLaunchKernelGGL((k_group_slab<STEP, WA, MAXN>), dim3(blocks), dim3(kThreads), lds, s, a, a.scratch, slice, ls)
-#define LFBM5D_SLAB2(STEP, WA) do { if (a.N <= 16) LFBM5D_SLAB1(STEP, WA, 16); else LFBM5D_SLAB1(STEP, WA, 32); } while (0)
-#define LFBM5D_SLAB3(STEP) do { if (a.A == 9) LFBM5D_SLAB2(STEP, 3); else if (a.A == 25) LFBM5D_SLAB2(STEP, 5); else if (a.A == 49) LFBM5D_SLAB2(STEP, 7); else LFBM5D_SLAB2(STEP, 9); } while (0)
-    if (a.step == 2) LFBM5D_SLAB3(2); else LFBM5D_SLAB3(1);
-#undef LFBM5D_SLAB3
-#undef LFBM5D_SLAB2
-#undef LFBM5D_SLAB1
+    const bool n16 = a.N <= 16;
+#define LFBM5D_LS(WA) do { if (n16) launch_slab<WA, 16>(s, a, blocks, lds, slice, ls); else launch_slab<WA, 32>(s, a, blocks, lds, slice, ls); } while (0)
+    switch (slab_window_side(a.A)) {
+        case 3: LFBM5D_LS(3); break;
+        case 5: LFBM5D_LS(5); break;
+        case 7: LFBM5D_LS(7); break;
+        case 9: LFBM5D_LS(9); break;
+        case 11: launch_slab<11, 16>(s, a, blocks, lds, slice, ls); break;
+        case 13: launch_slab<13, 16>(s, a, blocks, lds, slice, ls); break;
+        case 15: launch_slab<15, 16>(s, a, blocks, lds, slice, ls); break;
+        default: launch_slab<17, 16>(s, a, blocks, lds, slice, ls); break;
+    }
+#undef LFBM5D_LS
     return hipGetLastError();
 }
 

@@ -366,35 +366,61 @@ __global__ void k_group_idw_weight(GroupArgs a) {
 
 } /* namespace */
 
-hipError_t prepare_group_wide() {
-    const void* fns[] = {reinterpret_cast<const void*>(&k_group_idw<5, 64, false>), reinterpret_cast<const void*>(&k_group_idw<7, 32, false>),
-                         reinterpret_cast<const void*>(&k_group_idw<5, 64, true>), reinterpret_cast<const void*>(&k_group_idw<7, 32, true>),
-                         reinterpret_cast<const void*>(&k_group_idw<9, 16, false>), reinterpret_cast<const void*>(&k_group_idw<9, 16, true>)};
+/* window side -> pixels per slab (the slab's stack of up to 8 matches within 51 KB; a power of two, so that a thread's 16-byte loads
+ * all fetch the same pixels) */
+template <int AW> struct WideSlab { static constexpr int value = AW == 5 ? 64 : AW == 7 ? 32 : AW == 9 ? 16 : AW <= 13 ? 8 : 4; };
+
+template <int AW>
+static hipError_t prepare_idw() {
+    constexpr int SLAB = WideSlab<AW>::value;
+    const void* fns[] = {reinterpret_cast<const void*>(&k_group_idw<AW, SLAB, false>), reinterpret_cast<const void*>(&k_group_idw<AW, SLAB, true>)};
     for (const void* f : fns) {
-        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kDedicatedLdsLimit);
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * AW * AW * SLAB * (int)sizeof(float));   /* N <= 8 */
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
+hipError_t prepare_group_wide() {
+    hipError_t e = prepare_idw<5>();
+    if (e == hipSuccess) e = prepare_idw<7>();
+    if (e == hipSuccess) e = prepare_idw<9>();
+    if (e == hipSuccess) e = prepare_idw<11>();
+    if (e == hipSuccess) e = prepare_idw<13>();
+    if (e == hipSuccess) e = prepare_idw<15>();
+    if (e == hipSuccess) e = prepare_idw<17>();
+    return e;
+}
+
+template <int AW>
+static void launch_idw(hipStream_t s, const GroupArgs& a, bool split) {
+    constexpr int SLAB = WideSlab<AW>::value;
+    const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
+    const size_t lds = (size_t)a.N * AW * AW * SLAB * sizeof(float);
+    if (split) hipLaunchKernelGGL((k_group_idw<AW, SLAB, true>), dim3(gx, a.C, (a.k * a.k + SLAB - 1) / SLAB), dim3(256), lds, s, a);
+    else       hipLaunchKernelGGL((k_group_idw<AW, SLAB, false>), dim3(gx, a.C), dim3(256), lds, s, a);
+}
 
 hipError_t launch_group_wide(hipStream_t s, const GroupArgs& a, bool* launched) {
     *launched = false;
-    if (!(a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (a.A == 25 || a.A == 49 || a.A == 81) && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull)) return hipSuccess;
+    int aw = 0;
+    for (int w = 5; w <= 17; w += 2) if (a.A == (unsigned)(w * w)) aw = w;
+    if (!(aw && a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull)) return hipSuccess;
     *launched = true;
-    const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
-    const unsigned k2 = a.k * a.k;
-    if (a.useSD || getenv("LFBM5D_WIDE_NOSPLIT")) {
-        if (a.A == 25)      hipLaunchKernelGGL((k_group_idw<5, 64, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 25 * 64 * sizeof(float), s, a);
-        else if (a.A == 49) hipLaunchKernelGGL((k_group_idw<7, 32, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 49 * 32 * sizeof(float), s, a);
-        else                hipLaunchKernelGGL((k_group_idw<9, 16, false>), dim3(gx, a.C), dim3(256), (size_t)a.N * 81 * 16 * sizeof(float), s, a);
-        return hipGetLastError();
+    const bool split = !(a.useSD || getenv("LFBM5D_WIDE_NOSPLIT"));
+    if (split) {
+        const hipError_t e = hipMemsetAsync(a.wgt + (size_t)a.ref_begin * a.C, 0, (size_t)a.n_groups * a.C * sizeof(float), s);
+        if (e != hipSuccess) return e;
     }
-    hipError_t e = hipMemsetAsync(a.wgt + (size_t)a.ref_begin * a.C, 0, (size_t)a.n_groups * a.C * sizeof(float), s);
-    if (e != hipSuccess) return e;
-    if (a.A == 25)      hipLaunchKernelGGL((k_group_idw<5, 64, true>), dim3(gx, a.C, (k2 + 63) / 64), dim3(256), (size_t)a.N * 25 * 64 * sizeof(float), s, a);
-    else if (a.A == 49) hipLaunchKernelGGL((k_group_idw<7, 32, true>), dim3(gx, a.C, (k2 + 31) / 32), dim3(256), (size_t)a.N * 49 * 32 * sizeof(float), s, a);
-    else                hipLaunchKernelGGL((k_group_idw<9, 16, true>), dim3(gx, a.C, (k2 + 15) / 16), dim3(256), (size_t)a.N * 81 * 16 * sizeof(float), s, a);
-    hipLaunchKernelGGL(k_group_idw_weight, grid1d((size_t)a.n_groups * a.C), dim3(256), 0, s, a);
+    switch (aw) {
+        case 5: launch_idw<5>(s, a, split); break;
+        case 7: launch_idw<7>(s, a, split); break;
+        case 9: launch_idw<9>(s, a, split); break;
+        case 11: launch_idw<11>(s, a, split); break;
+        case 13: launch_idw<13>(s, a, split); break;
+        case 15: launch_idw<15>(s, a, split); break;
+        default: launch_idw<17>(s, a, split); break;
+    }
+    if (split) hipLaunchKernelGGL(k_group_idw_weight, grid1d((size_t)a.n_groups * a.C), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

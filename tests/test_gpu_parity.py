@@ -825,6 +825,16 @@ def test_11x11_window_pass_matches_oracle(ctx):
     _wide_window_pass(ctx, ("wien-dct-dct-haar", 2, (2, 4, 2, 8, 4, "dct", "dct", "haar"), 40, ()), 11)
 
 
+@pytest.mark.parametrize("aw", [13, 17])
+def test_largest_window_passes_match_oracle(ctx, aw):
+    """aswSize 6 and 8 (13x13, 17x17: the whole light field of the headline as ONE window): the wide-window kernel (HT, tau_2D = id)
+    and the slab kernel (2-D transform) at their smallest slabs, with empty SAIs -- shape-adaptive passes on the large shape record."""
+    A = aw * aw
+    _wide_window_pass(ctx, ("ht-id-sadct-haar-holes", 1, (2, 4, 2, 8, 4, "id", "sadct", "haar"), 40, (3, A // 2 + 1, A - 1)), aw)
+    _wide_window_pass(ctx, ("ht-bior-sadct-hw", 1, (4, 4, 2, 8, 4, "bior", "sadct", "hw"), 40, ()), aw)
+    _wide_window_pass(ctx, ("wien-dct-sadct-haar-holes", 2, (2, 4, 2, 8, 4, "dct", "sadct", "haar"), 40, (0, A - 2)), aw)
+
+
 @pytest.mark.parametrize("ah,aw,an", [(5, 5, 2), (7, 6, 2), (8, 7, 3), (9, 10, 4)])
 def test_whole_steps_with_5x5_windows_match_oracle(ctx, ah, aw, an):
     """aswSize 2 and 3: the window schedule with 5x5 / 7x7 windows (compute_LF_angular_search_window's clamping at the
