@@ -25,6 +25,7 @@ namespace lfbm5d {
 namespace {
 
 constexpr int kSlabFloats = 18432;    /* LDS stack of a slab: 72 KB -- the registers (170-320) allow two workgroups per CU at most */
+constexpr int kSlabFloatsMax = 28800; /* ... and 112 KB, one workgroup per CU, for stacks that need it to hold four pixels (13x13 / 15x15 windows, Wiener N = 16) */
 constexpr unsigned kSlabBlocks = 1024;
 
 /* ---- 2-D transforms of the patches of a work area [patch][K][K+1], K threads per patch (thread r: row r, then column r) ---- */
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
     GroupArgs a, float* scratch, unsigned long long slice_floats, int ls) {
     constexpr int A = WA * WA, NST = STEP == 2 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ unsigned pos[MAXN * A < kSlabFloats / 4 ? MAXN * A : kSlabFloats / 4];   /* (group_uses_slab: N * A <= kSlabFloats / 4) */
+    __shared__ unsigned pos[MAXN * A < kSlabFloatsMax / 4 ? MAXN * A : kSlabFloatsMax / 4];   /* (group_uses_slab: N * A <= kSlabFloatsMax / 4) */
     __shared__ float red[kThreads / 64];
     __shared__ float cn4s[A], cni4s[A];
     const int tid = threadIdx.x;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
     const TbPtr tb = (TbPtr)a.tb;
     const bool id2 = a.tau2 == 4;
     float* const slice = id2 ? nullptr : scratch + (size_t)blockIdx.x * slice_floats;   /* [stack][n * A + st][k2] coefficients (tau_2D = id: none) */
-    if (tid < A) { cn4s[tid] = tb->cn4[tid]; cni4s[tid] = tb->cni4[tid]; }
+    for (int i = tid; i < A; i += kThreads) { cn4s[i] = tb->cn4[i]; cni4s[i] = tb->cni4[i]; }   /* (A = 289 > kThreads) */
     const unsigned items = a.n_groups * a.C;
     for (unsigned it = blockIdx.x; it < items; it += gridDim.x) {
         const unsigned g = a.ref_begin + it / a.C;
@@ -541,7 +542,7 @@ bool group_uses_slab(const GroupArgs& a) {
     if (a.tau2 == 5 && !(a.k == 8 || a.k == 12 || a.k == 16)) return false;
     if (a.tau2 == 7 && !(a.k == 8 || a.k == 16)) return false;
     if (a.tau2 == 4 && a.k > 16) return false;
-    if (((size_t)(a.step == 2 ? 2 : 1) * a.N * a.A << 2) > (size_t)kSlabFloats) return false;   /* (not even four pixels per slab) */
+    if (((size_t)(a.step == 2 ? 2 : 1) * a.N * a.A << 2) > (size_t)kSlabFloatsMax) return false;   /* (not even four pixels per slab) */
     /* stacks the general kernel would keep in HBM slices (beyond ~150 KB); with a 2-D transform also those it would hold in LDS at
      * one workgroup per CU (measured: N = 32, k = 8, Wiener: dct 3.9 ms here / 4.8 there, id 3.1 / 2.7) */
     const size_t stacks = (size_t)(a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);
@@ -556,7 +557,7 @@ template <int WA, int MAXN>
 static hipError_t prepare_slab() {
     const void* fns[] = {reinterpret_cast<const void*>(&k_group_slab<1, WA, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, WA, MAXN>)};
     for (const void* f : fns) {
-        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);   /* slab stack <= 72 KB, two work areas <= 35 KB */
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (WA > 9 ? 116 : 80) * 1024);   /* slab stack <= 72 (112) KB, two work areas <= 35 KB */
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

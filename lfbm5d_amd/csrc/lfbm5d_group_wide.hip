@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
     const int k = a.k, k2 = k * k, N = a.N;
     const size_t plane = (size_t)a.Wb * a.Hb;
     const TbPtr tb = (TbPtr)a.tb;
-    if (tid < A) { cn4s[tid] = tb->cn4[tid]; cni4s[tid] = tb->cni4[tid]; }   /* (first read behind the barrier that follows the gather) */
+    for (int i = tid; i < A; i += NT) { cn4s[i] = tb->cn4[i]; cni4s[i] = tb->cni4[i]; }   /* (first read behind the barrier that follows the gather; A = 289 > NT) */
     const int nSx = (int)a.self_cnt[g];
     /* prologue: everything the workgroup needs from memory is requested at once -- the group's size and shape, sigma, the norm
      * tables, and the positions of the patches each thread will fetch (16-byte gather: straight into registers, no LDS round trip

@@ -833,6 +833,8 @@ def test_largest_window_passes_match_oracle(ctx, aw):
     _wide_window_pass(ctx, ("ht-id-sadct-haar-holes", 1, (2, 4, 2, 8, 4, "id", "sadct", "haar"), 40, (3, A // 2 + 1, A - 1)), aw)
     _wide_window_pass(ctx, ("ht-bior-sadct-hw", 1, (4, 4, 2, 8, 4, "bior", "sadct", "hw"), 40, ()), aw)
     _wide_window_pass(ctx, ("wien-dct-sadct-haar-holes", 2, (2, 4, 2, 8, 4, "dct", "sadct", "haar"), 40, (0, A - 2)), aw)
+    if aw == 13:   # the README's N = 16 in the Wiener step: 2 x 16 x 169 values per coefficient -- the slab kernel's 112 KB tier (four coefficients per slab)
+        _wide_window_pass(ctx, ("wien-dct-sadct-haar-n16", 2, (16, 4, 2, 8, 4, "dct", "sadct", "haar"), 40, ()), aw)
 
 
 @pytest.mark.parametrize("ah,aw,an", [(5, 5, 2), (7, 6, 2), (8, 7, 3), (9, 10, 4)])
