@@ -64,6 +64,9 @@ __device__ __forceinline__ void filter5_pair(v2f* S2, int base, int stride, unsi
  * different slabs overlap.  The survivor count of a (group, channel) is then summed with atomics in wgt (whole numbers: exact in any
  * order; the buffer is zeroed before the launch) and turned into the weight by k_group_idw_weight.  useSD (float sums whose value
  * depends on the order) keeps the walking form. */
+/* slabs a workgroup of the SPLIT form takes one after the other (one prologue for them): two up to 7x7, four beyond (measured:
+ * 5x5 1.09 / 1.06 / 1.13 ms with 1 / 2 / 4, 7x7 2.45 / 2.40 / 2.48, 9x9 7.8 / 7.5 / 7.2, 13x13 34.2 (2) / 33.7 (4)) */
+template <int AW> constexpr int wide_spw() { return AW <= 7 ? 2 : 4; }
 template <int AW, int SLAB, bool SPLIT>
 __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 threads at six waves per SIMD: slower, 80 registers spill) */
     constexpr int A = AW * AW, NT = 256;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
 #else
 #define WIDE_MARK(i) do {} while (0)
 #endif
-    for (int p0 = SPLIT ? (int)slab * SLAB : 0; p0 < (SPLIT ? min(k2, ((int)slab + 1) * SLAB) : k2); p0 += SLAB) {
+    for (int p0 = SPLIT ? (int)slab * SLAB * wide_spw<AW>() : 0; p0 < (SPLIT ? min(k2, ((int)slab + 1) * SLAB * wide_spw<AW>()) : k2); p0 += SLAB) {
         const int npx = min(SLAB, k2 - p0);
         /* gather (core:286-299): item = (patch, pixel), pixel fastest */
         if (quads) {   /* four pixels of a patch row per 16-byte load (4-byte aligned), every load of the slab in flight at once */
@@ -396,7 +399,7 @@ static void launch_idw(hipStream_t s, const GroupArgs& a, bool split) {
     constexpr int SLAB = WideSlab<AW>::value;
     const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
     const size_t lds = (size_t)a.N * AW * AW * SLAB * sizeof(float);
-    if (split) hipLaunchKernelGGL((k_group_idw<AW, SLAB, true>), dim3(gx, a.C, (a.k * a.k + SLAB - 1) / SLAB), dim3(256), lds, s, a);
+    if (split) hipLaunchKernelGGL((k_group_idw<AW, SLAB, true>), dim3(gx, a.C, (a.k * a.k + SLAB * wide_spw<AW>() - 1) / (SLAB * wide_spw<AW>())), dim3(256), lds, s, a);
     else       hipLaunchKernelGGL((k_group_idw<AW, SLAB, false>), dim3(gx, a.C), dim3(256), lds, s, a);
 }
 
