@@ -606,81 +606,130 @@ __device__ __noinline__ void sadctw_inv(float* v, int aw, SHR sh, TbPtr tb) {
 /* The shape-adaptive angular transform (core:1969-2264) as SEPARABLE passes over a stack in LDS, two pixels per lane: a thread owns
  * one row (then one column) of a match's aw x aw block -- `row` / `col` point at its first element, consecutive elements P / AW * P
  * pairs apart.  The same products in the same order as sadctw_fwd / sadctw_inv (which hold the whole block of one pixel in private
- * memory: hundreds of times slower on the 6 % shape-adaptive groups of a 9x9 window). */
-/* Out of line, so that the registers of this rare path are not the kernel's (inlined, the 9x9 instance needs 245 instead of 155 and
- * the plain groups lose their occupancy); the pointers keep their address spaces -- LDS, constant -- through the call: ds_ and
- * s_load instructions, not flat ones.  Outputs in registers, statically indexed; inputs re-read from LDS in run-time loops. */
+ * memory: hundreds of times slower on the 6 - 30 % shape-adaptive groups of windows of 9x9 SAIs and more).
+ * A lane's row differs from its neighbour's, so everything indexed by the row -- its length, its index list, the cosine table of that
+ * length -- is a per-lane access: from the group's shape record and the constant tables that is a dependent global load per TERM
+ * (100 us per four-pixel slab of a 15x15 window); the workgroup therefore copies them into an LDS table first (sa_fill), laid out
+ *   idx[A] | idx_col[A] | mask[A] | mask_dct[A] | row_n[AW] | col_n[AW] | cos1 of length 1, 2, ... AW packed (n^2 each) |
+ *   cn1[AW+1][AW] | cni1[AW+1][AW] | c1inv[AW+1]
+ * Out of line, so that the registers of this rarer path are not the kernel's; the pointers keep their LDS address space through
+ * the call. */
 typedef __attribute__((address_space(3))) v2f* LdsV2;
+typedef const __attribute__((address_space(3))) int* SaTab;
+template <int AW> struct SaLayout {
+    static constexpr int A = AW * AW;
+    static constexpr int idx = 0, idx_col = A, mask = 2 * A, mask_dct = 3 * A, row_n = 4 * A, col_n = 4 * A + AW, cos = 4 * A + 2 * AW;
+    static constexpr int cos_words = AW * (AW + 1) * (2 * AW + 1) / 6;
+    static constexpr int cn1 = cos + cos_words, cni1 = cn1 + (AW + 1) * AW, c1inv = cni1 + (AW + 1) * AW, words = c1inv + AW + 1;
+    __device__ static __forceinline__ int cos_off(int n) { return cos + (n - 1) * n * (2 * n - 1) / 6; }   /* lengths 1 .. n-1 in front */
+};
 template <int AW, class SHR>
-__device__ __noinline__ void sadctw_rows_fwd2(LdsV2 row, int P, int s, SHR sh, TbPtr tb) {
-    const int n = sh.row_n[s];
-    if (n == 1) { row[0] = row[sh.idx[s * AW] * P]; return; }
+__device__ __forceinline__ void sa_fill(int* tab, SHR sh, TbPtr tb, int tid, int nthreads) {   /* all threads; a barrier follows */
+    typedef SaLayout<AW> L;
+    float* tf = reinterpret_cast<float*>(tab);
+    for (int i = tid; i < L::A; i += nthreads) {
+        tab[L::idx + i] = sh.idx[i]; tab[L::idx_col + i] = sh.idx_col[i]; tab[L::mask + i] = sh.mask[i]; tab[L::mask_dct + i] = sh.mask_dct[i];
+    }
+    for (int i = tid; i < AW; i += nthreads) { tab[L::row_n + i] = sh.row_n[i]; tab[L::col_n + i] = sh.col_n[i]; }
+    for (int n = 1; n <= AW; n++)
+        for (int i = tid; i < n * n; i += nthreads) tf[L::cos_off(n) + i] = tb->cos1[n][i];
+    for (int i = tid; i < (AW + 1) * AW; i += nthreads) { tf[L::cn1 + i] = tb->cn1[i / AW][i % AW]; tf[L::cni1 + i] = tb->cni1[i / AW][i % AW]; }
+    for (int i = tid; i <= AW; i += nthreads) tf[L::c1inv + i] = tb->c1inv[i];
+}
+template <int AW>
+__device__ __noinline__ void sadctw_rows_fwd2(LdsV2 row, int P, int s, SaTab tab) {
+    typedef SaLayout<AW> L;
+    const __attribute__((address_space(3))) float* tf = reinterpret_cast<const __attribute__((address_space(3))) float*>(tab);
+    const int n = tab[L::row_n + s];
+    if (n == 1) { row[0] = row[tab[L::idx + s * AW] * P]; return; }
     if (n < 2) return;
-    v2f y[AW];
+    const int co = L::cos_off(n);
+    v2f x[AW], y[AW];
 #pragma unroll
-    for (int u = 0; u < AW; u++) if (u < n) {
+    for (int t = 0; t < AW; t++) x[t] = t < n ? row[tab[L::idx + s * AW + t] * P] : v2f{0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < AW; u++) {
         v2f a = {0.0f, 0.0f};
-        for (int j = 0; j < n; j++) a += row[sh.idx[s * AW + j] * P] * tb->cos1[n][u * n + j];
+#pragma unroll
+        for (int j = 0; j < AW; j++) if (j < n && u < n) a += x[j] * tf[co + u * n + j];
         y[u] = 2.0f * a;
     }
 #pragma unroll
-    for (int t = 0; t < AW; t++) if (t < n) row[t * P] = y[t] * tb->cn1[n][t];
+    for (int t = 0; t < AW; t++) if (t < n) row[t * P] = y[t] * tf[L::cn1 + n * AW + t];
 }
-template <int AW, class SHR>
-__device__ __noinline__ void sadctw_cols_fwd2(LdsV2 col, int P, int t, SHR sh, TbPtr tb) {   /* ... and the closing scale by mask_dct */
-    const int n = sh.col_n[t];
-    if (n == 1) col[0] = col[sh.idx_col[t] * AW * P];
+template <int AW>
+__device__ __noinline__ void sadctw_cols_fwd2(LdsV2 col, int P, int t, SaTab tab) {   /* ... and the closing scale by mask_dct */
+    typedef SaLayout<AW> L;
+    const __attribute__((address_space(3))) float* tf = reinterpret_cast<const __attribute__((address_space(3))) float*>(tab);
+    const int n = tab[L::col_n + t];
+    if (n == 1) col[0] = col[tab[L::idx_col + t] * AW * P];
     else if (n > 1) {
-        v2f y[AW];
+        const int co = L::cos_off(n);
+        v2f x[AW], y[AW];
 #pragma unroll
-        for (int u = 0; u < AW; u++) if (u < n) {
+        for (int q = 0; q < AW; q++) x[q] = q < n ? col[tab[L::idx_col + q * AW + t] * AW * P] : v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < AW; u++) {
             v2f a = {0.0f, 0.0f};
-            for (int j = 0; j < n; j++) a += col[sh.idx_col[j * AW + t] * AW * P] * tb->cos1[n][u * n + j];
+#pragma unroll
+            for (int j = 0; j < AW; j++) if (j < n && u < n) a += x[j] * tf[co + u * n + j];
             y[u] = 2.0f * a;
         }
 #pragma unroll
-        for (int q = 0; q < AW; q++) if (q < n) col[q * AW * P] = y[q] * tb->cn1[n][q];
+        for (int q = 0; q < AW; q++) if (q < n) col[q * AW * P] = y[q] * tf[L::cn1 + n * AW + q];
     }
     const float coef = 0.5f * 0.70710678118654752f;
 #pragma unroll
-    for (int q = 0; q < AW; q++) col[q * AW * P] *= (float)sh.mask_dct[q * AW + t] * coef;
+    for (int q = 0; q < AW; q++) col[q * AW * P] *= (float)tab[L::mask_dct + q * AW + t] * coef;
 }
-template <int AW, class SHR>
-__device__ __noinline__ void sadctw_cols_inv2(LdsV2 col, int P, int t, SHR sh, TbPtr tb) {
-    const int n = sh.col_n[t];
+template <int AW>
+__device__ __noinline__ void sadctw_cols_inv2(LdsV2 col, int P, int t, SaTab tab) {
+    typedef SaLayout<AW> L;
+    const __attribute__((address_space(3))) float* tf = reinterpret_cast<const __attribute__((address_space(3))) float*>(tab);
+    const int n = tab[L::col_n + t];
     const float coef = 2.0f * 1.41421356237309505f;
-    if (n == 1) { const v2f v0 = col[0]; col[sh.idx_col[t] * AW * P] = v0 * coef; }
+    if (n == 1) { const v2f v0 = col[0]; col[tab[L::idx_col + t] * AW * P] = v0 * coef; }
     else if (n > 1) {
-        v2f y[AW];
-        const v2f x0 = col[0] * tb->cni1[n][0] * coef;
+        const int co = L::cos_off(n);
+        v2f x[AW], y[AW];
 #pragma unroll
-        for (int j = 0; j < AW; j++) if (j < n) {
+        for (int q = 0; q < AW; q++) x[q] = q < n ? col[q * AW * P] * tf[L::cni1 + n * AW + q] * coef : v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < AW; j++) {
             v2f a = {0.0f, 0.0f};
-            for (int u = 1; u < n; u++) a += (col[u * AW * P] * tb->cni1[n][u] * coef) * tb->cos1[n][u * n + j];
-            y[j] = x0 + 2.0f * a;
-        }
 #pragma unroll
-        for (int q = 0; q < AW; q++) if (q < n) col[sh.idx_col[q * AW + t] * AW * P] = y[q] * tb->c1inv[n];
+            for (int u = 1; u < AW; u++) if (u < n && j < n) a += x[u] * tf[co + u * n + j];
+            y[j] = x[0] + 2.0f * a;
+        }
+        const float ci = tf[L::c1inv + n];
+#pragma unroll
+        for (int q = 0; q < AW; q++) if (q < n) col[tab[L::idx_col + q * AW + t] * AW * P] = y[q] * ci;
     }
 }
-template <int AW, class SHR>
-__device__ __noinline__ void sadctw_rows_inv2(LdsV2 row, int P, int s, SHR sh, TbPtr tb) {   /* ... and the closing scale by mask */
-    const int n = sh.row_n[s];
-    if (n == 1) { const v2f v0 = row[0]; row[sh.idx[s * AW] * P] = v0; }
+template <int AW>
+__device__ __noinline__ void sadctw_rows_inv2(LdsV2 row, int P, int s, SaTab tab) {   /* ... and the closing scale by mask */
+    typedef SaLayout<AW> L;
+    const __attribute__((address_space(3))) float* tf = reinterpret_cast<const __attribute__((address_space(3))) float*>(tab);
+    const int n = tab[L::row_n + s];
+    if (n == 1) { const v2f v0 = row[0]; row[tab[L::idx + s * AW] * P] = v0; }
     else if (n > 1) {
-        v2f y[AW];
-        const v2f x0 = row[0] * tb->cni1[n][0];
+        const int co = L::cos_off(n);
+        v2f x[AW], y[AW];
 #pragma unroll
-        for (int j = 0; j < AW; j++) if (j < n) {
+        for (int t = 0; t < AW; t++) x[t] = t < n ? row[t * P] * tf[L::cni1 + n * AW + t] : v2f{0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < AW; j++) {
             v2f a = {0.0f, 0.0f};
-            for (int u = 1; u < n; u++) a += (row[u * P] * tb->cni1[n][u]) * tb->cos1[n][u * n + j];
-            y[j] = x0 + 2.0f * a;
-        }
 #pragma unroll
-        for (int t = 0; t < AW; t++) if (t < n) row[sh.idx[s * AW + t] * P] = y[t] * tb->c1inv[n];
+            for (int u = 1; u < AW; u++) if (u < n && j < n) a += x[u] * tf[co + u * n + j];
+            y[j] = x[0] + 2.0f * a;
+        }
+        const float ci = tf[L::c1inv + n];
+#pragma unroll
+        for (int t = 0; t < AW; t++) if (t < n) row[tab[L::idx + s * AW + t] * P] = y[t] * ci;
     }
 #pragma unroll
-    for (int t = 0; t < AW; t++) row[t * P] *= (float)sh.mask[s * AW + t];
+    for (int t = 0; t < AW; t++) row[t * P] *= (float)tab[L::mask + s * AW + t];
 }
 
 /* lib_transforms.cpp:403-471 / :290-321 on a register vector of compile-time length */

@@ -167,6 +167,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
     __shared__ unsigned pos[MAXN * A < kSlabFloatsMax / 4 ? MAXN * A : kSlabFloatsMax / 4];   /* (group_uses_slab: N * A <= kSlabFloatsMax / 4) */
     __shared__ float red[kThreads / 64];
     __shared__ float cn4s[A], cni4s[A];
+    __shared__ int sa_tab[WA > 3 ? SaLayout<WA>::words : 1];   /* shape-adaptive groups of the larger windows (sa_fill) */
     const int tid = threadIdx.x;
     const int k = a.k, k2 = k * k, N = a.N;
     const int SLAB = 1 << ls, P2 = SLAB >> 1;
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
         const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
         const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
         const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+        if constexpr (WA > 3) { if (do_sa4) sa_fill<WA, SH>(sa_tab, sh, tb, tid, kThreads); }   /* (read behind the barrier below) */
         const float sig = a.sigma[c];
         const float T = a.lambda * sig * 1.41421356237309505f;   /* core:2431 */
         const float sig2 = sig * sig;
@@ -347,12 +349,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
                     v2f* const S2 = reinterpret_cast<v2f*>(lds);
                     for (int e = tid; e < (NST * nSx * WA) << (ls - 1); e += kThreads) {
                         const int pp = e & (P2 - 1), r = e >> (ls - 1);
-                        sadctw_rows_fwd2<WA, SH>((LdsV2)(S2 + ((size_t)r * WA << (ls - 1)) + pp), P2, r % WA, sh, tb);
+                        sadctw_rows_fwd2<WA>((LdsV2)(S2 + ((size_t)r * WA << (ls - 1)) + pp), P2, r % WA, (SaTab)sa_tab);
                     }
                     __syncthreads();
                     for (int e = tid; e < (NST * nSx * WA) << (ls - 1); e += kThreads) {
                         const int pp = e & (P2 - 1), r = e >> (ls - 1), u = r % WA, sn = r / WA;
-                        sadctw_cols_fwd2<WA, SH>((LdsV2)(S2 + ((size_t)(sn * A + u) << (ls - 1)) + pp), P2, u, sh, tb);
+                        sadctw_cols_fwd2<WA>((LdsV2)(S2 + ((size_t)(sn * A + u) << (ls - 1)) + pp), P2, u, (SaTab)sa_tab);
                     }
                 }
                 __syncthreads();
@@ -443,12 +445,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN >
                     v2f* const F2 = reinterpret_cast<v2f*>(F);
                     for (int e = tid; e < (nSx * WA) << (ls - 1); e += kThreads) {
                         const int pp = e & (P2 - 1), r = e >> (ls - 1), u = r % WA, n = r / WA;
-                        sadctw_cols_inv2<WA, SH>((LdsV2)(F2 + ((size_t)(n * A + u) << (ls - 1)) + pp), P2, u, sh, tb);
+                        sadctw_cols_inv2<WA>((LdsV2)(F2 + ((size_t)(n * A + u) << (ls - 1)) + pp), P2, u, (SaTab)sa_tab);
                     }
                     __syncthreads();
                     for (int e = tid; e < (nSx * WA) << (ls - 1); e += kThreads) {
                         const int pp = e & (P2 - 1), r = e >> (ls - 1);
-                        sadctw_rows_inv2<WA, SH>((LdsV2)(F2 + ((size_t)r * WA << (ls - 1)) + pp), P2, r % WA, sh, tb);
+                        sadctw_rows_inv2<WA>((LdsV2)(F2 + ((size_t)r * WA << (ls - 1)) + pp), P2, r % WA, (SaTab)sa_tab);
                     }
                 }
                 __syncthreads();

@@ -71,9 +71,9 @@ template <int AW, int SLAB, bool SPLIT>
 __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 threads at six waves per SIMD: slower, 80 registers spill) */
     constexpr int A = AW * AW, NT = 256;
     extern __shared__ float S[];                      /* [n][st][SLAB] */
-    __shared__ unsigned pos[8 * A];
     __shared__ float red[3][NT / 64];
     __shared__ float cn4s[A], cni4s[A];               /* coef_norm_4d / coef_norm_inv_4d: indexed per thread in the column / row passes */
+    __shared__ int sa_tab[SaLayout<AW>::words];       /* shape-adaptive groups: the shape record and the tables of every row length (sa_fill) */
     constexpr int P2 = SLAB / 2;                      /* the angular passes work on pixel PAIRS: v_pk_fma_f32, 8-byte LDS accesses */
     v2f* const S2 = reinterpret_cast<v2f*>(S);
     const int tid = threadIdx.x;
@@ -95,18 +95,17 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
     if (quads) {
 #pragma unroll
         for (int u = 0; u < GQ; u++) pv[u] = a.gpos[(size_t)g * N * A + min((tid + u * NT) / QS, N * A - 1)];
-    } else
-        for (int i = tid; i < N * A; i += NT) pos[i] = a.gpos[(size_t)g * N * A + i];
+    }   /* (patch sides that are no multiple of four: one pixel per load, the positions from the table load by load -- no LDS copy) */
     /* (windows beyond 7x7: the large shape record of the pre-pass) */
     typedef typename std::conditional<(AW > 7), ShRefBig, ShRef>::type SH;
     SH sh = [&]() -> SH { if constexpr (AW > 7) return group_shape_big(a, g); else return group_shape(a, g); }();
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
     const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    if (do_sa4) sa_fill<AW, SH>(sa_tab, sh, tb, tid, NT);   /* (read behind the barrier that follows the first gather) */
     const float sig = a.sigma[c];
     const float T = a.lambda * sig * 1.41421356237309505f;   /* core:2431 */
     const float sig2 = sig * sig;
-    if (!quads) __syncthreads();
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     float* const out = a.filt + (size_t)g * N * A * a.C * k2;
     const float* const img = a.noisy + (size_t)c * plane;
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
                     v[u] = 0.0f;
                     if (e < total) {
                         const int px = e % SLAB, ns = e / SLAB, pq = p0 + px;
-                        const unsigned p = pos[ns];
+                        const unsigned p = a.gpos[(size_t)g * N * A + ns];
                         if (p != 0xffffffffu && px < npx) v[u] = img[(unsigned)(ns % A) * cplane + p + (unsigned)(pq / k) * a.Wb + (unsigned)(pq % k)];
                     }
                 }
@@ -206,12 +205,12 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
         } else if (do_sa4) {   /* shape-adaptive groups: the same separable form, row / column lengths from the group's shape record */
             for (int e = tid; e < nSx * AW * P2; e += NT) {
                 const int pp = e % P2, r = e / P2;
-                sadctw_rows_fwd2<AW, SH>((LdsV2)(S2 + (size_t)r * AW * P2 + pp), P2, r % AW, sh, tb);
+                sadctw_rows_fwd2<AW>((LdsV2)(S2 + (size_t)r * AW * P2 + pp), P2, r % AW, (SaTab)sa_tab);
             }
             __syncthreads();
             for (int e = tid; e < nSx * AW * P2; e += NT) {
                 const int pp = e % P2, r = e / P2, u = r % AW, n = r / AW;
-                sadctw_cols_fwd2<AW, SH>((LdsV2)(S2 + (size_t)(n * A + u) * P2 + pp), P2, u, sh, tb);
+                sadctw_cols_fwd2<AW>((LdsV2)(S2 + (size_t)(n * A + u) * P2 + pp), P2, u, (SaTab)sa_tab);
             }
             __syncthreads();
         }
@@ -313,12 +312,12 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
             if (do_sa4) {
                 for (int e = tid; e < nSx * AW * P2; e += NT) {
                     const int pp = e % P2, r = e / P2, u = r % AW, n = r / AW;
-                    sadctw_cols_inv2<AW, SH>((LdsV2)(S2 + (size_t)(n * A + u) * P2 + pp), P2, u, sh, tb);
+                    sadctw_cols_inv2<AW>((LdsV2)(S2 + (size_t)(n * A + u) * P2 + pp), P2, u, (SaTab)sa_tab);
                 }
                 __syncthreads();
                 for (int e = tid; e < nSx * AW * P2; e += NT) {
                     const int pp = e % P2, r = e / P2;
-                    sadctw_rows_inv2<AW, SH>((LdsV2)(S2 + (size_t)r * AW * P2 + pp), P2, r % AW, sh, tb);
+                    sadctw_rows_inv2<AW>((LdsV2)(S2 + (size_t)r * AW * P2 + pp), P2, r % AW, (SaTab)sa_tab);
                 }
                 __syncthreads();
             }

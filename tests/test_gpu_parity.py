@@ -736,6 +736,8 @@ ASW2_CASES = [
     # the README's HT parameters on a wide window: the slab kernel of lfbm5d_group_wide.hip (round 5)
     ("ht-id-sadct-haar-k16-n8", 1, (8, 6, 2, 16, 4, "id", "sadct", "haar"), 72, ()),
     ("ht-id-sadct-hw-k12-holes", 1, (4, 6, 2, 12, 4, "id", "sadct", "hw"), 64, (2, 20)),
+    ("ht-id-sadct-haar-k10", 1, (4, 6, 2, 10, 4, "id", "sadct", "haar"), 64, ()),        # a side that is no multiple of four: one pixel per load
+    ("ht-id-dct-haar-k6-holes", 1, (8, 6, 2, 6, 3, "id", "sadct", "haar"), 56, (5, 23)),
 ]
 
 

@@ -4,6 +4,7 @@ kern=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/tcpcmd; rm -rf $out; mkdir -p $out
 sets=(
+ "TCP_UTCL1_REQUEST TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_MISS_UNDER_MISS"
  "TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCP_LATENCY TCP_TOTAL_ACCESSES"
  "TCP_PENDING_STALL_CYCLES TCP_TCR_TCP_STALL_CYCLES TCP_READ_TAGCONFLICT_STALL_CYCLES TCP_GATE_EN1"
  "TCP_TOTAL_READ TCP_TOTAL_WRITE TCP_TOTAL_CACHE_ACCESSES TCP_CACHE_MISS"
