@@ -13,9 +13,10 @@
  *   the fibres along the matches, two per lane: Haar / Hadamard / DCT, hard threshold, inverse;
  *   the inverse angular passes, the second writing four filtered pixels per 16-byte store straight to `filt`.
  * The general kernel keeps the whole 200 KB stack of such a group in an HBM scratch slice: 5.8 / 12.8 ms per 304^2 pass (5x5 / 7x7,
- * k = 16, N = 8; 9x9: 200 ms) where this one takes 1.11 / 2.48 ms (9x9: 7.7); same operations in the same order per value, hence the same
+ * k = 16, N = 8; 9x9: 200 ms) where this one takes 1.01 / 2.26 ms (9x9: 5.8); same operations in the same order per value, hence the same
  * results.  Shape-adaptive groups (2 / 9 / 223 of 3721 there) run the same separable passes with the row / column lengths of their shape
- * record (sadctw_*2, out of line): as a per-pixel block in private memory nine such groups cost the 7x7 pass 0.4 ms.
+ * record (sadctw_*2, out of line, on an LDS copy of the record): as a per-pixel block in private memory nine such groups cost the
+ * 7x7 pass 0.4 ms.
  * Where the time goes now (in-kernel clocks of a sample of workgroups, profiles/r05_d_wide_window.txt): a workgroup lives 14 us of
  * which the gather is 4, the four angular passes 6, the fibres 2.7; VALU issue is ~55 % busy at three waves per SIMD (1900 VALU
  * instructions per wave, a fifth of them the transforms' FMAs), and `filt` itself is 2.3 / 4.5 GB per pass.
