@@ -1,6 +1,6 @@
 /*
  * lfbm5d_group_slab.hip -- the group stage of configurations whose stacks do not fit the LDS (round 5): the Wiener step with 12x12 or
- * 16x16 patches or N = 32, either step on 5x5 / 7x7 angular windows with a 2-D transform (core:277-481, :1044-1280).
+ * 16x16 patches or N = 32, either step on 5x5 ... 17x17 angular windows with a 2-D transform (core:277-481, :1044-1280).
  *
  * A group's stack(s) are nSx x A x k^2 floats (x 2 in the Wiener step): 288 KB for k = 16, N = 16, A = 9.  The three transforms run
  * along three different axes, so no piece of the stack is closed under all of them -- but each stage is closed under a DIFFERENT
@@ -13,10 +13,12 @@
  *            (tau_2D = id: straight to `filt`);
  *   stage 3  per patch again: filtered coefficients from the slice, inverse 2-D transform in the work area, pixels to `filt`.
  * Round 4's general kernel (k_group_big, lfbm5d_group_generic.hip) keeps the whole stack in the slice and runs EVERY stage on it
- * with 4-byte accesses at one wave per SIMD (280-410 registers): 5-45 ms per 304^2 pass where this one takes 1-5.
+ * with 4-byte accesses at one wave per SIMD (280-410 registers): 5-45 ms per 304^2 pass where this one takes 2.5-13 (3x3 windows;
+ * profiles/r05_e_slab_kernel.txt), 174-800 ms on 9x9 ... 15x15 windows where this one takes 25-110.
  * The same transform routines / the same sums in the same order as the general kernel: the same results.
- * Not here (the general kernel keeps them): windows above 7x7, patches above 16x16 or of a side the 2-D routines have no row form
- * for, useSD (its float sums depend on the order of the fibres), the per-SAI BM3D flavour.
+ * Not here (the general kernel keeps them): stacks of which not even four coefficients of every patch fit 112 KB of LDS (a 17x17 window
+ * with N = 16 in the Wiener step), patches above 16x16 or of a side the 2-D routines have no row form for, useSD (its float sums depend
+ * on the order of the fibres), the per-SAI BM3D flavour.
  */
 #include "lfbm5d_group_device.h"
 
