@@ -741,14 +741,14 @@ ASW2_CASES = [
 ]
 
 
-def _wide_window_pass(ctx, case, aw):
+def _wide_window_pass(ctx, case, aw, Cc=3):
     name, step, pk, crop, holes = case
     sigma = 25.0
     A, cc = aw * aw, (aw * aw) // 2
-    lf = Hh.textured_lf(aw, aw, crop, crop)
+    lf = Hh.textured_lf(aw, aw, crop, crop)[:, :Cc]
     _, noisy = Hh.noisy_lf(lf, sigma)
     N, nSim, nDisp, k = pk[0], pk[1], pk[2], pk[3]
-    win, Wb, Hb = Hh.padded_window(noisy, crop, crop, 3, nSim + nDisp)
+    win, Wb, Hb = Hh.padded_window(noisy, crop, crop, Cc, nSim + nDisp)
     mask = np.ones(A, np.uint32)
     for h in holes:
         mask[h] = 0
@@ -756,18 +756,18 @@ def _wide_window_pass(ctx, case, aw):
     proc = (mask == 0).astype(np.uint32)      # the schedule marks empty SAIs as processed (bm5d.cpp:268-270)
     basic = None
     if step == 2:
-        n1, d1, _ = Hh.oracle_pass(1, sigma, (4,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, 3, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
+        n1, d1, _ = Hh.oracle_pass(1, sigma, (4,) + pk[1:5] + ("id", "sadct", "haar"), win, None, Wb, Hb, Cc, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
         basic = np.ascontiguousarray(Hh.estimate(n1, d1, win).astype(np.float32))
-    num_o, den_o, st = Hh.oracle_pass(step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
+    num_o, den_o, st = Hh.oracle_pass(step, sigma, pk, win, basic, Wb, Hb, Cc, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
     ctx.reset_stats()
-    num_g, den_g = gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, 3, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
+    num_g, den_g = gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
     s = ctx.stats()
     assert (s.groups, s.stack_patches, s.sadct_groups) == (st.groups, st.stack_patches, st.sadct_groups)
     if holes:
         assert st.sadct_groups == st.groups or pk[6] in ("dct", "id")
     refs, idx, cnt, best, shape = ctx.last_bm(N, A, Wb * Hb)
     est = (win if step == 1 else basic)[:, :Wb * Hb]
-    tau = Hh.tau_match(sigma, 3, step)
+    tau = Hh.tau_match(sigma, Cc, step)
     regr, regc = slice(nDisp, Hb - k - nDisp + 1), slice(nDisp, Wb - k - nDisp + 1)
     for st_i in (0, aw + 1, cc + 1, A - 1):
         if not mask[st_i]:
@@ -825,6 +825,13 @@ def test_9x9_window_pass_matches_oracle(ctx, case):
 def test_11x11_window_pass_matches_oracle(ctx):
     _wide_window_pass(ctx, ("ht-id-sadct-haar-holes", 1, (2, 4, 2, 8, 4, "id", "sadct", "haar"), 40, (7, 61, 120)), 11)
     _wide_window_pass(ctx, ("wien-dct-dct-haar", 2, (2, 4, 2, 8, 4, "dct", "dct", "haar"), 40, ()), 11)
+
+
+def test_greyscale_wide_window_passes_match_oracle(ctx):
+    """One channel through the wide-window and slab kernels (their grids and the `filt` layout carry the channel count)."""
+    _wide_window_pass(ctx, ("grey-ht-id-sadct-haar-k16-n8", 1, (8, 6, 2, 16, 4, "id", "sadct", "haar"), 72, (3,)), 5, Cc=1)
+    _wide_window_pass(ctx, ("grey-wien-dct-sadct-haar-n16", 2, (16, 6, 2, 8, 4, "dct", "sadct", "haar"), 64, ()), 5, Cc=1)
+    _wide_window_pass(ctx, ("grey-ht-bior-dct-hw-k16", 1, (4, 5, 2, 16, 4, "bior", "dct", "hw"), 64, ()), 7, Cc=1)
 
 
 @pytest.mark.parametrize("aw", [13, 17])
