@@ -458,6 +458,36 @@ def test_greyscale_multi_window_steps(ctx):
     assert abs(O.psnr_lf(d_den.cpu().numpy(), clean) - O.psnr_lf(d_o, clean)) < bar
 
 
+def test_greyscale_steps_with_a_5x5_window(ctx):
+    """The same light field as ONE 5x5 window (aswSize 2): the centre pass and the subset passes of the other 24 SAIs through the
+    wide-window kernel (step 1: tau_2D = id) and the slab kernel (step 2: 2 x 8 x 25 x 64 floats per stack pair)."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    lf = np.ascontiguousarray(Hh.textured_lf(5, 5, 64, 64)[:, :1])
+    clean, noisy = Hh.noisy_lf(lf, 25.0)
+    mask = np.ones(25, np.uint32)
+    p1 = (4, 5, 2, 8, 4, "id", "sadct", "haar")
+    p2 = (8, 5, 2, 8, 4, "dct", "sadct", "haar")
+    n1, b_o, st1 = O.run_step1(O.make_params(25.0, 2.7, *p1, cs="rgb"), noisy.copy(), mask, O.ROWMAJOR, 5, 5, 2, 64, 64, 1)
+    w1_o = O.last_windows()
+    _, _, d_o, st2 = O.run_step2(O.make_params(25.0, 2.7, *p2, cs="rgb"), n1.copy(), b_o.copy(), mask, O.ROWMAJOR, 5, 5, 2, 64, 64, 1)
+    w2_o = O.last_windows()
+    d_noisy = torch.from_numpy(noisy).cuda()
+    d_basic, d_den = torch.zeros_like(d_noisy), torch.zeros_like(d_noisy)
+    ctx.reset_stats()
+    ctx.step1(core.make_params(25.0, 2.7, *p1, color_space="rgb"), d_noisy, mask, d_basic, L.ROWMAJOR, 5, 5, 2, 64, 64, 1)
+    s1 = ctx.stats()
+    assert np.array_equal(ctx.last_windows(), w1_o)
+    assert abs(int(s1.passes) - int(st1.passes)) <= 2 * len(w1_o) and s1.passes > s1.windows
+    assert abs(O.psnr_lf(d_basic.cpu().numpy(), clean) - O.psnr_lf(b_o, clean)) < (0.01 if s1.passes == st1.passes else 0.05)
+    ctx.reset_stats()
+    ctx.step2(core.make_params(25.0, 2.7, *p2, color_space="rgb"), d_noisy, mask, d_basic, d_den, L.ROWMAJOR, 5, 5, 2, 64, 64, 1)
+    s2 = ctx.stats()
+    assert np.array_equal(ctx.last_windows(), w2_o)
+    assert abs(int(s2.passes) - int(st2.passes)) <= 2 * len(w2_o)
+    assert abs(O.psnr_lf(d_den.cpu().numpy(), clean) - O.psnr_lf(d_o, clean)) < (0.01 if s2.passes == st2.passes else 0.05)
+
+
 def test_subset_passes_on_the_full_grid_scan_equal_the_position_map_form(ctx, monkeypatch):
     """Round 4: the subset passes of a greyscale light field run the second-generation table kernel on the full regular grid and
     take a reference's scores from its place in it (before: round 2's kernel with a position map, LFBM5D_SUBSET_SCAN_V1=1).  Same
