@@ -371,7 +371,8 @@ __global__ void k_group_idw_weight(GroupArgs a) {
 
 /* window side -> pixels per slab (the slab's stack of up to 8 matches within 51 KB; a power of two, so that a thread's 16-byte loads
  * all fetch the same pixels) */
-template <int AW> struct WideSlab { static constexpr int value = AW == 5 ? 64 : AW == 7 ? 32 : AW == 9 ? 16 : AW <= 13 ? 8 : 4; };
+template <int AW> struct WideSlab { static constexpr int value = AW == 5 ? 64 : AW == 7 ? 32 : AW == 9 ? 16 : AW <= 15 ? 8 : 4; };   /* (15x15: 58 KB -- its 190
+ * registers allow two workgroups per CU anyway: 23 ms per launch against 46 with four-pixel slabs; 17x17 with eight: 74 + 17 KB, one workgroup per CU, 51 against 40) */
 
 template <int AW>
 static hipError_t prepare_idw() {
