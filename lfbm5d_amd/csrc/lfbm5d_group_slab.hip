@@ -111,15 +111,16 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
 #define SUB_MARK(i) do {} while (0)
 #endif
     constexpr int PPI = kThreads / K, RS = K + 1;
+    constexpr int PT = K == 8 ? 2 : 1, PR = PPI * PT;   /* 8x8: two patches per thread and round -- twice the rows in flight, half the rounds */
     const int tid = threadIdx.x, slot = tid / K, r = tid % K;
-    float* Tp = tmp + slot * K * RS;   /* two work areas of PPI patches each */
+    float* Tp = tmp + slot * K * RS;   /* two work areas of PR patches each; a thread's patches PPI apart */
     /* K = 8, 16: the K threads of a patch share a wavefront and no other thread touches their part of the work area -- no workgroup
      * barrier anywhere in the stage (a wave's DS operations execute in order), the waves drift apart and hide each other's loads */
     constexpr bool wave_local = (64 % K) == 0;
     /* the per-thread norms, once per stage (indexed by the thread's row / column: vector loads, which inside the transform
      * cost a memory round trip per output) */
     float nrm[K];
-    if (tau2 == 5) {
+    if (tau2 == 5 && K != 8) {
 #pragma unroll
         for (int t = 0; t < K; t++) nrm[t] = fwd ? tb->cn2[t * K + r] : tb->cni2[r * K + t];
     }
@@ -127,47 +128,62 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
     /* Software pipeline over the rounds: the rows of the NEXT round are requested before this round is transformed, and the results
      * of the PREVIOUS round leave while this one is transformed (two work areas): the wait for the next rows -- vmcnt counts loads
      * and stores in order -- then finds stores that have had a whole round to be acknowledged */
-    float xn[K];
-    if (slot < PPI && slot < np) src(std::integral_constant<int, K>{}, slot, r, xn);
-    float* TpPrev = Tp + PPI * K * RS;
-    for (int p0 = 0; p0 < np; p0 += PPI) {
-        const int patch = p0 + slot;
-        const bool on = slot < PPI && patch < np;
-        if (on) {
+    float xn[PT][K];
 #pragma unroll
-            for (int t = 0; t < K; t++) Tp[r * RS + t] = xn[t];
+    for (int h = 0; h < PT; h++) if (slot < PPI && slot + h * PPI < np) src(std::integral_constant<int, K>{}, slot + h * PPI, r, xn[h]);
+    float* TpPrev = Tp + PR * K * RS;
+    for (int p0 = 0; p0 < np; p0 += PR) {
+        bool on[PT];
+#pragma unroll
+        for (int h = 0; h < PT; h++) {
+            on[h] = slot < PPI && p0 + slot + h * PPI < np;
+            if (on[h]) {
+#pragma unroll
+                for (int t = 0; t < K; t++) Tp[h * PPI * K * RS + r * RS + t] = xn[h][t];
+            }
         }
         if (p0 > 0 && slot < PPI) {   /* (the previous round was full) */
-            float x[K];
 #pragma unroll
-            for (int t = 0; t < K; t++) x[t] = TpPrev[r * RS + t];
-            dst(std::integral_constant<int, K>{}, patch - PPI, r, x);
+            for (int h = 0; h < PT; h++) {
+                float x[K];
+#pragma unroll
+                for (int t = 0; t < K; t++) x[t] = TpPrev[h * PPI * K * RS + r * RS + t];
+                dst(std::integral_constant<int, K>{}, p0 - PR + slot + h * PPI, r, x);
+            }
         }
-        if (slot < PPI && patch + PPI < np) src(std::integral_constant<int, K>{}, patch + PPI, r, xn);
+#pragma unroll
+        for (int h = 0; h < PT; h++) if (slot < PPI && p0 + PR + slot + h * PPI < np) src(std::integral_constant<int, K>{}, p0 + PR + slot + h * PPI, r, xn[h]);
         SLAB_SYNC();
         SUB_MARK(0);
         if (tau2 == 5) {
-            if (on) dct_tp_rows<K>(Tp, r, fwd, nrm, tb);
+#pragma unroll
+            for (int h = 0; h < PT; h++) if (on[h]) dct_tp_rows<K>(Tp + h * PPI * K * RS, r, fwd, nrm, tb);
             SLAB_SYNC();
             SUB_MARK(1);
-            if (on) dct_tp_cols<K>(Tp, r, fwd, nrm, tb);
+#pragma unroll
+            for (int h = 0; h < PT; h++) if (on[h]) dct_tp_cols<K>(Tp + h * PPI * K * RS, r, fwd, nrm, tb);
         } else if constexpr (K != 12) {
-            if (on) bior_tp<K>(Tp, r, fwd, tb);
+#pragma unroll
+            for (int h = 0; h < PT; h++) if (on[h]) bior_tp<K>(Tp + h * PPI * K * RS, r, fwd, tb);
         }
         SLAB_SYNC();
         SUB_MARK(2);
         { float* const sw = Tp; Tp = TpPrev; TpPrev = sw; }
     }
-    {   /* the last round's results */
-        const int patch = ((np - 1) / PPI) * PPI + slot;
-        if (np > 0 && slot < PPI && patch < np) {
-            float x[K];
+    if (np > 0 && slot < PPI) {   /* the last round's results */
+        const int base = ((np - 1) / PR) * PR;
 #pragma unroll
-            for (int t = 0; t < K; t++) x[t] = TpPrev[r * RS + t];
-            dst(std::integral_constant<int, K>{}, patch, r, x);
+        for (int h = 0; h < PT; h++) {
+            const int patch = base + slot + h * PPI;
+            if (patch < np) {
+                float x[K];
+#pragma unroll
+                for (int t = 0; t < K; t++) x[t] = TpPrev[h * PPI * K * RS + r * RS + t];
+                dst(std::integral_constant<int, K>{}, patch, r, x);
+            }
         }
-        SUB_MARK(3);
     }
+    SUB_MARK(3);
 #undef SLAB_SYNC
 #undef SUB_MARK
     __syncthreads();   /* (what the stage wrote is read by other waves next) */
@@ -175,7 +191,7 @@ __device__ __forceinline__ void patches_2d(float* tmp, int np, unsigned tau2, bo
 
 /* ---- the kernel ---- */
 template <int STEP, int WA, int MAXN>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(MAXN > 16 ? 2 : 1, 8))) void k_group_slab(   /* N = 32: 256 registers, two workgroups per CU (caps
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))) void k_group_slab(   /* at most 256 registers: two workgroups per CU (caps
                                                                                                                          * for three / four waves per SIMD: +-10 %) */
     GroupArgs a, float* scratch, unsigned long long slice_floats, int ls) {
     constexpr int A = WA * WA, NST = STEP == 2 ? 2 : 1;
@@ -541,7 +557,7 @@ int slab_log2(const GroupArgs& a) {
 }
 size_t slab_lds_bytes(const GroupArgs& a) {
     const size_t stack = (size_t)((a.step == 2 ? 2 : 1) * a.N * a.A) << slab_log2(a);
-    const size_t work = a.tau2 == 4 ? 0 : (size_t)2 * (kThreads / a.k) * a.k * (a.k + 1);   /* two work areas (patches_2d) */
+    const size_t work = a.tau2 == 4 ? 0 : (size_t)2 * (a.k == 8 ? 2 : 1) * (kThreads / a.k) * a.k * (a.k + 1);   /* two work areas of a round's patches (patches_2d) */
     return std::max(stack, work) * sizeof(float);
 }
 
