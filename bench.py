@@ -410,6 +410,7 @@ def main():
             nHW = pk[1] + pk[2]
             comp[kind] = (S + 4) * 4.0 * 9 * 3 * (W + 2 * nHW) * (H + 2 * nHW)
         SIMDS, CLK = 1024, 2.4e9      # 256 CUs x 4 SIMD-32; a wave64 VALU instruction occupies its SIMD for 2 cycles (MI355X_MICROARCH.md)
+        HBM_ACHIEVABLE_GBS = 6300.0   # what a streaming kernel reaches on MI355X (MI355X_MICROARCH.md, HBM section): the floors' rate
 
         def valu_frac(classes, ms):
             """share of the chip's VALU issue slots the kernels of `classes` use during `ms` (their time alone on the GPU)"""
@@ -419,7 +420,11 @@ def main():
             if any(c not in k for c in classes):
                 return None
             insts = sum(k[c]["valu_insts_per_launch"] for c in classes)
-            return {"valu_insts": insts, "valu_frac": insts * 2.0 / (SIMDS * CLK * ms * 1e-3)}
+            # valu_frac prices every instruction at 2 cycles; the packed-fp32 instructions these kernels are largely made of take 4
+            # (measured, profiles/r06_a_valu_rate.txt: v_pk_fma / mul / add_f32 2.0-2.2 ns per wave-instruction and SIMD against 1.0-1.2
+            # for the plain forms), as do DPP moves and v_mad_u32_u24: valu_frac_all_packed is the same count at 4 cycles -- the truth lies between
+            return {"valu_insts": insts, "valu_frac": insts * 2.0 / (SIMDS * CLK * ms * 1e-3),
+                    "valu_frac_all_packed": insts * 4.0 / (SIMDS * CLK * ms * 1e-3)}
 
         def pair(kind):
             a = roof[kind]
@@ -438,6 +443,23 @@ def main():
                 d["frac_physical"] = tb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None
                 d["traffic_over_compulsory"] = tb / comp[kind]
             d["compulsory_bytes"] = comp[kind]
+            # distance to the floor of THIS design (round 6; `frac` is saturated by the byte model): what each kernel class must move
+            # through HBM once -- group: the window images in (the stack gathers re-read them from L2) + `filt` out; aggregation: `filt`
+            # in + num / den in and out -- at the rate a streaming kernel reaches, next to the class's time alone on the GPU
+            pk_, S_ = (wl["p1"], 1) if kind == "ht" else (wl["p2"], 2)
+            nHW_, k_ = pk_[1] + pk_[2], pk_[3]
+            plane_b = 4.0 * 9 * 3 * (W + 2 * nHW_) * (H + 2 * nHW_)
+            n_pass = max(1, int(a.get("passes", 0)))
+            filt_b = a.get("stack_patches", 0.0) / n_pass * 9 * 3 * k_ * k_ * 4.0
+            design = {"group": S_ * plane_b + filt_b, "aggregate": filt_b + 4 * plane_b}
+            d["filt_bytes"] = filt_b
+            d["gather_bytes_from_l2"] = S_ * filt_b
+            d["design_bytes"] = design["group"] + design["aggregate"]
+            d["floor_ms"] = d["design_bytes"] / HBM_ACHIEVABLE_GBS / 1e6
+            d["x_over_floor"] = ms / d["floor_ms"] if d["floor_ms"] > 0 else None
+            d["floor_by_class"] = {cn: {"design_bytes": design[cn], "floor_ms": design[cn] / HBM_ACHIEVABLE_GBS / 1e6,
+                                        "ms": d["ms_" + cn], "x_over_floor": (d["ms_" + cn] / (design[cn] / HBM_ACHIEVABLE_GBS / 1e6)) if design[cn] > 0 else None}
+                                   for cn in ("group", "aggregate")}
             # what binds: per kernel class of this pass, the share of VALU issue slots it uses next to the share of the HBM peak it
             # moves (PMC bytes of the class / its time); neither near 1 = latency- / occupancy-bound
             n_p = max(1, int(a.get("passes", 0)))
@@ -455,7 +477,7 @@ def main():
                     for c in classes:
                         kk = tk.get(c) or tk.get(c.split("/")[0] + "/both")
                         if kk:
-                            by_c += (kk["fetch_bytes_per_launch_x2"] if c.startswith("group") else kk["fetch_bytes_per_launch_raw"]) + kk["write_bytes_per_launch"]
+                            by_c += kk["fetch_bytes_per_launch_x2"] + kk["write_bytes_per_launch"]   # FETCH_SIZE halves every shape (profiles/r06_b_fetch_calib.txt)
                     if by_c:
                         e["hbm_bytes"] = by_c
                         e["hbm_frac"] = by_c / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -503,6 +525,16 @@ def main():
                          "valu_note": "VALU wave-instructions (rocprofv3 --pmc SQ_INSTS_VALU of this command, profiles/valu_latest.json) x 2 cycles / "
                                       "(1024 SIMDs x 2.4 GHz x live kernel time); per kernel class under per_step.*.bound_by_class",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pair_ms, "launches": n_all,
+                         # the contract's `frac` per step, and the distance to this design's own floor (what to read instead of a saturated frac)
+                         "frac_ht": ph["frac"], "frac_wiener": pw["frac"],
+                         "design_bytes": (ph["design_bytes"] * ph["launches"] + pw["design_bytes"] * pw["launches"]) / n_all,
+                         "floor_ms": (ph["floor_ms"] * ph["launches"] + pw["floor_ms"] * pw["launches"]) / n_all,
+                         "x_over_floor": pair_ms / ((ph["floor_ms"] * ph["launches"] + pw["floor_ms"] * pw["launches"]) / n_all) if (ph["floor_ms"] + pw["floor_ms"]) > 0 else None,
+                         "x_over_floor_by_class": {"ht": {cn: v["x_over_floor"] for cn, v in ph["floor_by_class"].items()},
+                                                   "wiener": {cn: v["x_over_floor"] for cn, v in pw["floor_by_class"].items()}},
+                         "floor_note": "design_bytes = window images read once + filt written once (group), filt read once + num/den read and written "
+                                       "once (aggregation); floor_ms = design_bytes / 6.3 TB/s (the rate MI355X_MICROARCH.md calls achievable); the stack "
+                                       "gathers (gather_bytes_from_l2 under per_step) are served by L2 and are not in the floor",
                          "measured_with": ((f"the timed region ({lanes_timed} lane{'s' if lanes_timed != 1 else ''}"
                                             + ("; kernels of different windows overlap, the intervals are not kernel-alone times)" if lanes_timed != 1 else ")"))
                                            if roof is timed else

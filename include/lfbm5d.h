@@ -218,7 +218,12 @@ int lfbm5d_denoise_device(lfbm5d_ctx* ctx, const lfbm5d_params* P1, const lfbm5d
                           unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H, unsigned C);
 
 /* ---- outer seam, host buffers (what the run_bm5d_* wrappers of the drop-in call): same
- * semantics, the library stages through HBM (PCIe-inclusive). ---- */
+ * semantics, the library stages through HBM (PCIe-inclusive).
+ * ERRORS: the host forms write their in / out buffers (h_noisy, h_basic, h_denoised) while the job runs -- the streamed form
+ * delivers a SAI's outputs as soon as the last window on it has run.  After a NON-ZERO return the contents of every in / out
+ * buffer of the call are UNDEFINED (partly inputs, partly colour-round-tripped outputs): a caller that wants to retry keeps its
+ * own copy of the inputs.  (The reference has the same contract: run_bm5d_* transform LF_noisy in place before anything can
+ * fail, bm5d.cpp:133.) ---- */
 int lfbm5d_step1_host(lfbm5d_ctx* ctx, const lfbm5d_params* P, float* h_noisy,
                       const unsigned* h_mask, float* h_basic, unsigned ang_major, unsigned awidth,
                       unsigned aheight, unsigned an, unsigned W, unsigned H, unsigned C);

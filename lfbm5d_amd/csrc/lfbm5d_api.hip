@@ -117,8 +117,6 @@ struct lfbm5d_ctx {
     DevBuf ipc_flags, ipc_out;
     struct IpcPeer { unsigned char handle[7][64]; void* ptr[7]; };   /* flags, g_num[0..1], g_den[0..1], basic, out -- as this process maps them */
     std::vector<IpcPeer> ipc_peers;
-    const struct HostIO* io = nullptr;
-    bool io_streamed = false;              /* the graph has uploaded the inputs (and, when it completed, delivered the outputs) SAI by SAI */
     DevBuf pristine, pristine_b;
     hipStream_t io_in = nullptr, io_out = nullptr;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
@@ -831,6 +829,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
      * rank.  With real ranks the way out is to abort the communicators: RCCL then fails the pending operations here, the peers
      * see the failure through their own RCCL error paths (or their caller's watchdog -- bench.py has one), and every later call
      * on this context reports that the communicator is gone instead of hanging.  Disarmed when the graph has run through. */
+    const bool ipc = c->ipc && nranks > 1 && !emulate;   /* ranks = processes on this GPU */
     struct AbortCommsOnError {
         lfbm5d_ctx* c; bool armed;
         ~AbortCommsOnError() {
@@ -840,17 +839,31 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             (void)hipDeviceSynchronize();
             c->err += " (multi-GPU step aborted: the RCCL communicators of this context were torn down, call lfbm5d_comm_init again)";
         }
-    } abort_guard{c, nranks > 1 && !emulate};
-    /* ... and on one rank an error return must not leave kernels of other lanes running on the caller's buffers (which the caller
-     * is free to release once the call has failed): wait for whatever has been enqueued */
-    struct DrainOnError { bool armed; ~DrainOnError() { if (armed) (void)hipDeviceSynchronize(); } } drain_guard{true};
+    } abort_guard{c, nranks > 1 && !emulate && !ipc};
+    /* The IPC transport has no communicator to abort: its gating kernels end by their own watchdog.  After an error the ranks may
+     * have stopped at different points of the issue order (and of the rendezvous epochs), so the transport of this context is
+     * closed: the next job fails at once instead of waiting for peers that are out of step. */
+    struct CloseIpcOnError {
+        lfbm5d_ctx* c; bool armed;
+        ~CloseIpcOnError() {
+            if (!armed) return;
+            (void)hipDeviceSynchronize();
+            for (lfbm5d_ctx::IpcPeer& P : c->ipc_peers) for (void*& q : P.ptr) if (q) { (void)hipIpcCloseMemHandle(q); q = nullptr; }
+            c->ipc = false;
+            c->err += " (multi-process step aborted: the IPC transport of this context was closed, call lfbm5d_comm_init_ipc again)";
+        }
+    } ipc_guard{c, ipc};
+    /* ... and where no RCCL operation can be pending (one rank, emulated ranks, the IPC transport) an error return must not leave
+     * kernels of other lanes running on the caller's buffers (which the caller is free to release once the call has failed): wait
+     * for whatever has been enqueued.  With real RCCL ranks the synchronisation belongs behind the abort (abort_guard does it): in
+     * front of it, it would wait for sends / receives whose peers never post their counterparts. */
+    struct DrainOnError { bool armed; ~DrainOnError() { if (armed) (void)hipDeviceSynchronize(); } } drain_guard{nranks == 1 || emulate || ipc};
 
     std::vector<RankState> states(emulate ? (size_t)nranks : 1);
     /* two-step jobs: SAIs no window of the first step touches (LFBM5D_MAX_WINDOWS) keep the first step's input as their basic
      * estimate (bm5d.cpp:405 with den == 0), i.e. what the second step reads as noisy */
     /* the streamed host seam runs on one rank (several ranks: the caller uploads first and downloads at the end) */
     const HostIO* const io = (nranks == 1 && !emulate) ? J.io : nullptr;
-    const bool ipc = c->ipc && nranks > 1 && !emulate;   /* ranks = processes on this GPU */
     if (ipc && G.xfers.size() > kIpcMaxMsgs) return fail(c, "ipc transport: too many messages");
     if (ipc) c->ipc_epoch += 1;
     const int Ls = J.n_steps - 1;   /* the slot whose sums are the job's result */
@@ -874,7 +887,6 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         HIPCK(c, hipStreamWaitEvent(c->io_in, ev_setup, 0));
         for (unsigned st = 0; st < asize; st++)
             if (h_mask[st] && G.last_touch[Ls][st] >= 0) outs[(size_t)G.last_touch[Ls][st]].push_back(st);
-        c->io_streamed = true;
     }
     const bool basic_in = io && !two && J.step[0] == 2;   /* run_bm5d_2nd_step alone: LF_basic is an input */
     /* one SAI of the caller's light field(s) into HBM and into the form the windows read: what run_bm5d_* does to the whole light
@@ -1244,7 +1256,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
     }
     abort_guard.armed = false;   /* every exchange of the graph has completed; what follows are plain collectives */
     *complete_out = complete;
-    if (!complete) return 0;
+    if (!complete) { ipc_guard.armed = false; return 0; }   /* (agreed on by all ranks above) */
     for (size_t n = 0; n < NN; n++) if (mine[n]) c->stats.windows += 1;
     c->stats.messages += n_msgs;
     if (nranks > 1) {
@@ -1312,6 +1324,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
             HIPCK(c, hipStreamSynchronize(s));
         }
     }
+    ipc_guard.armed = false;
     return 0;
 }
 
@@ -2215,7 +2228,6 @@ int host_job(lfbm5d_ctx* c, int kind /* 1 | 2: the step, 3: both */, const lfbm5
     HIPCK(c, c->h2d_basic.reserve(bytes));
     if (kind != 1) HIPCK(c, c->h2d_out.reserve(bytes));
     HostIO io; io.noisy = h_noisy; io.basic = h_basic; io.out = h_out;
-    c->io_streamed = false;
     float* const dn = c->h2d_noisy.as<float>(); float* const db = c->h2d_basic.as<float>(); float* const dd = c->h2d_out.as<float>();
     if (kind == 1) return run_step(c, 1, P1, dn, h_mask, nullptr, db, ang_major, awidth, aheight, an1, W, H, C, &io);
     if (kind == 2) return run_step(c, 2, P2, dn, h_mask, db, dd, ang_major, awidth, aheight, an2, W, H, C, &io);

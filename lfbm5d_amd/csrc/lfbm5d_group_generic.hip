@@ -287,7 +287,7 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
     float* out = a.filt + (size_t)g * N * A * a.C * k2;
     for (int e = tid; e < stack; e += kThreads) {
         const int pq = e % k2, ns = e / k2;
-        out[((size_t)ns * a.C + c) * k2 + pq] = F[e];
+        filt_put(&out[((size_t)ns * a.C + c) * k2 + pq], F[e]);
     }
 }
 

@@ -165,7 +165,7 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
         for (int st = 0; st < 9; st++) {
             const float r = n < NH ? V[n][st].x : V[n - NH][st].y;
             if (LDSW) work[(n * A + st) * kT16Patch + woff] = r;
-            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), 0);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), LFBM5D_FILT_STORE_AUX);
         }
 }
 
@@ -364,8 +364,8 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
                     float4* dst = reinterpret_cast<float4*>(out + ((size_t)(base + patch) * a.C + c) * K * K);
     #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        dst[r * 4 + q] = make_float4(o[4 * q].x, o[4 * q + 1].x, o[4 * q + 2].x, o[4 * q + 3].x);
-                        dst[(r + 8) * 4 + q] = make_float4(o[4 * q].y, o[4 * q + 1].y, o[4 * q + 2].y, o[4 * q + 3].y);
+                        filt_put4(&dst[r * 4 + q], make_float4(o[4 * q].x, o[4 * q + 1].x, o[4 * q + 2].x, o[4 * q + 3].x));
+                        filt_put4(&dst[(r + 8) * 4 + q], make_float4(o[4 * q].y, o[4 * q + 1].y, o[4 * q + 2].y, o[4 * q + 3].y));
                     }
                 }
             }
@@ -387,7 +387,7 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
                     dct16_inv(x);
                     float4* dst = reinterpret_cast<float4*>(out + ((size_t)(base + patch) * a.C + c) * K * K);
     #pragma unroll
-                    for (int q = 0; q < 4; q++) dst[r * 4 + q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+                    for (int q = 0; q < 4; q++) filt_put4(&dst[r * 4 + q], make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]));
                 }
             }
         }

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
                 constexpr int K = decltype(kt)::value;
                 float* o = slice + (size_t)p * K * K + r * K;
 #pragma unroll
-                for (int t = 0; t < K; t += 4) *reinterpret_cast<v4f*>(o + t) = v4f{x[t], x[t + 1], x[t + 2], x[t + 3]};
+                for (int t = 0; t < K; t += 4) filt_put4(reinterpret_cast<v4f*>(o + t), v4f{x[t], x[t + 1], x[t + 2], x[t + 3]});
             };
 #ifdef LFBM5D_SLAB_PHASES
             long long* const subp = tq + 8;
@@ -496,13 +496,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
                     if (q < npx) {
                         const v4f v = *reinterpret_cast<const v4f*>(F + 4 * (size_t)e);
                         float* o = id2 ? out + ((size_t)ns * a.C + c) * k2 + s0 + q : fslice + (size_t)ns * k2 + s0 + q;
-                        *reinterpret_cast<v4f*>(o) = v;
+                        if (id2) filt_put4(reinterpret_cast<v4f*>(o), v); else *reinterpret_cast<v4f*>(o) = v;   /* (the slice is read back by this workgroup) */
                     }
                 }
             } else {
                 for (int e = tid; e < NSA << ls; e += kThreads) {
                     const int q = e & (SLAB - 1), ns = e >> ls;
-                    if (q < npx) out[((size_t)ns * a.C + c) * k2 + s0 + q] = F[e];
+                    if (q < npx) filt_put(&out[((size_t)ns * a.C + c) * k2 + s0 + q], F[e]);
                 }
             }
             __syncthreads();
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
                 constexpr int K = decltype(kt)::value;
                 float* o = out + ((size_t)p * a.C + c) * K * K + r * K;
 #pragma unroll
-                for (int t = 0; t < K; t += 4) *reinterpret_cast<v4f*>(o + t) = v4f{x[t], x[t + 1], x[t + 2], x[t + 3]};
+                for (int t = 0; t < K; t += 4) filt_put4(reinterpret_cast<v4f*>(o + t), v4f{x[t], x[t + 1], x[t + 2], x[t + 3]});
             };
             if (k == 16) patches_2d<16>(lds, NSA, a.tau2, false, tb, src, dst);
             else if (k == 12) patches_2d<12>(lds, NSA, a.tau2, false, tb, src, dst);
@@ -591,7 +591,9 @@ template <int WA, int MAXN>
 static hipError_t prepare_slab() {
     const void* fns[] = {reinterpret_cast<const void*>(&k_group_slab<1, WA, MAXN>), reinterpret_cast<const void*>(&k_group_slab<2, WA, MAXN>)};
     for (const void* f : fns) {
-        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (WA > 9 ? 116 : 80) * 1024);   /* slab stack <= 72 (112) KB, two work areas <= 35 KB */
+        /* the cap follows the SAME bound as eligibility (group_uses_slab admits any stack whose four-pixel slab is within
+         * kSlabFloatsMax floats, e.g. 9x9 windows, Wiener step, N = 32: 81 KB): a cap per window side once refused such a launch */
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 116 * 1024);   /* slab stack <= 112 KB, two work areas <= 35 KB */
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
                             v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                             for (int v = 1; v < AW; v++) acc += t[v] * tb->cosw[v * AW + i];
-                            *reinterpret_cast<v4f*>(out + ((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px) = (t[0] + 2.0f * acc) * tb->coef4inv;
+                            filt_put4(reinterpret_cast<v4f*>(out + ((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px), (t[0] + 2.0f * acc) * tb->coef4inv);
                         }
                     }
                 }
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
                         for (int v = 1; v < AW; v++) acc += t[v] * tb->cosw[v * AW + i];
                         const v2f y = (t[0] + 2.0f * acc) * tb->coef4inv;
                         float* o = out + ((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px;
-                        if (both && even) *reinterpret_cast<v2f*>(o) = y;
-                        else { o[0] = y.x; if (both) o[1] = y.y; }
+                        if (both && even) filt_put2(reinterpret_cast<v2f*>(o), y);
+                        else { filt_put(o, y.x); if (both) filt_put(o + 1, y.y); }
                     }
                 }
             }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
             }
             for (int e = tid; e < nSx * A * SLAB; e += NT) {
                 const int px = e % SLAB, ns = e / SLAB;
-                if (px < npx) out[((size_t)ns * a.C + c) * k2 + p0 + px] = S[e];
+                if (px < npx) filt_put(&out[((size_t)ns * a.C + c) * k2 + p0 + px], S[e]);
             }
         }
         WIDE_MARK(7);

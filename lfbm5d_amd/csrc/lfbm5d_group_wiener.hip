@@ -174,8 +174,8 @@ __global__ __launch_bounds__(kDct8Threads) void k_group_dct8(GroupArgs a) {
         float4* out = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + patch) * a.C * K2 + (size_t)c * K2);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            out[2 * i] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
-            out[2 * i + 1] = make_float4(x[i][4], x[i][5], x[i][6], x[i][7]);
+            filt_put4(&out[2 * i], make_float4(x[i][0], x[i][1], x[i][2], x[i][3]));
+            filt_put4(&out[2 * i + 1], make_float4(x[i][4], x[i][5], x[i][6], x[i][7]));
         }
     }
 }
@@ -597,15 +597,15 @@ __global__ __launch_bounds__(kDct8wThreads) void k_group_dct8w(GroupArgs a) {
         float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            oa[2 * i] = make_float4(x[i][0].x, x[i][1].x, x[i][2].x, x[i][3].x);
-            oa[2 * i + 1] = make_float4(x[i][4].x, x[i][5].x, x[i][6].x, x[i][7].x);
+            filt_put4(&oa[2 * i], make_float4(x[i][0].x, x[i][1].x, x[i][2].x, x[i][3].x));
+            filt_put4(&oa[2 * i + 1], make_float4(x[i][4].x, x[i][5].x, x[i][6].x, x[i][7].x));
         }
         if (has_b) {
             float4* ob = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pb) * a.C * K2 + (size_t)c * K2);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                ob[2 * i] = make_float4(x[i][0].y, x[i][1].y, x[i][2].y, x[i][3].y);
-                ob[2 * i + 1] = make_float4(x[i][4].y, x[i][5].y, x[i][6].y, x[i][7].y);
+                filt_put4(&ob[2 * i], make_float4(x[i][0].y, x[i][1].y, x[i][2].y, x[i][3].y));
+                filt_put4(&ob[2 * i + 1], make_float4(x[i][4].y, x[i][5].y, x[i][6].y, x[i][7].y));
             }
         }
     }
@@ -857,12 +857,12 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
         for (int j = 0; j < 8; j++) x[j] = v2f{ra[2 * j * NPp], rb[2 * j * NPp]};
         dct8_inv_t(x);
         float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
-        oa[0] = make_float4(x[0].x, x[1].x, x[2].x, x[3].x);
-        oa[1] = make_float4(x[4].x, x[5].x, x[6].x, x[7].x);
+        filt_put4(&oa[0], make_float4(x[0].x, x[1].x, x[2].x, x[3].x));
+        filt_put4(&oa[1], make_float4(x[4].x, x[5].x, x[6].x, x[7].x));
         if (has_b) {
             float4* ob = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pb) * a.C * K2 + (size_t)c * K2 + i * 8);
-            ob[0] = make_float4(x[0].y, x[1].y, x[2].y, x[3].y);
-            ob[1] = make_float4(x[4].y, x[5].y, x[6].y, x[7].y);
+            filt_put4(&ob[0], make_float4(x[0].y, x[1].y, x[2].y, x[3].y));
+            filt_put4(&ob[1], make_float4(x[4].y, x[5].y, x[6].y, x[7].y));
         }
     }
 #else
@@ -874,8 +874,8 @@ __global__ __launch_bounds__(kDct8w2Threads) void k_group_dct8w2(GroupArgs a) {
         for (int j = 0; j < 8; j++) x[j] = ra[2 * j * NPp];
         dct8_inv_t(x);
         float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + patch) * a.C * K2 + (size_t)c * K2 + i * 8);
-        oa[0] = make_float4(x[0], x[1], x[2], x[3]);
-        oa[1] = make_float4(x[4], x[5], x[6], x[7]);
+        filt_put4(&oa[0], make_float4(x[0], x[1], x[2], x[3]));
+        filt_put4(&oa[1], make_float4(x[4], x[5], x[6], x[7]));
     }
 #endif
 #ifdef LFBM5D_PHASE_TIMING
@@ -1164,13 +1164,13 @@ __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsi
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = v2f{ra[j * NPf], ra[j * NPf + (NP > NPh ? NPh : 0)]};
         dct8_inv_t(x);
-        float4* oa = reinterpret_cast<float4*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
-        oa[0] = make_float4(x[0].x, x[1].x, x[2].x, x[3].x);
-        oa[1] = make_float4(x[4].x, x[5].x, x[6].x, x[7].x);
+        v4f* oa = reinterpret_cast<v4f*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
+        filt_put4(oa, v4f{x[0].x, x[1].x, x[2].x, x[3].x});
+        filt_put4(oa + 1, v4f{x[4].x, x[5].x, x[6].x, x[7].x});
         if (has_b) {
-            float4* ob = oa + (size_t)NPh * a.C * (K2 / 4);
-            ob[0] = make_float4(x[0].y, x[1].y, x[2].y, x[3].y);
-            ob[1] = make_float4(x[4].y, x[5].y, x[6].y, x[7].y);
+            v4f* ob = oa + (size_t)NPh * a.C * (K2 / 4);
+            filt_put4(ob, v4f{x[0].y, x[1].y, x[2].y, x[3].y});
+            filt_put4(ob + 1, v4f{x[4].y, x[5].y, x[6].y, x[7].y});
         }
     }
 }
@@ -1351,8 +1351,8 @@ __global__ __launch_bounds__(64 * kBm3dWaves) void k_group_bm3d8(GroupArgs a) {
         float4* dst = reinterpret_cast<float4*>(a.filt + (((size_t)g * N + lane) * a.C + c) * K2);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            dst[2 * i] = make_float4(x[i][0], x[i][1], x[i][2], x[i][3]);
-            dst[2 * i + 1] = make_float4(x[i][4], x[i][5], x[i][6], x[i][7]);
+            filt_put4(&dst[2 * i], make_float4(x[i][0], x[i][1], x[i][2], x[i][3]));
+            filt_put4(&dst[2 * i + 1], make_float4(x[i][4], x[i][5], x[i][6], x[i][7]));
         }
     }
 }

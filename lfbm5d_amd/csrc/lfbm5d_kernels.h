@@ -9,6 +9,47 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 
+/* Cache policy of the `filt` stream (written once by the group kernels, read once or twice by the aggregation): the aux operand
+ * of the buffer instructions -- 0 default, 2 = nt (streaming), 1 = sc0, 16 = sc1.  Round 6, measured on the headline window
+ * (profiles/r06_a_nt_filt_ab.txt): non-temporal STORES take k_group_id_haar from 0.93-1.06 to 0.81-0.85 ms per pass and every other
+ * group / aggregation kernel 3 % down (the write stream no longer evicts the window rows the gathers of the same XCD re-read from
+ * its L2); non-temporal LOADS in the aggregation cost it half its speed (a filtered row is read by two neighbouring tiles).
+ * Build-time knobs for A/B runs (tools/build_variant_files.sh). */
+#ifndef LFBM5D_FILT_STORE_AUX
+#define LFBM5D_FILT_STORE_AUX 2
+#endif
+#ifndef LFBM5D_FILT_LOAD_AUX
+#define LFBM5D_FILT_LOAD_AUX 0
+#endif
+
+#if defined(__HIPCC__)
+/* stores of filtered patches (global pointers; the register-resident HT kernel passes the aux operand to its buffer stores itself) */
+typedef float filt_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void filt_put(float* p, const float v) {
+#if LFBM5D_FILT_STORE_AUX == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void filt_put4(filt_v4f* p, const filt_v4f v) {
+#if LFBM5D_FILT_STORE_AUX == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+typedef float filt_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void filt_put2(filt_v2f* p, const filt_v2f v) {
+#if LFBM5D_FILT_STORE_AUX == 2
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void filt_put4(float4* p, const float4 v) { filt_put4(reinterpret_cast<filt_v4f*>(p), filt_v4f{v.x, v.y, v.z, v.w}); }
+#endif
+
 namespace lfbm5d {
 
 constexpr int kMaxK = 32;       /* largest patch side (dedicated kernels: 8, 12, 16; the general forms take any) */

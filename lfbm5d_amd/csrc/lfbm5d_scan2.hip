@@ -48,6 +48,14 @@ constexpr unsigned kRsrcFlags = 0x00020000u;
 #ifndef LFBM5D_S2_EXP
 #define LFBM5D_S2_EXP 0
 #endif
+/* cache policy of the (value, order) pairs: written once here, read once by the arg-min -- non-temporal on both sides (round 6:
+ * block matching 1-2 % shorter per pass, profiles/r06_a_nt_knobs_ab.txt; the estimate rows every workgroup's loader re-reads stay in L2) */
+#ifndef LFBM5D_PAIR_STORE_AUX
+#define LFBM5D_PAIR_STORE_AUX 2
+#endif
+#ifndef LFBM5D_PAIR_LOAD_NT
+#define LFBM5D_PAIR_LOAD_NT 1
+#endif
 #ifndef LFBM5D_S2_HAND_AUX
 #define LFBM5D_S2_HAND_AUX 17   /* sc0 sc1 */
 #endif
@@ -514,7 +522,7 @@ __device__ __forceinline__ void scan2_table(const ScanArgs& a, const Scan2Wg& g,
             const int bo = __builtin_amdgcn_ds_bpermute(bq << 2, ordv);
             typedef int v2i __attribute__((ext_vector_type(2)));
             const v2i pr = {__float_as_int(best), bo};
-            __builtin_amdgcn_raw_buffer_store_b64(pr, rP, rok ? (int)(((strip * NCH + cprev) * 512 + rp) * 8) : -1, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(pr, rP, rok ? (int)(((strip * NCH + cprev) * 512 + rp) * 8) : -1, 0, LFBM5D_PAIR_STORE_AUX);
         };
 
         /* chain flavours: steady -- every lane active on every step, every row in the band; edge (ramp-up, ramp-down, short
@@ -911,7 +919,13 @@ __global__ __launch_bounds__(256) void k_stereo_argmin3(Argmin3Args a) {
         for (int j0 = 0; j0 < a.nwg_slot; j0 += 16) {
             v4f w8[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) w8[u] = src[(size_t)min(j0 + u, a.nwg_slot - 1) * (pstride >> 1)];
+            for (int u = 0; u < 16; u++) {
+#if LFBM5D_PAIR_LOAD_NT
+                w8[u] = __builtin_nontemporal_load(src + (size_t)min(j0 + u, a.nwg_slot - 1) * (pstride >> 1));
+#else
+                w8[u] = src[(size_t)min(j0 + u, a.nwg_slot - 1) * (pstride >> 1)];
+#endif
+            }
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int o0 = __float_as_int(w8[u][1]), o1 = __float_as_int(w8[u][3]);

@@ -42,10 +42,16 @@ def test_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "per_step"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # round 6: the distance to this design's own floor next to the (saturated) contract fraction, and the per-step fractions up front
+    for k in ("frac_ht", "frac_wiener", "design_bytes", "floor_ms", "x_over_floor", "x_over_floor_by_class"):
+        assert k in r, k
+    assert r["design_bytes"] > 0 and r["floor_ms"] > 0 and abs(r["x_over_floor"] - r["avg_launch_ms"] / r["floor_ms"]) < 1e-6 * r["x_over_floor"]
     for step in ("ht", "wiener"):
         p = r["per_step"][step]
         assert p["launches"] >= 1 and p["avg_launch_ms"] > 0
         assert p["frac"] <= 1.0 or "flag" in p               # a fraction above 1 is never printed unflagged
+        assert abs(p["design_bytes"] - sum(v["design_bytes"] for v in p["floor_by_class"].values())) < 1.0
+        assert p["filt_bytes"] > 0 and p["x_over_floor"] > 0
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k

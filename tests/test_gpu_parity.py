@@ -843,6 +843,9 @@ ASW4_CASES = [
     ("ht-dct-dct-hw-holes", 1, (4, 5, 2, 8, 4, "dct", "dct", "hw"), 48, (0, 13, 41, 80)),
     ("ht-bior-sadct-haar-holes", 1, (2, 5, 2, 8, 4, "bior", "sadct", "haar"), 48, (5, 44, 77)),
     ("wien-dct-sadct-haar", 2, (4, 5, 2, 8, 4, "dct", "sadct", "haar"), 48, ()),
+    # round 6 (advisor): the slab kernel's largest request on a 9x9 window -- 2 x 32 x 81 x 4 pixels = 81 KB of LDS, above the
+    # 80 KB its instances of windows up to 9x9 were capped at (the launch failed instead of falling back)
+    ("wien-dct-sadct-haar-n32", 2, (32, 5, 2, 8, 4, "dct", "sadct", "haar"), 48, ()),
 ]
 
 

@@ -4,10 +4,15 @@ HBM bytes per launch of the roofline kernels (k_group* + k_aggregate), for the w
 into the HT and the Wiener pass.
 
 gfx950 corrections applied (MI355X_MICROARCH.md, HBM section): rocprofv3 reports the two counters in
-units of 1 KB (bytes = value * 1024); FETCH_SIZE reports half the bytes of wide coalesced streaming
-reads (16 B per lane), so the group kernels' 16-byte gathers are doubled; the aggregation's 4-byte
-gathers are taken raw (calibrated: it reads `filt` exactly once and the raw figure equals the
-buffer's size).
+units of 1 KB (bytes = value * 1024); FETCH_SIZE tallies the L2's 128-byte memory-side read requests
+at 64 bytes, i.e. reports HALF of the bytes fetched -- for EVERY access shape: round 6's calibration
+(tools/fetch_calib.hip, profiles/r06_b_fetch_calib.txt) reads a 2 GiB buffer exactly once with
+16-byte-per-lane streaming loads, 4-byte-per-lane streaming loads and the aggregation's own shape
+(four 64-byte rows of a 1 KB patch per wave-instruction, scattered patches) and the counter says
+1.074 GB for all of them (TCC_EA0_RDREQ: 16.8 M requests = 128 B each).  Rounds 1-5 took the
+aggregation's figure raw ("calibrated": raw 3.29 GB ~ filt's 3.46 GB was a coincidence) -- the
+aggregation really fetches 1.9x (HT) / 2.4x (Wiener) the size of filt, because a filtered row is read
+by the two or three tiles it overlaps and their reads are too far apart in time for the 4 MB L2.
 usage: pmc_traffic.py <fetch_dir> <write_dir> <workload> <out.json> [source-tag]"""
 import csv
 import glob
@@ -45,7 +50,8 @@ def per_kernel(d, counter):
 
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-res = {"workload": sys.argv[3], "source": sys.argv[5] if len(sys.argv) > 5 else None, "unit": "bytes", "kernels": {}, "per_step": {}}
+res = {"workload": sys.argv[3], "source": sys.argv[5] if len(sys.argv) > 5 else None, "unit": "bytes",
+       "fetch_correction": "x2 for every kernel (profiles/r06_b_fetch_calib.txt)", "kernels": {}, "per_step": {}}
 tot = {"ht": [0.0, 0.0, 0], "wiener": [0.0, 0.0, 0]}
 for k in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(k, (0.0, 1))
@@ -55,8 +61,8 @@ for k in sorted(set(fetch) | set(write)):
                                    "write_bytes_per_launch": wb}
     if k[0] == "group" and k[1] in tot:        # gather of window pixels: coalesced 16-byte row segments -> the 1/2 rule applies
         tot[k[1]][0] += fb + wb; tot[k[1]][1] += 2 * fb + wb; tot[k[1]][2] = max(tot[k[1]][2], nf)
-    if k[0] == "aggregate" and k[1] in tot:    # 4 B/lane row-segment reads are not halved (calibrated on filt's size)
-        tot[k[1]][0] += fb + wb; tot[k[1]][1] += fb + wb; tot[k[1]][2] = max(tot[k[1]][2], nf)
+    if k[0] == "aggregate" and k[1] in tot:    # ... and so are the aggregation's row gathers (round 6 calibration)
+        tot[k[1]][0] += fb + wb; tot[k[1]][1] += 2 * fb + wb; tot[k[1]][2] = max(tot[k[1]][2], nf)
 for kind, (raw, corr, n) in tot.items():
     res["per_step"][kind] = {"hbm_bytes_per_launch": corr, "hbm_bytes_per_launch_fetch_uncorrected": raw, "launches": n}
 n = tot["ht"][2] + tot["wiener"][2]
