@@ -95,6 +95,20 @@ void lfbm5d_get_stats(const lfbm5d_ctx* ctx, lfbm5d_stats* out);
 /* The HIP stream (hipStream_t) the context launches on, for callers that time with events. */
 void* lfbm5d_stream(lfbm5d_ctx* ctx);
 
+/* ---- run-time options (round 6; lfbm5d_amd/csrc/lfbm5d_options.h has the list) ----
+ * Every knob of the library is a per-context option.  lfbm5d_create fills them ONCE from the environment (LFBM5D_LANES=3 exported
+ * before the context exists still means three window lanes); afterwards they change only through lfbm5d_set_option -- no entry
+ * point reads the environment, so two contexts of one process can run different settings.  Keys: "lanes" (window lanes of the
+ * graph form, 1..8, default 2), "fused" (0: lfbm5d_denoise_* runs the two calls), "step_sharding" ("rows" / "blocks" / 0),
+ * "max_windows", "emulate_world", "data_driven_schedule", "host_blocking", "band_mb", "bm3d_lanes"; test hooks that select
+ * between implementations of the same arithmetic ("scan_v1", "scan_any", "scan_full_tables", "dct8w_v2", "group_generic",
+ * "no_sa_kernels", "no_slab_kernel", "wide_nosplit", "agg_64bit", "agg_scalar_scan", "subset_list_host", "subset_scan_v1",
+ * "scan_lds_cap", "force_redo").  The old variable names ("LFBM5D_LANES" ...) are accepted as keys.  Values are spelled as the
+ * environment spelled them (integers; "rows" / "blocks"; flags: anything but "0" is on); value NULL or "" restores the default.
+ * Unknown key: returns 1.  lfbm5d_get_option writes the current value as text (size: bytes of `value`). */
+int lfbm5d_set_option(lfbm5d_ctx* ctx, const char* key, const char* value);
+int lfbm5d_get_option(lfbm5d_ctx* ctx, const char* key, char* value, unsigned long long size);
+
 /* ---- multi-GPU: one process per GPU, every rank holds the whole (read-only) light field.
  * Whole steps (lfbm5d_step*) and the two-step job (lfbm5d_denoise_*): the windows of the reference's schedule
  * (bm5d.cpp:165-407; a pure function of the SAI mask, see lfbm5d_plan_windows) form a dependency graph -- a window has to

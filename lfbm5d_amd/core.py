@@ -86,6 +86,9 @@ def lib():
     L.lfbm5d_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.lfbm5d_stream.argtypes = [vp]
     L.lfbm5d_stream.restype = vp
+    if hasattr(L, "lfbm5d_set_option"):      # (absent from older builds loaded through LFBM5D_HIP_LIB for A/B runs: they read the environment themselves)
+        L.lfbm5d_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+        L.lfbm5d_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_ulonglong]
     L.lfbm5d_comm_unique_id.argtypes = [vp]
     L.lfbm5d_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     if hasattr(L, "lfbm5d_comm_init_ipc"):   # (absent from older builds loaded through LFBM5D_HIP_LIB for A/B runs)
@@ -247,6 +250,17 @@ def _sai_ptrs(arrays, mask):
     return out
 
 
+# The library's run-time options (lfbm5d_amd/csrc/lfbm5d_options.h) and the environment variables they came from: the library
+# reads the environment ONCE, at lfbm5d_create; afterwards options change through lfbm5d_set_option.  This Python mirror keeps
+# the old convenience -- os.environ["LFBM5D_LANES"] = "3" between two calls on one Context takes effect -- by handing changed
+# variables to lfbm5d_set_option before every library call (Context._h).
+OPTION_ENV = ("LFBM5D_LANES", "LFBM5D_EMULATE_WORLD", "LFBM5D_MAX_WINDOWS", "LFBM5D_FUSED", "LFBM5D_STEP_SHARDING",
+              "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_HOST_BLOCKING", "LFBM5D_BAND_MB", "LFBM5D_BM3D_LANES", "LFBM5D_SCAN_LDS_CAP",
+              "LFBM5D_FORCE_REDO", "LFBM5D_SCAN_V1", "LFBM5D_SCAN_ANY", "LFBM5D_SCAN_FULL_TABLES", "LFBM5D_DCT8W_V2",
+              "LFBM5D_GROUP_GENERIC", "LFBM5D_NO_SA_KERNELS", "LFBM5D_NO_SLAB_KERNEL", "LFBM5D_WIDE_NOSPLIT", "LFBM5D_AGG_64BIT",
+              "LFBM5D_AGG_SCALAR_SCAN", "LFBM5D_SUBSET_LIST_HOST", "LFBM5D_SUBSET_SCAN_V1")
+
+
 class Context:
     """lfbm5d_ctx: one per process / GPU."""
 
@@ -255,13 +269,39 @@ class Context:
         h = C.c_void_p()
         if self._L.lfbm5d_create(C.byref(h), int(device)) != 0:
             raise LfBm5dError(self._L.lfbm5d_last_error(None).decode())
-        self._h = h
+        self._handle = h
+        self._env_seen = {k: os.environ.get(k) for k in OPTION_ENV}   # what lfbm5d_create has just read
         self.device = int(device)
 
+    @property
+    def _h(self):
+        """The context handle, with the options brought up to date with the environment (see OPTION_ENV)."""
+        h = self._handle
+        if h and hasattr(self._L, "lfbm5d_set_option"):
+            for k in OPTION_ENV:
+                v = os.environ.get(k)
+                if v != self._env_seen[k]:
+                    self._env_seen[k] = v
+                    # a variable that is present but empty counted as "set" for the presence flags
+                    self._L.lfbm5d_set_option(h, k.encode(), None if v is None else (v or "1").encode())
+        return h
+
+    def set_option(self, key, value):
+        """lfbm5d_set_option: `key` as in lfbm5d_options.h ("lanes", "step_sharding", ...; the old variable names work too); None
+        resets it to its default."""
+        if self._L.lfbm5d_set_option(self._handle, key.encode(), None if value is None else str(value).encode()) != 0:
+            raise LfBm5dError(self._L.lfbm5d_last_error(self._handle).decode())
+
+    def get_option(self, key):
+        buf = C.create_string_buffer(64)
+        if self._L.lfbm5d_get_option(self._handle, key.encode(), buf, 64) != 0:
+            raise LfBm5dError(self._L.lfbm5d_last_error(self._handle).decode())
+        return buf.value.decode()
+
     def close(self):
-        if getattr(self, "_h", None):
-            self._L.lfbm5d_destroy(self._h)
-            self._h = None
+        if getattr(self, "_handle", None):
+            self._L.lfbm5d_destroy(self._handle)
+            self._handle = None
 
     def __del__(self):
         try:

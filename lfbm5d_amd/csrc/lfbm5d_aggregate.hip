@@ -296,13 +296,13 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
     const unsigned tw = wide ? 16 : 8, th = wide ? 4 : 8;
     const unsigned tiles = ((a.Wb + tw - 1) / tw) * ((a.Hb + th - 1) / th) * a.A;
     const dim3 grid(((tiles + 7) / 8) * 8), block(64);
-    const bool big = a.filt_bytes > 0xfffff000ull || getenv("LFBM5D_AGG_64BIT") != nullptr;   /* env: exercise the 64-bit path in tests */
-    /* four candidates per lane and 16-byte position loads when a reference patch's N matches come in fours (LFBM5D_AGG_SCALAR_SCAN: the
+    const bool big = a.filt_bytes > 0xfffff000ull || (a.opt & kOptAgg64Bit);   /* option agg_64bit: exercise the 64-bit path in tests */
+    /* four candidates per lane and 16-byte position loads when a reference patch's N matches come in fours (option agg_scalar_scan: the
      * one-candidate-per-lane scan of rounds 1-3, for A/B runs; N = 1, 2 always take it) */
     /* Measured at the headline window (same box, rounds of tools/pass_time.py; instruction counts: tools/pmc_agg_ab.sh): VALU instructions
      * -14 % (k = 8) / -11 % (k = 16), scalar -51 % / -43 %, time 0.648 against 0.658 ms (k = 8), 0.973 against 0.964 (k = 16) -- the
      * kernel's time is its consume phase, not the scan -- so only the 8 x 8 tiles take it. */
-    const bool vec4 = a.N % 4 == 0 && !wide && getenv("LFBM5D_AGG_SCALAR_SCAN") == nullptr;
+    const bool vec4 = a.N % 4 == 0 && !wide && !(a.opt & kOptAggScalarScan);
 #define LFBM5D_AGG(W_, TW_, TH_, PF_, U_) \
     do { if (big && vec4) hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, true, true>), grid, block, 0, s, a); \
          else if (big)    hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, true, false>), grid, block, 0, s, a); \

@@ -10,6 +10,7 @@
 #include "../../include/lfbm5d.h"
 #include "lfbm5d_kernels.h"
 #include "lfbm5d_plan.h"
+#include "lfbm5d_options.h"
 
 #include <rccl/rccl.h>
 
@@ -103,7 +104,7 @@ struct lfbm5d_ctx {
      * re-uploading (and without the stream synchronisation an upload from a stack object needs) */
     GeomCache gc[2]; int gslot = 0;
     bool est_ready = false;                /* the caller of pass_impl has formed the matching estimate in `est` already (graph form) */
-    DevBuf est, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gofs, gok, gshape, counters, small, t_num, t_den, d_mask;
+    DevBuf est, refmap, scores, tables, self_idx, self_cnt, best, shape, filt, wgt, aggpos, gpos, gofs, gok, sa_list, gshape, counters, small, t_num, t_den, d_mask;
     /* step-level buffers (g_num2 / g_den2 / n2: second step of a two-step job; e_basic: an emulated rank's own basic estimate) */
     DevBuf g_num, g_den, g_num2, g_den2, n2, e_basic, w_noisy, w_basic, w_num, w_den, h2d_noisy, h2d_basic, h2d_out, d_own, gscratch;
     /* streamed host seam (lfbm5d_*_host): the caller's light fields as host pointers per SAI, set for the duration of a job; the
@@ -118,6 +119,9 @@ struct lfbm5d_ctx {
     struct IpcPeer { unsigned char handle[7][64]; void* ptr[7]; };   /* flags, g_num[0..1], g_den[0..1], basic, out -- as this process maps them */
     std::vector<IpcPeer> ipc_peers;
     DevBuf pristine, pristine_b;
+    /* run-time options (lfbm5d_options.h): filled from the environment once at lfbm5d_create, changed by lfbm5d_set_option; lane contexts
+     * point at their parent's */
+    Options opt_store; Options* opt = &opt_store;
     hipStream_t io_in = nullptr, io_out = nullptr;
     unsigned* h_small = nullptr; /* pinned, 64 uints */
     /* window lanes (run_step, pipelined form): extra contexts on the same device, each with its own stream, window
@@ -261,6 +265,15 @@ void build_tables(GroupTables& t, unsigned k, unsigned aw, unsigned ah) {
     t.hpd[4] = -s; t.hpd[5] = s; t.lpr[4] = s; t.lpr[5] = s;
     t.coef2inv = 1.0f / (float)(k * 2);
     t.coef4inv = 1.0f / (std::sqrt((float)aw) * std::sqrt((float)ah) * 2.0f);
+    if (aw == 3 && ah == 3) {   /* group_id_compute_fast: see GroupTables */
+        const double r3 = std::sqrt(3.0), alpha[3] = {2.0, r3, 1.0}, gamma[3] = {1.0, r3, 1.0};
+        for (unsigned v = 0; v < 3; v++)
+            for (unsigned u = 0; u < 3; u++) {
+                const double F = alpha[v] * alpha[u] * (double)t.cn4[v * 3 + u];
+                t.ht3_f[v * 3 + u] = (float)F;
+                t.ht3_gf[v * 3 + u] = (float)(F * (double)t.cni4[v * 3 + u] * (double)t.coef4inv * gamma[v] * gamma[u]);
+            }
+    }
 }
 
 bool is_pow2(unsigned n) { return n && !(n & (n - 1)); }
@@ -357,7 +370,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     /* the list on the device (round 4): the flagged patches of the regular grid in raster order -- what the host loop below
      * produces, without the copy of the plane and the 4 M comparisons a pass (1 / 0.4 ms of host time, a third of a greyscale job).
      * Row shards need the rows' first entries on the host and keep the host form */
-    const bool dev_list = !centre && c->pass_world == 1 && std::memcmp(key, gc.rslot_key, sizeof(key)) == 0 && std::getenv("LFBM5D_SUBSET_LIST_HOST") == nullptr;
+    const bool dev_list = !centre && c->pass_world == 1 && std::memcmp(key, gc.rslot_key, sizeof(key)) == 0 && !(c->opt->kernels & kOptSubsetListHost);
     if (dev_list) {
         HIPCK(c, c->sub_flags.reserve((size_t)R_full));
         HIPCK(c, c->sub_cnt.reserve(sizeof(unsigned)));
@@ -373,7 +386,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         HIPCK(c, hipMemcpyAsync(gc.last_refs_host.data(), gc.refs.p, R * sizeof(unsigned), hipMemcpyDeviceToHost, s));   /* lfbm5d_last_bm */
         HIPCK(c, hipStreamSynchronize(s));
         row_start.assign({0u, R});
-        if (N > 1 && std::getenv("LFBM5D_SUBSET_SCAN_V1")) {   /* (the test hook's table kernel stores through the position map) */
+        if (N > 1 && (c->opt->kernels & kOptSubsetScanV1)) {   /* (the test hook's table kernel stores through the position map) */
             HIPCK(c, c->refmap.reserve(plane * sizeof(int)));
             HIPCK(c, launch_fill_i32(s, c->refmap.as<int>(), -1, plane));
             HIPCK(c, launch_refmap(s, gc.refs.as<unsigned>(), R, c->refmap.as<int>()));
@@ -434,7 +447,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
      * on the full grid exactly as in a centre pass -- the second-generation kernel, whose score stores follow the grid's pattern --
      * and the selection takes a reference's scores from its place in that grid.  (Before: round 2's kernel with a position map,
      * 2.4 instead of 0.8 ms per pass, five passes per window on a greyscale light field.) */
-    const bool full_scan = !centre && N > 1 && std::memcmp(key, gc.rslot_key, sizeof(key)) == 0 && std::getenv("LFBM5D_SUBSET_SCAN_V1") == nullptr;
+    const bool full_scan = !centre && N > 1 && std::memcmp(key, gc.rslot_key, sizeof(key)) == 0 && !(c->opt->kernels & kOptSubsetScanV1);
     const unsigned R_sc = full_scan ? R_full : R;   /* rows of the score table */
     if (N > 1 && (size_t)R_sc * NsS * NsS * sizeof(float) > 0x7fffffffull) return fail(c, "unsupported: candidate score table of 2 GiB or more (reference patches x (2 nSim + 1)^2 x 4 B)");
     if (N > 1) HIPCK(c, c->scores.reserve((size_t)R_sc * NsS * NsS * sizeof(float)));
@@ -453,7 +466,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     {
         constexpr size_t kFiltCapBytes = (size_t)12 << 30;
         size_t cap = std::min<size_t>(kFiltCapBytes, (size_t)0xfff00000ull * sizeof(float));   /* 32-bit float offsets inside a band */
-        if (const char* e = std::getenv("LFBM5D_BAND_MB")) { const long mb = std::atol(e); if (mb > 0) cap = std::min<size_t>(cap, (size_t)mb << 20); }
+        if (c->opt->band_mb > 0) cap = std::min<size_t>(cap, (size_t)c->opt->band_mb << 20);
         const size_t row_groups = centre ? gc.n_ref_cols : 1;   /* bands are whole rows of the reference grid (a list: any cut) */
         if ((size_t)R * per_group * sizeof(float) > cap) {
             const size_t rows_fit = std::max<size_t>(1, cap / (per_group * sizeof(float) * row_groups));
@@ -466,6 +479,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     HIPCK(c, c->gpos.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gofs.reserve((size_t)A * R * Nst * sizeof(unsigned)));
     HIPCK(c, c->gok.reserve((size_t)R * Nst * sizeof(unsigned)));
+    HIPCK(c, c->sa_list.reserve((size_t)(4 * (size_t)R + 1) * sizeof(unsigned)));   /* a group's three channels can be listed one by one, and once as a whole */
     HIPCK(c, c->gshape.reserve((size_t)R * (A > (unsigned)kMaxA ? kShapeInfoBigBytes : kShapeInfoBytes)));
     HIPCK(c, gc.tb.reserve(sizeof(GroupTables)));
     if (!c->counters.p) {   /* [step slot][16]: sum nSx, shape-adaptive groups, development clocks */
@@ -510,10 +524,10 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     if (N > 1) HIPCK(c, launch_fill_f32(s, c->scores.as<float>(), 2 * thr, (size_t)R_sc * NsS * NsS));
     /* which generation of the table kernel, and its workgroup list: functions of the search geometry (and of the two
      * environment switches bm_scan_version reads), cached with it */
-    const char* env_v1 = std::getenv("LFBM5D_SCAN_V1"); const char* const env_ft = std::getenv("LFBM5D_SCAN_FULL_TABLES");
-    if (const char* env_any = std::getenv("LFBM5D_SCAN_ANY")) if (env_any[0] && env_any[0] != '0') env_v1 = env_any;
+    sa.opt = c->opt->kernels; sa.lds_cap = (unsigned)std::max(0, c->opt->scan_lds_cap);
+    const bool opt_v1 = (sa.opt & (kOptScanV1 | kOptScanAny)) != 0, opt_ft = (sa.opt & kOptScanFullTables) != 0;
     const unsigned skey[8] = {sa.n_self, sa.n_stereo, sa.nSim, sa.nDisp, sa.k, Hb, Wb,
-                              1u | ((centre || full_scan) ? 0u : 2u) | ((env_v1 && env_v1[0] && env_v1[0] != '0') ? 4u : 0u) | ((env_ft && env_ft[0] && env_ft[0] != '0') ? 8u : 0u)};
+                              1u | ((centre || full_scan) ? 0u : 2u) | (opt_v1 ? 4u : 0u) | (opt_ft ? 8u : 0u) | ((sa.opt & kOptScanAny) ? 16u : 0u)};
     const bool scan_changed = std::memcmp(skey, gc.scan_key, sizeof(skey)) != 0;
     if (scan_changed) gc.scan_version = bm_scan_version(sa);
     const int scan_version = gc.scan_version;
@@ -575,14 +589,24 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     ga.noisy = d_noisy; ga.basic = d_basic; ga.num = d_num; ga.den = d_den;
     ga.refs = gc.refs.as<unsigned>(); ga.self_idx = c->self_idx.as<unsigned>(); ga.self_cnt = c->self_cnt.as<unsigned>();
     ga.best = c->best.as<unsigned>(); ga.shape = c->shape.as<unsigned char>(); ga.tb = gc.tb.as<GroupTables>();
-    ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gofs = c->gofs.as<unsigned>(); ga.gok = c->gok.as<unsigned>(); ga.gshape = c->gshape.p; ga.n_refs_total = R; ga.counters = d_counters;
+    ga.wgt = c->wgt.as<float>(); ga.aggpos = c->aggpos.as<unsigned>(); ga.gpos = c->gpos.as<unsigned>(); ga.gofs = c->gofs.as<unsigned>(); ga.gok = c->gok.as<unsigned>(); ga.sa_list = c->sa_list.as<unsigned>(); ga.gshape = c->gshape.p; ga.n_refs_total = R; ga.counters = d_counters;
     ga.ref_begin = ref_begin; ga.n_groups = n_groups;
     ga.Wb = Wb; ga.Hb = Hb; ga.C = C; ga.A = A; ga.k = k; ga.N = Nst; ga.pst = pst;
     ga.mask_bits = mask_bits; ga.proc_bits = proc_bits;
     ga.tau2 = P->tau_2D; ga.tau4 = P->tau_4D; ga.tau5 = P->tau_5D; ga.useSD = P->useSD;
     ga.step = step; ga.lambda = lambda; ga.fill_quirk = centre ? 1u : 0u;
     for (int i = 0; i < 3; i++) ga.sigma[i] = sig[i];
+    if (A == 9 && step == 1) {   /* thresholds of the unnormalised transform chain (3x3 windows, Haar fibres): GroupArgs::ht3_T */
+        GroupTables ht;   /* (the same constants as the device table's) */
+        build_tables(ht, k, 3, 3);
+        for (int ch = 0; ch < 3; ch++) {
+            const float T = lambda * sig[ch] * 1.41421356237309505f;   /* the kernels' own float expression (core:2431) */
+            for (int st = 0; st < 9; st++)
+                for (int l = 0; l < 4; l++) ga.ht3_T[ch][st][l] = (float)((double)T / ((double)ht.ht3_f[st] * std::pow(2.0, -0.5 * l)));
+        }
+    }
     ga.bm3d = bm3d ? 1u : 0u;
+    ga.opt = c->opt->kernels;
     if (const size_t sb = group_scratch_bytes(ga)) {   /* generic path with stacks beyond the 160 KiB LDS: HBM scratch slices */
         HIPCK(c, c->gscratch.reserve(sb));
         ga.scratch = c->gscratch.as<float>(); ga.scratch_floats = sb / sizeof(float);
@@ -596,6 +620,7 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     aa.nHW = nHW; aa.nSim = P->nSim; aa.nDisp = P->nDisp;
     aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D; aa.irregular = centre ? 0u : 1u;
     aa.wchan0 = (bm3d && P->useSD) ? 1u : 0u;
+    aa.opt = c->opt->kernels;
     if (n_groups <= band_groups) {   /* the whole pass (or this rank's rows) at once */
         ga.filt = c->filt.as<float>() - (size_t)ref_begin * per_group;   /* (the group kernels index filt by absolute group number) */
         aa.filt = c->filt.as<float>(); aa.filt_bytes = (unsigned long long)n_groups * per_group * sizeof(float);
@@ -822,6 +847,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         std::string e;
         lfbm5d_ctx* x = new_ctx(c->device, e);
         if (!x) return fail(c, "lane context: " + e);
+        x->opt = c->opt;
         c->lanes.push_back(x);
     }
     /* An error return in the middle of the graph (a failed HIP call, an RCCL call that reports an error) would leave this
@@ -1222,7 +1248,7 @@ int run_graph(lfbm5d_ctx* c, const GraphJob& J, const plan::Graph& G, const unsi
         const float pct = (float)covered * 100.0f / (float)n_mask / (float)(H - J.P[sl]->k + 1) / (float)(W - J.P[sl]->k + 1);
         if (!(pct >= 100.0f)) complete = 0;
     }
-    if (std::getenv("LFBM5D_FORCE_REDO") && nranks == 1) complete = 0;   /* test hook: exercise the sequential redo */
+    if (c->opt->force_redo && nranks == 1) complete = 0;   /* test hook: exercise the sequential redo */
     /* fold the other lanes' / emulated ranks' counters and event times into this context */
     auto fold_all = [&](lfbm5d_ctx* x) -> int {
         drain_events(x);
@@ -1602,25 +1628,21 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
      * LFBM5D_STEP_SHARDING selects the alternatives: "rows" (every core pass sharded by reference-patch rows, exact,
      * barely scales) and "blocks" (round 1: one contiguous block of windows per rank + one all-reduce per step; a rank's
      * block matching then only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks). */
-    const char* emu_s = std::getenv("LFBM5D_EMULATE_WORLD");
-    const int emu = emu_s ? std::atoi(emu_s) : 0;                    /* test hook: play all ranks on this GPU */
-    const char* shard_s = std::getenv("LFBM5D_STEP_SHARDING");
+    const int emu = c->opt->emulate_world;                           /* test hook: play all ranks on this GPU */
     /* "rows": keep the reference's window-after-window order on several GPUs too and shard every core pass by
      * reference-patch rows (bit-for-bit the single-GPU schedule, two all-reduces per pass, little speed-up) */
-    const bool by_rows = c->world > 1 && shard_s && std::strcmp(shard_s, "rows") == 0;
+    const bool by_rows = c->world > 1 && c->opt->step_sharding == 1;
     /* "blocks": the round-1 scheme -- the planned sequence cut into one contiguous block of windows per rank, ONE
      * all-reduce of num / den per step.  It scales with the rank count but is NOT the reference's result: a rank's block
      * matching only sees its own earlier windows' estimates (-0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks).  Opt-in. */
-    const bool by_blocks = (c->world > 1 || emu > 1) && shard_s && std::strcmp(shard_s, "blocks") == 0;
+    const bool by_blocks = (c->world > 1 || emu > 1) && c->opt->step_sharding == 2;
     /* LFBM5D_MAX_WINDOWS: stop after that many windows of the planned sequence (for
      * bisecting a multi-window difference, bounded timing samples); the estimate is still formed */
-    const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
-    const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
-    const char* lanes_s = std::getenv("LFBM5D_LANES");
-    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : kDefaultLanes));
+    const int max_windows = c->opt->max_windows;
+    const int n_lanes = std::max(1, std::min(8, c->opt->lanes));
     /* LFBM5D_DATA_DRIVEN_SCHEDULE: select every window from the zero-weight counts like the reference does (one
      * device round trip per window); the default takes the same sequence from plan_windows() */
-    const bool planned = (c->world > 1 && !by_rows) || emu > 1 || std::getenv("LFBM5D_DATA_DRIVEN_SCHEDULE") == nullptr;   /* several ranks always plan */
+    const bool planned = (c->world > 1 && !by_rows) || emu > 1 || !c->opt->data_driven_schedule;   /* several ranks always plan */
     struct PassShard {   /* restores the unsharded default whatever way the function returns */
         lfbm5d_ctx* c;
         PassShard(lfbm5d_ctx* cc, bool on) : c(cc) { if (on) { c->pass_rank = c->rank; c->pass_world = c->world; c->pass_reduce = c->comm != nullptr; } }
@@ -1648,7 +1670,7 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
     if (graph_mode && c->world > 1 && emu <= 1 && !c->comm && !c->ipc) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
     /* host seam: the single-rank graph takes the caller's SAIs in and out as its windows need and finish them; every other form
      * gets the whole light field(s) first */
-    const bool streamable = io && graph_mode && nranks == 1 && std::getenv("LFBM5D_HOST_BLOCKING") == nullptr;
+    const bool streamable = io && graph_mode && nranks == 1 && !c->opt->host_blocking;
     bool streamed_out = false;
     if (streamable) {
         HIPCK(c, c->pristine.reserve(asize * img * sizeof(float)));
@@ -1789,16 +1811,12 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
                 float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
                 unsigned C, const HostIO* io = nullptr) {
     const unsigned asize = awidth * aheight;
-    const char* emu_s = std::getenv("LFBM5D_EMULATE_WORLD");
-    const int emu = emu_s ? std::atoi(emu_s) : 0;
-    const char* lanes_s = std::getenv("LFBM5D_LANES");
-    const int n_lanes = std::max(1, std::min(8, lanes_s ? std::atoi(lanes_s) : kDefaultLanes));
-    const char* maxw_s = std::getenv("LFBM5D_MAX_WINDOWS");
-    const int max_windows = maxw_s ? std::atoi(maxw_s) : 0;
-    const char* fused_s = std::getenv("LFBM5D_FUSED");
+    const int emu = c->opt->emulate_world;
+    const int n_lanes = std::max(1, std::min(8, c->opt->lanes));
+    const int max_windows = c->opt->max_windows;
     const int nranks = emu > 1 ? emu : c->world;
-    bool fused = C == 3 && c->tiles <= 1 && !std::getenv("LFBM5D_STEP_SHARDING") && !std::getenv("LFBM5D_DATA_DRIVEN_SCHEDULE") &&
-                 !(fused_s && fused_s[0] == '0') && P1->color_space == P2->color_space &&
+    bool fused = C == 3 && c->tiles <= 1 && !c->opt->step_sharding && !c->opt->data_driven_schedule &&
+                 c->opt->fused != 0 && P1->color_space == P2->color_space &&
                  2 * an1 + 1 <= std::min(awidth, aheight) && 2 * an2 + 1 <= std::min(awidth, aheight);
     plan::Graph G;
     if (fused) {
@@ -1831,7 +1849,7 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
     J.n_steps = 2; J.step[0] = 1; J.step[1] = 2; J.P[0] = P1; J.P[1] = P2; J.an[0] = an1; J.an[1] = an2;
     J.d_basic = d_basic; J.d_out = d_out; J.d_mask = d_mask;
     /* host seam: the single-rank graph takes the caller's SAIs in and out as its windows need and finish them */
-    const bool streamable = io && nranks == 1 && std::getenv("LFBM5D_HOST_BLOCKING") == nullptr;
+    const bool streamable = io && nranks == 1 && !c->opt->host_blocking;
     if (io && !streamable && io_upload_all(c, io, h_mask, asize, img, d_noisy, nullptr)) return 1;
     /* the light field as it arrived: what the fallback below starts from (on one rank) */
     if (nranks == 1) {
@@ -1909,8 +1927,22 @@ int lfbm5d_create(lfbm5d_ctx** out, int device) {
     if (device < 0 || device >= n) { g_create_error = "device index out of range"; return 1; }
     if ((e = hipSetDevice(device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return 1; }
     lfbm5d_ctx* c = new_ctx(device, g_create_error);
+    if (c) options_from_env(c->opt_store);   /* the library's only read of the environment (lfbm5d_options.h) */
     if (!c) return 1;
     *out = c;
+    return 0;
+}
+
+int lfbm5d_set_option(lfbm5d_ctx* c, const char* key, const char* value) {
+    if (!c || !key) return 1;
+    if (!option_set(c->opt_store, key, value)) return fail(c, std::string("unknown option: ") + key);
+    return 0;
+}
+int lfbm5d_get_option(lfbm5d_ctx* c, const char* key, char* value, unsigned long long size) {
+    if (!c || !key || !value || size == 0) return 1;
+    std::string v;
+    if (!option_get(c->opt_store, key, v)) return fail(c, std::string("unknown option: ") + key);
+    std::snprintf(value, (size_t)size, "%s", v.c_str());
     return 0;
 }
 
@@ -1930,7 +1962,7 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
     for (GeomCache& g : c->gc) { g.refs.release(); g.rslot.release(); g.tb.release(); g.scan_wgs.release(); }
     DevBuf* bufs[] = {&c->est, &c->g_num2, &c->g_den2, &c->n2, &c->e_basic, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->sub_flags, &c->sub_cnt, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->gshape, &c->counters, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->sub_flags, &c->sub_cnt, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->sa_list, &c->gshape, &c->counters, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch, &c->scan_lcol};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -2340,14 +2372,14 @@ int run_bm3d_lf(lfbm5d_ctx* c, const lfbm5d_bm3d_params* Hd, const lfbm5d_bm3d_p
      * work buffers of their own -- so that the kernels of several SAIs are in flight together.  One SAI's launches are small (a
      * 512 x 512 image: 99 workgroups of the table kernel, whose duration is one table walk however few they are).
      * LFBM5D_BM3D_LANES (default 3: 64 -> 105 SAI-MP/s on 512 x 512 SAIs; 1: the sequential form); results do not depend on it. */
-    const char* lanes_s = std::getenv("LFBM5D_BM3D_LANES");
     unsigned n_sai = 0;
     for (unsigned st = 0; st < asize; st++) n_sai += h_mask[st] ? 1u : 0u;
-    const unsigned n_l = std::max(1u, std::min({8u, (unsigned)(lanes_s ? std::max(1, std::atoi(lanes_s)) : 3), std::max(1u, n_sai)}));
+    const unsigned n_l = std::max(1u, std::min({8u, (unsigned)std::max(1, c->opt->bm3d_lanes), std::max(1u, n_sai)}));
     while (c->lanes.size() + 1 < n_l) {
         std::string e;
         lfbm5d_ctx* x = new_ctx(c->device, e);
         if (!x) return fail(c, "lane context: " + e);
+        x->opt = c->opt;
         c->lanes.push_back(x);
     }
     HIPCK(c, hipStreamSynchronize(c->stream));   /* the caller's stream has produced d_noisy */

@@ -1009,13 +1009,12 @@ hipError_t launch_bm_scan(hipStream_t s, const ScanArgs& a) {
     const unsigned n = a.n_self + a.n_stereo;
     if (!n) return hipSuccess;
 #ifdef LFBM5D_SCAN_LDS_EXPERIMENT   /* development builds: timing at a smaller LDS footprint (results are garbage) */
-    if (const char* cap = getenv("LFBM5D_SCAN_LDS_CAP")) lds = std::min<size_t>(lds, (size_t)atoi(cap));
+    if (a.lds_cap) lds = std::min<size_t>(lds, (size_t)a.lds_cap);   /* option scan_lds_cap */
 #endif
 #define LFBM5D_SCAN(K_) do { if (wide) hipLaunchKernelGGL((k_bm_scan<K_, true>), dim3(n), dim3(64), lds, s, a); \
                              else      hipLaunchKernelGGL((k_bm_scan<K_, false>), dim3(n), dim3(64), lds, s, a); } while (0)
-    /* LFBM5D_SCAN_ANY: test hook, the plain any-patch-size kernel for 8 / 12 / 16 too (compared bit for bit with the dedicated ones) */
-    const char* any_s = getenv("LFBM5D_SCAN_ANY");
-    switch ((any_s && any_s[0] && any_s[0] != '0') ? 0u : a.k) {
+    /* option scan_any: test hook, the plain any-patch-size kernel for 8 / 12 / 16 too (compared bit for bit with the dedicated ones) */
+    switch ((a.opt & kOptScanAny) ? 0u : a.k) {
         case 8:  LFBM5D_SCAN(8); break;
         case 12: LFBM5D_SCAN(12); break;
         case 16: LFBM5D_SCAN(16); break;

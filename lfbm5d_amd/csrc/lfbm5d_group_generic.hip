@@ -21,6 +21,7 @@ __global__ __launch_bounds__(256) void k_group_pos(GroupArgs a) {
     const int A = a.A, N = a.N, NA = N * A;
     const size_t plane = (size_t)a.Wb * a.Hb;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0 && a.sa_list) a.sa_list[0] = 0u;   /* (k_group_shape, the next launch on the stream, appends) */
     if (idx >= (size_t)a.n_groups * N) return;
     const unsigned g = a.ref_begin + (unsigned)(idx / N);
     const int n = (int)(idx % N);
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void k_group_shape(GroupArgs a) {
     }
     for (int q = 0; q < aw; q++) { out->row_n[q] = sh.row_n[q]; out->col_n[q] = sh.col_n[q]; }
     out->use_sadct = sh.use_sadct;
+    if (sh.use_sadct && a.sa_list) a.sa_list[1u + atomicAdd(&a.sa_list[0], 1u)] = g | (7u << 29);   /* every channel */
 }
 /* One (group, channel) of the generic path.  S0 / S1: the group's stack(s) [n][st][pq] -- in LDS (k_group) or, when the
  * stacks do not fit the 160 KiB, in a per-workgroup slice of an HBM scratch buffer (k_group_big); tmp: the 2-D stage's
@@ -350,7 +352,7 @@ size_t group_lds_bytes(const GroupArgs& a) {
     return ((a.step == 2 ? 2 : 1) * stack + group_tmp_floats(a)) * sizeof(float);
 }
 static bool group_uses_generic(const GroupArgs& a) {   /* mirrors the dispatch of launch_group_ht / launch_group_wiener */
-    if (getenv("LFBM5D_GROUP_GENERIC") != nullptr) return true;
+    if (a.opt & kOptGroupGeneric) return true;
     bool wide_window = false;
     for (unsigned w = 5; w <= 17; w += 2) wide_window |= a.A == w * w;
     if (wide_window && a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull) return false;   /* lfbm5d_group_wide.hip */
@@ -363,7 +365,7 @@ static bool group_uses_generic(const GroupArgs& a) {   /* mirrors the dispatch o
     return true;
 }
 size_t group_scratch_bytes(const GroupArgs& a) {
-    if (group_uses_generic(a) && getenv("LFBM5D_GROUP_GENERIC") == nullptr && group_uses_slab(a)) return group_slab_scratch_bytes(a);
+    if (group_uses_generic(a) && !(a.opt & kOptGroupGeneric) && group_uses_slab(a)) return group_slab_scratch_bytes(a);
     if (!group_uses_generic(a) || (group_lds_bytes(a) <= (size_t)kGenericLdsLimit && a.A <= (unsigned)kMaxA)) return 0;
     return (size_t)kBigBlocks * (a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);
 }
@@ -374,9 +376,9 @@ hipError_t launch_group(hipStream_t s, const GroupArgs& a) {
     if (bigA) hipLaunchKernelGGL(k_group_shape<true>, grid1d(a.n_groups), dim3(256), 0, s, a);
     else      hipLaunchKernelGGL(k_group_shape<false>, grid1d(a.n_groups), dim3(256), 0, s, a);
     /* a window with an empty SAI: tau_4D is the shape-adaptive transform (bm5d.cpp:276-280) and every group uses it */
-    const bool all_sa = a.tau4 == 6 && !a.mask_bits.holds_all(a.A) && getenv("LFBM5D_NO_SA_KERNELS") == nullptr;
-    /* LFBM5D_GROUP_GENERIC: test hook, every configuration through the generic LDS kernel (the dedicated kernels' cross-check) */
-    if (getenv("LFBM5D_GROUP_GENERIC") == nullptr) {
+    const bool all_sa = a.tau4 == 6 && !a.mask_bits.holds_all(a.A) && !(a.opt & kOptNoSaKernels);
+    /* option group_generic: test hook, every configuration through the generic LDS kernel (the dedicated kernels' cross-check) */
+    if (!(a.opt & kOptGroupGeneric)) {
         bool launched = false;
         hipError_t e = launch_group_ht(s, a, all_sa, &launched);
         if (launched) return e;

@@ -26,14 +26,141 @@ namespace {
  * V[h][st] = {patch h, patch h + NS/2} (the register stage shared by the tau_2D = id kernel and the 16x16 kernels) */
 /* SA_MODE: how the (rare) shape-adaptive transform is reached -- 0: calls (scratch vector; keeps its code out of the caller's
  * register allocation), 1: inline on sa_lds, nine floats of LDS of this thread's, 2: inline in registers (the *_sa kernels, which
- * the host launches for windows with an empty SAI, where EVERY group is shape-adaptive) */
+ * the host launches for windows with an empty SAI, where EVERY group is shape-adaptive, and over the list of the few such groups
+ * of an ordinary window), 3: none -- the kernel skips shape-adaptive groups (round 6: k_group_id_haar / _any) */
+/* Round 6: the same stage for groups that take the full 3x3 DCT and Haar fibres (the README configuration; every group of a
+ * window without empty SAIs except the one in a thousand whose shape is not the whole window) with EVERY normalisation constant
+ * moved out of the transforms, and the reference-order form as its referee.  Measured (profiles/r06_c_*): k_group_id_haar
+ * alone, without its loads and stores, took 0.55 of its 0.86 ms -- the kernel is bound by VALU cycles, and packed fp32
+ * instructions take 4 cycles, not 2 (profiles/r06_a_valu_rate.txt).  The reference-order form spends 153 packed instructions
+ * per pair of 3x3 blocks and 24 + 8 per pair of Haar fibres; here
+ *   forward 3x3    unnormalised rows, then columns: (x0 + x2) + x1, x0 - x2, (x0 + x2) - 2 x1                  24 packed
+ *   Haar           sums and differences only; a coefficient of level l carries 2^(l/2)                           6 packed + 2
+ *   threshold      |c| > T / (F[st] 2^(-l/2)) =: Tq, F = alpha_v alpha_u coef_norm_4d, alpha = (2, sqrt 3, 1): the reference's
+ *                  comparison (core:2431-2437), scaled; Tq comes from the host (GroupArgs::ht3_T); survivors counted
+ *                  from the comparison masks (s_bcnt1) instead of a select and an add per value
+ *   inverse Haar   fma by 2 and by 4 (exact); the 1 / nSx goes into the next constant                            6 packed + 2
+ *   inverse 3x3    one multiplication per value by ht3_g[st] F[st] / nSx, then additions and fma by -2            33 packed
+ * -- about 0.4 of the VALU cycles.  Mathematically the same numbers; in floating point a coefficient within round-off of
+ * the threshold could decide differently than the reference-order form (tools/flip_count.py, profiles/r06_c_ht_fast_flips.txt:
+ * 1, 1, 1 decisions of 864 M per 560 x 560 pass against the CPU oracle, where the reference-order form has 0, 0, 1).  So the
+ * chain also watches its distance to the threshold: a wave in which ANY coefficient comes within a guard band of its threshold
+ * (2^-16 ... 2^-18 of it, ht_guard) reports it, and its (group, channel) is redone in the reference-order form by the list launch behind the kernel
+ * (one to two in a hundred on natural data, whose coefficients are far denser around the threshold than noise alone).  The two forms differ by float round-off of sums of at most 72 pixel values -- below 1e-5 of
+ * a threshold for 8-bit-range data, a tenth of the guard band -- so every decision is the reference-order form's decision:
+ * the survivor counts, hence the weights and `den`, are bit-identical to rounds 1-5; the filtered values agree to an ulp or two.
+ * Returns true when the caller has to fall back.  LFBM5D_HT_REFERENCE_ORDER (build flag): no fast chain at all. */
+/* guard band, relative to the threshold, by angular frequency: emulated over 3 M near-threshold coefficients of 8-bit-range data
+ * (brightness 0..255, contrast up to +-100, sigma 25) the two forms differ by at most 7.9e-6 of a threshold at st = 0 (sums of
+ * 72 bright pixels), 2.3e-6 at st = 3, 6 and 1.2e-6 elsewhere */
+__device__ __forceinline__ constexpr float ht_guard(int st) { return st == 0 ? 1.0f / 65536.0f : (st == 3 || st == 6) ? 1.0f / 131072.0f : 1.0f / 262144.0f; }
+template <int NS> __device__ __forceinline__ void haar_fwd_pairs_u(v2f* P) {
+    if (NS == 8) {
+        const v2f S01 = P[0] + P[1], D01 = P[0] - P[1], S23 = P[2] + P[3], D23 = P[2] - P[3];
+        const v2f SS = S01 + S23, DD = S01 - S23;
+        P[0] = v2f{SS.x + SS.y, SS.x - SS.y}; P[1] = DD; P[2] = D01; P[3] = D23;
+    } else if (NS == 4) {
+        const v2f S = P[0] + P[1], D = P[0] - P[1];
+        P[0] = v2f{S.x + S.y, S.x - S.y}; P[1] = D;
+    } else if (NS == 2) {
+        P[0] = v2f{P[0].x + P[0].y, P[0].x - P[0].y};
+    }
+}
+template <int NS> __device__ __forceinline__ void haar_inv_pairs_u(v2f* P) {   /* nSx times the orthonormal inverse of the orthonormal coefficients */
+    if (NS == 8) {
+        const v2f X = v2f{P[0].x + P[0].y, P[0].x - P[0].y};
+        const v2f U = P[1] * 2.0f + X, V = X - P[1] * 2.0f, D01 = P[2], D23 = P[3];
+        P[0] = D01 * 4.0f + U; P[1] = U - D01 * 4.0f; P[2] = D23 * 4.0f + V; P[3] = V - D23 * 4.0f;
+    } else if (NS == 4) {
+        const v2f X = v2f{P[0].x + P[0].y, P[0].x - P[0].y}, D = P[1];
+        P[0] = D * 2.0f + X; P[1] = X - D * 2.0f;
+    } else if (NS == 2) {
+        P[0] = v2f{P[0].x + P[0].y, P[0].x - P[0].y};
+    }
+}
+template <int NS>
+__device__ __forceinline__ bool group_id_compute_fast(const GroupArgs& a, int c, v2f (&V)[NS > 1 ? NS / 2 : 1][9], float& wacc, float& s1, float& s2) {
+    constexpr int NH = NS > 1 ? NS / 2 : 1;
+    constexpr int LV = NS == 8 ? 3 : NS == 4 ? 2 : NS == 2 ? 1 : 0;       /* Haar levels; the pair P[h] holds coefficients of level lvl(h) */
+    const TbPtr tb = (TbPtr)a.tb;
+    /* forward 3x3, unnormalised: along u (x[s*3 + u]), then along s */
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        v2f t[9];
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            const v2f p = V[h][s * 3] + V[h][s * 3 + 2];
+            t[s * 3] = p + V[h][s * 3 + 1]; t[s * 3 + 1] = V[h][s * 3] - V[h][s * 3 + 2]; t[s * 3 + 2] = p - 2.0f * V[h][s * 3 + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const v2f p = t[u] + t[6 + u];
+            V[h][u] = p + t[3 + u]; V[h][3 + u] = t[u] - t[6 + u]; V[h][6 + u] = p - 2.0f * t[3 + u];
+        }
+    }
+    const float inv_n = 1.0f / (float)NS;
+    unsigned kept = 0;                 /* survivors of this WAVE (uniform) */
+    unsigned long long near = 0ull;    /* lanes with a coefficient inside the guard band (uniform) */
+#pragma unroll
+    for (int st = 0; st < 9; st++) {
+        v2f P[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) P[h] = V[h][st];
+        haar_fwd_pairs_u<NS>(P);
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int lvl = h == 0 ? LV : (NS == 8 && h == 1) ? 2 : 1;
+            const float Tq = a.ht3_T[c][st][lvl], Gq = Tq * ht_guard(st);
+            const float ax = fabsf(P[h].x), ay = fabsf(P[h].y);
+            const bool kx = ax > Tq, ky = (NS > 1) && ay > Tq;
+            near |= __ballot(fabsf(ax - Tq) < Gq);
+            if (NS > 1) near |= __ballot(fabsf(ay - Tq) < Gq);
+            kept += (unsigned)__popcll(__ballot(kx)) + (NS > 1 ? (unsigned)__popcll(__ballot(ky)) : 0u);
+            P[h].x = kx ? P[h].x : 0.0f;
+            P[h].y = ky ? P[h].y : 0.0f;
+        }
+        haar_inv_pairs_u<NS>(P);
+#pragma unroll
+        for (int h = 0; h < NH; h++) V[h][st] = P[h];
+    }
+    if (near) return true;
+    wacc += (__lane_id() == 0) ? (float)kept : 0.0f;   /* (the caller sums wacc over the lanes) */
+    if (a.useSD) {   /* sd_weighting_5d on the filtered 4-D coefficients (core:3140-3173): back to their normalised scale */
+#pragma unroll
+        for (int h = 0; h < NH; h++)
+#pragma unroll
+            for (int st = 0; st < 9; st++) {
+                const v2f y = V[h][st] * (tb->ht3_f[st] * inv_n);
+                s1 += y.x; s2 += y.x * y.x;
+                if (NS > 1) { s1 += y.y; s2 += y.y * y.y; }
+            }
+    }
+    /* inverse 3x3: Z = g f / nSx * value, then along u, then along s */
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+        v2f t[9];
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            const v2f Z0 = V[h][s * 3] * (tb->ht3_gf[s * 3] * inv_n), Z1 = V[h][s * 3 + 1] * (tb->ht3_gf[s * 3 + 1] * inv_n), Z2 = V[h][s * 3 + 2] * (tb->ht3_gf[s * 3 + 2] * inv_n);
+            const v2f p = Z0 + Z2;
+            t[s * 3] = p + Z1; t[s * 3 + 1] = Z0 - 2.0f * Z2; t[s * 3 + 2] = p - Z1;
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const v2f p = t[j] + t[6 + j];
+            V[h][j] = p + t[3 + j]; V[h][3 + j] = t[j] - 2.0f * t[6 + j]; V[h][6 + j] = p - t[3 + j];
+        }
+    }
+    return false;
+}
+
 template <int NS, bool HAAR, int SA_MODE = 0>
 __device__ __forceinline__ void group_id_compute(const GroupArgs& a, int c, ShRef sh, bool use_sadct, v2f (&V)[NS > 1 ? NS / 2 : 1][9],
                                                  float& wacc, float& s1, float& s2, float* sa_lds = nullptr) {
     constexpr int NH = NS > 1 ? NS / 2 : 1;
     const TbPtr tb = (TbPtr)a.tb;
     const bool do_dct4 = a.tau4 == 5 || (a.tau4 == 6 && !use_sadct);
-    const bool do_sa4 = !do_dct4 && a.tau4 == 6;
+    const bool do_sa4 = SA_MODE != 3 && !do_dct4 && a.tau4 == 6;   /* SA_MODE 3: the caller never hands over a shape-adaptive group */
     auto sadct_pairs = [&](bool fwd) {   /* rare: shape-adaptive transform on the scalar path, staged through t9 */
 #pragma unroll
         for (int h = 0; h < NH; h++)
@@ -106,8 +233,10 @@ __device__ __forceinline__ void group_id_compute(const GroupArgs& a, int c, ShRe
     } else if (do_sa4) sadct_pairs(false);
 }
 
-template <int NS, bool HAAR, bool LDSW = false, int SA_MODE = 0>   /* LDSW: values come from / go back to an LDS work area [patch][k][k+1] (2-D transformed patches) */
-__device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
+/* FAST: the unnormalised chain (group_id_compute_fast) instead of the reference-order form; returns true when the wave came within
+ * the guard band of a threshold, i.e. when its results must not be used (the caller lists the group for the reference-order launch) */
+template <int NS, bool HAAR, bool LDSW = false, int SA_MODE = 0, bool FAST = false>   /* LDSW: values come from / go back to an LDS work area [patch][k][k+1] (2-D transformed patches) */
+__device__ __forceinline__ bool group_id_body(const GroupArgs& a, unsigned g, int c, int pq, const __attribute__((address_space(4))) unsigned* pos,
                                               ShRef sh, bool use_sadct, float& wacc, float& s1, float& s2, float* work = nullptr) {
     const int k = a.k, k2 = k * k, A = 9;
     const unsigned plane = a.Wb * a.Hb;
@@ -124,39 +253,49 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
     typedef const __attribute__((address_space(4))) unsigned* cuptr_;
     const cuptr_ ofs = (cuptr_)(a.gofs + (size_t)g * a.N * A), ok = (cuptr_)(a.gok + (size_t)g * a.N);
     const unsigned cbase = (unsigned)c * plane * 4u;
-    if (LDSW) {
+    auto load_all = [&]() {
+        if (LDSW) {
+#pragma unroll
+            for (int n = 0; n < NS; n++)
+#pragma unroll
+                for (int st = 0; st < 9; st++) {
+                    const float x = work[(n * A + st) * kT16Patch + woff];
+                    if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
+                    okbits[n] = 0x1ffu;
+                }
+        } else
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            okbits[n] = ok[n];                            /* uniform: scalar loads (pre-pass: k_group_pos) */
+#pragma unroll
+            for (int st = 0; st < 9; st++) {
+                const unsigned so = ofs[n * A + st] + cbase;   /* absent patches read offset 0 and are zeroed below */
+#if defined(LFBM5D_HT_EXP) && (LFBM5D_HT_EXP & 1)   /* timing experiment: one gather per thread instead of NS * 9 */
+                const float x = (n | st) ? V[0][0].x * 1.0001f + (float)(n + st) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
+#else
+                const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
+#endif
+                if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
+            }
+        }
+        if (NS == 1) {
+#pragma unroll
+            for (int st = 0; st < 9; st++) V[0][st].y = 0.0f;
+        }
 #pragma unroll
         for (int n = 0; n < NS; n++)
+            if (okbits[n] != 0x1ffu) {   /* uniform, rare: patches of empty SAIs / never-filled table column read as zeros */
 #pragma unroll
-            for (int st = 0; st < 9; st++) {
-                const float x = work[(n * A + st) * kT16Patch + woff];
-                if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
-                okbits[n] = 0x1ffu;
+                for (int st = 0; st < 9; st++) {
+                    if (n < NH) V[n][st].x = ((okbits[n] >> st) & 1) ? V[n][st].x : 0.0f;
+                    else V[n - NH][st].y = ((okbits[n] >> st) & 1) ? V[n - NH][st].y : 0.0f;
+                }
             }
-    } else
-#pragma unroll
-    for (int n = 0; n < NS; n++) {
-        okbits[n] = ok[n];                            /* uniform: scalar loads (pre-pass: k_group_pos) */
-#pragma unroll
-        for (int st = 0; st < 9; st++) {
-            const unsigned so = ofs[n * A + st] + cbase;   /* absent patches read offset 0 and are zeroed below */
-            const float x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)so, 0));
-            if (n < NH) V[n][st].x = x; else V[n - NH][st].y = x;
-        }
-    }
-    if (NS == 1) {
-#pragma unroll
-        for (int st = 0; st < 9; st++) V[0][st].y = 0.0f;
-    }
-#pragma unroll
-    for (int n = 0; n < NS; n++)
-        if (okbits[n] != 0x1ffu) {   /* uniform, rare: patches of empty SAIs / never-filled table column read as zeros */
-#pragma unroll
-            for (int st = 0; st < 9; st++) {
-                if (n < NH) V[n][st].x = ((okbits[n] >> st) & 1) ? V[n][st].x : 0.0f;
-                else V[n - NH][st].y = ((okbits[n] >> st) & 1) ? V[n - NH][st].y : 0.0f;
-            }
-        }
+    };
+    load_all();
+    bool near = false;
+    if (FAST) near = group_id_compute_fast<NS>(a, c, V, wacc, s1, s2);   /* true: the wave's results are not to be used (the caller lists the group) */
+    else
     group_id_compute<NS, HAAR, SA_MODE>(a, c, sh, use_sadct, V, wacc, s1, s2);
     const int vout = pq * 4;
 #pragma unroll
@@ -165,18 +304,20 @@ __device__ __forceinline__ void group_id_body(const GroupArgs& a, unsigned g, in
         for (int st = 0; st < 9; st++) {
             const float r = n < NH ? V[n][st].x : V[n - NH][st].y;
             if (LDSW) work[(n * A + st) * kT16Patch + woff] = r;
+#if defined(LFBM5D_HT_EXP) && (LFBM5D_HT_EXP & 2)   /* timing experiment: the stores are issued at an out-of-range offset (dropped by the buffer's bounds check) */
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, (n | st) ? 0x7ffffff0 : vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), LFBM5D_FILT_STORE_AUX);
+#else
             else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, r), rs_out, vout, (int)((((unsigned)(n * A + st) * a.C + c) * k2) * 4u), LFBM5D_FILT_STORE_AUX);
+#endif
         }
+    return near;
 }
 
-template <bool HAAR, bool SA = false>
-__device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
-    __shared__ float red[3][4];
+/* SA_MODE 3 (the kernels of ordinary windows): groups whose shape is not the whole window are left to the list launch;
+ * SA_MODE 2: every group handed over goes through the inline shape-adaptive form where its shape asks for it */
+template <bool HAAR, int SA_MODE, bool FAST = false>
+__device__ __forceinline__ void group_id_one(const GroupArgs& a, const unsigned g, const int c, float (*red)[4]) {
     const int tid = threadIdx.x;
-    const unsigned gi = xcd_group_index(a);
-    if (gi >= a.n_groups) return;
-    const unsigned g = a.ref_begin + gi;
-    const int c = blockIdx.y;
     const int A = 9, N = a.N;
     const int nSx = (int)a.self_cnt[g];
     /* positions are uniform per workgroup and constant during this kernel: constant address space -> scalar loads */
@@ -184,19 +325,31 @@ __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
     const cuptr pos = (cuptr)(a.gpos + (size_t)g * N * A);
     ShRef sh = group_shape(a, g);
     const bool use_sadct = a.tau4 == 6 && sh.use_sadct;
+    if (SA_MODE == 3 && use_sadct) return;   /* (uniform) */
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    bool near = false;   /* FAST: wave-uniform */
     if (tid < (int)(a.k * a.k)) {
         switch (nSx) {
-            case 1:  group_id_body<1, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            case 2:  group_id_body<2, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            case 4:  group_id_body<4, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
-            default: group_id_body<8, HAAR, false, SA ? 2 : 0>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 1:  near = group_id_body<1, HAAR, false, SA_MODE, FAST>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 2:  near = group_id_body<2, HAAR, false, SA_MODE, FAST>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            case 4:  near = group_id_body<4, HAAR, false, SA_MODE, FAST>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
+            default: near = group_id_body<8, HAAR, false, SA_MODE, FAST>(a, g, c, tid, pos, sh, use_sadct, wacc, s1, s2); break;
         }
     }
     for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; if (FAST) red[3][tid >> 6] = near ? 1.0f : 0.0f; }
     __syncthreads();
     if (tid == 0) {
+        if (FAST) {   /* a wave came within the guard band of a threshold: the (group, channel) goes on the list; the reference-order launch overwrites what was stored here */
+            float nr = 0.0f;
+            for (unsigned i = 0; i < (blockDim.x + 63) / 64; i++) nr += red[3][i];
+            if (nr != 0.0f) {
+#ifdef LFBM5D_HT_COUNT_NEAR   /* development: the guard-band cases show up as "shape-adaptive groups" in the pass statistics */
+                atomicAdd(&a.counters[1], 1ull);
+#endif
+                a.sa_list[1u + atomicAdd(&a.sa_list[0], 1u)] = g | (1u << (29 + c)); return;
+            }
+        }
         float w = 0.0f, m = 0.0f, q = 0.0f;
         for (unsigned i = 0; i < (blockDim.x + 63) / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
         float wx;
@@ -216,13 +369,50 @@ __device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
     }
 }
 
-/* Haar configuration (README): capped at 168 VGPRs so that three waves fit a SIMD (a dozen spilled values buy 20 %);
- * the Hadamard / DCT fibre transforms need more registers and keep two */
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar(GroupArgs a) { group_id_kernel<true>(a); }
-__global__ __launch_bounds__(256) void k_group_id_any(GroupArgs a) { group_id_kernel<false>(a); }
-/* the same kernels for windows with an empty SAI (every group shape-adaptive): the transform inline, in registers */
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar_sa(GroupArgs a) { group_id_kernel<true, true>(a); }
-__global__ __launch_bounds__(256) void k_group_id_any_sa(GroupArgs a) { group_id_kernel<false, true>(a); }
+/* Ordinary windows (round 6).  The kernels carry no shape-adaptive code -- as a call it cost every group 74 VGPRs (values live
+ * across a call sit in the sparse callee-saved registers), inline a second copy of the register stage -- and k_group_id_haar_fast
+ * no reference-order code either (inline it doubled the registers; as a call the argument block went through scratch memory: 3 ms):
+ * what they cannot finish goes on a LIST (GroupArgs::sa_list: group number | channel mask << 29) that k_group_id_*_list
+ * (reference-order arithmetic, inline shape-adaptive form; a workgroup per entry) works off behind them -- the one group in a
+ * thousand whose angular shape is not the whole window (all channels; listed by k_group_shape), and the (group, channel) pairs
+ * in which a wave of the fast chain came within the guard band of a threshold (one to two in a hundred). */
+#ifndef LFBM5D_HT_WAVES
+#define LFBM5D_HT_WAVES 0
+#endif
+template <bool HAAR, int SA_MODE, bool FAST>
+__device__ __forceinline__ void group_id_kernel(const GroupArgs& a) {
+    __shared__ float red[4][4];
+    const unsigned gi = xcd_group_index(a);
+    if (gi >= a.n_groups) return;
+    group_id_one<HAAR, SA_MODE, FAST>(a, a.ref_begin + gi, (int)blockIdx.y, red);
+}
+template <bool HAAR>
+__device__ __forceinline__ void group_id_list_kernel(const GroupArgs& a) {
+    __shared__ float red[4][4];
+    const unsigned n = a.sa_list[0];
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        const unsigned e = a.sa_list[1u + i];
+        for (unsigned c = 0; c < a.C; c++)
+            if ((e >> (29 + c)) & 1u) {
+                group_id_one<HAAR, 2>(a, e & 0x1fffffffu, (int)c, red);
+                __syncthreads();   /* red is reused */
+            }
+    }
+}
+#if LFBM5D_HT_WAVES > 0
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LFBM5D_HT_WAVES, LFBM5D_HT_WAVES))) void k_group_id_haar_fast(GroupArgs a) { group_id_kernel<true, 3, true>(a); }
+#else
+__global__ __launch_bounds__(256) void k_group_id_haar_fast(GroupArgs a) { group_id_kernel<true, 3, true>(a); }
+#endif
+__global__ __launch_bounds__(256) void k_group_id_haar(GroupArgs a) { group_id_kernel<true, 3, false>(a); }   /* tau_4D = id (no angular DCT to speed up) and -DLFBM5D_HT_REFERENCE_ORDER builds */
+__global__ __launch_bounds__(256) void k_group_id_any(GroupArgs a) { group_id_kernel<false, 3, false>(a); }
+/* windows with an empty SAI (every group shape-adaptive): the transform inline, in registers; 168 VGPRs: three waves per SIMD */
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_group_id_haar_sa(GroupArgs a) { group_id_kernel<true, 2, false>(a); }
+__global__ __launch_bounds__(256) void k_group_id_any_sa(GroupArgs a) { group_id_kernel<false, 2, false>(a); }
+/* ... and the listed groups of an ordinary window */
+constexpr unsigned kSaListBlocks = 2048;   /* an entry per workgroup while the list is shorter: the launch lasts one group's latency */
+__global__ __launch_bounds__(256) void k_group_id_haar_list(GroupArgs a) { group_id_list_kernel<true>(a); }
+__global__ __launch_bounds__(256) void k_group_id_any_list(GroupArgs a) { group_id_list_kernel<false>(a); }
 
 /* ------------------------------------------------------------------------------------------
  * Hard-thresholding step with tau_2D = bior1.5 or dct and 16x16 patches (BASELINE configurations 2, 4 and 5):
@@ -536,8 +726,21 @@ hipError_t launch_group_ht(hipStream_t s, const GroupArgs& a, bool all_sa, bool*
             if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar_sa, dim3(gx, a.C), dim3(threads), 0, s, a);
             else             hipLaunchKernelGGL(k_group_id_any_sa, dim3(gx, a.C), dim3(threads), 0, s, a);
         }
-        else if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(gx, a.C), dim3(threads), 0, s, a);
-        else                  hipLaunchKernelGGL(k_group_id_any, dim3(gx, a.C), dim3(threads), 0, s, a);
+        else {
+            if (!a.sa_list) return hipErrorInvalidValue;
+#ifndef LFBM5D_HT_REFERENCE_ORDER
+            const bool fast = a.tau5 == 9 && (a.tau4 == 5 || a.tau4 == 6) && a.C <= 3;
+#else
+            const bool fast = false;
+#endif
+            if (fast)             hipLaunchKernelGGL(k_group_id_haar_fast, dim3(gx, a.C), dim3(threads), 0, s, a);
+            else if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar, dim3(gx, a.C), dim3(threads), 0, s, a);
+            else                  hipLaunchKernelGGL(k_group_id_any, dim3(gx, a.C), dim3(threads), 0, s, a);
+            if (a.tau4 == 6 || fast) {   /* what the kernel above has left: shape-adaptive groups (k_group_shape's entries), guard-band cases */
+                if (a.tau5 == 9) hipLaunchKernelGGL(k_group_id_haar_list, dim3(kSaListBlocks), dim3(threads), 0, s, a);
+                else             hipLaunchKernelGGL(k_group_id_any_list, dim3(kSaListBlocks), dim3(threads), 0, s, a);
+            }
+        }
         return hipGetLastError();
     }
     if ((a.tau2 == 7 || a.tau2 == 5) && a.k == 16 && a.N <= 8 && a.step == 1 && a.A == 9) {   /* bior1.5 / DCT on 16x16 patches, HT step */

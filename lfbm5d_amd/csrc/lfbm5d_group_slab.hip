@@ -570,7 +570,7 @@ static int slab_window_side(unsigned A) {   /* 3, 5, ... 17, or 0 */
     return 0;
 }
 bool group_uses_slab(const GroupArgs& a) {
-    if (getenv("LFBM5D_NO_SLAB_KERNEL") != nullptr) return false;
+    if (a.opt & kOptNoSlabKernel) return false;
     const int wa = slab_window_side(a.A);
     if (a.bm3d || a.useSD || !wa || a.N > (wa > 9 ? 16u : 32u)) return false;   /* (windows beyond 9x9: the N <= 16 instances only) */
     if (a.tau2 == 5 && !(a.k == 8 || a.k == 12 || a.k == 16)) return false;

@@ -410,7 +410,7 @@ hipError_t launch_group_wide(hipStream_t s, const GroupArgs& a, bool* launched) 
     for (int w = 5; w <= 17; w += 2) if (a.A == (unsigned)(w * w)) aw = w;
     if (!(aw && a.tau2 == 4 && a.step == 1 && !a.bm3d && a.N <= 8 && a.k * a.k <= 256 && (size_t)a.A * a.C * a.Wb * a.Hb * 4 < 0x7fffffffull)) return hipSuccess;
     *launched = true;
-    const bool split = !(a.useSD || getenv("LFBM5D_WIDE_NOSPLIT"));
+    const bool split = !(a.useSD || (a.opt & kOptWideNoSplit));
     if (split) {
         const hipError_t e = hipMemsetAsync(a.wgt + (size_t)a.ref_begin * a.C, 0, (size_t)a.n_groups * a.C * sizeof(float), s);
         if (e != hipSuccess) return e;

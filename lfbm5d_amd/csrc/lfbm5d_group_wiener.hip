@@ -257,6 +257,72 @@ template <int NS> __device__ __forceinline__ void haar_inv2(v2f* v) {
     }
 }
 
+/* Round 6: the Haar pair without its 1/sqrt 2 factors.  Forward: sums and differences only, the coefficient at index n (the
+ * reference's order: approximation, then details from the coarsest level L = log2 NS down to level 1) carries 2^(l/2), l = its
+ * level.  Inverse: of coefficients in that scale, NS times the orthonormal inverse -- additions and fma by the exact weights
+ * 1, 2, 4, 8.  The Wiener step has no threshold an ulp could flip, its shrinkage e^2 / (e^2 + sigma^2) is evaluated with
+ * sigma^2 scaled to the coefficient's own scale, and every dropped factor is a power of two or ends in one constant of the
+ * inverse angular transform (w3_body). */
+template <int NS> __device__ __forceinline__ constexpr int haar_level(int n) {   /* level of coefficient n of an NS-point transform (NS = 1: 0) */
+    int l = 0, m = NS;
+    while (m > 1) { m /= 2; l++; }          /* l = log2 NS */
+    int lo = 1;                              /* n = 0, 1: level L; [2, 4): L - 1; [4, 8): L - 2; ... */
+    int lev = l;
+    while (lo * 2 <= n) { lo *= 2; lev--; }
+    return NS == 1 ? 0 : lev;
+}
+template <int NS, class T> __device__ __forceinline__ void haar_fwd_u(T* v) {
+#pragma unroll
+    for (int n = NS; n > 1; n /= 2) {
+        T t[NS > 1 ? NS : 1];
+#pragma unroll
+        for (int i = 0; i < n / 2; i++) { t[i] = v[2 * i] + v[2 * i + 1]; t[n / 2 + i] = v[2 * i] - v[2 * i + 1]; }
+#pragma unroll
+        for (int i = 0; i < n; i++) v[i] = t[i];
+    }
+}
+template <int NS, class T> __device__ __forceinline__ void haar_inv_u(T* v) {
+#pragma unroll
+    for (int h = 1; h < NS; h *= 2) {
+        T t[NS > 1 ? NS : 1];
+        const float w = (float)h;
+#pragma unroll
+        for (int i = 0; i < h; i++) { t[2 * i] = v[i] + w * v[h + i]; t[2 * i + 1] = v[i] - w * v[h + i]; }
+#pragma unroll
+        for (int i = 0; i < 2 * h; i++) v[i] = t[i];
+    }
+}
+/* the 3x3 angular DCT without its constants: forward = the reference's value / (alpha_v alpha_u coef_norm_4d), alpha = (2, sqrt 3, 1)
+ * (GroupTables::ht3_f); the inverse takes values pre-multiplied by ht3_gf[st] / NS */
+__device__ __forceinline__ void dct9_fwd2_u(v2f* x) {
+    v2f t[9];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const v2f p = x[s * 3] + x[s * 3 + 2];
+        t[s * 3] = p + x[s * 3 + 1]; t[s * 3 + 1] = x[s * 3] - x[s * 3 + 2]; t[s * 3 + 2] = p - 2.0f * x[s * 3 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const v2f p = t[u] + t[6 + u];
+        x[u] = p + t[3 + u]; x[3 + u] = t[u] - t[6 + u]; x[6 + u] = p - 2.0f * t[3 + u];
+    }
+}
+__device__ __forceinline__ void dct9_inv2_u(v2f* x, TbPtr tb, const float scale) {
+    const auto& g = tb->ht3_gf;
+    v2f t[9];
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const v2f Z0 = x[s * 3] * (g[s * 3] * scale), Z1 = x[s * 3 + 1] * (g[s * 3 + 1] * scale), Z2 = x[s * 3 + 2] * (g[s * 3 + 2] * scale);
+        const v2f p = Z0 + Z2;
+        t[s * 3] = p + Z1; t[s * 3 + 1] = Z0 - 2.0f * Z2; t[s * 3 + 2] = p - Z1;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const v2f p = t[j] + t[6 + j];
+        x[j] = p + t[3 + j]; x[3 + j] = t[j] - 2.0f * t[6 + j]; x[6 + j] = p - t[3 + j];
+    }
+}
+
 /* a / b for the Wiener coefficient e^2 / (e^2 + sigma^2) (0 <= a < b, both normal or a = 0): reciprocal estimate and
  * one correction step instead of the IEEE division sequence -- within one ulp of the quotient, which is well inside
  * the float tolerance of this stage (the division was a tenth of the kernel's instructions) */
@@ -912,7 +978,7 @@ constexpr int kW3Stride = 146;
 constexpr unsigned kW3Lds = 64 * kW3Stride * sizeof(float);
 constexpr unsigned kW3Empty = 0xf0000000u;   /* byte offset of an absent patch: beyond any window this kernel is launched on */
 
-template <int NS, int TH, bool SA>
+template <int NS, int TH, bool SA, bool U = false>   /* U: the unnormalised chain (full-shape groups only) */
 __device__ __forceinline__ void w3_forward(__amdgpu_buffer_rsrc_t img, unsigned row_bytes, float* S, const unsigned* pos,
                                            int tid, ShRef sh, bool do_dct4, bool do_sa4, TbPtr tb) {
     constexpr int A = 9, NP = NS * A, NPh = (NP + 1) / 2, NPf = kW3Stride;
@@ -973,7 +1039,8 @@ __device__ __forceinline__ void w3_forward(__amdgpu_buffer_rsrc_t img, unsigned 
             v2f x[9];
 #pragma unroll
             for (int st = 0; st < 9; st++) x[st] = v2f{b0[st], b1[st]};
-            if (do_dct4) dct9_fwd2_fast(x, tb);
+            if (U) dct9_fwd2_u(x);
+            else if (do_dct4) dct9_fwd2_fast(x, tb);
             else {   /* rare: shape-adaptive transform on the scalar path */
                 float t9[9];
 #pragma unroll
@@ -1175,6 +1242,165 @@ __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsi
     }
 }
 
+/* Round 6: the same body for groups whose angular shape is the whole window (all but one in a thousand), on the UNNORMALISED
+ * chain: angular 3x3 by additions (24 packed instructions instead of 39 forward, 33 instead of 42 backward), Haar by additions
+ * forward and fma by 1, 2, 4, 8 backward (30 instead of 60 each).  A coefficient (st, n) in this scale is the reference's divided
+ * by ht3_f[st] 2^(-l/2), l = haar_level(n): the shrinkage e^2 / (e^2 + sigma^2) compares in the coefficient's own scale with
+ * sigma^2 2^l / ht3_f[st]^2 (four constants per fibre, formed once per thread), is itself scale-free, and the filtered values go
+ * back through ht3_gf[st] / nSx.  No shape-adaptive code: k_group_dct8w3_u skips the groups k_group_shape has listed
+ * (GroupArgs::sa_list) and k_group_dct8w3_list takes them through the normalised body behind it. */
+template <int NS, int TH>
+__device__ __forceinline__ void w3_body_u(const GroupArgs& a, float* S, const unsigned* pos, float (*red)[TH / 64], int tid, unsigned g, int c) {
+    constexpr int A = 9, K2 = 64, NP = NS * A, NPh = (NP + 1) / 2, NPf = kW3Stride;
+    constexpr int L = NS == 16 ? 4 : NS == 8 ? 3 : NS == 4 ? 2 : NS == 2 ? 1 : 0;
+    static_assert(TH == 256, "the fibre phases deal st 0..3 / 4..7 to 256 threads");
+    const int N = a.N;
+    const unsigned win_bytes = (unsigned)((size_t)A * a.C * a.Wb * a.Hb * 4);
+    const TbPtr tb = (TbPtr)a.tb;
+    ShRef sh = group_shape(a, g);   /* (unused by the U forms; the signature of w3_forward) */
+    const float sig = a.sigma[c];
+    const float sig2 = sig * sig;
+    const bool useSD = a.useSD != 0;
+
+    w3_forward<NS, TH, false, true>(__builtin_amdgcn_make_buffer_rsrc((void*)a.basic, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, true, false, tb);
+    /* fibres (st, pq): every thread owns st and st + 4 (st < 4) as a packed pair, the first wave also st = 8 */
+    const int fpq = (tid & 15) | ((tid >> 1) & 48), fst = ((tid >> 4) & 1) | ((tid >> 6) & 2);
+    float* const fbase = S + fpq * NPf + fst;
+    float* const f8base = S + (tid & 63) * NPf + 8;
+    const bool own8 = tid < 64;
+    /* sigma^2 in the scale of level l of this thread's fibres: sigma^2 2^l / F^2 */
+    v2f kq[L + 1];
+    float k8[L + 1];
+    {
+        const float fa = tb->ht3_f[fst], fb = tb->ht3_f[fst + 4], f8 = tb->ht3_f[8];
+        const v2f q = v2f{sig2 / (fa * fa), sig2 / (fb * fb)};
+        const float q8 = sig2 / (f8 * f8);
+#pragma unroll
+        for (int l = 0; l <= L; l++) { kq[l] = q * (float)(1 << l); k8[l] = q8 * (float)(1 << l); }
+    }
+    v2f vv[NS];
+    float v8[NS];
+    {
+        v2f e[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) e[n] = v2f{fbase[n * A], fbase[n * A + 4]};
+        haar_fwd_u<NS>(e);
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            const v2f value = e[n] * e[n], den = value + kq[haar_level<NS>(n)];
+            vv[n] = v2f{wiener_div(value.x, den.x), wiener_div(value.y, den.y)};
+        }
+    }
+    if (own8) {
+        float e[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) e[n] = f8base[n * A];
+        haar_fwd_u<NS>(e);
+#pragma unroll
+        for (int n = 0; n < NS; n++) {
+            const float value = e[n] * e[n];
+            v8[n] = wiener_div(value, value + k8[haar_level<NS>(n)]);
+        }
+    }
+    __syncthreads();
+    w3_forward<NS, TH, false, true>(__builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, true, false, tb);
+    float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    const float inv_n = 1.0f / (float)NS;
+    {
+        v2f o[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) o[n] = v2f{fbase[n * A], fbase[n * A + 4]};
+        haar_fwd_u<NS>(o);
+        v2f w2 = v2f{0.f, 0.f};
+#pragma unroll
+        for (int n = 0; n < NS; n++) { o[n] = o[n] * vv[n]; w2 += vv[n]; }
+        wacc = w2.x + w2.y;
+        haar_inv_u<NS>(o);
+#pragma unroll
+        for (int n = 0; n < NS; n++) { fbase[n * A] = o[n].x; fbase[n * A + 4] = o[n].y; }
+        if (useSD) {   /* sd_weighting_5d sums the filtered 4-D coefficients in the reference's scale */
+            const v2f f2 = v2f{tb->ht3_f[fst], tb->ht3_f[fst + 4]} * inv_n;
+#pragma unroll
+            for (int n = 0; n < NS; n++) { const v2f y = o[n] * f2; s1 += y.x + y.y; s2 += y.x * y.x + y.y * y.y; }
+        }
+    }
+    if (own8) {
+        float o[NS];
+#pragma unroll
+        for (int n = 0; n < NS; n++) o[n] = f8base[n * A];
+        haar_fwd_u<NS>(o);
+#pragma unroll
+        for (int n = 0; n < NS; n++) { o[n] = o[n] * v8[n]; wacc += v8[n]; }
+        haar_inv_u<NS>(o);
+#pragma unroll
+        for (int n = 0; n < NS; n++) f8base[n * A] = o[n];
+        if (useSD) {
+            const float f2 = tb->ht3_f[8] * inv_n;
+#pragma unroll
+            for (int n = 0; n < NS; n++) { const float y = o[n] * f2; s1 += y; s2 += y * y; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { wacc += __shfl_xor(wacc, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = wacc; red[1][tid >> 6] = s1; red[2][tid >> 6] = s2; }
+    __syncthreads();
+    for (int f = tid; f < NS * 32; f += TH) {
+        int n, pq;
+        if (NS > 1) { pq = (f & 15) | ((f >> 1) & 16); n = ((f >> 4) & 1) | ((f >> 5) & ~1); }
+        else { n = 0; pq = f; }
+        float* b0 = S + pq * NPf + n * A;
+        float* b1 = b0 + 32 * NPf;
+        v2f x[9];
+#pragma unroll
+        for (int st = 0; st < 9; st++) x[st] = v2f{b0[st], b1[st]};
+        dct9_inv2_u(x, tb, inv_n);
+#pragma unroll
+        for (int st = 0; st < 9; st++) { b0[st] = x[st].x; b1[st] = x[st].y; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float w = 0.0f, m = 0.0f, q = 0.0f;
+        for (int i = 0; i < TH / 64; i++) { w += red[0][i]; m += red[1][i]; q += red[2][i]; }
+        float wx;
+        if (a.useSD) {
+            const float Nn = (float)(NS * A);
+            const float res = (q - m * m / Nn) / (Nn - 1.0f);
+            wx = res > 0.0f ? 1.0f / sqrtf(res) : 0.0f;
+        } else {
+            wx = w > 0.0f ? (sig > 0.0f ? 1.0f / (sig * sig * w) : 1.0f / w) : 1.0f;
+        }
+        a.wgt[(size_t)g * a.C + c] = wx;
+        if (c == 0) atomicAdd(&a.counters[0], (unsigned long long)NS);
+    }
+    for (int it = tid; it < NPh * 8; it += TH) {
+        const int j = it / NPh, pp = it - j * NPh;
+        float* col = S + j * NPf + 2 * pp;
+        v2f x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = *reinterpret_cast<const v2f*>(col + (i * 8) * NPf);
+        dct8_inv_t(x);
+#pragma unroll
+        for (int i = 0; i < 8; i++) *reinterpret_cast<v2f*>(col + (i * 8) * NPf) = x[i];
+    }
+    __syncthreads();
+    for (int it = tid; it < NPh * 8; it += TH) {
+        const int pa = it >> 3, i = it & 7;
+        const bool has_b = pa + NPh < NP;
+        const float* ra = S + (i * 8) * NPf + pa;
+        v2f x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = v2f{ra[j * NPf], ra[j * NPf + (NP > NPh ? NPh : 0)]};
+        dct8_inv_t(x);
+        v4f* oa = reinterpret_cast<v4f*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
+        filt_put4(oa, v4f{x[0].x, x[1].x, x[2].x, x[3].x});
+        filt_put4(oa + 1, v4f{x[4].x, x[5].x, x[6].x, x[7].x});
+        if (has_b) {
+            v4f* ob = oa + (size_t)NPh * a.C * (K2 / 4);
+            filt_put4(ob, v4f{x[0].y, x[1].y, x[2].y, x[3].y});
+            filt_put4(ob + 1, v4f{x[4].y, x[5].y, x[6].y, x[7].y});
+        }
+    }
+}
+
 #ifndef LFBM5D_W3SA_WAVES
 #define LFBM5D_W3SA_WAVES 4   /* 128 VGPRs (a few spills): four workgroups per CU beat 129 without */
 #endif
@@ -1205,6 +1431,62 @@ __global__ __launch_bounds__(kDct8w3Threads) __attribute__((amdgpu_waves_per_eu(
         case 4:  w3_body<4, TH, SA>(a, lds, pos, red, tid, g, c); break;
         case 8:  w3_body<8, TH, SA>(a, lds, pos, red, tid, g, c); break;
         default: w3_body<16, TH, SA>(a, lds, pos, red, tid, g, c); break;
+    }
+}
+
+/* ordinary windows (round 6): full-shape groups on the unnormalised chain, the listed shape-adaptive ones left to k_group_dct8w3_list */
+__global__ __launch_bounds__(kDct8w3Threads) void k_group_dct8w3_u(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[3][kDct8w3Threads / 64];
+    __shared__ unsigned pos[kMaxN * kA3];
+    constexpr int TH = kDct8w3Threads;
+    const int tid = threadIdx.x;
+    const unsigned gi = xcd_group_index(a);
+    if (gi >= a.n_groups) return;
+    const unsigned g = a.ref_begin + gi;
+    if (a.tau4 == 6 && group_shape(a, g).use_sadct) return;   /* (uniform) */
+    const int c = blockIdx.y;
+    const int nSx = (int)a.self_cnt[g];
+    const unsigned plane = a.Wb * a.Hb;
+    for (int i = tid; i < nSx * 9; i += TH) {
+        const unsigned p = a.gpos[(size_t)g * a.N * 9 + i];
+        pos[i] = p != 0xffffffffu ? (((unsigned)(i % 9) * a.C + c) * plane + p) * 4u : kW3Empty;
+    }
+    __syncthreads();
+    switch (nSx) {
+        case 1:  w3_body_u<1, TH>(a, lds, pos, red, tid, g, c); break;
+        case 2:  w3_body_u<2, TH>(a, lds, pos, red, tid, g, c); break;
+        case 4:  w3_body_u<4, TH>(a, lds, pos, red, tid, g, c); break;
+        case 8:  w3_body_u<8, TH>(a, lds, pos, red, tid, g, c); break;
+        default: w3_body_u<16, TH>(a, lds, pos, red, tid, g, c); break;
+    }
+}
+constexpr unsigned kW3ListBlocks = 256;
+__global__ __launch_bounds__(kDct8w3Threads) void k_group_dct8w3_list(GroupArgs a) {
+    extern __shared__ float lds[];
+    __shared__ float red[3][kDct8w3Threads / 64];
+    __shared__ unsigned pos[kMaxN * kA3];
+    constexpr int TH = kDct8w3Threads;
+    const int tid = threadIdx.x;
+    const unsigned n_list = a.sa_list[0];
+    const int c = blockIdx.y;
+    for (unsigned li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const unsigned g = a.sa_list[1u + li] & 0x1fffffffu;
+        const int nSx = (int)a.self_cnt[g];
+        const unsigned plane = a.Wb * a.Hb;
+        for (int i = tid; i < nSx * 9; i += TH) {
+            const unsigned p = a.gpos[(size_t)g * a.N * 9 + i];
+            pos[i] = p != 0xffffffffu ? (((unsigned)(i % 9) * a.C + c) * plane + p) * 4u : kW3Empty;
+        }
+        __syncthreads();
+        switch (nSx) {
+            case 1:  w3_body<1, TH, true>(a, lds, pos, red, tid, g, c); break;
+            case 2:  w3_body<2, TH, true>(a, lds, pos, red, tid, g, c); break;
+            case 4:  w3_body<4, TH, true>(a, lds, pos, red, tid, g, c); break;
+            case 8:  w3_body<8, TH, true>(a, lds, pos, red, tid, g, c); break;
+            default: w3_body<16, TH, true>(a, lds, pos, red, tid, g, c); break;
+        }
+        __syncthreads();   /* pos / red / the stack are reused */
     }
 }
 
@@ -1385,11 +1667,20 @@ hipError_t launch_group_wiener(hipStream_t s, const GroupArgs& a, bool all_sa, b
         if (a.step == 2) {
             const unsigned gx = ((a.n_groups + 7) / 8) * 8;   /* xcd_group_index */
             /* the README's Wiener step: k_group_dct8w3.  Its two-image predecessor k_group_dct8w2 stays for Hadamard / DCT fibres and for
-             * windows of 1.9 GB and more (32-bit offsets); LFBM5D_DCT8W_V2: test hook, that kernel for every configuration.  (Round 1's
+             * windows of 1.9 GB and more (32-bit offsets); option dct8w_v2: test hook, that kernel for every configuration.  (Round 1's
              * k_group_dct8w and the unpacked k_group_dct8<2> were retired as Wiener DCT kernels in round 5: nothing selected them.) */
-            if (a.tau5 == 9 && (size_t)9 * a.C * a.Wb * a.Hb * 4 < 0x70000000ull && !getenv("LFBM5D_DCT8W_V2")) {
+            if (a.tau5 == 9 && (size_t)9 * a.C * a.Wb * a.Hb * 4 < 0x70000000ull && !(a.opt & kOptDct8wV2)) {
                 if (all_sa) hipLaunchKernelGGL(k_group_dct8w3<true>, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a);
+#ifdef LFBM5D_W3_NORMALISED   /* build flag: round 3-5's normalised body for every group (A/B runs) */
                 else        hipLaunchKernelGGL(k_group_dct8w3<false>, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a);
+#else
+                else if (a.tau4 == 5 || a.tau4 == 6) {
+                    if (!a.sa_list) return hipErrorInvalidValue;
+                    hipLaunchKernelGGL(k_group_dct8w3_u, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a);
+                    if (a.tau4 == 6) hipLaunchKernelGGL(k_group_dct8w3_list, dim3(kW3ListBlocks, a.C), dim3(kDct8w3Threads), kW3Lds, s, a);   /* the groups skipped above (usually none) */
+                }
+                else        hipLaunchKernelGGL(k_group_dct8w3<false>, dim3(gx, a.C), dim3(kDct8w3Threads), kW3Lds, s, a);   /* tau_4D = id */
+#endif
             }
             else if (a.tau5 == 9) hipLaunchKernelGGL((k_group_dct8w2<true>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);
             else                  hipLaunchKernelGGL((k_group_dct8w2<false>), dim3(gx, a.C), dim3(kDct8w2Threads), l8, s, a);

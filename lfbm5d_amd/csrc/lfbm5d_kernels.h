@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 
+#include "lfbm5d_options.h"
+
 /* Cache policy of the `filt` stream (written once by the group kernels, read once or twice by the aggregation): the aux operand
  * of the buffer instructions -- 0 default, 2 = nt (streaming), 1 = sc0, 16 = sc1.  Round 6, measured on the headline window
  * (profiles/r06_a_nt_filt_ab.txt): non-temporal STORES take k_group_id_haar from 0.93-1.06 to 0.81-0.85 ms per pass and every other
@@ -96,6 +98,10 @@ struct GroupTables {
     float lpd[10], hpd[10], lpr[10], hpr[10];
     float coef2inv;             /* 1 / (2k)                       (bm3d.cpp:1064) */
     float coef4inv;             /* 1 / (2 sqrt(aw) sqrt(ah))      (core:1945)     */
+    /* 3x3 windows, hard-thresholding step with Haar fibres (round 6): constants of the unnormalised chain group_id_compute_fast
+     * (lfbm5d_group_ht.hip), evaluated in double.  alpha = (2, sqrt 3, 1), gamma = (1, sqrt 3, 1). */
+    float ht3_f[9];             /* F[st] = alpha_v alpha_u cn4[st]: unnormalised forward coefficient -> the reference's normalised one */
+    float ht3_gf[9];            /* F[st] cni4[st] coef4inv gamma_v gamma_u: times 1 / nSx, the inverse's input scale */
 };
 
 constexpr unsigned kShapeInfoBytes = (5 * kMaxA + 2 * kMaxAw + 1) * 4;          /* per-group SADCT record, windows of up to 7x7 SAIs */
@@ -117,6 +123,9 @@ struct GroupArgs {
     float* wgt;                 /* [R][C] aggregation weights */
     unsigned* aggpos;           /* [A][R][N] where each filtered patch is aggregated (0xffffffff: nowhere) */
     unsigned* gpos;             /* [R][N][A] window position of every patch of every group (pre-pass output) */
+    unsigned* sa_list;          /* [1 + 4 R] round 6: [0] = number of entries, then group number | channel mask << 29 (any order; k_group_pos zeroes
+                                 * the count): what the register-resident HT kernels leave to k_group_id_*_list -- groups whose angular shape is not
+                                 * the whole window (k_group_shape appends them), guard-band cases of the fast chain (lfbm5d_group_ht.hip) */
     unsigned* gofs;             /* [R][N][A] the same as a byte offset into channel 0 of the patch's SAI (0 for an absent patch), and ...        */
     unsigned* gok;              /* [R][N] ... bit st set where patch (n, st) is there: what the register-resident HT kernel's scalar loads need */
     void* gshape;               /* [R] kShapeInfoBytes (A > 49: kShapeInfoBigBytes) each: SADCT bookkeeping of the group (pre-pass output) */
@@ -130,8 +139,11 @@ struct GroupArgs {
     int step;
     float lambda;
     float sigma[3];
+    float ht3_T[3][9][4];       /* group_id_compute_fast: the hard threshold of channel c for the UNNORMALISED Haar coefficients of level l at
+                                 * angular frequency st: T_c / (ht3_f[st] 2^(-l/2)), evaluated in double on the host (run_pass) */
     float* scratch;             /* generic path, stacks beyond the LDS: HBM slices for k_group_big (or NULL) */
     unsigned long long scratch_floats;   /* size of scratch */
+    unsigned opt;               /* kOpt* bits (lfbm5d_options.h): kernel-generation selectors of the context */
     unsigned bm3d;              /* per-SAI BM3D arithmetic (bm3d.cpp:914-1027, :1345-1373): threshold without sqrt2, SD weight over nSx*k^2 */
 };
 
@@ -154,6 +166,7 @@ struct AggArgs {
     unsigned Wb, Hb, C, A, k, N, pst, p, nHW, nSim, nDisp;
     SaiMask mask_bits, proc_bits; unsigned tau4;
     unsigned irregular;         /* reference list is not the regular grid (subset path): scan every reference */
+    unsigned opt;               /* kOpt* bits (lfbm5d_options.h) */
     unsigned wchan0;            /* every channel uses channel 0's group weight (sd_weighting of bm3d.cpp:1345-1373) */
 };
 
@@ -224,6 +237,8 @@ struct ScanArgs {
     unsigned scores_bytes;
     /* stereo */
     unsigned long long* dbg;    /* development builds (LFBM5D_PHASE_TIMING): phase clocks; else unused */
+    unsigned opt;               /* kOpt* bits (lfbm5d_options.h): which table-kernel generation */
+    unsigned lds_cap;           /* > 0: LDS bytes the first-generation kernel may use (option scan_lds_cap) */
     float* tables;              /* [n_slots][Ns*Ns][stereo_table_stride]: strip-major [strip][row][64 columns] */
     unsigned st_of_slot[kBigA];
     /* second-generation kernel */

@@ -780,17 +780,16 @@ template <int K> size_t scan2_lds_bytes(const ScanArgs& a, int rh_max, int ch_ma
 
 /* Which kernel generation a pass's distance tables are built with (and hence the layout the arg-min reads):
  * 2 unless the configuration is outside what the ring-sharing kernel covers (12x12 patches, irregular reference lists,
- * search windows whose rings do not fit) or LFBM5D_SCAN_V1 asks for round 2's kernel. */
+ * search windows whose rings do not fit) or the option scan_v1 asks for round 2's kernel. */
 int bm_scan_version(const ScanArgs& a) {
-    if (const char* e = std::getenv("LFBM5D_SCAN_V1")) if (e[0] && e[0] != '0') return 1;
-    if (const char* e = std::getenv("LFBM5D_SCAN_ANY")) if (e[0] && e[0] != '0') return 1;   /* (test hook: the any-patch-size kernel, first-generation layout) */
+    if (a.opt & (kOptScanV1 | kOptScanAny)) return 1;   /* (test hooks: round 2's kernel / the any-patch-size kernel, first-generation layout) */
     if (a.k != 8 && a.k != 16) return 1;
     if (a.n_self && a.refmap) return 1;
     /* the loader wave addresses all planes of the estimate through ONE buffer resource with 32-bit offsets */
     if ((size_t)a.est_planes * a.W * a.H * 4 + kLeadBytes + 1024 > 0x7fffffffull) return 1;
     std::vector<Scan2Wg> wgs; size_t lds = 0;
     if (!scan2_plan(a, wgs, &lds)) return 1;
-    if (const char* e = std::getenv("LFBM5D_SCAN_FULL_TABLES")) if (e[0] && e[0] != '0') return 2;
+    if (a.opt & kOptScanFullTables) return 2;
     return 3;
 }
 

@@ -60,3 +60,40 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("the CPU oracle", "").replace("oracle/", "") or f == "__none__", f
+
+
+def test_library_reads_the_environment_in_one_place():
+    """Round 6: the run-time knobs are per-context options (lfbm5d_set_option); the library's only getenv is options_from_env
+    (lfbm5d_options.h, called once by lfbm5d_create).  The drop-in and the CLI keep the program-level variables they read at start-up."""
+    csrc = os.path.join(ROOT, "lfbm5d_amd", "csrc")
+    sites = {}
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            n = len(re.findall(r"\bgetenv\s*\(", re.sub(r"/\*.*?\*/|//[^\n]*", "", open(os.path.join(csrc, f)).read(), flags=re.S)))
+            if n:
+                sites[f] = n
+    assert sites.get("lfbm5d_options.h") == 1
+    assert set(sites) <= {"lfbm5d_options.h", "run_bm5d.cpp", "lfbm5d_cli.cpp"}, sites
+    assert sum(sites.values()) <= 8, sites
+    # every option key has its old variable as an alias, and the Python mirror hands exactly those variables over
+    src = open(os.path.join(csrc, "lfbm5d_options.h")).read()
+    envs = set(re.findall(r'"(LFBM5D_[A-Z0-9_]+)"', src))
+    assert envs == set(core.OPTION_ENV)
+
+
+@pytest.mark.gpu
+def test_options_are_per_context():
+    a, b = L.Context(0), L.Context(0)
+    try:
+        assert a.get_option("lanes") == os.environ.get("LFBM5D_LANES", "2")
+        a.set_option("lanes", 3)
+        a.set_option("LFBM5D_STEP_SHARDING", "rows")
+        a.set_option("dct8w_v2", 1)
+        assert (a.get_option("lanes"), a.get_option("step_sharding"), a.get_option("dct8w_v2")) == ("3", "rows", "1")
+        assert (b.get_option("lanes"), b.get_option("step_sharding"), b.get_option("dct8w_v2")) == (os.environ.get("LFBM5D_LANES", "2"), "0", "0")
+        a.set_option("lanes", None)
+        assert a.get_option("lanes") == "2"
+        with pytest.raises(L.LfBm5dError, match="unknown option"):
+            a.set_option("no_such_option", 1)
+    finally:
+        a.close(); b.close()

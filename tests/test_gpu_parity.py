@@ -1289,7 +1289,11 @@ def test_wiener_kernel_generations_agree_at_full_window_size(ctx, monkeypatch):
     both = d3 > 0
     np.testing.assert_allclose(d3[both], d2[both], rtol=2e-5)
     diff = np.abs(n3[both] / d3[both] - n2[both] / d2[both])
-    assert diff.max() < 2e-3 and diff.mean() < 2e-5
+    # round 6: k_group_dct8w3_u evaluates the angular and Haar stages unnormalised (additions; the constants folded into the shrinkage
+    # and the inverse's input scale), k_group_dct8w2 in the reference's scale: the estimates differ by an ulp and a half of a
+    # grey level around 150 on average (measured 2.3e-5; 1.9e-5 between the two normalised kernels) -- the bar against the ORACLE
+    # (test_core_pass_matches_oracle, wien-* cases) is unchanged
+    assert diff.max() < 2e-3 and diff.mean() < 3e-5
 
 
 @pytest.mark.parametrize("case", DEDICATED, ids=[c[0] for c in DEDICATED])
