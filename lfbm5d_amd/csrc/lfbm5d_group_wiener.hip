@@ -978,27 +978,44 @@ constexpr int kW3Stride = 146;
 constexpr unsigned kW3Lds = 64 * kW3Stride * sizeof(float);
 constexpr unsigned kW3Empty = 0xf0000000u;   /* byte offset of an absent patch: beyond any window this kernel is launched on */
 
+/* the gathered rows of one image: item q of a thread = row i of the patch pair (2 pp, 2 pp + 1), 32 bytes of each */
+template <int NS, int TH> struct W3Rows {
+    static constexpr int kIt = (((NS * 9 + 1) / 2) * 8 + TH - 1) / TH;
+    v4f ra0[kIt], ra1[kIt], rb0[kIt], rb1[kIt];
+};
+template <int NS, int TH>
+__device__ __forceinline__ void w3_load_rows(__amdgpu_buffer_rsrc_t img, unsigned row_bytes, const unsigned* pos, int tid, W3Rows<NS, TH>& r) {
+    constexpr int A = 9, NP = NS * A, NPh = (NP + 1) / 2;
+    /* pos[] holds byte offsets into the window (out of range for an empty SAI / never-filled column: the buffer load returns zeros) */
+#pragma unroll
+    for (int q = 0; q < W3Rows<NS, TH>::kIt; q++) {
+        const int it = tid + q * TH;
+        if (it < NPh * 8) {
+            const int i = it / NPh, pp = it - i * NPh;
+            const int pA = 2 * pp, pB = pA + 1 < NP ? pA + 1 : pA;
+#if defined(LFBM5D_W3_EXP) && (LFBM5D_W3_EXP & 4)   /* timing experiment: the same loads at consecutive addresses (eight lines per instruction instead of 64) */
+            const int oa = (int)((pos[0] & ~15u) + (unsigned)((tid & 63) * 64 + q * 4096)), ob = oa + 32;
+            (void)pA; (void)pB; (void)i;
+#else
+            const int oa = (int)(pos[pA] + (unsigned)i * row_bytes), ob = (int)(pos[pB] + (unsigned)i * row_bytes);
+#endif
+            r.ra0[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, oa, 0, 0));
+            r.ra1[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, oa + 16, 0, 0));
+            r.rb0[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, ob, 0, 0));
+            r.rb1[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, ob + 16, 0, 0));
+        }
+    }
+}
 template <int NS, int TH, bool SA, bool U = false>   /* U: the unnormalised chain (full-shape groups only) */
 __device__ __forceinline__ void w3_forward(__amdgpu_buffer_rsrc_t img, unsigned row_bytes, float* S, const unsigned* pos,
-                                           int tid, ShRef sh, bool do_dct4, bool do_sa4, TbPtr tb) {
+                                           int tid, ShRef sh, bool do_dct4, bool do_sa4, TbPtr tb, const W3Rows<NS, TH>* pre = nullptr) {
     constexpr int A = 9, NP = NS * A, NPh = (NP + 1) / 2, NPf = kW3Stride;
     constexpr int kIt = (NPh * 8 + TH - 1) / TH;
     {
-        /* pos[] holds byte offsets into the window (out of range for an empty SAI / never-filled column: the buffer load returns zeros) */
-        v4f ra0[kIt], ra1[kIt], rb0[kIt], rb1[kIt];
-#pragma unroll
-        for (int q = 0; q < kIt; q++) {
-            const int it = tid + q * TH;
-            if (it < NPh * 8) {
-                const int i = it / NPh, pp = it - i * NPh;
-                const int pA = 2 * pp, pB = pA + 1 < NP ? pA + 1 : pA;
-                const int oa = (int)(pos[pA] + (unsigned)i * row_bytes), ob = (int)(pos[pB] + (unsigned)i * row_bytes);
-                ra0[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, oa, 0, 0));
-                ra1[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, oa + 16, 0, 0));
-                rb0[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, ob, 0, 0));
-                rb1[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(img, ob + 16, 0, 0));
-            }
-        }
+        W3Rows<NS, TH> own;
+        if (!pre) w3_load_rows<NS, TH>(img, row_bytes, pos, tid, own);
+        const W3Rows<NS, TH>& R = pre ? *pre : own;
+        const v4f (&ra0)[kIt] = R.ra0; const v4f (&ra1)[kIt] = R.ra1; const v4f (&rb0)[kIt] = R.rb0; const v4f (&rb1)[kIt] = R.rb1;
 #pragma unroll
         for (int q = 0; q < kIt; q++) {
             const int it = tid + q * TH;
@@ -1303,6 +1320,8 @@ __device__ __forceinline__ void w3_body_u(const GroupArgs& a, float* S, const un
         }
     }
     __syncthreads();
+    /* (asking for these rows before the pilot's fibre phase -- 128 VGPRs, still four waves per SIMD -- changes nothing: 1.00 ms either way;
+     * timing builds, profiles/r06_f_w3_experiments.txt: without the gathers 0.80, with them at consecutive addresses 0.92, without the stores 0.92) */
     w3_forward<NS, TH, false, true>(__builtin_amdgcn_make_buffer_rsrc((void*)a.noisy, 0, (int)win_bytes, 0x00020000u), a.Wb * 4u, S, pos, tid, sh, true, false, tb);
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
     const float inv_n = 1.0f / (float)NS;
@@ -1390,11 +1409,19 @@ __device__ __forceinline__ void w3_body_u(const GroupArgs& a, float* S, const un
 #pragma unroll
         for (int j = 0; j < 8; j++) x[j] = v2f{ra[j * NPf], ra[j * NPf + (NP > NPh ? NPh : 0)]};
         dct8_inv_t(x);
+#if defined(LFBM5D_W3_EXP) && (LFBM5D_W3_EXP & 2)   /* timing experiment: the whole workgroup stores into one patch's 256 bytes (no HBM write stream) */
+        v4f* oa = reinterpret_cast<v4f*>(a.filt + (size_t)g * N * A * a.C * K2 + i * 8);
+#else
         v4f* oa = reinterpret_cast<v4f*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
+#endif
         filt_put4(oa, v4f{x[0].x, x[1].x, x[2].x, x[3].x});
         filt_put4(oa + 1, v4f{x[4].x, x[5].x, x[6].x, x[7].x});
         if (has_b) {
+#if defined(LFBM5D_W3_EXP) && (LFBM5D_W3_EXP & 2)
+            v4f* ob = oa;
+#else
             v4f* ob = oa + (size_t)NPh * a.C * (K2 / 4);
+#endif
             filt_put4(ob, v4f{x[0].y, x[1].y, x[2].y, x[3].y});
             filt_put4(ob + 1, v4f{x[4].y, x[5].y, x[6].y, x[7].y});
         }
@@ -1435,7 +1462,14 @@ __global__ __launch_bounds__(kDct8w3Threads) __attribute__((amdgpu_waves_per_eu(
 }
 
 /* ordinary windows (round 6): full-shape groups on the unnormalised chain, the listed shape-adaptive ones left to k_group_dct8w3_list */
+#ifndef LFBM5D_W3U_WAVES
+#define LFBM5D_W3U_WAVES 0
+#endif
+#if LFBM5D_W3U_WAVES > 0
+__global__ __launch_bounds__(kDct8w3Threads) __attribute__((amdgpu_waves_per_eu(LFBM5D_W3U_WAVES, LFBM5D_W3U_WAVES))) void k_group_dct8w3_u(GroupArgs a) {
+#else
 __global__ __launch_bounds__(kDct8w3Threads) void k_group_dct8w3_u(GroupArgs a) {
+#endif
     extern __shared__ float lds[];
     __shared__ float red[3][kDct8w3Threads / 64];
     __shared__ unsigned pos[kMaxN * kA3];
@@ -1451,6 +1485,9 @@ __global__ __launch_bounds__(kDct8w3Threads) void k_group_dct8w3_u(GroupArgs a) 
     for (int i = tid; i < nSx * 9; i += TH) {
         const unsigned p = a.gpos[(size_t)g * a.N * 9 + i];
         pos[i] = p != 0xffffffffu ? (((unsigned)(i % 9) * a.C + c) * plane + p) * 4u : kW3Empty;
+#if defined(LFBM5D_W3_EXP) && (LFBM5D_W3_EXP & 1)   /* timing experiment: every patch absent -- the gathers go out of range and move nothing */
+        pos[i] = kW3Empty;
+#endif
     }
     __syncthreads();
     switch (nSx) {
