@@ -310,7 +310,7 @@ def test_plan_windows_matches_the_reference_rule():
 
 
 def _simulate_exchange(aw, ah, world, lanes, single_channel=False, perturb=False, n_steps=1):
-    """Replay of what run_graph enqueues on every rank (lfbm5d_api.hip): every rank walks the nodes of the job in ISSUE ORDER;
+    """Replay of what run_graph enqueues on every rank (lfbm5d_graph.hip): every rank walks the nodes of the job in ISSUE ORDER;
     a window goes to its lane's stream (FIFO) and waits for the previous toucher of each of its SAIs -- an event of the same
     rank, or the arrival of that SAI's message -- and, in the second step of a two-step job, for each SAI's basic estimate
     (finalised behind a window of the same rank, or arrived as a message); after a window, the messages it feeds are enqueued on

@@ -10,7 +10,7 @@ F="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-result -Wno-unus
 hipcc $F -ffp-contract=off -c lfbm5d_bm.hip -o $out/obj_$name/bm.o &
 hipcc $F -ffp-contract=off -c lfbm5d_scan2.hip -o $out/obj_$name/scan2.o &
 for f in window aggregate group_generic group_ht group_wiener group_wide group_slab; do hipcc $F -c lfbm5d_$f.hip -o $out/obj_$name/$f.o & done
-hipcc $F -c lfbm5d_api.hip -o $out/obj_$name/api.o &
+for f in pass graph steps api; do hipcc $F -c lfbm5d_$f.hip -o $out/obj_$name/$f.o & done
 wait
 hipcc --offload-arch=gfx950 -shared -o $out/lib_$name.so $out/obj_$name/*.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 echo built $out/lib_$name.so

@@ -8,7 +8,7 @@ name=$1; extra=$2; shift 2
 out=../variants; mkdir -p $out/obj_$name
 F="-O3 -fPIC --offload-arch=gfx950 -std=c++17 -Wall -Wno-unused-result -Wno-unused-function $extra"
 objs=""
-for f in bm scan2 window aggregate group_generic group_ht group_wiener group_wide group_slab api; do
+for f in bm scan2 window aggregate group_generic group_ht group_wiener group_wide group_slab pass graph steps api; do
   if [[ " $* " == *" $f "* ]]; then
     c=""; [ $f = bm -o $f = scan2 ] && c="-ffp-contract=off"
     hipcc $F $c -c lfbm5d_$f.hip -o $out/obj_$name/$f.o &
