@@ -1249,12 +1249,12 @@ __device__ __forceinline__ void w3_body(const GroupArgs& a, float* S, const unsi
         for (int j = 0; j < 8; j++) x[j] = v2f{ra[j * NPf], ra[j * NPf + (NP > NPh ? NPh : 0)]};
         dct8_inv_t(x);
         v4f* oa = reinterpret_cast<v4f*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
-        filt_put4(oa, v4f{x[0].x, x[1].x, x[2].x, x[3].x});
-        filt_put4(oa + 1, v4f{x[4].x, x[5].x, x[6].x, x[7].x});
+        filt_put4_nt(oa, v4f{x[0].x, x[1].x, x[2].x, x[3].x});
+        filt_put4_nt(oa + 1, v4f{x[4].x, x[5].x, x[6].x, x[7].x});
         if (has_b) {
             v4f* ob = oa + (size_t)NPh * a.C * (K2 / 4);
-            filt_put4(ob, v4f{x[0].y, x[1].y, x[2].y, x[3].y});
-            filt_put4(ob + 1, v4f{x[4].y, x[5].y, x[6].y, x[7].y});
+            filt_put4_nt(ob, v4f{x[0].y, x[1].y, x[2].y, x[3].y});
+            filt_put4_nt(ob + 1, v4f{x[4].y, x[5].y, x[6].y, x[7].y});
         }
     }
 }
@@ -1414,16 +1414,16 @@ __device__ __forceinline__ void w3_body_u(const GroupArgs& a, float* S, const un
 #else
         v4f* oa = reinterpret_cast<v4f*>(a.filt + ((size_t)g * N * A + pa) * a.C * K2 + (size_t)c * K2 + i * 8);
 #endif
-        filt_put4(oa, v4f{x[0].x, x[1].x, x[2].x, x[3].x});
-        filt_put4(oa + 1, v4f{x[4].x, x[5].x, x[6].x, x[7].x});
+        filt_put4_nt(oa, v4f{x[0].x, x[1].x, x[2].x, x[3].x});
+        filt_put4_nt(oa + 1, v4f{x[4].x, x[5].x, x[6].x, x[7].x});
         if (has_b) {
 #if defined(LFBM5D_W3_EXP) && (LFBM5D_W3_EXP & 2)
             v4f* ob = oa;
 #else
             v4f* ob = oa + (size_t)NPh * a.C * (K2 / 4);
 #endif
-            filt_put4(ob, v4f{x[0].y, x[1].y, x[2].y, x[3].y});
-            filt_put4(ob + 1, v4f{x[4].y, x[5].y, x[6].y, x[7].y});
+            filt_put4_nt(ob, v4f{x[0].y, x[1].y, x[2].y, x[3].y});
+            filt_put4_nt(ob + 1, v4f{x[4].y, x[5].y, x[6].y, x[7].y});
         }
     }
 }

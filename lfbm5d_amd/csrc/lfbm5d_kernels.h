@@ -13,8 +13,8 @@
 
 /* Cache policy of the `filt` stream (written once by the group kernels, read once or twice by the aggregation): the aux operand
  * of the buffer instructions -- 0 default, 2 = nt (streaming), 1 = sc0, 16 = sc1.  Round 6, measured on the headline window
- * (profiles/r06_a_nt_filt_ab.txt): non-temporal STORES take k_group_id_haar from 0.93-1.06 to 0.81-0.85 ms per pass and every other
- * group / aggregation kernel 3 % down (the write stream no longer evicts the window rows the gathers of the same XCD re-read from
+ * (profiles/r06_a_nt_filt_ab.txt): non-temporal STORES take k_group_id_haar from 0.93-1.06 to 0.81-0.85 ms per pass and k_group_dct8w3
+ * and both aggregation kernels 3 % down (the write stream no longer evicts the window rows the gathers of the same XCD re-read from
  * its L2); non-temporal LOADS in the aggregation cost it half its speed (a filtered row is read by two neighbouring tiles).
  * Build-time knobs for A/B runs (tools/build_variant_files.sh). */
 #ifndef LFBM5D_FILT_STORE_AUX
@@ -25,31 +25,24 @@
 #endif
 
 #if defined(__HIPCC__)
-/* stores of filtered patches (global pointers; the register-resident HT kernel passes the aux operand to its buffer stores itself) */
+/* Stores of filtered patches through global pointers.  The non-temporal form ONLY where a wave-instruction (or two back to back)
+ * writes whole lines -- the register-resident HT kernel (256 contiguous bytes per instruction; it passes the aux operand to its buffer
+ * stores itself) and k_group_dct8w3 (eight lanes write a patch's 256 bytes) --: measured on the 16 x 16 wavelet kernel, whose
+ * instructions scatter 16-byte pieces 64 bytes apart and complete a line over four of them, non-temporal stores cost 2.2 -> 4.8 ms
+ * per pass (partial-line writes at the memory side; profiles/r06_g_nt_partial_lines.txt).  Everything else stores plainly. */
 typedef float filt_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void filt_put(float* p, const float v) {
-#if LFBM5D_FILT_STORE_AUX == 2
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ void filt_put4(filt_v4f* p, const filt_v4f v) {
-#if LFBM5D_FILT_STORE_AUX == 2
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
 typedef float filt_v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void filt_put2(filt_v2f* p, const filt_v2f v) {
+__device__ __forceinline__ void filt_put(float* p, const float v) { *p = v; }
+__device__ __forceinline__ void filt_put2(filt_v2f* p, const filt_v2f v) { *p = v; }
+__device__ __forceinline__ void filt_put4(filt_v4f* p, const filt_v4f v) { *p = v; }
+__device__ __forceinline__ void filt_put4(float4* p, const float4 v) { *p = v; }
+__device__ __forceinline__ void filt_put4_nt(filt_v4f* p, const filt_v4f v) {
 #if LFBM5D_FILT_STORE_AUX == 2
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
 #endif
 }
-__device__ __forceinline__ void filt_put4(float4* p, const float4 v) { filt_put4(reinterpret_cast<filt_v4f*>(p), filt_v4f{v.x, v.y, v.z, v.w}); }
 #endif
 
 namespace lfbm5d {

@@ -45,7 +45,8 @@ def per_kernel(d, counter):
                 continue
             e = out.setdefault(key, [0.0, set()])
             e[0] += float(r["Counter_Value"])
-            e[1].add(r["Dispatch_Id"])
+            if "_list" not in r["Kernel_Name"]:   # round 6: k_group_*_list belongs to the pass of its main kernel: bytes yes, launch count no
+                e[1].add(r["Dispatch_Id"])
     return {k: (v[0], len(v[1])) for k, v in out.items()}
 
 

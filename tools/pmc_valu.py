@@ -33,7 +33,8 @@ for f in glob.glob(f"{sys.argv[1]}/**/*counter_collection.csv", recursive=True):
         e = acc.setdefault(classify(r["Kernel_Name"]), {"SQ_INSTS_VALU": 0.0, "SQ_WAVES": 0.0, "ids": set()})
         if r["Counter_Name"] in e:
             e[r["Counter_Name"]] += float(r["Counter_Value"])
-        e["ids"].add(r["Dispatch_Id"])
+        if "_list" not in r["Kernel_Name"]:   # round 6: a group kernel's list launch (k_group_*_list) belongs to its pass: counters yes, launch count no
+            e["ids"].add(r["Dispatch_Id"])
 res = {"workload": sys.argv[2], "source": sys.argv[4] if len(sys.argv) > 4 else None,
        "unit": "VALU wave-instructions per launch (SQ_INSTS_VALU summed over the device)", "kernels": {}}
 for k in sorted(acc):
