@@ -237,6 +237,10 @@ def main():
                     help="multi-GPU step scheme: graph = windows as a dependency graph, chains of windows per rank, one message per SAI "
                          "between ranks (default; bit-identical to one GPU); rows = row-sharded passes (exact); blocks = round 1's "
                          "contiguous window blocks + one all-reduce (scales, but not the reference's result)")
+    ap.add_argument("--bands", default="auto",
+                    help="several GPUs, fused job: spatial bands S (S teams of N / S ranks, each runs the window graph on a horizontal band of every "
+                         "SAI + halo, one all-gather stitches the result; PSNR within 1e-3 dB of one GPU, not bit-identical).  auto: "
+                         "lfbm5d_amd.core.auto_bands (1 up to the ranks the graph can keep busy); 1: the graph alone (bit-identical)")
     args = ap.parse_args()
 
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
@@ -328,6 +332,11 @@ def main():
               "ms_comm", "launches_group", "launches_aggregate", "lane_windows", "messages")
 
     fused = args.job in ("auto", "fused") and args.sharding == "graph"
+    bands = 1
+    if world > 1 and fused:
+        halo = max(pk[1] + pk[2] + pk[3] for pk in (wl["p1"], wl["p2"]))      # the library's default halo: nSim + nDisp + k of the wider step
+        bands = core.auto_bands(aw, ah, H, halo, world) if args.bands == "auto" else max(1, int(args.bands))
+        ctx.set_option("spatial_bands", bands)
 
     def one_step(acc=None, two_calls=False):
         """HT + Wiener; acc: {"ht": {...}, "wiener": {...}} accumulates the library's counters per step kind (the fused job's
@@ -506,7 +515,11 @@ def main():
                        "window_lanes": lanes_timed,
                        "job": ("fused: both steps as one dependency graph of windows (lfbm5d_denoise_device), bit-identical to the two calls"
                                if fused else "two calls: lfbm5d_step1_device, lfbm5d_step2_device"),
+                       "spatial_bands": bands,
                        "parallelism": ("single GPU" if world == 1 else
+                                       f"{bands} spatial bands (rows of every SAI + halo, stitched by one RCCL all-gather; PSNR within 1e-3 dB of one GPU, not "
+                                       f"bit-identical) x {world // bands} ranks per band on the dependency graph of both steps' angular windows (RCCL send/recv "
+                                       "of num/den per shared SAI and of each SAI's basic estimate to the ranks that read it)" if bands > 1 else
                                        f"{world} ranks x chains of angular windows (dependency graph" + (" of both steps" if fused else "") + "), RCCL send/recv of num/den per shared SAI"
                                        + (" and of each SAI's basic estimate to the ranks that read it" if fused else "") +
                                        ", final broadcast of the estimates; bit-identical to one GPU" if args.sharding == "graph" else

@@ -100,7 +100,8 @@ void* lfbm5d_stream(lfbm5d_ctx* ctx);
  * before the context exists still means three window lanes); afterwards they change only through lfbm5d_set_option -- no entry
  * point reads the environment, so two contexts of one process can run different settings.  Keys: "lanes" (window lanes of the
  * graph form, 1..8, default 2), "fused" (0: lfbm5d_denoise_* runs the two calls), "step_sharding" ("rows" / "blocks" / 0),
- * "max_windows", "emulate_world", "data_driven_schedule", "host_blocking", "band_mb", "bm3d_lanes"; test hooks that select
+ * "max_windows", "emulate_world", "data_driven_schedule", "host_blocking", "band_mb", "bm3d_lanes", "spatial_bands" / "band_halo"
+ * (several ranks, lfbm5d_denoise_*: teams of ranks denoise horizontal bands of every SAI, see the multi-GPU notes below); test hooks that select
  * between implementations of the same arithmetic ("scan_v1", "scan_any", "scan_full_tables", "dct8w_v2", "group_generic",
  * "no_sa_kernels", "no_slab_kernel", "wide_nosplit", "agg_64bit", "agg_scalar_scan", "subset_list_host", "subset_scan_v1",
  * "scan_lds_cap", "force_redo").  The old variable names ("LFBM5D_LANES" ...) are accepted as keys.  Values are spelled as the
@@ -128,6 +129,12 @@ int lfbm5d_get_option(lfbm5d_ctx* ctx, const char* key, char* value, unsigned lo
  * row-sharded as below (exact, two all-reduces per pass; also what greyscale light fields need); "blocks" = round 1's
  * contiguous blocks of windows per rank + ONE all-reduce per step, which scales with the rank count but is NOT the
  * reference's result (a rank's block matching only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks).
+ * Option "spatial_bands" = S > 1 (lfbm5d_denoise_* only) adds a level above the graph for rank counts beyond what the graph keeps
+ * busy: S teams of world / S ranks (rank = band * team size + team rank), team b runs the whole two-step job on rows
+ * [b H / S, (b + 1) H / S) of every SAI plus "band_halo" rows on either side (default nSim + nDisp + k of the wider step) as a
+ * light field of its own -- the same window graph, on a communicator split off for the team -- and ONE all-gather stitches the
+ * three light fields.  NOT bit-identical to one GPU (a band's distance tables start their float recurrences at its first row, near
+ * ties fall differently); PSNR within 1e-3 dB on 512 x 512 SAIs, a tenth of the +-0.01 dB the reference's own tile mode is held to.
  * Single core passes (lfbm5d_pass_device): the reference patches are sharded by rows over the ranks and
  * the window's num/den all-reduced.
  * Replaces the reference's only parallelism, the OpenMP tile loop + undivide_LF merge

@@ -203,6 +203,21 @@ def plan_job(awidth, aheight, world, lanes=1, an=(1, 1), cost=None, ang_major=No
                                                      "centre_ok": bool(cnt[3])}
 
 
+def auto_bands(awidth, aheight, height, halo, world):
+    """Spatial bands S for a two-step job on `world` ranks (option spatial_bands; tools/scale_model.py): the window graph of an
+    a x a light field keeps about 0.8 ceil(a / 3) ranks busy (its rows of windows, less the dependency stalls), a band costs
+    (H / S + 2 halo) / H of a pass -- so the graph takes the ranks it can use (a power of two) and bands take the rest, as long
+    as a band stays twice as tall as its halo.  1 = the graph alone (bit-identical to one GPU)."""
+    a = min(int(awidth), int(aheight))
+    t_max = 1
+    while t_max * 2 <= 0.8 * ((a + 2) // 3):
+        t_max *= 2
+    s = max(1, int(world) // min(int(world), t_max))
+    while s > 1 and (int(world) % s or int(height) // s < 2 * int(halo)):
+        s -= 1
+    return s
+
+
 def shard_rows(n_rows, rank, world):
     b, e = C.c_uint(), C.c_uint()
     lib().lfbm5d_shard_rows(n_rows, rank, world, C.byref(b), C.byref(e))
@@ -256,7 +271,7 @@ def _sai_ptrs(arrays, mask):
 # variables to lfbm5d_set_option before every library call (Context._h).
 OPTION_ENV = ("LFBM5D_LANES", "LFBM5D_EMULATE_WORLD", "LFBM5D_MAX_WINDOWS", "LFBM5D_FUSED", "LFBM5D_STEP_SHARDING",
               "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_HOST_BLOCKING", "LFBM5D_BAND_MB", "LFBM5D_BM3D_LANES", "LFBM5D_SCAN_LDS_CAP",
-              "LFBM5D_FORCE_REDO", "LFBM5D_SCAN_V1", "LFBM5D_SCAN_ANY", "LFBM5D_SCAN_FULL_TABLES", "LFBM5D_DCT8W_V2",
+              "LFBM5D_FORCE_REDO", "LFBM5D_SPATIAL_BANDS", "LFBM5D_BAND_HALO", "LFBM5D_SCAN_V1", "LFBM5D_SCAN_ANY", "LFBM5D_SCAN_FULL_TABLES", "LFBM5D_DCT8W_V2",
               "LFBM5D_GROUP_GENERIC", "LFBM5D_NO_SA_KERNELS", "LFBM5D_NO_SLAB_KERNEL", "LFBM5D_WIDE_NOSPLIT", "LFBM5D_AGG_64BIT",
               "LFBM5D_AGG_SCALAR_SCAN", "LFBM5D_SUBSET_LIST_HOST", "LFBM5D_SUBSET_SCAN_V1")
 

@@ -64,12 +64,14 @@ void lfbm5d_destroy(lfbm5d_ctx* c) {
     c->ipc_flags.release(); c->ipc_out.release(); c->pristine.release(); c->pristine_b.release();
     if (c->io_in) (void)hipStreamDestroy(c->io_in);
     if (c->io_out) (void)hipStreamDestroy(c->io_out);
+    if (c->team_comm2) ncclCommDestroy(c->team_comm2);
+    if (c->team_comm) ncclCommDestroy(c->team_comm);
     if (c->comm2) ncclCommDestroy(c->comm2);
     if (c->comm) ncclCommDestroy(c->comm);
     for (int i = 0; i < 2; i++) if (c->cs[i]) (void)hipStreamDestroy(c->cs[i]);
     for (GeomCache& g : c->gc) { g.refs.release(); g.rslot.release(); g.tb.release(); g.scan_wgs.release(); }
     DevBuf* bufs[] = {&c->est, &c->g_num2, &c->g_den2, &c->n2, &c->e_basic, &c->refmap, &c->scores, &c->tables, &c->self_idx, &c->self_cnt, &c->best,
-                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->sub_flags, &c->sub_cnt, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->sa_list, &c->gshape, &c->counters, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
+                      &c->t_noisy, &c->t_basic, &c->t_tnum, &c->t_tden, &c->und_num, &c->und_den, &c->sub_flags, &c->sub_cnt, &c->shape, &c->filt, &c->wgt, &c->aggpos, &c->gpos, &c->gofs, &c->gok, &c->sa_list, &c->gshape, &c->band_noisy, &c->band_basic, &c->band_out, &c->band_src, &c->band_pack, &c->band_gather, &c->counters, &c->small, &c->t_num, &c->t_den, &c->d_mask, &c->g_num, &c->g_den, &c->w_noisy,
                       &c->w_basic, &c->w_num, &c->w_den, &c->h2d_noisy, &c->h2d_basic, &c->h2d_out, &c->d_own, &c->gscratch, &c->scan_lcol};
     for (DevBuf* b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

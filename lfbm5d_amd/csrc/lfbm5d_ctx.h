@@ -128,6 +128,10 @@ struct lfbm5d_ctx {
     struct IpcPeer { unsigned char handle[7][64]; void* ptr[7]; };   /* flags, g_num[0..1], g_den[0..1], basic, out -- as this process maps them */
     std::vector<IpcPeer> ipc_peers;
     DevBuf pristine, pristine_b;
+    /* spatial bands (option spatial_bands, lfbm5d_steps.hip): a band's crop of the three light fields, the input as it arrived (emulated
+     * ranks), the all-gather's buffers; the communicators of this rank's team (split from comm once per band count) */
+    DevBuf band_noisy, band_basic, band_out, band_src, band_pack, band_gather;
+    ncclComm_t team_comm = nullptr, team_comm2 = nullptr; int team_S = 0;
     /* run-time options (lfbm5d_options.h): filled from the environment once at lfbm5d_create, changed by lfbm5d_set_option; lane contexts
      * point at their parent's */
     Options opt_store; Options* opt = &opt_store;

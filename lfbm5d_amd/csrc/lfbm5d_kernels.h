@@ -298,6 +298,8 @@ hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* d
 hipError_t launch_copy_rect(hipStream_t s, float* dst, size_t dst_stride, unsigned dW, unsigned dH, unsigned dx0, unsigned dy0,
                             const float* src, size_t src_stride, unsigned sW, unsigned sH, unsigned sx0, unsigned sy0,
                             unsigned w, unsigned h, unsigned C, unsigned n_slots, const SaiMask& mask_bits);
+hipError_t launch_copy_rows(hipStream_t s, const float* src, unsigned src_H, unsigned src_row0, float* dst, unsigned dst_H, unsigned dst_row0,
+                            unsigned n_rows, unsigned W, unsigned planes);
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n);
 hipError_t launch_fill_i32(hipStream_t s, int* p, int v, size_t n);
 hipError_t launch_add(hipStream_t s, float* dst, const float* src, size_t n);   /* dst += src */

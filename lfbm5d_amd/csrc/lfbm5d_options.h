@@ -49,6 +49,9 @@ struct Options {
     int bm3d_lanes = 3;             /* SAIs of LFBM3Ddenoising processed concurrently */
     int scan_lds_cap = 0;           /* > 0: LDS bytes the first-generation table kernel may use */
     int force_redo = 0;             /* test hook: treat the graph as incomplete once (exercises the sequential redo) */
+    int spatial_bands = 1;          /* S > 1, several ranks, lfbm5d_denoise_*: S teams of ranks, each denoises a horizontal band of every SAI (+ halo) on its own
+                                     * window graph; NOT bit-identical to one GPU, PSNR within 1e-3 dB (lfbm5d_steps.hip) */
+    int band_halo = 0;              /* rows of halo of a band; 0: nSim + nDisp + k of the wider step */
     unsigned kernels = 0;           /* kOpt* bits: kernel-generation selectors */
 };
 
@@ -62,7 +65,8 @@ inline const OptionKey* option_keys(size_t* n) {
         {"data_driven_schedule", "LFBM5D_DATA_DRIVEN_SCHEDULE", &Options::data_driven_schedule, 0},
         {"host_blocking", "LFBM5D_HOST_BLOCKING", &Options::host_blocking, 0}, {"band_mb", "LFBM5D_BAND_MB", &Options::band_mb, 0},
         {"bm3d_lanes", "LFBM5D_BM3D_LANES", &Options::bm3d_lanes, 0}, {"scan_lds_cap", "LFBM5D_SCAN_LDS_CAP", &Options::scan_lds_cap, 0},
-        {"force_redo", "LFBM5D_FORCE_REDO", &Options::force_redo, 0},
+        {"force_redo", "LFBM5D_FORCE_REDO", &Options::force_redo, 0}, {"spatial_bands", "LFBM5D_SPATIAL_BANDS", &Options::spatial_bands, 0},
+        {"band_halo", "LFBM5D_BAND_HALO", &Options::band_halo, 0},
         {"scan_v1", "LFBM5D_SCAN_V1", nullptr, kOptScanV1}, {"scan_any", "LFBM5D_SCAN_ANY", nullptr, kOptScanAny},
         {"scan_full_tables", "LFBM5D_SCAN_FULL_TABLES", nullptr, kOptScanFullTables}, {"dct8w_v2", "LFBM5D_DCT8W_V2", nullptr, kOptDct8wV2},
         {"group_generic", "LFBM5D_GROUP_GENERIC", nullptr, kOptGroupGeneric}, {"no_sa_kernels", "LFBM5D_NO_SA_KERNELS", nullptr, kOptNoSaKernels},

@@ -463,9 +463,9 @@ int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, co
  * forward colour transform: bm5d.cpp:405, :711-714, :827-830) happens SAI by SAI.  Bit-identical to the two calls.  Light fields
  * the graph form does not cover (greyscale, an empty SAI at a window centre, tile mode, the data-driven schedule, the
  * alternative multi-GPU schemes) take the two calls. */
-int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask, float* d_basic,
-                float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
-                unsigned C, const HostIO* io) {
+static int run_denoise_whole(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask, float* d_basic,
+                             float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
+                             unsigned C, const HostIO* io) {
     const unsigned asize = awidth * aheight;
     const int emu = c->opt->emulate_world;
     const int n_lanes = std::max(1, std::min(8, c->opt->lanes));
@@ -555,6 +555,154 @@ int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2,
         HIPCK(c, launch_color_lf(s, d_noisy, img, asize, d_mask, P1->color_space, W * H, 0));
     }
     HIPCK(c, hipStreamSynchronize(s));
+    return io ? io_download_all(c, io, h_mask, asize, img, d_noisy, d_basic, d_out) : 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Spatial bands (round 6, option spatial_bands = S): the ranks form S teams, team b denoises the horizontal BAND b of every SAI --
+ * its H / S rows plus a halo (option band_halo; default nSim + nDisp + k of the wider step) -- as a complete two-step job of its
+ * own on the window graph of its world / S ranks, and the bands' interiors are stitched.  The reference's tile mode
+ * (bm5d.cpp:411-708, undivide_LF) is the same idea with OpenMP tiles; here a band is a whole-width strip, there are few of them,
+ * and inside a band everything is the untiled algorithm.
+ *
+ * Why: the window graph alone stops at the light field's dependency chains (8 ranks: 4.2x on 17x17 SAIs, 3.2x on 15x15, 2.0x on
+ * 9x9: tools/scale_model.py) and a window pass cannot be shared exactly -- the table kernel's recurrence is serial in rows
+ * (DESIGN.md section 7).  A band's tables start their recurrence at the band's first row, so its distances differ from the
+ * whole image's in the last bits, a fraction of a per cent of the matches differ, and pixels decorrelate exactly as they do
+ * between this library and the CPU oracle (profiles/r06_d_near_tie_tail.txt): the result is NOT bit-identical to one GPU.  What
+ * was measured instead (tools/band_accuracy.py, profiles/r06_i_band_accuracy.txt): the stitched light field's PSNR is within
+ * 1e-3 dB of the whole-field job's for halos of 40 ... 96 rows -- a tenth of BASELINE.json's tolerance.  Off by default.
+ * ------------------------------------------------------------------------------------------ */
+struct BandRows { unsigned y0, y1, c0, c1; };   /* the band's own rows [y0, y1), the rows it is computed on [c0, c1) */
+static BandRows band_rows(unsigned H, int S, int b, unsigned halo) {
+    BandRows r;
+    r.y0 = (unsigned)((unsigned long long)H * (unsigned)b / (unsigned)S); r.y1 = (unsigned)((unsigned long long)H * (unsigned)(b + 1) / (unsigned)S);
+    r.c0 = r.y0 > halo ? r.y0 - halo : 0u; r.c1 = std::min(H, r.y1 + halo);
+    return r;
+}
+
+static int run_denoise_banded(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask, float* d_basic,
+                              float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
+                              unsigned C, int S) {
+    const unsigned asize = awidth * aheight, planes = asize * C;
+    const int emu = c->opt->emulate_world, nranks = emu > 1 ? emu : c->world, T = nranks / S;
+    const unsigned halo = c->opt->band_halo > 0 ? (unsigned)c->opt->band_halo
+                                                : std::max(P1->nSim + P1->nDisp + P1->k, P2->nSim + P2->nDisp + P2->k);
+    hipStream_t s = c->stream;
+    unsigned Hc_max = 0;
+    for (int b = 0; b < S; b++) { const BandRows r = band_rows(H, S, b, halo); Hc_max = std::max(Hc_max, r.c1 - r.c0); }
+    const size_t crop_bytes = (size_t)planes * Hc_max * W * sizeof(float);
+    HIPCK(c, c->band_noisy.reserve(crop_bytes)); HIPCK(c, c->band_basic.reserve(crop_bytes)); HIPCK(c, c->band_out.reserve(crop_bytes));
+    float* const bn = c->band_noisy.as<float>(); float* const bb = c->band_basic.as<float>(); float* const bo = c->band_out.as<float>();
+    auto job_on_band = [&](const float* src_noisy, const BandRows& r) -> int {
+        const unsigned Hc = r.c1 - r.c0;
+        HIPCK(c, launch_copy_rows(s, src_noisy, H, r.c0, bn, Hc, 0, Hc, W, planes));
+        return run_denoise_whole(c, P1, P2, bn, h_mask, bb, bo, ang_major, awidth, aheight, an1, an2, W, Hc, C, nullptr);
+    };
+    auto interior_back = [&](const BandRows& r) -> int {   /* the band's own rows of the three outputs into the caller's light fields */
+        const unsigned Hc = r.c1 - r.c0, n = r.y1 - r.y0, o = r.y0 - r.c0;
+        HIPCK(c, launch_copy_rows(s, bn, Hc, o, d_noisy, H, r.y0, n, W, planes));
+        HIPCK(c, launch_copy_rows(s, bb, Hc, o, d_basic, H, r.y0, n, W, planes));
+        HIPCK(c, launch_copy_rows(s, bo, Hc, o, d_out, H, r.y0, n, W, planes));
+        return 0;
+    };
+    if (emu > 1) {
+        /* every rank played on this GPU: band after band, each as a job of T emulated ranks; the bands are cut from the light field
+         * as it arrived (a band's halo lies in its neighbour's rows, which the neighbour's outputs overwrite) */
+        HIPCK(c, c->band_src.reserve((size_t)planes * H * W * sizeof(float)));
+        HIPCK(c, hipMemcpyAsync(c->band_src.p, d_noisy, (size_t)planes * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+        struct EmuScope { Options* o; int saved; ~EmuScope() { o->emulate_world = saved; } } scope{c->opt, c->opt->emulate_world};
+        c->opt->emulate_world = T > 1 ? T : 0;
+        for (int b = 0; b < S; b++) {
+            const BandRows r = band_rows(H, S, b, halo);
+            if (job_on_band(c->band_src.as<float>(), r)) return 1;
+            if (interior_back(r)) return 1;
+        }
+        HIPCK(c, hipStreamSynchronize(s));
+        return 0;
+    }
+    /* real ranks: rank = band * T + team rank.  The team gets communicators of its own (split once, kept), the job runs on them,
+     * then ONE all-gather over all ranks stitches the light fields: every member of a team holds its band's whole result, so
+     * member t contributes the t-th share of the band's rows -- equal chunks, every byte sent once. */
+    if (c->ipc) return fail(c, "spatial bands need RCCL ranks (the IPC test transport has no teams)");
+    if (!c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
+    const int band = c->rank / T, trank = c->rank % T;
+    if (c->team_S != S) {
+        if (c->team_comm2) { (void)ncclCommDestroy(c->team_comm2); c->team_comm2 = nullptr; }
+        if (c->team_comm) { (void)ncclCommDestroy(c->team_comm); c->team_comm = nullptr; }
+        if (ncclCommSplit(c->comm, band, trank, &c->team_comm, nullptr) != ncclSuccess) return fail(c, "ncclCommSplit (band team) failed");
+        if (T > 1 && ncclCommSplit(c->team_comm, 0, trank, &c->team_comm2, nullptr) != ncclSuccess) c->team_comm2 = nullptr;
+        c->team_S = S;
+    }
+    const BandRows r = band_rows(H, S, band, halo);
+    int rc;
+    {
+        struct TeamScope {   /* the team's communicators and numbering stand in for the context's while its job runs */
+            lfbm5d_ctx* c; ncclComm_t g1, g2; int rank, world;
+            ~TeamScope() {
+                /* run_graph aborts the communicators it ran on when it fails: those were the team's */
+                if (!c->comm) { c->team_comm = nullptr; c->team_comm2 = nullptr; c->team_S = 0; } else { c->team_comm = c->comm; c->team_comm2 = c->comm2; }
+                c->comm = g1; c->comm2 = g2; c->rank = rank; c->world = world;
+            }
+        } scope{c, c->comm, c->comm2, c->rank, c->world};
+        c->comm = c->team_comm; c->comm2 = c->team_comm2; c->rank = trank; c->world = T;
+        rc = job_on_band(d_noisy, r);
+    }
+    if (rc) {   /* the other teams wait in the all-gather below: take the whole job down, like run_graph does for its exchange */
+        if (c->comm2) { (void)ncclCommAbort(c->comm2); c->comm2 = nullptr; }
+        if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+        c->team_S = 0;
+        c->err += " (banded job aborted: the RCCL communicators of this context were torn down, call lfbm5d_comm_init again)";
+        return 1;
+    }
+    if (interior_back(r)) return 1;
+    const unsigned rows_band_max = (H + (unsigned)S - 1) / (unsigned)S, chunk_rows = (rows_band_max + (unsigned)T - 1) / (unsigned)T;
+    const size_t chunk_floats = (size_t)3 * planes * chunk_rows * W;
+    HIPCK(c, c->band_pack.reserve(chunk_floats * sizeof(float)));
+    HIPCK(c, c->band_gather.reserve(chunk_floats * sizeof(float) * (size_t)nranks));
+    auto chunk_of = [&](int rk, unsigned& ya, unsigned& n) {
+        const BandRows q = band_rows(H, S, rk / T, halo);
+        ya = std::min(q.y1, q.y0 + (unsigned)(rk % T) * chunk_rows);
+        n = std::min(q.y1, ya + chunk_rows) - ya;
+    };
+    float* const lf[3] = {d_noisy, d_basic, d_out};
+    {
+        unsigned ya, n; chunk_of(c->rank, ya, n);
+        for (int i = 0; i < 3; i++)
+            HIPCK(c, launch_copy_rows(s, lf[i], H, ya, c->band_pack.as<float>() + (size_t)i * planes * chunk_rows * W, chunk_rows, 0, n, W, planes));
+    }
+    hipEvent_t e0 = get_event(c), e1 = get_event(c);
+    HIPCK(c, hipEventRecord(e0, s));
+    if (ncclAllGather(c->band_pack.p, c->band_gather.p, chunk_floats, ncclFloat, c->comm, s) != ncclSuccess) return fail(c, "ncclAllGather of the bands failed");
+    HIPCK(c, hipEventRecord(e1, s));
+    for (int rk = 0; rk < nranks; rk++) {
+        if (rk / T == band) continue;   /* this team's rows are in place */
+        unsigned ya, n; chunk_of(rk, ya, n);
+        for (int i = 0; i < 3; i++)
+            HIPCK(c, launch_copy_rows(s, c->band_gather.as<float>() + (size_t)rk * chunk_floats + (size_t)i * planes * chunk_rows * W, chunk_rows, 0,
+                                      lf[i], H, ya, n, W, planes));
+    }
+    HIPCK(c, hipStreamSynchronize(s));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->stats.ms_comm += ms;
+    return 0;
+}
+
+/* lfbm5d_denoise_*: the whole light field as one job (the default), or band by band (option spatial_bands) */
+int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask, float* d_basic,
+                float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
+                unsigned C, const HostIO* io) {
+    const int S = c->opt->spatial_bands;
+    const int emu = c->opt->emulate_world, nranks = emu > 1 ? emu : c->world;
+    if (S <= 1 || nranks <= 1) return run_denoise_whole(c, P1, P2, d_noisy, h_mask, d_basic, d_out, ang_major, awidth, aheight, an1, an2, W, H, C, io);
+    if (nranks % S) return fail(c, "spatial_bands must divide the number of ranks");
+    const unsigned halo = c->opt->band_halo > 0 ? (unsigned)c->opt->band_halo : std::max(P1->nSim + P1->nDisp + P1->k, P2->nSim + P2->nDisp + P2->k);
+    if (H / (unsigned)S < std::max(halo, 2 * std::max(P1->k, P2->k))) return fail(c, "spatial_bands: the bands would be narrower than their halo");
+    if (c->tiles > 1) return fail(c, "spatial bands and the tile mode exclude each other");
+    const unsigned asize = awidth * aheight;
+    const size_t img = (size_t)C * W * H;
+    if (io && io_upload_all(c, io, h_mask, asize, img, d_noisy, nullptr)) return 1;
+    if (run_denoise_banded(c, P1, P2, d_noisy, h_mask, d_basic, d_out, ang_major, awidth, aheight, an1, an2, W, H, C, S)) return 1;
     return io ? io_download_all(c, io, h_mask, asize, img, d_noisy, d_basic, d_out) : 0;
 }
 

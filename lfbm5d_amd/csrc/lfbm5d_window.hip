@@ -222,6 +222,15 @@ __global__ void k_copy_rect(float* __restrict__ dst, size_t dst_stride, int dW, 
     dst[blockIdx.y * dst_stride + ((size_t)c * dH + dy0 + y) * dW + dx0 + x] =
         src[blockIdx.y * src_stride + ((size_t)c * sH + sy0 + y) * sW + sx0 + x];
 }
+/* rows [src_row0, src_row0 + n_rows) of every plane of `src` (planes of src_H rows) to rows dst_row0 ... of `dst` (planes of dst_H rows):
+ * the crop of a light field to a horizontal band and back (spatial bands, lfbm5d_steps.hip) */
+__global__ void k_copy_rows(const float* __restrict__ src, unsigned src_H, unsigned src_row0, float* __restrict__ dst, unsigned dst_H,
+                            unsigned dst_row0, unsigned n_rows, unsigned W) {
+    const size_t n = (size_t)n_rows * W;
+    const float* sp = src + ((size_t)blockIdx.y * src_H + src_row0) * W;
+    float* dp = dst + ((size_t)blockIdx.y * dst_H + dst_row0) * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dp[i] = sp[i];
+}
 __global__ void k_fill_f32(float* p, float v, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -453,6 +462,14 @@ hipError_t launch_estimate_multi(hipStream_t s, const float* num, const float* d
 }
 hipError_t launch_estimate(hipStream_t s, const float* num, const float* den, const float* sub, float* est, size_t n) {
     hipLaunchKernelGGL(k_estimate, grid1d(n), dim3(256), 0, s, num, den, sub, est, n);
+    return hipGetLastError();
+}
+hipError_t launch_copy_rows(hipStream_t s, const float* src, unsigned src_H, unsigned src_row0, float* dst, unsigned dst_H, unsigned dst_row0,
+                            unsigned n_rows, unsigned W, unsigned planes) {
+    if (!n_rows || !planes) return hipSuccess;
+    const size_t n = (size_t)n_rows * W;
+    const unsigned gx = (unsigned)std::min<size_t>(256, (n + 1023) / 1024);
+    hipLaunchKernelGGL(k_copy_rows, dim3(gx, planes), dim3(256), 0, s, src, src_H, src_row0, dst, dst_H, dst_row0, n_rows, W);
     return hipGetLastError();
 }
 hipError_t launch_fill_f32(hipStream_t s, float* p, float v, size_t n) {

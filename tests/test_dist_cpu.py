@@ -76,28 +76,19 @@ def _window_cover(aw, ah, pst):
     return [(s0 + s) * aw + (t0 + t) for s in range(3) for t in range(3)], (ps - s0) * 3 + (pt - t0)
 
 
-def _graph_worker(rank, world, port, q, n_steps):
-    """One rank of the graph form of a job (one step, or both steps as lfbm5d_denoise_* runs them), with the oracle's core
-    pass standing in for the device kernels and gloo send / recv for RCCL's: the rank walks the nodes of lfbm5d_plan_job in
-    ISSUE ORDER, runs the windows it owns on num / den (and a basic estimate) of its own, and handles the messages in their
-    issue order -- sums of a shared SAI between consecutive touchers, basic estimates from the rank that finalised them."""
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    os.environ["OMP_NUM_THREADS"] = "2"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _graph_job(noisy, ah, aw, H, W, pks, team, me, group):
+    """One rank's part of the graph form of a job on the light field `noisy` (A x C*H*W): the oracle's core pass stands in for the
+    device kernels and gloo send / recv for RCCL's.  `team` = the global ranks that share the job (plan rank i = team[i]), `me` =
+    this rank's index in it, `group` = their process group (None: the world).  The rank walks the nodes of lfbm5d_plan_job in
+    ISSUE ORDER, runs the windows it owns on num / den (and a basic estimate) of its own, and handles the messages in their issue
+    order -- sums of a shared SAI between consecutive touchers, basic estimates from the rank that finalised them.  Returns the
+    last step's estimate and the basic estimate (both inverse colour-transformed, complete on every rank of the team) and counters."""
     import helpers as Hh
     from oracle import oracle as O
     from lfbm5d_amd import core
     lib = O.lib()
-    # two rows of windows for two ranks, three for three
-    ah, aw = (5, 7) if world == 2 else (7, 11)
-    H, W, Cc, sigma = 40, 40, 3, 25.0
-    pks = [(4, 5, 2, 8, 4, "id", "sadct", "haar"), (8, 4, 2, 8, 3, "dct", "sadct", "haar")][:n_steps]
+    n_steps, world, Cc, sigma = len(pks), len(team), 3, 25.0
     A = ah * aw
-    clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, H, W), sigma)
-    mask = np.ones(A, np.uint32)
     nodes, msgs, info = core.plan_job(aw, ah, world, 1, an=(1,) * n_steps)
     order = np.argsort(nodes[:, 6])
     assert sorted(nodes[:, 6].tolist()) == list(range(len(nodes)))
@@ -125,7 +116,7 @@ def _graph_worker(rank, world, port, q, n_steps):
     n_sent = n_recv = 0
     for i in order:
         sl, pst, r = int(nodes[i][0]), int(nodes[i][2]), int(nodes[i][3])
-        if r == rank:
+        if r == me:
             pk = pks[sl]
             nHW = pk[1] + pk[2]
             Wb, Hb = W + 2 * nHW, H + 2 * nHW
@@ -153,13 +144,13 @@ def _graph_worker(rank, world, port, q, n_steps):
             if kind == 0:
                 assert int(nodes[to_node][3]) == to_rank != r and int(nodes[to_node][0]) == sl
             bufs = [num[sl][st], den[sl][st]] if kind == 0 else [basic[st]]
-            if r == rank:
+            if r == me:
                 for bf in bufs:
-                    dist.send(torch.from_numpy(bf), to_rank)
+                    dist.send(torch.from_numpy(bf), team[to_rank], group=group)
                 n_sent += 1
-            elif to_rank == rank:
+            elif to_rank == me:
                 for bf in bufs:
-                    dist.recv(torch.from_numpy(bf), r)
+                    dist.recv(torch.from_numpy(bf), team[r], group=group)
                 n_recv += 1
     assert mi == len(msgs)
     # every SAI's final sums live on the rank of the last window that touched it; basic estimates where they were finalised
@@ -167,25 +158,134 @@ def _graph_worker(rank, world, port, q, n_steps):
     est = np.zeros_like(lf[0])
     for st in range(A):
         owner = int(nodes[last[ls][st]][3])
-        if owner == rank:
+        if owner == me:
             sub = lf[0][st] if ls == 0 else basic[st]
             est[st] = np.where(den[ls][st] != 0, num[ls][st] / np.where(den[ls][st] != 0, den[ls][st], 1), sub)
-        dist.broadcast(torch.from_numpy(est[st]), owner)
+        dist.broadcast(torch.from_numpy(est[st]), team[owner], group=group)
         lib.orc_color_transform(est[st], O.OPP, W, H, Cc, 0)
         if n_steps == 2:
-            dist.broadcast(torch.from_numpy(basic[st]), int(nodes[last[0][st]][3]))
+            dist.broadcast(torch.from_numpy(basic[st]), team[int(nodes[last[0][st]][3])], group=group)
             lib.orc_color_transform(basic[st], O.OPP, W, H, Cc, 0)
+    return est, basic, dict(plan=plan, n_win=int(sum(1 for n in nodes if n[3] == me)), n_sent=n_sent, n_recv=n_recv, n_msgs=len(msgs))
+
+
+def _graph_worker(rank, world, port, q, n_steps):
+    """One rank of the graph form of a job (one step, or both steps as lfbm5d_denoise_* runs them) over the whole world: see _graph_job."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import helpers as Hh
+    from oracle import oracle as O
+    # two rows of windows for two ranks, three for three
+    ah, aw = (5, 7) if world == 2 else (7, 11)
+    H, W, Cc, sigma = 40, 40, 3, 25.0
+    pks = [(4, 5, 2, 8, 4, "id", "sadct", "haar"), (8, 4, 2, 8, 3, "dct", "sadct", "haar")][:n_steps]
+    clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, H, W), sigma)
+    mask = np.ones(ah * aw, np.uint32)
+    est, basic, info = _graph_job(noisy, ah, aw, H, W, pks, list(range(world)), rank, None)
     # the single-process oracle (data-driven windows, one rank): the two reference calls one after the other
     n_o, b_o, st1 = O.run_step1(O.make_params(sigma, 2.7, *pks[0]), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
-    same_plan = bool(np.array_equal(O.last_windows(), plan))
+    same_plan = bool(np.array_equal(O.last_windows(), info["plan"]))
     if n_steps == 1:
         ok = bool(np.array_equal(est, b_o)); err = float(np.abs(est - b_o).max())
     else:
         _, b2_o, d_o, _ = O.run_step2(O.make_params(sigma, 2.7, *pks[1]), n_o, b_o, mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
         ok = bool(np.array_equal(est, d_o) and np.array_equal(basic, b2_o)); err = float(max(np.abs(est - d_o).max(), np.abs(basic - b2_o).max()))
-    q.put((rank, ok, err, int(sum(1 for n in nodes if n[3] == rank)), n_sent, n_recv, len(msgs), same_plan))
+    q.put((rank, ok, err, info["n_win"], info["n_sent"], info["n_recv"], info["n_msgs"], same_plan))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _banded_worker(rank, world, port, q):
+    """Spatial bands x window graph (option spatial_bands, lfbm5d_steps.hip run_denoise_banded) on four gloo ranks: two teams of two.
+    Team b runs the two-step job on band b of every SAI (its rows + a halo) as a graph job of its own on a process group of its own
+    (_graph_job); then ONE all-gather over the world stitches the light fields, member t of a team contributing the t-th share of
+    its band's rows -- the exchange run_denoise_banded does with ncclAllGather."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import helpers as Hh
+    from oracle import oracle as O
+    S, T = 2, world // 2
+    groups = [dist.new_group(list(range(b * T, (b + 1) * T))) for b in range(S)]   # (every rank creates every group)
+    ah, aw, H, W, Cc, sigma = 5, 7, 96, 40, 3, 25.0
+    pks = [(4, 5, 2, 8, 4, "id", "sadct", "haar"), (8, 4, 2, 8, 3, "dct", "sadct", "haar")]
+    # halo: at least nSim + nDisp + k of the wider step (the library's default), rounded up so that a band's first row keeps the
+    # phase of BOTH steps' reference grids (p = 4 and 3): the band then processes the reference patches the whole field does
+    halo = 24
+    assert halo >= max(pk[1] + pk[2] + pk[3] for pk in pks) and (H // S - halo) % 12 == 0
+    A = ah * aw
+    clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, H, W), sigma)
+    mask = np.ones(A, np.uint32)
+    band, t = rank // T, rank % T
+    y0, y1 = band * H // S, (band + 1) * H // S
+    c0, c1 = max(0, y0 - halo), min(H, y1 + halo)
+    img = lambda a, h: a.reshape(A, Cc, h, W)
+    crop = np.ascontiguousarray(img(noisy, H)[:, :, c0:c1, :]).reshape(A, -1)
+    est_c, basic_c, info = _graph_job(crop, ah, aw, c1 - c0, W, pks, list(range(band * T, (band + 1) * T)), t, groups[band])
+    # inside a team the graph is exact: the band's job equals the single-process oracle on the same crop, bit for bit
+    n_o, b_o, _ = O.run_step1(O.make_params(sigma, 2.7, *pks[0]), crop.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, c1 - c0, Cc)
+    _, b2_o, d_o, _ = O.run_step2(O.make_params(sigma, 2.7, *pks[1]), n_o, b_o, mask, O.ROWMAJOR, aw, ah, 1, W, c1 - c0, Cc)
+    team_exact = bool(np.array_equal(est_c, d_o) and np.array_equal(basic_c, b2_o))
+    # the all-gather: equal chunks of rows, rank order = (band, member)
+    rows = (H + S - 1) // S
+    chunk = (rows + T - 1) // T
+    ya = min(y1, y0 + t * chunk)
+    n = min(y1, ya + chunk) - ya
+    send = np.zeros((2, A, Cc, chunk, W), np.float32)
+    send[0, :, :, :n] = img(est_c, c1 - c0)[:, :, ya - c0:ya - c0 + n]
+    send[1, :, :, :n] = img(basic_c, c1 - c0)[:, :, ya - c0:ya - c0 + n]
+    parts = [torch.zeros(send.shape) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(send))
+    den_all, bas_all = np.zeros((A, Cc, H, W), np.float32), np.zeros((A, Cc, H, W), np.float32)
+    for rk in range(world):
+        b_, t_ = rk // T, rk % T
+        q0, q1 = b_ * H // S, (b_ + 1) * H // S
+        a_ = min(q1, q0 + t_ * chunk)
+        m = min(q1, a_ + chunk) - a_
+        den_all[:, :, a_:a_ + m] = parts[rk].numpy()[0, :, :, :m]
+        bas_all[:, :, a_:a_ + m] = parts[rk].numpy()[1, :, :, :m]
+    # against the whole-field single-process result: not bit-identical (a band's tables start their recurrence at its first row),
+    # PSNR within BASELINE.json's tolerance
+    n_w, b_w, _ = O.run_step1(O.make_params(sigma, 2.7, *pks[0]), noisy.copy(), mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
+    _, b2_w, d_w, _ = O.run_step2(O.make_params(sigma, 2.7, *pks[1]), n_w, b_w, mask, O.ROWMAJOR, aw, ah, 1, W, H, Cc)
+    ps = lambda x: O.psnr_lf(x.reshape(A, -1), clean)
+    q.put((rank, team_exact, ps(den_all) - ps(d_w), ps(bas_all) - ps(b2_w), float(np.abs(den_all.reshape(A, -1) - d_w).mean()), info["n_win"], info["n_sent"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_spatial_bands_times_window_graph_on_four_ranks():
+    """2 bands x 2-rank window graph on gloo world-4 (the round-5 review's item 3): every team's job is bit-identical to the
+    single-process oracle on its crop, every rank ends with the same stitched light field, all four ranks own windows and the
+    teams exchange messages.  Against the whole-field result the stitched field is NOT bit-identical, at any halo: a band's
+    distance tables start their float recurrences at its first row, near-tie matches and threshold decisions re-roll, and later
+    windows build on them (with halo 48 = 2 (2 nHW + k), beyond the reach of both steps' border effects, the 144 x 40 field still
+    differs by 0.11 grey levels on average).  The PSNR moves by the noise of the sample: +-0.03 dB on these 35 x 96 x 40 pixels
+    (bound here 0.05 dB, mean |difference| 0.5 grey levels); on the device at 512 x 512 the same comparison holds 0.01 dB with
+    room (tests/test_gpu_denoise.py test_spatial_bands_stay_within_the_psnr_tolerance: < 1e-3 dB measured)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_banded_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res                                  # team jobs exact on their crops
+    assert all(abs(r[2]) < 0.05 and abs(r[3]) < 0.05 and r[4] < 0.5 for r in res), res   # stitched PSNR, denoised and basic; mean |difference|
+    assert len({(round(r[2], 9), round(r[3], 9), round(r[4], 9)) for r in res}) == 1   # every rank ends with the same light fields
+    assert all(r[5] > 0 for r in res) and sum(r[6] for r in res) > 0    # all four ranks own windows; messages travel inside the teams
 
 
 @pytest.mark.parametrize("world,n_steps", [(2, 1), (3, 1), (2, 2), (3, 2)])

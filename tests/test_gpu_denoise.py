@@ -208,3 +208,55 @@ def test_seeded_sweep_of_job_configurations():
                        env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "12 of 12 cases identical" in r.stdout
+
+
+def test_spatial_bands_stay_within_the_psnr_tolerance(ctx, monkeypatch):
+    """Option spatial_bands (round 6): S teams of ranks, each denoises a horizontal band of every SAI plus a halo as a job of its own
+    on the window graph of its ranks, interiors stitched -- played on this GPU through the emulated-rank form.  A band's distance
+    tables start their recurrence at the band's first row, so matches within float round-off differ and the result is NOT
+    bit-identical to one rank; what must hold is BASELINE.json's bar: PSNR against the clean light field within 0.01 dB of the
+    whole-field job (measured at full size: 1e-3 dB, profiles/r06_i_band_accuracy.txt), no seam at the cuts, and the rows far
+    above the first cut -- whose recurrences share their history with the whole image's -- close to the whole-field result."""
+    import lfbm5d_amd as L
+    from lfbm5d_amd import core
+    ah, aw, Hs, Ws = 5, 7, 160, 96
+    clean, noisy = Hh.noisy_lf(Hh.textured_lf(ah, aw, Hs, Ws), 25.0)
+    mask = np.ones(ah * aw, np.uint32)
+    P1 = core.make_params(25.0, 2.7, 4, 6, 2, 8, 4, "id", "sadct", "haar")
+    P2 = core.make_params(25.0, 2.7, 8, 6, 2, 8, 4, "dct", "sadct", "haar")
+    for k in ENV:
+        monkeypatch.delenv(k, raising=False)
+    n0, b0, d0, w0, s0 = _one_job(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+    p_b0, p_d0 = O.psnr_lf(b0, clean), O.psnr_lf(d0, clean)
+    img = lambda a: a.reshape(ah * aw, 3, Hs, Ws)
+    try:
+        for emu, S in ((2, 2), (4, 2), (4, 4)):
+            ctx.set_option("emulate_world", emu)
+            ctx.set_option("spatial_bands", S)
+            n1, b1, d1, w1, s1 = _one_job(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+            assert s1.windows == S * len(w0)                                  # every band ran the whole schedule
+            assert abs(O.psnr_lf(b1, clean) - p_b0) < 0.01 and abs(O.psnr_lf(d1, clean) - p_d0) < 0.01, (emu, S)
+            assert np.isfinite(d1).all() and np.isfinite(b1).all() and np.isfinite(n1).all()
+            # LF_noisy comes back colour-round-tripped row by row exactly as from one rank (no matching involved)
+            assert np.abs(n1 - n0).max() < 1e-3
+            # no seam: the rows either side of a cut differ from the whole-field result no more than rows elsewhere do
+            diff = np.abs(img(d1) - img(d0)).mean(axis=(0, 1, 3))             # per image row
+            for b in range(1, S):
+                y = b * Hs // S
+                assert diff[y - 2:y + 2].max() < 4 * max(np.median(diff), 1e-3), (emu, S, y)
+            # band 0 shares the top of the image with the whole-field job: its first rows agree closely
+            assert diff[:8].mean() < 0.05
+    finally:
+        ctx.set_option("emulate_world", None)
+        ctx.set_option("spatial_bands", None)
+    # a band count that does not divide the ranks is refused, one rank ignores the option
+    ctx.set_option("spatial_bands", 2)
+    try:
+        n2, b2, d2, _, _ = _one_job(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+        assert np.array_equal(d2, d0) and np.array_equal(b2, b0)
+        ctx.set_option("emulate_world", 3)
+        with pytest.raises(L.LfBm5dError, match="divide"):
+            _one_job(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+    finally:
+        ctx.set_option("emulate_world", None)
+        ctx.set_option("spatial_bands", None)
