@@ -19,7 +19,7 @@ def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     H = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     W = H
-    sigma = 25.0
+    sigma = float(os.environ.get("PASS_TIME_SIGMA", "25"))
     lf = synth.make_lf(3, 3, H, W).reshape(9, 3, H, W).astype(np.float32)
     rng = np.random.default_rng(1)
     lf += sigma * rng.standard_normal(lf.shape).astype(np.float32)
