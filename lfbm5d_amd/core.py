@@ -273,7 +273,7 @@ OPTION_ENV = ("LFBM5D_LANES", "LFBM5D_EMULATE_WORLD", "LFBM5D_MAX_WINDOWS", "LFB
               "LFBM5D_DATA_DRIVEN_SCHEDULE", "LFBM5D_HOST_BLOCKING", "LFBM5D_BAND_MB", "LFBM5D_BM3D_LANES", "LFBM5D_SCAN_LDS_CAP",
               "LFBM5D_FORCE_REDO", "LFBM5D_SPATIAL_BANDS", "LFBM5D_BAND_HALO", "LFBM5D_SCAN_V1", "LFBM5D_SCAN_ANY", "LFBM5D_SCAN_FULL_TABLES", "LFBM5D_DCT8W_V2",
               "LFBM5D_GROUP_GENERIC", "LFBM5D_NO_SA_KERNELS", "LFBM5D_NO_SLAB_KERNEL", "LFBM5D_WIDE_NOSPLIT", "LFBM5D_AGG_64BIT",
-              "LFBM5D_AGG_SCALAR_SCAN", "LFBM5D_SUBSET_LIST_HOST", "LFBM5D_SUBSET_SCAN_V1")
+              "LFBM5D_AGG_SCALAR_SCAN", "LFBM5D_SUBSET_LIST_HOST", "LFBM5D_SUBSET_SCAN_V1", "LFBM5D_FILT_GROUP_MAJOR")
 
 
 class Context:

@@ -97,11 +97,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
     const unsigned div_m = ((1u << 20) + (unsigned)max(ncols_span, 1) - 1) / (unsigned)max(ncols_span, 1);
     const unsigned g_end = a.ref_begin + a.n_groups;
     /* every patch index (g N + n) A + st below 2^24: full-rate 24-bit multiplies for the per-candidate index arithmetic */
-    const bool small24 = (((unsigned long long)a.n_refs_total << logN) + 1) * A < (1ull << 24);
+    /* SAI-major filt (wide windows, kernels.h filt_patch): this SAI's patches are a filt of their own, [g][n][c][k2] */
+    const bool sai_major = a.filt_sai_stride != 0;
+    const unsigned Af = sai_major ? 1u : (unsigned)A, stf = sai_major ? 0u : (unsigned)st;
+    const float* const filt = a.filt + (sai_major ? (size_t)st * a.filt_sai_stride : (size_t)0);
+    const unsigned long long filt_bytes = sai_major ? a.filt_sai_stride * sizeof(float) : a.filt_bytes;
+    const bool small24 = (((unsigned long long)a.n_refs_total << logN) + 1) * Af < (1ull << 24);
     const unsigned* apos = a.aggpos + (size_t)st * a.n_refs_total * N;
     /* channel stride inside a filtered patch, bytes; greyscale: all three loads read channel 0 (its weights are 0) */
     const unsigned cstride = C > 1 ? (unsigned)k2 * 4u : 0u;
-    const __amdgpu_buffer_rsrc_t rs_filt = __builtin_amdgcn_make_buffer_rsrc((void*)a.filt, 0, BIG ? 0 : (int)(unsigned)a.filt_bytes, 0x00020000u);
+    const __amdgpu_buffer_rsrc_t rs_filt = __builtin_amdgcn_make_buffer_rsrc((void*)filt, 0, BIG ? 0 : (int)(unsigned)filt_bytes, 0x00020000u);
     unsigned nh = 0;   /* hits in the list (uniform) */
 
     auto consume = [&]() {
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
                 const unsigned o = __umul24((unsigned)min(max(dy, 0), k - 1), (unsigned)k) + (unsigned)min(max(dx, 0), k - 1);   /* v_mad_u32_u24: a 32-bit multiply is quarter rate */
                 const float kz = WINDOWED ? kai[o] : 1.0f;
                 if (BIG) {
-                    const char* fp = reinterpret_cast<const char*>(a.filt) + ((size_t)ha.y + o) * 4;
+                    const char* fp = reinterpret_cast<const char*>(filt) + ((size_t)ha.y + o) * 4;
                     val[u][0] = *reinterpret_cast<const float*>(fp);
                     val[u][1] = *reinterpret_cast<const float*>(fp + cstride);
                     val[u][2] = *reinterpret_cast<const float*>(fp + 2 * cstride);
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
         constexpr unsigned cap_hits = (unsigned)(kAggCap - kAggU);
         const unsigned lo_y = (unsigned)(ty0 - k + 1), lo_x = (unsigned)(tx0 - k + 1);          /* (wrap around for tiles at the border: the */
         const unsigned span_y = (unsigned)(TH + k - 1), span_x = (unsigned)(TW + k - 1);        /*  unsigned test below still means lo <= v < lo + span) */
-        const unsigned pstep = (unsigned)(A * C * k2);                                          /* filt offset from match n to n + 1 */
+        const unsigned pstep = Af * (unsigned)(C * k2);                                          /* filt offset from match n to n + 1 */
         /* the candidates c0 + 4 lane .. + 3 of the lanes [l0, l1): test, and append the hits if the list has room (else: false, nothing
          * appended).  Nothing computed here is alive across a consume phase -- that is what keeps the kernel at its wave count. */
         auto try_append = [&](const int c0, const unsigned l0, const unsigned l1) -> bool {
@@ -205,8 +210,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
                 unsigned slot = nh + below(b0) + 2u * below(b1) + 4u * below(b2);
                 size_t wbase; unsigned off;
                 const unsigned gl = g - a.ref_begin;   /* filt holds the launch's groups: [g - ref_begin][n][st][c][k2] */
-                if (small24) { wbase = __umul24(g, (unsigned)C); off = __umul24(__umul24((gl << logN) + n0, (unsigned)A) + (unsigned)st, (unsigned)(C * k2)); }
-                else { asm volatile("" ::: "memory"); wbase = (size_t)g * C; off = (((gl << logN) + n0) * A + st) * C * k2; }
+                if (small24) { wbase = __umul24(g, (unsigned)C); off = __umul24(__umul24((gl << logN) + n0, Af) + stf, (unsigned)(C * k2)); }
+                else { asm volatile("" ::: "memory"); wbase = (size_t)g * C; off = (((gl << logN) + n0) * Af + stf) * C * k2; }
                 float w[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) w[c] = c < C ? a.wgt[wbase + (a.wchan0 ? 0 : c)] : 0.0f;
@@ -275,8 +280,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((VEC4 && TW 
                 const unsigned slot = nh + __popcll(bal & ((1ull << lane) - 1ull));
                 unsigned off;
                 const unsigned gl = g[u] - a.ref_begin;
-                if (small24) off = __umul24(__umul24((gl << logN) + nn[u], (unsigned)A) + (unsigned)st, (unsigned)(C * k2));
-                else { asm volatile("" ::: "memory"); off = (((gl << logN) + nn[u]) * A + st) * C * k2; }
+                if (small24) off = __umul24(__umul24((gl << logN) + nn[u], Af) + stf, (unsigned)(C * k2));
+                else { asm volatile("" ::: "memory"); off = (((gl << logN) + nn[u]) * Af + stf) * C * k2; }
                 hit_a[slot] = make_uint4(p[u], off, __float_as_uint(w[u][0]), __float_as_uint(w[u][1]));
                 hit_w2[slot] = w[u][2];
             }
@@ -296,7 +301,7 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
     const unsigned tw = wide ? 16 : 8, th = wide ? 4 : 8;
     const unsigned tiles = ((a.Wb + tw - 1) / tw) * ((a.Hb + th - 1) / th) * a.A;
     const dim3 grid(((tiles + 7) / 8) * 8), block(64);
-    const bool big = a.filt_bytes > 0xfffff000ull || (a.opt & kOptAgg64Bit);   /* option agg_64bit: exercise the 64-bit path in tests */
+    const bool big = (a.filt_sai_stride ? a.filt_sai_stride * sizeof(float) : a.filt_bytes) > 0xfffff000ull || (a.opt & kOptAgg64Bit);   /* option agg_64bit: exercise the 64-bit path in tests */
     /* four candidates per lane and 16-byte position loads when a reference patch's N matches come in fours (option agg_scalar_scan: the
      * one-candidate-per-lane scan of rounds 1-3, for A/B runs; N = 1, 2 always take it) */
     /* Measured at the headline window (same box, rounds of tools/pass_time.py; instruction counts: tools/pmc_agg_ab.sh): VALU instructions

@@ -286,10 +286,9 @@ __device__ __forceinline__ void group_generic(const GroupArgs& a, const unsigned
     if (a.tau2 != 4) inv2d(F, tmp, nSx * A, k, a.tau2, tb);
 
     /* filtered patches out: [g][n][st][c][k2] */
-    float* out = a.filt + (size_t)g * N * A * a.C * k2;
     for (int e = tid; e < stack; e += kThreads) {
         const int pq = e % k2, ns = e / k2;
-        filt_put(&out[((size_t)ns * a.C + c) * k2 + pq], F[e]);
+        filt_put(&a.filt[filt_patch(a, g, ns / A, ns % A, k2) + (size_t)c * k2 + pq], F[e]);
     }
 }
 

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
         const float sig = a.sigma[c];
         const float T = a.lambda * sig * 1.41421356237309505f;   /* core:2431 */
         const float sig2 = sig * sig;
-        float* const out = a.filt + (size_t)g * N * A * a.C * k2;
+        float* const out = a.filt;   /* + filt_patch(a, g, n, st, k2) */
         __syncthreads();
 #ifdef LFBM5D_SLAB_PHASES   /* development builds: cycles per stage, thread 0 of every 64th workgroup (lfbm5d_api.hip prints counters 4..15) */
         long long tq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
         for (int s0 = 0; s0 < k2; s0 += SLAB) {
             const int npx = min(SLAB, k2 - s0);
             /* load: [stack][ns][q], q fastest */
-            if ((k & 3) == 0) {
+            if ((k & 3) == 0 && ls >= 2) {
                 constexpr int G = 12;
                 const int QS = SLAB >> 2, total = (NST * NSA) << (ls - 2);
                 for (int e0 = tid; e0 < total; e0 += kThreads * G) {
@@ -302,14 +302,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
 #pragma unroll
                     for (int u = 0; u < G; u++) { const int e = e0 + u * kThreads; if (e < total) *reinterpret_cast<v4f*>(lds + 4 * (size_t)e) = v[u]; }
                 }
-            } else {   /* tau_2D = id with a patch side that is no multiple of four: one pixel per load */
+            } else {   /* one value per load: tau_2D = id with a patch side that is no multiple of four; slabs of two (17x17 windows, Wiener N = 16) */
                 const int total = (NST * NSA) << ls;
                 for (int e = tid; e < total; e += kThreads) {
                     const int q = e & (SLAB - 1), pidx = e >> ls, stack = pidx / NSA, ns = pidx - stack * NSA, pq = s0 + q;
-                    const unsigned pp = pos[ns];
                     float v = 0.0f;
-                    if (q < npx && pp != 0xffffffffu)
-                        v = ((STEP == 2 && stack ? a.basic : a.noisy) + ((size_t)(ns % A) * a.C + c) * plane)[pp + (size_t)(pq / k) * a.Wb + pq % k];
+                    if (q < npx) {
+                        if (id2) {
+                            const unsigned pp = pos[ns];
+                            if (pp != 0xffffffffu)
+                                v = ((STEP == 2 && stack ? a.basic : a.noisy) + ((size_t)(ns % A) * a.C + c) * plane)[pp + (size_t)(pq / k) * a.Wb + pq % k];
+                        } else
+                            v = slice[(size_t)pidx * k2 + pq];
+                    }
                     lds[e] = v;
                 }
             }
@@ -489,20 +494,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
             }
             SLAB_MARK(4);
             /* the filtered slab: back to the slice, or (tau_2D = id) out */
-            if ((k & 3) == 0) {
+            if ((k & 3) == 0 && ls >= 2) {
                 const int QS = SLAB >> 2, total = NSA << (ls - 2);
                 for (int e = tid; e < total; e += kThreads) {
                     const int q = 4 * (e & (QS - 1)), ns = e >> (ls - 2);
                     if (q < npx) {
                         const v4f v = *reinterpret_cast<const v4f*>(F + 4 * (size_t)e);
-                        float* o = id2 ? out + ((size_t)ns * a.C + c) * k2 + s0 + q : fslice + (size_t)ns * k2 + s0 + q;
+                        float* o = id2 ? out + filt_patch(a, g, ns / A, ns % A, k2) + (size_t)c * k2 + s0 + q : fslice + (size_t)ns * k2 + s0 + q;
                         if (id2) filt_put4(reinterpret_cast<v4f*>(o), v); else *reinterpret_cast<v4f*>(o) = v;   /* (the slice is read back by this workgroup) */
                     }
                 }
             } else {
                 for (int e = tid; e < NSA << ls; e += kThreads) {
                     const int q = e & (SLAB - 1), ns = e >> ls;
-                    if (q < npx) filt_put(&out[((size_t)ns * a.C + c) * k2 + s0 + q], F[e]);
+                    if (q < npx) {
+                        if (id2) filt_put(&out[filt_patch(a, g, ns / A, ns % A, k2) + (size_t)c * k2 + s0 + q], F[e]);
+                        else fslice[(size_t)ns * k2 + s0 + q] = F[e];
+                    }
                 }
             }
             __syncthreads();
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 8))
             };
             auto dst = [&](auto kt, int p, int r, const float* x) {
                 constexpr int K = decltype(kt)::value;
-                float* o = out + ((size_t)p * a.C + c) * K * K + r * K;
+                float* o = out + filt_patch(a, g, p / A, p % A, K * K) + (size_t)c * K * K + r * K;
 #pragma unroll
                 for (int t = 0; t < K; t += 4) filt_put4(reinterpret_cast<v4f*>(o + t), v4f{x[t], x[t + 1], x[t + 2], x[t + 3]});
             };
@@ -553,6 +561,7 @@ int slab_log2(const GroupArgs& a) {
     const int per_px = (a.step == 2 ? 2 : 1) * (int)a.N * (int)a.A;
     int ls = 6;
     while (ls > 2 && (per_px << ls) > kSlabFloats) ls--;
+    if ((per_px << ls) > kSlabFloatsMax) ls = 1;   /* slabs of two values, one packed pair per item (17x17 windows, Wiener N = 16: 74 KB) */
     return ls;
 }
 size_t slab_lds_bytes(const GroupArgs& a) {
@@ -576,7 +585,7 @@ bool group_uses_slab(const GroupArgs& a) {
     if (a.tau2 == 5 && !(a.k == 8 || a.k == 12 || a.k == 16)) return false;
     if (a.tau2 == 7 && !(a.k == 8 || a.k == 16)) return false;
     if (a.tau2 == 4 && a.k > 16) return false;
-    if (((size_t)(a.step == 2 ? 2 : 1) * a.N * a.A << 2) > (size_t)kSlabFloatsMax) return false;   /* (not even four pixels per slab) */
+    if (((size_t)(a.step == 2 ? 2 : 1) * a.N * a.A << 1) > (size_t)kSlabFloatsMax) return false;   /* (not even a pair of pixels per slab) */
     /* stacks the general kernel would keep in HBM slices (beyond ~150 KB); with a 2-D transform also those it would hold in LDS at
      * one workgroup per CU (measured: N = 32, k = 8, Wiener: dct 3.9 ms here / 4.8 there, id 3.1 / 2.7) */
     const size_t stacks = (size_t)(a.step == 2 ? 2 : 1) * a.N * a.A * a.k * a.k * sizeof(float);

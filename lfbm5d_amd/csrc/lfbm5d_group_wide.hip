@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
     const float T = a.lambda * sig * 1.41421356237309505f;   /* core:2431 */
     const float sig2 = sig * sig;
     float wacc = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    float* const out = a.filt + (size_t)g * N * A * a.C * k2;
+    float* const out = a.filt;   /* + filt_patch(a, g, n, st, k2): group-major, or SAI-major on windows of 11 x 11 SAIs and more */
     const float* const img = a.noisy + (size_t)c * plane;
 #ifdef LFBM5D_WIDE_PHASES   /* development builds (with -DLFBM5D_WIDE_PHASES, which makes lfbm5d_api.hip print them): cycles per phase of the slab loop, summed over the workgroups */
     long long tq[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = (long long)__builtin_readcyclecounter();
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
                             v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                             for (int v = 1; v < AW; v++) acc += t[v] * tb->cosw[v * AW + i];
-                            filt_put4(reinterpret_cast<v4f*>(out + ((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px), (t[0] + 2.0f * acc) * tb->coef4inv);
+                            filt_put4(reinterpret_cast<v4f*>(out + filt_patch(a, g, n, i * AW + j, k2) + (size_t)c * k2 + p0 + px), (t[0] + 2.0f * acc) * tb->coef4inv);
                         }
                     }
                 }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
 #pragma unroll
                         for (int v = 1; v < AW; v++) acc += t[v] * tb->cosw[v * AW + i];
                         const v2f y = (t[0] + 2.0f * acc) * tb->coef4inv;
-                        float* o = out + ((size_t)(n * A + i * AW + j) * a.C + c) * k2 + p0 + px;
+                        float* o = out + filt_patch(a, g, n, i * AW + j, k2) + (size_t)c * k2 + p0 + px;
                         if (both && even) filt_put2(reinterpret_cast<v2f*>(o), y);
                         else { filt_put(o, y.x); if (both) filt_put(o + 1, y.y); }
                     }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_group_idw(GroupArgs a) {   /* (512 thre
             }
             for (int e = tid; e < nSx * A * SLAB; e += NT) {
                 const int px = e % SLAB, ns = e / SLAB;
-                if (px < npx) filt_put(&out[((size_t)ns * a.C + c) * k2 + p0 + px], S[e]);
+                if (px < npx) filt_put(&out[filt_patch(a, g, ns / A, ns % A, k2) + (size_t)c * k2 + p0 + px], S[e]);
             }
         }
         WIDE_MARK(7);

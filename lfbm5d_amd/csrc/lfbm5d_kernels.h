@@ -137,13 +137,29 @@ struct GroupArgs {
     float* scratch;             /* generic path, stacks beyond the LDS: HBM slices for k_group_big (or NULL) */
     unsigned long long scratch_floats;   /* size of scratch */
     unsigned opt;               /* kOpt* bits (lfbm5d_options.h): kernel-generation selectors of the context */
+    unsigned long long filt_sai_stride;   /* 0: filt is group-major [g][n][st][c][k2]; > 0 (windows of kSaiMajorMinA SAIs and more, general kernels only):
+                                           * SAI-major [st][g][n][c][k2], that many floats per SAI -- see filt_patch */
     unsigned bm3d;              /* per-SAI BM3D arithmetic (bm3d.cpp:914-1027, :1345-1373): threshold without sqrt2, SD weight over nSx*k^2 */
 };
+
+/* Where the filtered patch (group g, stack position n, SAI st) starts in filt (channel 0; channels follow at k2 floats).
+ * Group-major [g][n][st][c][k2] is what the 3x3-window kernels write: a group's patches in one piece, and the aggregation of SAI st
+ * finds its patches A C k2 floats apart.  On wide angular windows that stride is the problem: at 13x13 SAIs consecutive patches of
+ * one SAI lie 519 KB apart, every gather of the aggregation lands on another 2 MB page and the pass is bound by address
+ * translation (profiles/r05_e, r06_l).  SAI-major [st][g][n][c][k2] (filt_sai_stride > 0) keeps the patches one SAI's aggregation reads
+ * together -- N C k2 floats per group, contiguous over the groups.  GroupArgs::filt is biased by the launch's first group in either layout. */
+constexpr unsigned kSaiMajorMinA = 121;   /* 11 x 11 SAIs and more (measured: profiles/r06_l_wide_windows.txt) */
+__device__ __forceinline__ size_t filt_patch(const GroupArgs& a, unsigned g, unsigned n, unsigned st, unsigned k2) {
+    return a.filt_sai_stride ? (size_t)st * a.filt_sai_stride + ((size_t)g * a.N + n) * a.C * k2
+                             : (((size_t)g * a.N + n) * a.A + st) * a.C * k2;
+}
+
 
 struct AggArgs {
     float* num;
     float* den;
-    const float* filt;               /* the launch's groups only: [g - ref_begin][N][A][C][k2] */
+    const float* filt;               /* the launch's groups only: [g - ref_begin][N][A][C][k2], or SAI-major [A][g - ref_begin][N][C][k2] */
+    unsigned long long filt_sai_stride;   /* 0: group-major; > 0: SAI-major, floats per SAI (GroupArgs::filt_sai_stride) */
     unsigned long long filt_bytes;   /* size of filt: below 4 GiB the gathers go through a buffer resource */
     const float* wgt;
     const unsigned* aggpos;     /* [A][R][N] */

@@ -34,6 +34,7 @@ enum : unsigned {
     kOptAggScalarScan = 1u << 9,    /* aggregation: one candidate per lane in the scan */
     kOptSubsetListHost = 1u << 10,  /* subset passes: reference list built on the host */
     kOptSubsetScanV1 = 1u << 11,    /* subset passes: round 2's table kernel through the position map */
+    kOptFiltGroupMajor = 1u << 12,  /* wide windows (11 x 11 SAIs and more): filtered patches group-major like the 3 x 3 windows' (rounds 1-5) instead of SAI-major */
 };
 
 struct Options {
@@ -73,6 +74,7 @@ inline const OptionKey* option_keys(size_t* n) {
         {"no_slab_kernel", "LFBM5D_NO_SLAB_KERNEL", nullptr, kOptNoSlabKernel}, {"wide_nosplit", "LFBM5D_WIDE_NOSPLIT", nullptr, kOptWideNoSplit},
         {"agg_64bit", "LFBM5D_AGG_64BIT", nullptr, kOptAgg64Bit}, {"agg_scalar_scan", "LFBM5D_AGG_SCALAR_SCAN", nullptr, kOptAggScalarScan},
         {"subset_list_host", "LFBM5D_SUBSET_LIST_HOST", nullptr, kOptSubsetListHost}, {"subset_scan_v1", "LFBM5D_SUBSET_SCAN_V1", nullptr, kOptSubsetScanV1},
+        {"filt_group_major", "LFBM5D_FILT_GROUP_MAJOR", nullptr, kOptFiltGroupMajor},
     };
     *n = sizeof(keys) / sizeof(keys[0]);
     return keys;

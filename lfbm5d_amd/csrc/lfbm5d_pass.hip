@@ -480,8 +480,12 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
     aa.mask_bits = mask_bits; aa.proc_bits = proc_bits; aa.tau4 = P->tau_4D; aa.irregular = centre ? 0u : 1u;
     aa.wchan0 = (bm3d && P->useSD) ? 1u : 0u;
     aa.opt = c->opt->kernels;
+    /* wide windows: filt SAI-major (kernels.h filt_patch) -- per SAI the launch's groups, [g][n][c][k2] */
+    const bool sai_major = A >= kSaiMajorMinA && !(c->opt->kernels & kOptFiltGroupMajor);
+    const size_t per_group_bias = sai_major ? per_group / A : per_group;   /* what one group takes in front of the patch the kernels address */
     if (n_groups <= band_groups) {   /* the whole pass (or this rank's rows) at once */
-        ga.filt = c->filt.as<float>() - (size_t)ref_begin * per_group;   /* (the group kernels index filt by absolute group number) */
+        ga.filt_sai_stride = aa.filt_sai_stride = sai_major ? (unsigned long long)n_groups * (per_group / A) : 0ull;
+        ga.filt = c->filt.as<float>() - (size_t)ref_begin * per_group_bias;   /* (the group kernels index filt by absolute group number) */
         aa.filt = c->filt.as<float>(); aa.filt_bytes = (unsigned long long)n_groups * per_group * sizeof(float);
         if (n_groups) HIPCK(c, launch_group(s, ga));
         HIPCK(c, hipEventRecord(pe.e[2], s));
@@ -492,7 +496,8 @@ int pass_impl(lfbm5d_ctx* c, int step, const lfbm5d_params* P, unsigned aw, unsi
         bool first = true;
         for (unsigned b0 = ref_begin; b0 < ref_begin + n_groups; b0 += band_groups) {
             const unsigned nb = std::min(band_groups, ref_begin + n_groups - b0);
-            ga.ref_begin = b0; ga.n_groups = nb; ga.filt = c->filt.as<float>() - (size_t)b0 * per_group;
+            ga.filt_sai_stride = aa.filt_sai_stride = sai_major ? (unsigned long long)nb * (per_group / A) : 0ull;
+            ga.ref_begin = b0; ga.n_groups = nb; ga.filt = c->filt.as<float>() - (size_t)b0 * per_group_bias;
             aa.ref_begin = b0; aa.n_groups = nb; aa.filt = c->filt.as<float>(); aa.filt_bytes = (unsigned long long)nb * per_group * sizeof(float);
             HIPCK(c, launch_group(s, ga));
             if (first) HIPCK(c, hipEventRecord(pe.e[2], s));

@@ -877,6 +877,9 @@ def test_largest_window_passes_match_oracle(ctx, aw):
     _wide_window_pass(ctx, ("wien-dct-sadct-haar-holes", 2, (2, 4, 2, 8, 4, "dct", "sadct", "haar"), 40, (0, A - 2)), aw)
     if aw == 13:   # the README's N = 16 in the Wiener step: 2 x 16 x 169 values per coefficient -- the slab kernel's 112 KB tier (four coefficients per slab)
         _wide_window_pass(ctx, ("wien-dct-sadct-haar-n16", 2, (16, 4, 2, 8, 4, "dct", "sadct", "haar"), 40, ()), aw)
+    else:          # round 6: the same on 17 x 17 -- 2 x 16 x 289 values per coefficient, slabs of TWO coefficients (74 KB); rounds 4-5 ran it on the general kernel
+        _wide_window_pass(ctx, ("wien-dct-sadct-haar-n16", 2, (16, 4, 2, 8, 4, "dct", "sadct", "haar"), 40, ()), aw)
+        _wide_window_pass(ctx, ("wien-id-dct-haar-n16-holes", 2, (16, 4, 2, 8, 4, "id", "dct", "haar"), 40, (1, A - 3)), aw)
 
 
 @pytest.mark.parametrize("ah,aw,an", [(5, 5, 2), (7, 6, 2), (8, 7, 3), (9, 10, 4)])
