@@ -104,6 +104,12 @@ int lfbm5d_comm_unique_id(void* id_out) {
 int lfbm5d_comm_init(lfbm5d_ctx* c, const void* idb, int rank, int world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return 1;
     (void)hipSetDevice(c->device);
+    /* a second call replaces the communicators (after a job that tore them down, or to change the ranks) */
+    if (c->team_comm2) { (void)ncclCommDestroy(c->team_comm2); c->team_comm2 = nullptr; }
+    if (c->team_comm) { (void)ncclCommDestroy(c->team_comm); c->team_comm = nullptr; }
+    c->team_S = 0;
+    if (c->comm2) { (void)ncclCommDestroy(c->comm2); c->comm2 = nullptr; }
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     c->rank = rank; c->world = world;
     if (world == 1) return 0;
     ncclUniqueId id;

@@ -471,6 +471,9 @@ __device__ __forceinline__ void group_t16_kernel(const GroupArgs& a) {
     auto patch_src = [&](int patch, bool& ok) -> const float* {
         const unsigned p = a.gpos[(size_t)g * N * A + patch];
         ok = p != 0xffffffffu;            /* empty SAI / never-filled table column: zeros */
+#if defined(LFBM5D_T16_EXP) && LFBM5D_T16_EXP == 1   /* timing experiment (results garbage): every patch row from one cached place */
+        return a.noisy + (size_t)c * plane + (patch & 7) * 16;
+#endif
         return a.noisy + ((size_t)(patch % A) * a.C + c) * plane + (ok ? p : 0u);
     };
     /* patches base .. base + np - 1 of the group -> work area slots 0 .. np - 1 */
