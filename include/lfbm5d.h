@@ -103,7 +103,7 @@ void* lfbm5d_stream(lfbm5d_ctx* ctx);
  * "max_windows", "emulate_world", "data_driven_schedule", "host_blocking", "band_mb", "bm3d_lanes", "spatial_bands" / "band_halo"
  * (several ranks, lfbm5d_denoise_*: teams of ranks denoise horizontal bands of every SAI, see the multi-GPU notes below); test hooks that select
  * between implementations of the same arithmetic ("scan_v1", "scan_any", "scan_full_tables", "dct8w_v2", "group_generic",
- * "no_sa_kernels", "no_slab_kernel", "wide_nosplit", "agg_64bit", "agg_scalar_scan", "subset_list_host", "subset_scan_v1",
+ * "no_sa_kernels", "no_slab_kernel", "wide_nosplit", "agg_64bit", "agg_scalar_scan", "subset_list_host", "subset_scan_v1", "filt_group_major",
  * "scan_lds_cap", "force_redo").  The old variable names ("LFBM5D_LANES" ...) are accepted as keys.  Values are spelled as the
  * environment spelled them (integers; "rows" / "blocks"; flags: anything but "0" is on); value NULL or "" restores the default.
  * Unknown key: returns 1.  lfbm5d_get_option writes the current value as text (size: bytes of `value`). */

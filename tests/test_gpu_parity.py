@@ -882,6 +882,38 @@ def test_largest_window_passes_match_oracle(ctx, aw):
         _wide_window_pass(ctx, ("wien-id-dct-haar-n16-holes", 2, (16, 4, 2, 8, 4, "id", "dct", "haar"), 40, (1, A - 3)), aw)
 
 
+def test_filt_layouts_of_wide_windows_agree_bit_for_bit(ctx, monkeypatch):
+    """Round 6: windows of 11 x 11 SAIs and more keep their filtered patches SAI-major (lfbm5d_kernels.h filt_patch); option
+    filt_group_major = the layout of the 3 x 3 windows.  Same patches, same order of additions: identical num / den, for the
+    wide-window kernel (HT, tau_2D = id), the slab kernel (Wiener) and a pass cut into bands of reference rows."""
+    aw, crop, sigma, Cc = 11, 40, 25.0, 3
+    A, cc = aw * aw, (aw * aw) // 2
+    _, noisy = Hh.noisy_lf(Hh.textured_lf(aw, aw, crop, crop), sigma)
+    for step, pk, band_mb in ((1, (2, 4, 2, 8, 4, "id", "sadct", "haar"), None), (2, (4, 4, 2, 8, 4, "dct", "sadct", "haar"), None),
+                              (1, (4, 4, 2, 8, 4, "id", "dct", "haar"), "2")):
+        win, Wb, Hb = Hh.padded_window(noisy, crop, crop, Cc, pk[1] + pk[2])
+        mask = np.ones(A, np.uint32)
+        mask[5] = 0
+        win[5] = 0
+        proc = (mask == 0).astype(np.uint32)
+        basic = np.ascontiguousarray(0.5 * win + 0.5 * np.roll(win, 1, axis=1)) if step == 2 else None
+        out = {}
+        for layout in ("sai-major", "group-major"):
+            if layout == "group-major":
+                monkeypatch.setenv("LFBM5D_FILT_GROUP_MAJOR", "1")
+            else:
+                monkeypatch.delenv("LFBM5D_FILT_GROUP_MAJOR", raising=False)
+            if band_mb:
+                monkeypatch.setenv("LFBM5D_BAND_MB", band_mb)
+            else:
+                monkeypatch.delenv("LFBM5D_BAND_MB", raising=False)
+            out[layout] = gpu_pass(ctx, step, sigma, pk, win, basic, Wb, Hb, Cc, mask=mask, proc=proc, cst=cc, pst=cc, aw=aw)
+        monkeypatch.delenv("LFBM5D_FILT_GROUP_MAJOR", raising=False)
+        monkeypatch.delenv("LFBM5D_BAND_MB", raising=False)
+        assert np.array_equal(out["sai-major"][0], out["group-major"][0]) and np.array_equal(out["sai-major"][1], out["group-major"][1]), (step, pk)
+        assert float(np.abs(out["sai-major"][1]).sum()) > 0
+
+
 @pytest.mark.parametrize("ah,aw,an", [(5, 5, 2), (7, 6, 2), (8, 7, 3), (9, 10, 4)])
 def test_whole_steps_with_5x5_windows_match_oracle(ctx, ah, aw, an):
     """aswSize 2 and 3: the window schedule with 5x5 / 7x7 windows (compute_LF_angular_search_window's clamping at the
