@@ -312,6 +312,28 @@ def test_graph_form_with_messages_equals_the_single_rank_step(world, n_steps):
     assert sum(r[4] for r in res) == sum(r[5] for r in res) == res[0][6] > 0   # every message sent once, received once
 
 
+def test_band_count_rule_and_scale_model():
+    """core.auto_bands (what bench.py --bands auto sets): the graph alone up to the ranks it keeps busy, bands for the rest, never a
+    band narrower than twice its halo, always a divisor of the rank count; and tools/scale_model.py's band model picks the same
+    counts as its best form at 8 ranks (host only: lfbm5d_plan_job)."""
+    from lfbm5d_amd import core
+    assert [core.auto_bands(17, 17, 512, 40, w) for w in (1, 2, 4, 8)] == [1, 1, 1, 2]
+    assert [core.auto_bands(15, 15, 434, 40, w) for w in (1, 2, 4, 8)] == [1, 1, 1, 2]
+    assert [core.auto_bands(9, 9, 512, 40, w) for w in (1, 2, 4, 8)] == [1, 1, 2, 4]
+    for a in (3, 5, 9, 13, 17):
+        for H in (96, 256, 512):
+            for w in (1, 2, 3, 4, 6, 8):
+                s = core.auto_bands(a, a, H, 40, w)
+                assert s >= 1 and w % s == 0 and (s == 1 or H // s >= 80), (a, H, w, s)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scale_model as M
+    for (a, H, W) in ((17, 512, 512), (9, 512, 512)):
+        tg, tf, *_ = M.simulate(a, a, 8, 2.62, 2.47, H, W, 50.0, 20.0)
+        best = min((sum(M.simulate_bands(a, a, 8, S, 2.62, 2.47, H, W, 50.0, 20.0, 40, 24)[:2]), S) for S in (2, 4) if H // S >= 80)
+        assert best[0] < tg + tf                                  # at eight ranks the banded form beats the graph alone ...
+        assert best[1] == core.auto_bands(a, a, H, 40, 8)         # ... and the rule picks the model's band count
+
+
 def test_graph_plan_properties():
     """Host-side properties of the graph form for 1..8 ranks, one step and both: every window has an owner, the simulated execution respects the dependencies (a window starts after every earlier window of its step it shares an
     SAI with; a second-step window after the last first-step window on each of its SAIs), the issue order is the start order,
