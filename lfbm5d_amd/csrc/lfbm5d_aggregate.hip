@@ -313,9 +313,22 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
          else if (big)    hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, true, false>), grid, block, 0, s, a); \
          else if (vec4)   hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, false, true>), grid, block, 0, s, a); \
          else             hipLaunchKernelGGL((k_aggregate<W_, TW_, TH_, PF_, U_, false, false>), grid, block, 0, s, a); } while (0)
+    /* scan / consume depths (candidate chunks per scan round, hits per load round): re-swept in round 6, profiles/r06_n_agg_depths.txt */
+#ifndef LFBM5D_AGG16_PF
+#define LFBM5D_AGG16_PF 3
+#endif
+#ifndef LFBM5D_AGG16_U
+#define LFBM5D_AGG16_U 12
+#endif
+#ifndef LFBM5D_AGG8_PF
+#define LFBM5D_AGG8_PF 3
+#endif
+#ifndef LFBM5D_AGG8_U
+#define LFBM5D_AGG8_U 6
+#endif
     if (a.k == 12)      LFBM5D_AGG(true, 16, 4, 3, 12);
-    else if (a.k == 8)  LFBM5D_AGG(true, 8, 8, 2, 6);
-    else if (wide)      LFBM5D_AGG(false, 16, 4, 3, 12);
+    else if (a.k == 8)  LFBM5D_AGG(true, 8, 8, LFBM5D_AGG8_PF, LFBM5D_AGG8_U);
+    else if (wide)      LFBM5D_AGG(false, 16, 4, LFBM5D_AGG16_PF, LFBM5D_AGG16_U);
     else                LFBM5D_AGG(false, 8, 8, 2, 6);
 #undef LFBM5D_AGG
     return hipGetLastError();
