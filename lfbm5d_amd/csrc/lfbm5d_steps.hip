@@ -606,18 +606,46 @@ static int run_denoise_banded(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm
         HIPCK(c, launch_copy_rows(s, bo, Hc, o, d_out, H, r.y0, n, W, planes));
         return 0;
     };
+    /* the stitch: every member of a team holds its band's whole result, so member t contributes the t-th share of the band's rows --
+     * equal chunks of chunk_rows rows (the last of a band may be shorter), every byte sent once */
+    const unsigned rows_band_max = (H + (unsigned)S - 1) / (unsigned)S, chunk_rows = (rows_band_max + (unsigned)T - 1) / (unsigned)T;
+    const size_t chunk_floats = (size_t)3 * planes * chunk_rows * W;
+    auto chunk_of = [&](int rk, unsigned& ya, unsigned& n) {
+        const BandRows q = band_rows(H, S, rk / T, halo);
+        ya = std::min(q.y1, q.y0 + (unsigned)(rk % T) * chunk_rows);
+        n = std::min(q.y1, ya + chunk_rows) - ya;
+    };
+    float* const lf[3] = {d_noisy, d_basic, d_out};
+    auto pack_chunk = [&](int rk, float* dst) -> int {     /* rank rk's share of the three light fields -> dst[3][planes][chunk_rows][W] */
+        unsigned ya, n; chunk_of(rk, ya, n);
+        for (int i = 0; i < 3; i++) HIPCK(c, launch_copy_rows(s, lf[i], H, ya, dst + (size_t)i * planes * chunk_rows * W, chunk_rows, 0, n, W, planes));
+        return 0;
+    };
+    auto unpack_chunk = [&](int rk, const float* src) -> int {
+        unsigned ya, n; chunk_of(rk, ya, n);
+        for (int i = 0; i < 3; i++) HIPCK(c, launch_copy_rows(s, src + (size_t)i * planes * chunk_rows * W, chunk_rows, 0, lf[i], H, ya, n, W, planes));
+        return 0;
+    };
     if (emu > 1) {
         /* every rank played on this GPU: band after band, each as a job of T emulated ranks; the bands are cut from the light field
-         * as it arrived (a band's halo lies in its neighbour's rows, which the neighbour's outputs overwrite) */
+         * as it arrived (a band's halo lies in its neighbour's rows, which the neighbour's outputs overwrite).  The stitch runs as
+         * between real ranks -- every rank's chunk packed into the gather buffer, the outputs cleared, every chunk unpacked -- so
+         * that the emulation covers the chunk arithmetic, not only the band jobs. */
         HIPCK(c, c->band_src.reserve((size_t)planes * H * W * sizeof(float)));
         HIPCK(c, hipMemcpyAsync(c->band_src.p, d_noisy, (size_t)planes * H * W * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCK(c, c->band_gather.reserve(chunk_floats * sizeof(float) * (size_t)nranks));
         struct EmuScope { Options* o; int saved; ~EmuScope() { o->emulate_world = saved; } } scope{c->opt, c->opt->emulate_world};
         c->opt->emulate_world = T > 1 ? T : 0;
         for (int b = 0; b < S; b++) {
             const BandRows r = band_rows(H, S, b, halo);
             if (job_on_band(c->band_src.as<float>(), r)) return 1;
             if (interior_back(r)) return 1;
+            for (int t = 0; t < T; t++)
+                if (pack_chunk(b * T + t, c->band_gather.as<float>() + (size_t)(b * T + t) * chunk_floats)) return 1;
         }
+        for (int i = 0; i < 3; i++) HIPCK(c, hipMemsetAsync(lf[i], 0, (size_t)planes * H * W * sizeof(float), s));
+        for (int rk = 0; rk < nranks; rk++)
+            if (unpack_chunk(rk, c->band_gather.as<float>() + (size_t)rk * chunk_floats)) return 1;
         HIPCK(c, hipStreamSynchronize(s));
         return 0;
     }
@@ -656,31 +684,16 @@ static int run_denoise_banded(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm
         return 1;
     }
     if (interior_back(r)) return 1;
-    const unsigned rows_band_max = (H + (unsigned)S - 1) / (unsigned)S, chunk_rows = (rows_band_max + (unsigned)T - 1) / (unsigned)T;
-    const size_t chunk_floats = (size_t)3 * planes * chunk_rows * W;
     HIPCK(c, c->band_pack.reserve(chunk_floats * sizeof(float)));
     HIPCK(c, c->band_gather.reserve(chunk_floats * sizeof(float) * (size_t)nranks));
-    auto chunk_of = [&](int rk, unsigned& ya, unsigned& n) {
-        const BandRows q = band_rows(H, S, rk / T, halo);
-        ya = std::min(q.y1, q.y0 + (unsigned)(rk % T) * chunk_rows);
-        n = std::min(q.y1, ya + chunk_rows) - ya;
-    };
-    float* const lf[3] = {d_noisy, d_basic, d_out};
-    {
-        unsigned ya, n; chunk_of(c->rank, ya, n);
-        for (int i = 0; i < 3; i++)
-            HIPCK(c, launch_copy_rows(s, lf[i], H, ya, c->band_pack.as<float>() + (size_t)i * planes * chunk_rows * W, chunk_rows, 0, n, W, planes));
-    }
+    if (pack_chunk(c->rank, c->band_pack.as<float>())) return 1;
     hipEvent_t e0 = get_event(c), e1 = get_event(c);
     HIPCK(c, hipEventRecord(e0, s));
     if (ncclAllGather(c->band_pack.p, c->band_gather.p, chunk_floats, ncclFloat, c->comm, s) != ncclSuccess) return fail(c, "ncclAllGather of the bands failed");
     HIPCK(c, hipEventRecord(e1, s));
     for (int rk = 0; rk < nranks; rk++) {
         if (rk / T == band) continue;   /* this team's rows are in place */
-        unsigned ya, n; chunk_of(rk, ya, n);
-        for (int i = 0; i < 3; i++)
-            HIPCK(c, launch_copy_rows(s, c->band_gather.as<float>() + (size_t)rk * chunk_floats + (size_t)i * planes * chunk_rows * W, chunk_rows, 0,
-                                      lf[i], H, ya, n, W, planes));
+        if (unpack_chunk(rk, c->band_gather.as<float>() + (size_t)rk * chunk_floats)) return 1;
     }
     HIPCK(c, hipStreamSynchronize(s));
     float ms = 0.0f;
