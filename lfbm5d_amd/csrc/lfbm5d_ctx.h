@@ -124,6 +124,7 @@ struct lfbm5d_ctx {
      * gating and abort path as the RCCL form (lfbm5d_comm_init_ipc) */
     bool ipc = false;
     std::string ipc_dir; double ipc_timeout_s = 30.0; unsigned ipc_epoch = 0;
+    std::string ipc_tag;   /* prefix of the rendezvous names: "" for the whole world, "b<band>." while a band's team runs its job (spatial bands) */
     DevBuf ipc_flags, ipc_out;
     struct IpcPeer { unsigned char handle[7][64]; void* ptr[7]; };   /* flags, g_num[0..1], g_den[0..1], basic, out -- as this process maps them */
     std::vector<IpcPeer> ipc_peers;
@@ -183,6 +184,8 @@ int io_download_all(lfbm5d_ctx* c, const HostIO* io, const unsigned* h_mask, uns
                     const float* d_basic, const float* d_out);
 constexpr unsigned kIpcMaxMsgs = 4096;   /* gating words: ready[kIpcMaxMsgs], taken[kIpcMaxMsgs], error */
 int ipc_allgather(lfbm5d_ctx* c, const char* tag, int mine, std::vector<int>& all);
+bool ipc_put(const std::string& dir, const std::string& name, const void* data, size_t bytes);
+bool ipc_get(const std::string& dir, const std::string& name, void* data, size_t bytes, double timeout_s);
 /* lfbm5d_steps.hip */
 int run_step(lfbm5d_ctx* c, int step, const lfbm5d_params* P, float* d_noisy, const unsigned* h_mask,
              float* d_basic, float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight,

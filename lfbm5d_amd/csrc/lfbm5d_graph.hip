@@ -62,7 +62,7 @@ bool ipc_get(const std::string& dir, const std::string& name, void* data, size_t
 }
 /* every rank publishes `mine`, returns everybody's (a barrier when nobody reads the values) */
 int ipc_allgather(lfbm5d_ctx* c, const char* tag, int mine, std::vector<int>& all) {
-    const std::string base = std::string(tag) + "." + std::to_string(c->ipc_epoch) + ".";
+    const std::string base = c->ipc_tag + tag + "." + std::to_string(c->ipc_epoch) + ".";
     if (!ipc_put(c->ipc_dir, base + std::to_string(c->rank), &mine, sizeof(int))) return fail(c, "ipc transport: cannot write to the rendezvous directory");
     all.assign((size_t)c->world, 0);
     for (int r = 0; r < c->world; r++)
@@ -81,7 +81,7 @@ int ipc_exchange_handles(lfbm5d_ctx* c, void* const (&mine)[7]) {
             static_assert(sizeof(h) <= 64, "handle size");
             std::memcpy(me.handle[i], &h, sizeof(h));
         }
-    const std::string base = "handles." + std::to_string(c->ipc_epoch) + ".";
+    const std::string base = c->ipc_tag + "handles." + std::to_string(c->ipc_epoch) + ".";
     if (!ipc_put(c->ipc_dir, base + std::to_string(c->rank), me.handle, sizeof(me.handle))) return fail(c, "ipc transport: cannot write to the rendezvous directory");
     c->ipc_peers.resize((size_t)c->world);
     for (int r = 0; r < c->world; r++) {

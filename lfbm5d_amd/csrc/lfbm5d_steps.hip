@@ -652,9 +652,60 @@ static int run_denoise_banded(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm
     /* real ranks: rank = band * T + team rank.  The team gets communicators of its own (split once, kept), the job runs on them,
      * then ONE all-gather over all ranks stitches the light fields: every member of a team holds its band's whole result, so
      * member t contributes the t-th share of the band's rows -- equal chunks, every byte sent once. */
-    if (c->ipc) return fail(c, "spatial bands need RCCL ranks (the IPC test transport has no teams)");
-    if (!c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
     const int band = c->rank / T, trank = c->rank % T;
+    if (c->ipc) {
+        /* processes on one GPU (the IPC test transport, lfbm5d_comm_init_ipc): the same teams, the same stitch.  A team's job runs
+         * under the team's numbering with rendezvous names of its own ("b<band>."); for the stitch every rank publishes the IPC
+         * handle of its packed chunk, reads the chunks of the other teams straight out of their owners' buffers, and all ranks
+         * leave together (nobody packs the next job's chunk over one that is still being read). */
+        const BandRows r = band_rows(H, S, band, halo);
+        c->ipc_epoch += 1;   /* names of this job's stitch; a team of one rank runs no exchange of its own that would advance it */
+        const unsigned stitch_epoch = c->ipc_epoch;
+        int rc;
+        {
+            struct IpcTeamScope {
+                lfbm5d_ctx* c; int rank, world; std::vector<lfbm5d_ctx::IpcPeer> peers;
+                ~IpcTeamScope() {
+                    for (lfbm5d_ctx::IpcPeer& P : c->ipc_peers) for (void*& q : P.ptr) if (q) { (void)hipIpcCloseMemHandle(q); q = nullptr; }
+                    c->ipc_peers = std::move(peers); c->rank = rank; c->world = world; c->ipc_tag.clear();
+                }
+            } scope{c, c->rank, c->world, std::move(c->ipc_peers)};
+            c->ipc_peers.clear();
+            c->rank = trank; c->world = T; c->ipc_tag = "b" + std::to_string(band) + ".";
+            rc = job_on_band(d_noisy, r);
+        }
+        if (rc) return 1;   /* (run_graph has closed the transport: the other teams end in their watchdogs) */
+        if (interior_back(r)) return 1;
+        HIPCK(c, c->band_pack.reserve(chunk_floats * sizeof(float)));
+        if (pack_chunk(c->rank, c->band_pack.as<float>())) return 1;
+        HIPCK(c, hipStreamSynchronize(s));
+        hipIpcMemHandle_t mine;
+        HIPCK(c, hipIpcGetMemHandle(&mine, c->band_pack.p));
+        const std::string base = "bandpack." + std::to_string(stitch_epoch) + ".";
+        if (!ipc_put(c->ipc_dir, base + std::to_string(c->rank), &mine, sizeof(mine))) return fail(c, "ipc transport: cannot write to the rendezvous directory");
+        std::vector<void*> opened;
+        int bad = 0;
+        for (int rk = 0; rk < nranks && !bad; rk++) {
+            if (rk / T == band) continue;   /* this team's rows are in place */
+            hipIpcMemHandle_t h;
+            if (!ipc_get(c->ipc_dir, base + std::to_string(rk), &h, sizeof(h), c->ipc_timeout_s)) { bad = 1; break; }
+            void* q = nullptr;
+            if (hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { bad = 2; break; }
+            opened.push_back(q);
+            if (unpack_chunk(rk, reinterpret_cast<const float*>(q))) { bad = 3; break; }
+        }
+        (void)hipStreamSynchronize(s);
+        for (void* q : opened) (void)hipIpcCloseMemHandle(q);
+        if (bad == 1) return fail(c, "ipc transport: a rank did not publish its band within the watchdog (peer gone?)");
+        if (bad == 2) return fail(c, "ipc transport: hipIpcOpenMemHandle of a peer's band failed");
+        if (bad) return 1;
+        std::vector<int> all;
+        const unsigned keep = c->ipc_epoch; c->ipc_epoch = stitch_epoch;          /* (the teams' jobs may have advanced their epochs differently) */
+        const int rs = ipc_allgather(c, "stitched", 1, all);
+        (void)keep; c->ipc_epoch = stitch_epoch + 8;   /* the same on every rank whatever its team's job used (a redo takes more) */
+        return rs;
+    }
+    if (!c->comm) return fail(c, "whole steps on several ranks need lfbm5d_comm_init");
     if (c->team_S != S) {
         if (c->team_comm2) { (void)ncclCommDestroy(c->team_comm2); c->team_comm2 = nullptr; }
         if (c->team_comm) { (void)ncclCommDestroy(c->team_comm); c->team_comm = nullptr; }

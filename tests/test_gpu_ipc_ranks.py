@@ -31,6 +31,16 @@ def test_processes_on_one_gpu_are_bit_identical_to_one_rank(world, case):
         assert all(r["messages"] > 0 for r in d["ranks"]), d
 
 
+@pytest.mark.parametrize("world,S,case", [(4, 2, "7x9"), (2, 2, "5x5"), (3, 3, "17x17x96")])
+def test_spatial_bands_between_processes_match_the_emulated_teams(world, S, case):
+    """Round 6: option spatial_bands between real processes -- S teams of world / S processes, a team's job on the IPC transport
+    under the team's numbering, the stitch through IPC handles of every rank's packed chunk.  Bit for bit the result of the same
+    teams played by emulated ranks on one context (which tests/test_gpu_denoise.py ties to the one-rank job on each band's crop)."""
+    rc, d = _run(f"bands{S}", str(world), case, "30")
+    assert rc == 0 and d["ok"], d
+    assert all(r["identical_to_single_rank"] and r["second_job_identical"] for r in d["ranks"]), d
+
+
 def test_a_peer_that_leaves_ends_the_job_with_an_error_not_a_hang():
     rc, d = _run("die", "2", "7x9", "8")
     assert rc == 0 and d["ok"], d

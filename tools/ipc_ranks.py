@@ -7,6 +7,9 @@ processes, and compares every rank's light fields with the single-rank result, b
   python tools/ipc_ranks.py run <world> <case> [timeout_s]      case: 5x5 | 7x9 | 17x17x96
   python tools/ipc_ranks.py die <world> <case> [timeout_s]      rank world-1 leaves after the rendezvous: the others must return an error
                                                                 within the watchdog (exit code 0 of THIS tool = they did), not hang
+  python tools/ipc_ranks.py bands<S> <world> <case> [timeout_s] spatial bands (option spatial_bands = S): S teams of world / S processes, each team's job
+                                                                on rendezvous names of its own, the stitch through IPC handles of the packed chunks; compared,
+                                                                bit for bit, with the same banded job played by emulated ranks in the parent
 prints one JSON line."""
 import json
 import os
@@ -50,10 +53,12 @@ def denoise(ctx, case, noisy):
     return d_n.cpu().numpy(), d_b.cpu().numpy(), d_o.cpu().numpy(), int(st.windows), int(st.messages)
 
 
-def worker(rank, world, rdir, case, die, timeout_s):
+def worker(rank, world, rdir, case, die, timeout_s, bands=1):
     import lfbm5d_amd as L
     ctx = L.Context(0)
     ctx.comm_init_ipc(rank, world, rdir, timeout_s)
+    if bands > 1:
+        ctx.set_option("spatial_bands", bands)
     if die and rank == world - 1:
         os._exit(0)          # gone after the rendezvous, before its first window
     noisy = light_field(case)
@@ -73,7 +78,8 @@ def worker(rank, world, rdir, case, die, timeout_s):
 def main():
     mode = sys.argv[1]
     if mode == "worker":
-        return worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] == "1", float(sys.argv[7]))
+        return worker(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6] == "1", float(sys.argv[7]), int(sys.argv[8]) if len(sys.argv) > 8 else 1)
+    bands = int(mode[5:]) if mode.startswith("bands") else 1
     world, case = int(sys.argv[2]), sys.argv[3]
     timeout_s = float(sys.argv[4]) if len(sys.argv) > 4 else 20.0
     die = mode == "die"
@@ -82,14 +88,18 @@ def main():
     if not die:
         import lfbm5d_amd as L
         ctx = L.Context(0)
+        if bands > 1:   # the reference of a banded job: the same teams played by emulated ranks (the bands are not bit-identical to one rank)
+            ctx.set_option("emulate_world", world)
+            ctx.set_option("spatial_bands", bands)
         ref = denoise(ctx, case, light_field(case))
         ctx.close()
         out["single_rank_windows"] = ref[3]
+        out["spatial_bands"] = bands
     rdir = tempfile.mkdtemp(prefix="lfbm5d_ipc_")
     env = dict(os.environ)
     env.pop("LFBM5D_EMULATE_WORLD", None)
     t0 = time.time()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker", str(r), str(world), rdir, case, "1" if die else "0", str(timeout_s)],
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker", str(r), str(world), rdir, case, "1" if die else "0", str(timeout_s), str(bands)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     codes, lines = [], []
     for p in procs:
@@ -124,7 +134,8 @@ def main():
             ok = ok and same and bool(z["same_again"][0])
             total_windows += int(z["windows"][0])
         out["windows_over_ranks"] = total_windows
-        ok = ok and total_windows == ref[3] and (world == 1 or case == "5x5" or all(rk.get("messages", 0) > 0 for rk in out["ranks"]))
+        # (a banded job: every TEAM runs the whole schedule, and every member reports its team's windows)
+        ok = ok and (total_windows == ref[3] if bands == 1 else total_windows > 0) and (world == 1 or case == "5x5" or bands == world or all(rk.get("messages", 0) > 0 for rk in out["ranks"]))
     out["ok"] = bool(ok)
     print(json.dumps(out))
     sys.exit(0 if ok else 1)
