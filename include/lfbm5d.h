@@ -129,7 +129,7 @@ int lfbm5d_get_option(lfbm5d_ctx* ctx, const char* key, char* value, unsigned lo
  * row-sharded as below (exact, two all-reduces per pass; also what greyscale light fields need); "blocks" = round 1's
  * contiguous blocks of windows per rank + ONE all-reduce per step, which scales with the rank count but is NOT the
  * reference's result (a rank's block matching only sees its own earlier windows: -0.01 / -0.03 / -0.07 dB at 2 / 4 / 8 ranks).
- * Option "spatial_bands" = S > 1 (lfbm5d_denoise_* only) adds a level above the graph for rank counts beyond what the graph keeps
+ * Option "spatial_bands" = S > 1 (lfbm5d_denoise_* only; "0" = S from lfbm5d_auto_bands) adds a level above the graph for rank counts beyond what the graph keeps
  * busy: S teams of world / S ranks (rank = band * team size + team rank), team b runs the whole two-step job on rows
  * [b H / S, (b + 1) H / S) of every SAI plus "band_halo" rows on either side (default nSim + nDisp + k of the wider step) as a
  * light field of its own -- the same window graph, on a communicator split off for the team -- and ONE all-gather stitches the
@@ -170,6 +170,11 @@ int lfbm5d_set_shard(lfbm5d_ctx* ctx, int rank, int world);
 int lfbm5d_set_tiles(lfbm5d_ctx* ctx, int nb_tiles);
 /* Row range [begin,end) of n_rows reference-patch rows owned by `rank` of `world`. */
 void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, unsigned* end);
+/* Spatial bands S for a two-step job on `world` ranks (option "spatial_bands"; host only): the window graph of an a x a light field
+ * (a = the smaller angular side) keeps about 0.8 ceil(a / 3) ranks busy, so the graph takes the largest power of two of ranks within
+ * that and bands take the rest -- while S divides `world` and a band (height / S rows) stays twice as tall as `halo` (0: 40, the
+ * README parameters' nSim + nDisp + k).  1 = the graph alone.  Option value "0" applies this rule inside lfbm5d_denoise_*. */
+int lfbm5d_auto_bands(unsigned awidth, unsigned aheight, unsigned height, unsigned halo, int world);
 /* The window schedule of a step as the processed SAI (index in `ang_major` order) of each window, in
  * order: the centre SAI first, then always the last SAI not covered yet (bm5d.cpp:187-213 -- all
  * candidates tie on the zero-weight count because a window always finishes all of its SAIs).  Host

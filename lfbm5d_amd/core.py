@@ -98,6 +98,8 @@ def lib():
     L.lfbm5d_comm_ranks.argtypes = [vp]
     L.lfbm5d_comm_ranks.restype = C.c_int
     L.lfbm5d_comm_selftest.argtypes = [vp, C.c_uint]
+    L.lfbm5d_auto_bands.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int]
+    L.lfbm5d_auto_bands.restype = C.c_int
     L.lfbm5d_shard_rows.argtypes = [C.c_uint, C.c_int, C.c_int, up, up]
     L.lfbm5d_shard_rows.restype = None
     L.lfbm5d_plan_windows.argtypes = [C.c_uint, C.c_uint, C.c_uint, C.c_uint, up, up, C.c_uint]
@@ -204,18 +206,10 @@ def plan_job(awidth, aheight, world, lanes=1, an=(1, 1), cost=None, ang_major=No
 
 
 def auto_bands(awidth, aheight, height, halo, world):
-    """Spatial bands S for a two-step job on `world` ranks (option spatial_bands; tools/scale_model.py): the window graph of an
-    a x a light field keeps about 0.8 ceil(a / 3) ranks busy (its rows of windows, less the dependency stalls), a band costs
-    (H / S + 2 halo) / H of a pass -- so the graph takes the ranks it can use (a power of two) and bands take the rest, as long
-    as a band stays twice as tall as its halo.  1 = the graph alone (bit-identical to one GPU)."""
-    a = min(int(awidth), int(aheight))
-    t_max = 1
-    while t_max * 2 <= 0.8 * ((a + 2) // 3):
-        t_max *= 2
-    s = max(1, int(world) // min(int(world), t_max))
-    while s > 1 and (int(world) % s or int(height) // s < 2 * int(halo)):
-        s -= 1
-    return s
+    """Spatial bands S for a two-step job on `world` ranks (lfbm5d_auto_bands, include/lfbm5d.h; tools/scale_model.py): the graph takes the
+    ranks it can keep busy (a power of two within 0.8 ceil(a / 3)), bands take the rest, as long as a band stays twice as tall as its
+    halo.  1 = the graph alone (bit-identical to one GPU)."""
+    return int(lib().lfbm5d_auto_bands(int(awidth), int(aheight), int(height), int(halo), int(world)))
 
 
 def shard_rows(n_rows, rank, world):

@@ -92,6 +92,10 @@ void lfbm5d_shard_rows(unsigned n_rows, int rank, int world, unsigned* begin, un
     *end = (unsigned)(((unsigned long long)n_rows * (unsigned)(rank + 1)) / (unsigned)world);
 }
 
+int lfbm5d_auto_bands(unsigned awidth, unsigned aheight, unsigned height, unsigned halo, int world) {
+    return auto_bands(awidth, aheight, height, halo ? halo : 40u, world);
+}
+
 int lfbm5d_comm_unique_id(void* id_out) {
     ncclUniqueId id;
     static_assert(sizeof(ncclUniqueId) <= LFBM5D_UNIQUE_ID_BYTES, "unique id size");

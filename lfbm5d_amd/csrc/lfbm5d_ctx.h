@@ -183,6 +183,7 @@ int io_upload_all(lfbm5d_ctx* c, const HostIO* io, const unsigned* h_mask, unsig
 int io_download_all(lfbm5d_ctx* c, const HostIO* io, const unsigned* h_mask, unsigned asize, size_t img, const float* d_noisy,
                     const float* d_basic, const float* d_out);
 constexpr unsigned kIpcMaxMsgs = 4096;   /* gating words: ready[kIpcMaxMsgs], taken[kIpcMaxMsgs], error */
+int auto_bands(unsigned awidth, unsigned aheight, unsigned height, unsigned halo, int world);   /* lfbm5d_steps.hip: lfbm5d_auto_bands */
 int ipc_allgather(lfbm5d_ctx* c, const char* tag, int mine, std::vector<int>& all);
 bool ipc_put(const std::string& dir, const std::string& name, const void* data, size_t bytes);
 bool ipc_get(const std::string& dir, const std::string& name, void* data, size_t bytes, double timeout_s);

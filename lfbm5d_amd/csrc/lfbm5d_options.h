@@ -50,7 +50,7 @@ struct Options {
     int bm3d_lanes = 3;             /* SAIs of LFBM3Ddenoising processed concurrently */
     int scan_lds_cap = 0;           /* > 0: LDS bytes the first-generation table kernel may use */
     int force_redo = 0;             /* test hook: treat the graph as incomplete once (exercises the sequential redo) */
-    int spatial_bands = 1;          /* S > 1, several ranks, lfbm5d_denoise_*: S teams of ranks, each denoises a horizontal band of every SAI (+ halo) on its own
+    int spatial_bands = 1;          /* 0: chosen by lfbm5d_auto_bands; S > 1, several ranks, lfbm5d_denoise_*: S teams of ranks, each denoises a horizontal band of every SAI (+ halo) on its own
                                      * window graph; NOT bit-identical to one GPU, PSNR within 1e-3 dB (lfbm5d_steps.hip) */
     int band_halo = 0;              /* rows of halo of a band; 0: nSim + nDisp + k of the wider step */
     unsigned kernels = 0;           /* kOpt* bits: kernel-generation selectors */

@@ -752,16 +752,27 @@ static int run_denoise_banded(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm
     return 0;
 }
 
+/* the band count the scale model picks (tools/scale_model.py; include/lfbm5d.h lfbm5d_auto_bands) */
+int auto_bands(unsigned awidth, unsigned aheight, unsigned height, unsigned halo, int world) {
+    if (world < 1) return 1;
+    const unsigned a = std::min(awidth, aheight);
+    int t_max = 1;
+    while (t_max * 2 <= 0.8 * (double)((a + 2) / 3)) t_max *= 2;
+    int s = std::max(1, world / std::min(world, t_max));
+    while (s > 1 && (world % s || height / (unsigned)s < 2 * halo)) s--;
+    return s;
+}
+
 /* lfbm5d_denoise_*: the whole light field as one job (the default), or band by band (option spatial_bands) */
 int run_denoise(lfbm5d_ctx* c, const lfbm5d_params* P1, const lfbm5d_params* P2, float* d_noisy, const unsigned* h_mask, float* d_basic,
                 float* d_out, unsigned ang_major, unsigned awidth, unsigned aheight, unsigned an1, unsigned an2, unsigned W, unsigned H,
                 unsigned C, const HostIO* io) {
-    const int S = c->opt->spatial_bands;
     const int emu = c->opt->emulate_world, nranks = emu > 1 ? emu : c->world;
+    const unsigned halo0 = c->opt->band_halo > 0 ? (unsigned)c->opt->band_halo : std::max(P1->nSim + P1->nDisp + P1->k, P2->nSim + P2->nDisp + P2->k);
+    const int S = c->opt->spatial_bands == 0 ? auto_bands(awidth, aheight, H, halo0, nranks) : c->opt->spatial_bands;   /* 0: the rule */
     if (S <= 1 || nranks <= 1) return run_denoise_whole(c, P1, P2, d_noisy, h_mask, d_basic, d_out, ang_major, awidth, aheight, an1, an2, W, H, C, io);
     if (nranks % S) return fail(c, "spatial_bands must divide the number of ranks");
-    const unsigned halo = c->opt->band_halo > 0 ? (unsigned)c->opt->band_halo : std::max(P1->nSim + P1->nDisp + P1->k, P2->nSim + P2->nDisp + P2->k);
-    if (H / (unsigned)S < std::max(halo, 2 * std::max(P1->k, P2->k))) return fail(c, "spatial_bands: the bands would be narrower than their halo");
+    if (H / (unsigned)S < std::max(halo0, 2 * std::max(P1->k, P2->k))) return fail(c, "spatial_bands: the bands would be narrower than their halo");
     if (c->tiles > 1) return fail(c, "spatial bands and the tile mode exclude each other");
     const unsigned asize = awidth * aheight;
     const size_t img = (size_t)C * W * H;

@@ -265,6 +265,18 @@ def test_spatial_bands_stay_within_the_psnr_tolerance(ctx, monkeypatch):
     finally:
         ctx.set_option("emulate_world", None)
         ctx.set_option("spatial_bands", None)
+    # option value 0 = the library's rule (lfbm5d_auto_bands): eight ranks on this 5 x 7 light field of 160 rows -> 4 bands x 2 ranks
+    assert core.auto_bands(aw, ah, Hs, 16, 8) == 4
+    try:
+        res = {}
+        for S in (0, 4):
+            ctx.set_option("emulate_world", 8)
+            ctx.set_option("spatial_bands", S)
+            res[S] = _one_job(ctx, P1, P2, noisy, mask, aw, ah, (1, 1), Ws, Hs, L.ROWMAJOR)
+        assert all(np.array_equal(res[0][i], res[4][i]) for i in range(3)) and res[0][4].windows == 4 * len(w0)
+    finally:
+        ctx.set_option("emulate_world", None)
+        ctx.set_option("spatial_bands", None)
     # a band count that does not divide the ranks is refused, one rank ignores the option
     ctx.set_option("spatial_bands", 2)
     try:
