@@ -93,6 +93,11 @@ def test_options_are_per_context():
         assert (b.get_option("lanes"), b.get_option("step_sharding"), b.get_option("dct8w_v2")) == (os.environ.get("LFBM5D_LANES", "2"), "0", "0")
         a.set_option("lanes", None)
         assert a.get_option("lanes") == "2"
+        # round 6's keys: spatial bands (0 = the library's rule), the halo, the filt layout hook
+        assert (a.get_option("spatial_bands"), a.get_option("band_halo"), a.get_option("filt_group_major")) == ("1", "0", "0")
+        a.set_option("spatial_bands", 0); a.set_option("band_halo", 48); a.set_option("LFBM5D_FILT_GROUP_MAJOR", "1")
+        assert (a.get_option("spatial_bands"), a.get_option("band_halo"), a.get_option("filt_group_major")) == ("0", "48", "1")
+        assert (b.get_option("spatial_bands"), b.get_option("band_halo"), b.get_option("filt_group_major")) == ("1", "0", "0")
         with pytest.raises(L.LfBm5dError, match="unknown option"):
             a.set_option("no_such_option", 1)
     finally:
