@@ -302,7 +302,11 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
 #define LFBM5D_AGG16_TW 16
 #define LFBM5D_AGG16_TH 4
 #endif
-    const unsigned tw = wide ? (a.k == 12 ? 16 : LFBM5D_AGG16_TW) : 8, th = wide ? (a.k == 12 ? 4 : LFBM5D_AGG16_TH) : 8;
+#ifndef LFBM5D_AGG8_TW
+#define LFBM5D_AGG8_TW 8
+#define LFBM5D_AGG8_TH 8
+#endif
+    const unsigned tw = wide ? (a.k == 12 ? 16 : LFBM5D_AGG16_TW) : (a.k == 8 ? LFBM5D_AGG8_TW : 8), th = wide ? (a.k == 12 ? 4 : LFBM5D_AGG16_TH) : (a.k == 8 ? LFBM5D_AGG8_TH : 8);
     const unsigned tiles = ((a.Wb + tw - 1) / tw) * ((a.Hb + th - 1) / th) * a.A;
     const dim3 grid(((tiles + 7) / 8) * 8), block(64);
     const bool big = (a.filt_sai_stride ? a.filt_sai_stride * sizeof(float) : a.filt_bytes) > 0xfffff000ull || (a.opt & kOptAgg64Bit);   /* option agg_64bit: exercise the 64-bit path in tests */
@@ -331,7 +335,7 @@ hipError_t launch_aggregate(hipStream_t s, const AggArgs& a) {
 #define LFBM5D_AGG8_U 6
 #endif
     if (a.k == 12)      LFBM5D_AGG(true, 16, 4, 3, 12);
-    else if (a.k == 8)  LFBM5D_AGG(true, 8, 8, LFBM5D_AGG8_PF, LFBM5D_AGG8_U);
+    else if (a.k == 8)  LFBM5D_AGG(true, LFBM5D_AGG8_TW, LFBM5D_AGG8_TH, LFBM5D_AGG8_PF, LFBM5D_AGG8_U);
     else if (wide)      LFBM5D_AGG(false, LFBM5D_AGG16_TW, LFBM5D_AGG16_TH, LFBM5D_AGG16_PF, LFBM5D_AGG16_U);
     else                LFBM5D_AGG(false, 8, 8, 2, 6);
 #undef LFBM5D_AGG
